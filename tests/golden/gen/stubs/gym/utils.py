@@ -1,0 +1,3 @@
+class EzPickle(object):
+    def __init__(self, *a, **k):
+        pass
