@@ -1,0 +1,187 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE — see oracle/dm_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MAXBODY, MAXJNT, MAXV, MAXQ, MAXU, MAXGEOM = 16, 32, 36, 40, 32, 20
+JNT_FREE, JNT_HINGE = 0, 3
+GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX = 0, 2, 3, 6
+
+
+class Spec(C.Structure):
+    """Mirror of `dmo_spec` (oracle/dm_oracle.h) for building small test rigs from Python."""
+    _fields_ = [
+        ("nbody", C.c_int), ("njnt", C.c_int), ("ngeom", C.c_int), ("nu", C.c_int),
+        ("body_parent", C.c_int * MAXBODY), ("body_pos", (C.c_double * 3) * MAXBODY),
+        ("jnt_type", C.c_int * MAXJNT), ("jnt_body", C.c_int * MAXJNT), ("jnt_limited", C.c_int * MAXJNT),
+        ("jnt_axis", (C.c_double * 3) * MAXJNT), ("jnt_range", (C.c_double * 2) * MAXJNT),
+        ("jnt_armature", C.c_double * MAXJNT), ("jnt_damping", C.c_double * MAXJNT),
+        ("geom_type", C.c_int * MAXGEOM), ("geom_body", C.c_int * MAXGEOM), ("geom_condim", C.c_int * MAXGEOM),
+        ("geom_contype", C.c_int * MAXGEOM), ("geom_conaffinity", C.c_int * MAXGEOM),
+        ("geom_has_fromto", C.c_int * MAXGEOM),
+        ("geom_size", (C.c_double * 3) * MAXGEOM), ("geom_pos", (C.c_double * 3) * MAXGEOM),
+        ("geom_fromto", (C.c_double * 6) * MAXGEOM),
+        ("geom_mass", C.c_double * MAXGEOM), ("geom_friction", (C.c_double * 3) * MAXGEOM),
+        ("geom_margin", C.c_double * MAXGEOM),
+        ("act_jnt", C.c_int * MAXU), ("act_gear", C.c_double * MAXU), ("act_ctrlrange", (C.c_double * 2) * MAXU),
+        ("nexclude", C.c_int), ("exclude", (C.c_int * 2) * 16),
+        ("timestep", C.c_double), ("gravity", C.c_double * 3), ("tolerance", C.c_double),
+        ("iterations", C.c_int),
+        ("solref", C.c_double * 2), ("solimp", C.c_double * 5),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = [os.path.join(_HERE, f) for f in ("dm_oracle.c", "dm_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.dmo_model_new.restype = C.c_void_p
+        L.dmo_model_new.argtypes = [C.c_void_p]
+        L.dmo_model_free.argtypes = [C.c_void_p]
+        L.dmo_data_create.restype = C.c_void_p
+        L.dmo_data_create.argtypes = [C.c_void_p]
+        L.dmo_data_destroy.argtypes = [C.c_void_p]
+        L.dmo_reset_data.argtypes = [C.c_void_p, C.c_void_p]
+        L.dmo_forward.argtypes = [C.c_void_p, C.c_void_p]
+        L.dmo_step.argtypes = [C.c_void_p, C.c_void_p]
+        L.dmo_humanoid_spec.argtypes = [C.c_void_p]
+        dp = C.POINTER(C.c_double)
+        L.dmo_model_get.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int]
+        L.dmo_model_set.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.dmo_data_get.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, dp, C.c_int]
+        L.dmo_data_set.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, dp, C.c_int]
+        L.dmo_get_obs.argtypes = [C.c_void_p, C.c_void_p, dp]
+        L.dmo_com_z.restype = C.c_double
+        L.dmo_com_z.argtypes = [C.c_void_p, C.c_void_p]
+        L.dmo_is_done.argtypes = [C.c_void_p, C.c_void_p]
+        L.dmo_set_state.argtypes = [C.c_void_p, C.c_void_p, dp, dp]
+        L.dmo_config_reward.restype = C.c_double
+        L.dmo_config_reward.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_int, C.POINTER(C.c_int)]
+        L.dmo_env_step.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_int, C.c_int, dp, C.c_int,
+                                   C.POINTER(C.c_int), C.c_int, dp, dp, C.POINTER(C.c_int)]
+        L.dmo_batch_step.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, dp, C.c_int, dp, dp,
+                                     C.POINTER(C.c_ubyte), C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def humanoid_spec():
+    s = Spec()
+    lib().dmo_humanoid_spec(C.byref(s))
+    return s
+
+
+class Model(object):
+    def __init__(self, spec=None):
+        self._spec = spec
+        self.h = lib().dmo_model_new(C.byref(spec) if spec is not None else None)
+        if not self.h:
+            raise RuntimeError("oracle: model compile failed")
+        self.nq = int(self.get("nq")[0]); self.nv = int(self.get("nv")[0]); self.nu = int(self.get("nu")[0])
+        self.nbody = int(self.get("nbody")[0]); self.ngeom = int(self.get("ngeom")[0])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().dmo_model_free(self.h); self.h = None
+
+    def get(self, field, maxn=8192):
+        buf = np.zeros(maxn)
+        n = lib().dmo_model_get(self.h, field.encode(), _dp(buf), maxn)
+        if n < 0:
+            raise KeyError(field)
+        return buf[:n].copy()
+
+    def set(self, field, value):
+        if lib().dmo_model_set(self.h, field.encode(), float(value)) != 0:
+            raise KeyError(field)
+
+
+class Data(object):
+    """One environment's simulator state: the analogue of mujoco_py.MjSim(model)."""
+
+    def __init__(self, model):
+        self.m = model
+        self.h = lib().dmo_data_create(model.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().dmo_data_destroy(self.h); self.h = None
+
+    def get(self, field, maxn=70000):
+        buf = np.zeros(maxn)
+        n = lib().dmo_data_get(self.m.h, self.h, field.encode(), _dp(buf), maxn)
+        if n < 0:
+            raise KeyError(field)
+        return buf[:n].copy()
+
+    def set(self, field, value):
+        a = np.ascontiguousarray(np.atleast_1d(value), dtype=np.float64)
+        if lib().dmo_data_set(self.m.h, self.h, field.encode(), _dp(a), a.size) != 0:
+            raise KeyError(field)
+
+    def reset(self):
+        lib().dmo_reset_data(self.m.h, self.h)
+
+    def forward(self):
+        lib().dmo_forward(self.m.h, self.h)
+
+    def step(self):
+        lib().dmo_step(self.m.h, self.h)
+
+    def set_state(self, qpos, qvel):
+        q = np.ascontiguousarray(qpos, dtype=np.float64); v = np.ascontiguousarray(qvel, dtype=np.float64)
+        lib().dmo_set_state(self.m.h, self.h, _dp(q), _dp(v))
+
+    def obs(self):
+        o = np.zeros(56); lib().dmo_get_obs(self.m.h, self.h, _dp(o)); return o
+
+    def com_z(self):
+        return lib().dmo_com_z(self.m.h, self.h)
+
+    def is_done(self):
+        return bool(lib().dmo_is_done(self.m.h, self.h))
+
+    def config_reward(self, data_config, idx_curr):
+        cfg = np.ascontiguousarray(data_config, dtype=np.float64)
+        i = C.c_int(int(idx_curr))
+        r = lib().dmo_config_reward(self.m.h, self.h, _dp(cfg), cfg.shape[0], C.byref(i))
+        return r, i.value
+
+    def env_step(self, action, n_substeps=1, reward_mode=0, data_config=None, idx_curr=0, idx_init=0):
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        cfg = np.zeros((1, 35)) if data_config is None else np.ascontiguousarray(data_config, dtype=np.float64)
+        o = np.zeros(56); r = C.c_double(0); dn = C.c_int(0); ic = C.c_int(int(idx_curr))
+        rr = np.zeros(1)
+        lib().dmo_env_step(self.m.h, self.h, _dp(a), n_substeps, reward_mode, _dp(cfg), cfg.shape[0],
+                           C.byref(ic), int(idx_init), _dp(o), _dp(rr), C.byref(dn))
+        return o, float(rr[0]), bool(dn.value), ic.value
+
+
+def batch_step(model, datas, actions, n_substeps=1, nthreads=1):
+    n = len(datas)
+    arr = (C.c_void_p * n)(*[d.h for d in datas])
+    a = np.ascontiguousarray(actions, dtype=np.float64)
+    obs = np.zeros((n, 56)); rew = np.zeros(n); done = np.zeros(n, dtype=np.uint8)
+    lib().dmo_batch_step(model.h, arr, n, _dp(a), n_substeps, _dp(obs), _dp(rew),
+                         done.ctypes.data_as(C.POINTER(C.c_ubyte)), nthreads)
+    return obs, rew, done
