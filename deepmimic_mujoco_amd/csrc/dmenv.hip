@@ -1,0 +1,336 @@
+// dmenv.hip — libdmenv.so: HIP kernels (gfx950) + the C ABI of include/dmenv.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I../../include dmenv.hip -o libdmenv.so
+// There is no CPU execution path in this library: every entry point that computes runs a HIP kernel.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dmenv.h"
+#include "env_step.h"
+#include "model_host.h"
+
+using namespace dm;
+typedef double Real;
+
+// ============================================ kernels ======================================================
+// one 64-lane workgroup (= one wavefront) per environment
+__global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ action,
+                                             Real* __restrict__ obs, Real* __restrict__ reward, unsigned char* __restrict__ done,
+                                             int n_substeps) {
+  __shared__ Shared<Real> s;
+  __shared__ StepScratch<Real> x;
+  const int env = blockIdx.x;
+  if (env >= B.n_envs) return;
+  env_step(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
+}
+
+__global__ __launch_bounds__(64) void k_set_state(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ qpos,
+                                                  const Real* __restrict__ qvel, const int* __restrict__ frame_idx,
+                                                  const unsigned char* __restrict__ mask) {
+  __shared__ Shared<Real> s;
+  const int env = blockIdx.x, lane = dmw::lane();
+  if (env >= B.n_envs) return;
+  if (mask && !mask[env]) return;
+  load_env(*Mp, B, s, env, lane, (const Real*)0);
+  if (lane < NQ) s.qpos[lane] = qpos[(size_t)env * NQ + lane];
+  if (lane < NV) s.qvel[lane] = qvel[(size_t)env * NV + lane];
+  if (frame_idx && lane == 0) { B.frame_idx[env] = frame_idx[env]; B.frame_init[env] = frame_idx[env]; }
+  dmw::sync();
+  store_state(B, s, env, lane);
+  forward(*Mp, s, lane, (const DebugOut*)0);   // sim.forward()
+  store_derived(B, *Mp, s, env, lane);
+}
+
+__global__ __launch_bounds__(64) void k_reset(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, int mode, int hard,
+                                              const unsigned char* __restrict__ mask) {
+  __shared__ Shared<Real> s;
+  const int env = blockIdx.x, lane = dmw::lane();
+  if (env >= B.n_envs) return;
+  if (mask && !mask[env]) return;
+  load_env(*Mp, B, s, env, lane, (const Real*)0);
+  reset_env(*Mp, B, s, env, lane, mode, hard);
+  store_state(B, s, env, lane);
+  forward(*Mp, s, lane, (const DebugOut*)0);
+  store_derived(B, *Mp, s, env, lane);
+}
+
+__global__ void k_get_obs(Batch<Real> B, Real* __restrict__ obs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B.n_envs * NOBS) return;
+  const int env = i / NOBS, k = i % NOBS;
+  obs[i] = k < 28 ? B.qpos[(size_t)env * NQ + 7 + k] : B.qvel[(size_t)env * NV + 6 + (k - 28)];
+}
+
+__global__ __launch_bounds__(64) void k_debug_forward(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, int env, double* out) {
+  __shared__ Shared<Real> s;
+  const int lane = dmw::lane();
+  load_env(*Mp, B, s, env, lane, (const Real*)0);
+  // actuator forces from the stored ctrl
+  if (lane < NU) { const int d = lane + 6; s.act[d] = Mp->gear[d] * clampr(B.ctrl[(size_t)env * NU + lane], Mp->ctrl_lo[d], Mp->ctrl_hi[d]); }
+  dmw::sync();
+  DebugOut dbg{out};
+  forward(*Mp, s, lane, &dbg);
+  store_derived(B, *Mp, s, env, lane);
+}
+
+// ============================================ host side ====================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(DM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct dm_model { DevModel<Real> h; };
+struct dm_mocap { std::vector<double> cfg, vel; int n_frames; double dt; };
+struct dm_batch {
+  int n = 0, device = 0;
+  hipStream_t stream = nullptr; bool own_stream = false;
+  DevModel<Real>* d_model = nullptr;
+  Batch<Real> B{};
+  Real *d_cfg = nullptr, *d_vel = nullptr;
+  // staging for DM_PTR_HOST callers
+  Real *d_action = nullptr, *d_obs = nullptr, *d_reward = nullptr; unsigned char *d_done = nullptr, *d_mask = nullptr;
+  Real *d_qpos_in = nullptr, *d_qvel_in = nullptr; int* d_fidx_in = nullptr;
+  double* d_debug = nullptr;
+  bool timing = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f; bool ev_pending = false;
+};
+
+extern "C" const char* dm_last_error(void) { return g_err.c_str(); }
+extern "C" int dm_abi_version(void) { return DM_ABI_VERSION; }
+extern "C" int dm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+extern "C" int dm_model_create(const dm_model_desc* d, dm_model** out) {
+  if (!d || !out) return fail(DM_EINVAL, "dm_model_create: null argument");
+  dm_model* m = new (std::nothrow) dm_model();
+  if (!m) return fail(DM_ENOMEM, "dm_model_create: out of memory");
+  std::string err;
+  const int rc = dm::build_dev_model(d, &m->h, &err);
+  if (rc != DM_OK) { delete m; return fail(rc, err); }
+  *out = m;
+  return DM_OK;
+}
+extern "C" void dm_model_destroy(dm_model* m) { delete m; }
+
+extern "C" int dm_mocap_create(const double* cfg, const double* vel, int32_t F, double dt, dm_mocap** out) {
+  if (!cfg || !vel || F <= 0 || !out) return fail(DM_EINVAL, "dm_mocap_create: bad argument");
+  dm_mocap* mc = new (std::nothrow) dm_mocap();
+  if (!mc) return fail(DM_ENOMEM, "dm_mocap_create: out of memory");
+  mc->cfg.assign(cfg, cfg + (size_t)F * NQ); mc->vel.assign(vel, vel + (size_t)F * NV); mc->n_frames = F; mc->dt = dt;
+  *out = mc;
+  return DM_OK;
+}
+extern "C" void dm_mocap_destroy(dm_mocap* mc) { delete mc; }
+
+template <class T> static hipError_t dalloc(T** p, size_t n) { hipError_t e = hipMalloc((void**)p, n * sizeof(T)); if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T)); return e; }
+
+extern "C" void dm_batch_destroy(dm_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  if (b->stream) hipStreamSynchronize(b->stream);
+  void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
+                  b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
+                  b->d_reward, b->d_done, b->d_mask, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
+  delete b;
+}
+
+extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n, int32_t device, uint32_t flags, dm_batch** out) {
+  if (!m || !mc || n <= 0 || !out) return fail(DM_EINVAL, "dm_batch_create: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DM_ENODEVICE, "dm_batch_create: no HIP device visible (libdmenv has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(DM_EINVAL, "dm_batch_create: bad device id");
+  HIPCHK(hipSetDevice(device));
+  dm_batch* b = new (std::nothrow) dm_batch();
+  if (!b) return fail(DM_ENOMEM, "dm_batch_create: out of memory");
+  b->n = n; b->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete b; return fail(DM_EHIP, "hipStreamCreate failed"); }
+  b->own_stream = true;
+  DevModel<Real> hm = m->h;
+  hm.enable_contact = (flags & DM_FLAG_NO_CONTACT) ? 0 : 1;
+  hm.enable_limit = (flags & DM_FLAG_NO_LIMIT) ? 0 : 1;
+  bool ok = true;
+#define A(p, cnt) ok = ok && (dalloc(&(p), (size_t)(cnt)) == hipSuccess)
+  A(b->d_model, 1);
+  A(b->B.qpos, (size_t)n * NQ); A(b->B.qvel, (size_t)n * NV); A(b->B.qws, (size_t)n * NV); A(b->B.time, n); A(b->B.ctrl, (size_t)n * NU);
+  A(b->B.xipos, (size_t)n * NB * 3); A(b->B.comz, n); A(b->B.frame_idx, n); A(b->B.frame_init, n); A(b->B.ncon, n); A(b->B.nefc, n);
+  A(b->B.cong, (size_t)n * MAXEFC * 2); A(b->B.status, n); A(b->B.solver_iter, n); A(b->B.episode, n);
+  A(b->d_cfg, (size_t)mc->n_frames * NQ); A(b->d_vel, (size_t)mc->n_frames * NV);
+  A(b->d_action, (size_t)n * NU); A(b->d_obs, (size_t)n * NOBS); A(b->d_reward, n); A(b->d_done, n); A(b->d_mask, n);
+  A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
+#undef A
+  if (!ok) { dm_batch_destroy(b); return fail(DM_ENOMEM, "dm_batch_create: hipMalloc failed"); }
+  ok = hipMemcpy(b->d_model, &hm, sizeof hm, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(b->d_cfg, mc->cfg.data(), mc->cfg.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(b->d_vel, mc->vel.data(), mc->vel.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  // initial state = MjSim(model): qpos0, zero velocity
+  std::vector<double> q0((size_t)n * NQ);
+  for (int e2 = 0; e2 < n; e2++) for (int k = 0; k < NQ; k++) q0[(size_t)e2 * NQ + k] = hm.qpos0[k];
+  ok = ok && hipMemcpy(b->B.qpos, q0.data(), q0.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { dm_batch_destroy(b); return fail(DM_EHIP, "dm_batch_create: upload failed"); }
+  b->B.mocap_cfg = b->d_cfg; b->B.mocap_vel = b->d_vel; b->B.n_frames = mc->n_frames; b->B.n_envs = n; b->B.env_offset = 0;
+  b->B.reward_mode = 0; b->B.autoreset = 0; b->B.action_mode = 0; b->B.seed = 0;
+  hipEventCreate(&b->ev0); hipEventCreate(&b->ev1);
+  *out = b;
+  return DM_OK;
+}
+
+extern "C" int dm_batch_set_stream(dm_batch* b, void* s) {
+  if (!b) return fail(DM_EINVAL, "null batch");
+  if (b->own_stream && b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
+  b->stream = (hipStream_t)s; b->own_stream = false;
+  return DM_OK;
+}
+
+extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
+  if (!b) return fail(DM_EINVAL, "null batch");
+  switch (opt) {
+    case DM_OPT_REWARD_MODE: if (v < 0 || v > 2) return fail(DM_EINVAL, "reward mode must be 0..2"); b->B.reward_mode = (int)v; break;
+    case DM_OPT_AUTORESET: if (v < 0 || v > 2) return fail(DM_EINVAL, "autoreset must be 0..2"); b->B.autoreset = (int)v; break;
+    case DM_OPT_ACTION_MODE: if (v < 0 || v > 1) return fail(DM_EINVAL, "action mode must be 0..1"); b->B.action_mode = (int)v; break;
+    case DM_OPT_SEED: b->B.seed = (unsigned long long)v; break;
+    case 100: b->B.env_offset = (int)v; break;  /* global id of env 0 (multi-GPU sharding) */
+    default: return fail(DM_EINVAL, "unknown option");
+  }
+  return DM_OK;
+}
+
+static int stage_in(dm_batch* b, void* dst, const void* src, size_t bytes, int kind, const void** use) {
+  if (!src) { *use = nullptr; return DM_OK; }
+  if (kind == DM_PTR_DEVICE) { *use = src; return DM_OK; }
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream));
+  *use = dst;
+  return DM_OK;
+}
+
+extern "C" int dm_batch_set_state(dm_batch* b, const double* qpos, const double* qvel, const int32_t* fidx, const uint8_t* mask, int32_t kind) {
+  if (!b || !qpos || !qvel) return fail(DM_EINVAL, "dm_batch_set_state: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  const void *q, *v, *f, *mk; int rc;
+  if ((rc = stage_in(b, b->d_qpos_in, qpos, (size_t)b->n * NQ * 8, kind, &q))) return rc;
+  if ((rc = stage_in(b, b->d_qvel_in, qvel, (size_t)b->n * NV * 8, kind, &v))) return rc;
+  if ((rc = stage_in(b, b->d_fidx_in, fidx, (size_t)b->n * 4, kind, &f))) return rc;
+  if ((rc = stage_in(b, b->d_mask, mask, (size_t)b->n, kind, &mk))) return rc;
+  hipLaunchKernelGGL(k_set_state, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)q, (const Real*)v, (const int*)f, (const unsigned char*)mk);
+  HIPCHK(hipGetLastError());
+  if (kind == DM_PTR_HOST) HIPCHK(hipStreamSynchronize(b->stream));
+  return DM_OK;
+}
+
+extern "C" int dm_batch_reset(dm_batch* b, int32_t mode, int32_t hard, const uint8_t* mask, int32_t kind) {
+  if (!b || mode < 0 || mode > 2) return fail(DM_EINVAL, "dm_batch_reset: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  const void* mk; int rc;
+  if ((rc = stage_in(b, b->d_mask, mask, (size_t)b->n, kind, &mk))) return rc;
+  hipLaunchKernelGGL(k_reset, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (int)mode, (int)hard, (const unsigned char*)mk);
+  HIPCHK(hipGetLastError());
+  if (kind == DM_PTR_HOST) HIPCHK(hipStreamSynchronize(b->stream));
+  return DM_OK;
+}
+
+extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t nsub, int32_t kind) {
+  if (!b || !action || !obs || !reward || !done || nsub < 1) return fail(DM_EINVAL, "dm_batch_step: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  const void* a; int rc;
+  if ((rc = stage_in(b, b->d_action, action, (size_t)b->n * NU * 8, kind, &a))) return rc;
+  Real* o = kind == DM_PTR_DEVICE ? obs : b->d_obs;
+  Real* r = kind == DM_PTR_DEVICE ? reward : b->d_reward;
+  unsigned char* dn = kind == DM_PTR_DEVICE ? done : b->d_done;
+  if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } HIPCHK(hipEventRecord(b->ev0, b->stream)); }
+  hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub);
+  HIPCHK(hipGetLastError());
+  if (b->timing) { HIPCHK(hipEventRecord(b->ev1, b->stream)); b->ev_pending = true; }
+  if (kind == DM_PTR_HOST) {
+    HIPCHK(hipMemcpyAsync(obs, b->d_obs, (size_t)b->n * NOBS * 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(reward, b->d_reward, (size_t)b->n * 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(done, b->d_done, (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+  }
+  return DM_OK;
+}
+
+extern "C" int dm_batch_get_obs(dm_batch* b, double* obs, int32_t kind) {
+  if (!b || !obs) return fail(DM_EINVAL, "dm_batch_get_obs: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  Real* o = kind == DM_PTR_DEVICE ? obs : b->d_obs;
+  const int tot = b->n * NOBS;
+  hipLaunchKernelGGL(k_get_obs, dim3((tot + 255) / 256), dim3(256), 0, b->stream, b->B, o);
+  HIPCHK(hipGetLastError());
+  if (kind == DM_PTR_HOST) { HIPCHK(hipMemcpyAsync(obs, b->d_obs, (size_t)tot * 8, hipMemcpyDeviceToHost, b->stream)); HIPCHK(hipStreamSynchronize(b->stream)); }
+  return DM_OK;
+}
+
+static int field_ptr(dm_batch* b, int field, void** p, size_t* bytes) {
+  const size_t n = b->n;
+  switch (field) {
+    case DM_F_QPOS: *p = b->B.qpos; *bytes = n * NQ * 8; break;
+    case DM_F_QVEL: *p = b->B.qvel; *bytes = n * NV * 8; break;
+    case DM_F_QACC_WARMSTART: *p = b->B.qws; *bytes = n * NV * 8; break;
+    case DM_F_TIME: *p = b->B.time; *bytes = n * 8; break;
+    case DM_F_FRAME_IDX: *p = b->B.frame_idx; *bytes = n * 4; break;
+    case DM_F_FRAME_INIT: *p = b->B.frame_init; *bytes = n * 4; break;
+    case DM_F_XIPOS: *p = b->B.xipos; *bytes = n * NB * 3 * 8; break;
+    case DM_F_COM_Z: *p = b->B.comz; *bytes = n * 8; break;
+    case DM_F_NCON: *p = b->B.ncon; *bytes = n * 4; break;
+    case DM_F_NEFC: *p = b->B.nefc; *bytes = n * 4; break;
+    case DM_F_CONTACT_GEOMS: *p = b->B.cong; *bytes = n * MAXEFC * 2 * 4; break;
+    case DM_F_STATUS: *p = b->B.status; *bytes = n * 4; break;
+    case DM_F_SOLVER_ITER: *p = b->B.solver_iter; *bytes = n * 4; break;
+    case DM_F_CTRL: *p = b->B.ctrl; *bytes = n * NU * 8; break;
+    case DM_F_EPISODE: *p = b->B.episode; *bytes = n * 4; break;
+    default: return fail(DM_EINVAL, "unknown field");
+  }
+  return DM_OK;
+}
+extern "C" int dm_batch_get(dm_batch* b, int32_t field, void* out, size_t bytes, int32_t kind) {
+  if (!b || !out) return fail(DM_EINVAL, "dm_batch_get: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  void* p; size_t need; int rc;
+  if ((rc = field_ptr(b, field, &p, &need))) return rc;
+  if (bytes != need) return fail(DM_EINVAL, "dm_batch_get: buffer size does not match the field");
+  HIPCHK(hipMemcpyAsync(out, p, need, kind == DM_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, b->stream));
+  if (kind == DM_PTR_HOST) HIPCHK(hipStreamSynchronize(b->stream));
+  return DM_OK;
+}
+extern "C" int dm_batch_set(dm_batch* b, int32_t field, const void* in, size_t bytes, int32_t kind) {
+  if (!b || !in) return fail(DM_EINVAL, "dm_batch_set: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  void* p; size_t need; int rc;
+  if ((rc = field_ptr(b, field, &p, &need))) return rc;
+  if (bytes != need) return fail(DM_EINVAL, "dm_batch_set: buffer size does not match the field");
+  if (field == DM_F_XIPOS || field == DM_F_COM_Z || field == DM_F_NCON || field == DM_F_NEFC || field == DM_F_CONTACT_GEOMS || field == DM_F_SOLVER_ITER)
+    return fail(DM_EINVAL, "dm_batch_set: derived field is read-only");
+  HIPCHK(hipMemcpyAsync(p, in, need, kind == DM_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->stream));
+  if (kind == DM_PTR_HOST) HIPCHK(hipStreamSynchronize(b->stream));
+  return DM_OK;
+}
+
+extern "C" int dm_batch_debug_forward(dm_batch* b, int32_t env, double* out_host) {
+  if (!b || !out_host || env < 0 || env >= b->n) return fail(DM_EINVAL, "dm_batch_debug_forward: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipMemsetAsync(b->d_debug, 0, DM_DEBUG_DOUBLES * 8, b->stream));
+  hipLaunchKernelGGL(k_debug_forward, dim3(1), dim3(64), 0, b->stream, b->d_model, b->B, (int)env, b->d_debug);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_host, b->d_debug, DM_DEBUG_DOUBLES * 8, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return DM_OK;
+}
+
+extern "C" int dm_batch_enable_timing(dm_batch* b, int32_t on) { if (!b) return fail(DM_EINVAL, "null batch"); b->timing = on != 0; b->ev_pending = false; return DM_OK; }
+extern "C" int dm_batch_last_step_ms(dm_batch* b, float* ms) {
+  if (!b || !ms) return fail(DM_EINVAL, "null argument");
+  if (!b->ev_pending) return fail(DM_EINVAL, "no timed step recorded");
+  HIPCHK(hipEventSynchronize(b->ev1));
+  HIPCHK(hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));
+  *ms = b->last_ms;
+  return DM_OK;
+}
+extern "C" int dm_batch_sync(dm_batch* b) { if (!b) return fail(DM_EINVAL, "null batch"); HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return DM_OK; }

@@ -1,0 +1,834 @@
+// env_kernel.h — the batched DeepMimic humanoid step as wave64 device code (gfx950 / CDNA4).
+//
+// One wavefront simulates one environment.  All per-environment working data of a forward-dynamics
+// evaluation lives in LDS (`Shared`, ~22 KB) or in registers; HBM is touched only to load the state row
+// (qpos/qvel/qacc_warmstart/action) at the start of a step and to store it plus obs/reward/done at the end.
+//
+// What one step computes is MuJoCo 2.0's mj_step for dp_env_v3.xml (RK4, PGS, pyramidal cones), i.e. what
+// `self.do_simulation(action, 1)` does at src/dp_env_v3.py:112, followed by the env epilogue of
+// src/dp_env_v3.py:115-132 (obs, reward, done).  The algorithms are chosen for the wave, not translated:
+//   * kinematics / RNE run level-by-level over the 4-deep body tree, one lane per body;
+//   * the mass matrix is built as 310 independent tree-sparse entries (lanes over entries) and factorised
+//     L^T D L in MuJoCo's sparse layout, one elimination column per step with lanes over the rank-1 update;
+//   * every constraint row owns a lane: the lane regenerates its Jacobian row from a 6-D contact wrench,
+//     half-solves it against the factor in registers (static indices, factor broadcast from LDS) and keeps
+//     its row of A = J M^-1 J^T + R in 64 registers — the Gauss-Seidel sweep then needs one v_readlane
+//     broadcast and one FMA per row and no memory at all;
+//   * collision runs lanes over the 104 candidate geom pairs with deterministic prefix-sum compaction, so
+//     the contact list (and hence the PGS row order) is bit-identical to a serial walk of the pair list.
+// fp64 throughout (the reference computes in float64; parity bar 1e-5 relative, test bar 1e-9).
+// f64 MFMA is deliberately not used: on gfx950 v_mfma_f64 runs at the f64 VALU rate (78.6 TF both), and the
+// only GEMM-shaped piece (64x34x64 for A) would need a fragment->row-per-lane re-layout on top.
+#pragma once
+
+#include "topology.h"
+#include "wave.h"
+
+namespace dm {
+
+using namespace dmt;
+
+DM_CONSTANT Topo TOPO = make_topo();
+
+#define DM_MINVAL 1e-15
+
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_BOX = 6 };
+enum { REW_ALIVE = 0, REW_V3_CONFIG = 1, REW_V2_POSE = 2 };
+enum { ROW_NONE = 0, ROW_LIMIT = 1, ROW_CONTACT = 2 };
+
+// ---------------------------------------------------------------------------------------------------------
+// device-resident constant model (one copy in HBM, L2-resident; uniform reads become scalar loads)
+template <class R>
+struct DevModel {
+  R body_pos[NB][3], body_ipos[NB][3], body_mass[NB], body_inertia[NB][6], body_invw[NB];
+  R jnt_axis[NJ][3], jnt_lo[NJ], jnt_hi[NJ];
+  int jnt_limited[NJ];
+  R dof_armature[NV], dof_damping[NV], dof_invw[NV];
+  R gear[NV], ctrl_lo[NV], ctrl_hi[NV];  // per dof (0 for the free joint)
+  int geom_type[NG], geom_body[NG], geom_condim[NG];
+  R geom_pos[NG][3], geom_mat[NG][9], geom_size[NG][3], geom_margin[NG], geom_mu[NG], geom_rbound[NG];
+  int npair;
+  short pair_g1[MAXPAIR], pair_g2[MAXPAIR];
+  R qpos0[NQ];
+  R timestep, gravity[3], tolerance, solref[2], solimp[5], meaninertia, total_mass;
+  R K, B, pgs_scale;  // constraint stiffness / damping (refsafe applied), 1/(meaninertia*nv)
+  int iterations, enable_contact, enable_limit;
+};
+
+// per-wave LDS working set
+template <class R>
+struct Shared {
+  R qpos[36], qvel[NV], act[NV], qws[NV];
+  R xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3];
+  R cdof[NV][6];
+  R sin[NB][10], crb[NB][10];
+  R qLD[312], dinv[NV], dsq[NV];
+  R tau[NV], qaccs[NV], qacc[NV];
+  R gpos[NG][3], gmat[NG][9];
+  union {
+    R fdof[NV][6];
+    struct { R cvel[NB][6], cacc[NB][6], cfrc[NB][6], csub[NB][6]; } v;
+    R ybuf[16][NV];
+    R tbuf[8][65];
+  } u;
+  R rowd[MAXEFC][10];  // w[6], dist, margin, dA, rscale
+  int rowi[MAXEFC];    // type | b1<<8 | b2<<16   (limit: type | dof<<8)
+  int cong[MAXEFC][2]; // contact geom ids
+  int nefc, ncon, status, solver_iter;
+};
+
+// optional dump of one forward evaluation (parity tests)
+struct DebugOut {
+  double* out;  // DM_DEBUG_DOUBLES
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// small math
+template <class R> DM_DEV R dot3(const R* a, const R* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class R> DM_DEV void cross3(R* r, const R* a, const R* b) {
+  R x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <class R> DM_DEV R dot6(const R* a, const R* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+template <class R> DM_DEV R rsqrt_nr(R x) { return R(1) / sqrt(x); }
+template <class R> DM_DEV R normalize3(R* v) {
+  R n = sqrt(dot3(v, v));
+  if (n < R(DM_MINVAL)) { v[0] = 1; v[1] = 0; v[2] = 0; }
+  else { R s = R(1) / n; v[0] *= s; v[1] *= s; v[2] *= s; }
+  return n;
+}
+template <class R> DM_DEV void normalize4(R* q) {
+  R n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < R(DM_MINVAL)) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+  else if (fabs(n - R(1)) > R(DM_MINVAL)) { R s = R(1) / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
+}
+template <class R> DM_DEV void quat_mul(R* r, const R* a, const R* b) {
+  R w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  R x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  R y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  R z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+template <class R> DM_DEV void quat2mat(R* m, const R* q) {
+  R q00 = q[0] * q[0], q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+  R q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3], q12 = q[1] * q[2], q13 = q[1] * q[3], q23 = q[2] * q[3];
+  m[0] = q00 + q11 - q22 - q33; m[1] = 2 * (q12 - q03);       m[2] = 2 * (q13 + q02);
+  m[3] = 2 * (q12 + q03);       m[4] = q00 - q11 + q22 - q33; m[5] = 2 * (q23 - q01);
+  m[6] = 2 * (q13 - q02);       m[7] = 2 * (q23 + q01);       m[8] = q00 - q11 - q22 + q33;
+}
+template <class R> DM_DEV void mat_vec(R* r, const R* m, const R* v) {
+  R x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <class R> DM_DEV void matT_vec(R* r, const R* m, const R* v) {
+  R x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2], z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <class R> DM_DEV void axisangle2quat(R* q, const R* axis, R angle) {
+  R s = sin(angle * R(0.5)), c = cos(angle * R(0.5));
+  q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+DM_DEV int imin(int a, int b) { return a < b ? a : b; }
+template <class R> DM_DEV R clampr(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// spatial algebra about the world origin, vectors [ang; lin]
+template <class R> DM_DEV void cross_motion(R* r, const R* v, const R* s) {
+  R a[3], b[3], c[3];
+  cross3(a, v, s); cross3(b, v, s + 3); cross3(c, v + 3, s);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+template <class R> DM_DEV void cross_force(R* r, const R* v, const R* f) {
+  R a[3], b[3], c[3];
+  cross3(a, v, f); cross3(b, v + 3, f + 3); cross3(c, v, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+// spatial inertia S = {Ixx,Iyy,Izz,Ixy,Ixz,Iyz (about origin), m*c[3], m};  f = S v
+template <class R> DM_DEV void sinert_mul(R* f, const R* S, const R* v) {
+  R t0 = S[0] * v[0] + S[3] * v[1] + S[4] * v[2];
+  R t1 = S[3] * v[0] + S[1] * v[1] + S[5] * v[2];
+  R t2 = S[4] * v[0] + S[5] * v[1] + S[2] * v[2];
+  R u[3];
+  cross3(u, S + 6, v + 3);
+  f[0] = t0 + u[0]; f[1] = t1 + u[1]; f[2] = t2 + u[2];
+  cross3(u, v, S + 6);
+  f[3] = S[9] * v[3] + u[0]; f[4] = S[9] * v[4] + u[1]; f[5] = S[9] * v[5] + u[2];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tree-sparse L^T D L solves with a vector held in registers (static indices once unrolled).
+// Factor entries are read from LDS at wave-uniform addresses (broadcast).
+template <class R> DM_DEV void solve_LT(R* x, const R* qLD) {  // x <- L^-T x
+  int z = 0;
+#pragma unroll
+  for (int i = NV - 1; i >= 0; i--) {
+    if ((i & 3) == 1) z = dmw::pin_zero();
+#pragma unroll
+    for (int a = 1; a < 16; a++) {
+      const int j = TOPO.dof_anc[i][a];
+      if (j >= 0) x[j] -= qLD[TOPO.madr[i] + a + z] * x[i];
+    }
+    if ((i & 3) == 2 && i > 0) dmw::pin_value(x[TOPO.dof_anc[i][1] >= 0 ? TOPO.dof_anc[i][1] : 0]);
+  }
+}
+template <class R> DM_DEV void solve_L(R* x, const R* qLD) {  // x <- L^-1 x
+  int z = 0;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    if ((i & 3) == 0) z = dmw::pin_zero();
+#pragma unroll
+    for (int a = 1; a < 16; a++) {
+      const int j = TOPO.dof_anc[i][a];
+      if (j >= 0) x[i] -= qLD[TOPO.madr[i] + a + z] * x[j];
+    }
+    if ((i & 3) == 3) dmw::pin_value(x[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// position stage: kinematics, geom poses, motion axes, spatial inertias   [MJ mj_kinematics, mj_comPos]
+template <class R>
+DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane) {
+  const int b = lane + 1;
+  const bool isbody = lane < NB - 1;
+  const int depth = isbody ? TOPO.body_depth[b] : 0;
+  if (lane == 0) {
+    s.xpos[0][0] = s.xpos[0][1] = s.xpos[0][2] = 0; s.xipos[0][0] = s.xipos[0][1] = s.xipos[0][2] = 0;
+    s.xquat[0][0] = 1; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0;
+    for (int k = 0; k < 9; k++) s.xmat[0][k] = (k % 4 == 0) ? R(1) : R(0);
+  }
+  for (int L = 1; L <= MAXDEPTH_BODY; L++) {
+    if (isbody && depth == L) {
+      R xp[3], q[4], mat[9];
+      const int da = TOPO.body_dofadr[b], nd = TOPO.body_dofnum[b];
+      if (b == 1) {
+        xp[0] = s.qpos[0]; xp[1] = s.qpos[1]; xp[2] = s.qpos[2];
+        q[0] = s.qpos[3]; q[1] = s.qpos[4]; q[2] = s.qpos[5]; q[3] = s.qpos[6];
+        normalize4(q);
+      } else {
+        const int p = TOPO.body_parent[b];
+        R v[3];
+        mat_vec(v, s.xmat[p], M.body_pos[b]);
+        xp[0] = s.xpos[p][0] + v[0]; xp[1] = s.xpos[p][1] + v[1]; xp[2] = s.xpos[p][2] + v[2];
+        q[0] = s.xquat[p][0]; q[1] = s.xquat[p][1]; q[2] = s.xquat[p][2]; q[3] = s.xquat[p][3];
+        for (int k = 0; k < nd; k++) {
+          const int d = da + k, j = d - 5;
+          R axl[3] = {M.jnt_axis[j][0], M.jnt_axis[j][1], M.jnt_axis[j][2]}, axw[3], ql[4], qm[9];
+          quat2mat(qm, q);
+          mat_vec(axw, qm, axl);
+          s.cdof[d][0] = axw[0]; s.cdof[d][1] = axw[1]; s.cdof[d][2] = axw[2];
+          cross3(&s.cdof[d][3], xp, axw);
+          axisangle2quat(ql, axl, s.qpos[d + 1] - M.qpos0[d + 1]);
+          quat_mul(q, q, ql);
+        }
+      }
+      normalize4(q);
+      quat2mat(mat, q);
+      for (int k = 0; k < 3; k++) s.xpos[b][k] = xp[k];
+      for (int k = 0; k < 4; k++) s.xquat[b][k] = q[k];
+      for (int k = 0; k < 9; k++) s.xmat[b][k] = mat[k];
+      R ip[3] = {M.body_ipos[b][0], M.body_ipos[b][1], M.body_ipos[b][2]}, v[3];
+      mat_vec(v, mat, ip);
+      s.xipos[b][0] = xp[0] + v[0]; s.xipos[b][1] = xp[1] + v[1]; s.xipos[b][2] = xp[2] + v[2];
+      if (b == 1) {
+        for (int k = 0; k < 3; k++) {
+          for (int r = 0; r < 6; r++) s.cdof[k][r] = (r == 3 + k) ? R(1) : R(0);
+          R ax[3] = {mat[k], mat[3 + k], mat[6 + k]};
+          s.cdof[3 + k][0] = ax[0]; s.cdof[3 + k][1] = ax[1]; s.cdof[3 + k][2] = ax[2];
+          cross3(&s.cdof[3 + k][3], xp, ax);
+        }
+      }
+      // own spatial inertia about the origin: Iw = R Ib R^T, then parallel-axis shift to the origin
+      {
+        const R* Ib = M.body_inertia[b];
+        R A[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]}, T[9], Iw[9];
+        for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) T[3 * i + jx] = mat[3 * i] * A[jx] + mat[3 * i + 1] * A[3 + jx] + mat[3 * i + 2] * A[6 + jx];
+        for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) Iw[3 * i + jx] = T[3 * i] * mat[3 * jx] + T[3 * i + 1] * mat[3 * jx + 1] + T[3 * i + 2] * mat[3 * jx + 2];
+        const R m = M.body_mass[b];
+        const R c[3] = {s.xipos[b][0], s.xipos[b][1], s.xipos[b][2]};
+        const R cc = dot3(c, c);
+        s.sin[b][0] = Iw[0] + m * (cc - c[0] * c[0]); s.sin[b][1] = Iw[4] + m * (cc - c[1] * c[1]); s.sin[b][2] = Iw[8] + m * (cc - c[2] * c[2]);
+        s.sin[b][3] = Iw[1] - m * c[0] * c[1]; s.sin[b][4] = Iw[2] - m * c[0] * c[2]; s.sin[b][5] = Iw[5] - m * c[1] * c[2];
+        s.sin[b][6] = m * c[0]; s.sin[b][7] = m * c[1]; s.sin[b][8] = m * c[2]; s.sin[b][9] = m;
+      }
+    }
+    dmw::sync();
+  }
+  // geom world poses
+  if (lane < NG) {
+    const int g = lane, gb = M.geom_body[g];
+    R v[3];
+    mat_vec(v, s.xmat[gb], M.geom_pos[g]);
+    s.gpos[g][0] = s.xpos[gb][0] + v[0]; s.gpos[g][1] = s.xpos[gb][1] + v[1]; s.gpos[g][2] = s.xpos[gb][2] + v[2];
+    const R* a = s.xmat[gb]; const R* bm = M.geom_mat[g];
+    for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) s.gmat[g][3 * i + jx] = a[3 * i] * bm[jx] + a[3 * i + 1] * bm[3 + jx] + a[3 * i + 2] * bm[6 + jx];
+  }
+  // composite inertias: sum over the (static) subtree   [MJ mj_crb backward pass]
+  if (isbody) {
+    R acc[10];
+    for (int k = 0; k < 10; k++) acc[k] = 0;
+    const unsigned msk = TOPO.subtree[b];
+    for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int k = 0; k < 10; k++) acc[k] += s.sin[c][k];
+    for (int k = 0; k < 10; k++) s.crb[b][k] = acc[k];
+  }
+  dmw::sync();
+}
+
+// mass matrix (tree-sparse, MuJoCo qM order) and its L^T D L factor   [MJ mj_crb, mj_factorM]
+template <class R>
+DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg) {
+  if (lane < NV) {
+    R f[6];
+    sinert_mul(f, s.crb[TOPO.dof_body[lane]], s.cdof[lane]);
+    for (int r = 0; r < 6; r++) s.u.fdof[lane][r] = f[r];
+  }
+  dmw::sync();
+  for (int e = lane; e < TOPO.nM; e += 64) {
+    const int i = TOPO.ent_i[e], j = TOPO.ent_j[e];
+    R v = dot6(s.cdof[j], s.u.fdof[i]);
+    if (i == j) v += M.dof_armature[i];
+    s.qLD[e] = v;
+    if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
+  }
+  dmw::sync();
+  // elimination, one dof k per step (last to first); lanes over the rank-1 update pairs (a, c):
+  //   row i = anc_a(k):  M(i, anc_c(i)) -= M(k, anc_{a+c}(k)) * M(k, i) / M(k, k)
+  for (int k = NV - 1; k >= 0; k--) {
+    const int nk = TOPO.dof_depth[k] - 1;  // proper ancestors (wave-uniform)
+    const int base = TOPO.madr[k];
+    const R mkk = s.qLD[base];
+    const R inv = R(1) / mkk;
+    if (nk > 0) {
+      const int npairs = nk * (nk + 1) / 2;
+      for (int t = lane; t < npairs; t += 64) {
+        // t -> (a, c), a = 1..nk, c = 0..nk-a : rows of lengths nk, nk-1, ..., 1
+        int a = 1, rem = t;
+        while (rem >= nk - a + 1) { rem -= nk - a + 1; a++; }
+        const int c = rem;
+        const int i = TOPO.dof_anc[k][a];
+        s.qLD[TOPO.madr[i] + c] -= s.qLD[base + a + c] * (s.qLD[base + a] * inv);
+      }
+      dmw::sync();
+      if (lane >= 1 && lane <= nk) s.qLD[base + lane] *= inv;
+    }
+    if (lane == 0) { s.dinv[k] = inv; s.dsq[k] = sqrt(inv); }
+    dmw::sync();
+  }
+}
+
+// velocity stage: bias forces C(q, v) incl. gravity; smooth generalized force   [MJ mj_comVel, mj_rne, mj_passive]
+template <class R>
+DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane) {
+  const int b = lane + 1;
+  const bool isbody = lane < NB - 1;
+  const int depth = isbody ? TOPO.body_depth[b] : 0;
+  if (lane == 0) {
+    for (int r = 0; r < 6; r++) { s.u.v.cvel[0][r] = 0; s.u.v.cacc[0][r] = 0; }
+    s.u.v.cacc[0][3] = -M.gravity[0]; s.u.v.cacc[0][4] = -M.gravity[1]; s.u.v.cacc[0][5] = -M.gravity[2];
+  }
+  dmw::sync();
+  for (int L = 1; L <= MAXDEPTH_BODY; L++) {
+    if (isbody && depth == L) {
+      const int p = TOPO.body_parent[b], da = TOPO.body_dofadr[b], nd = TOPO.body_dofnum[b];
+      R v[6], a[6];
+      for (int r = 0; r < 6; r++) { v[r] = s.u.v.cvel[p][r]; a[r] = s.u.v.cacc[p][r]; }
+      if (b == 1) {
+        for (int k = 0; k < 3; k++) { const R qd = s.qvel[k]; for (int r = 0; r < 6; r++) v[r] += s.cdof[k][r] * qd; }
+        R vb[6];
+        for (int r = 0; r < 6; r++) vb[r] = v[r];
+        for (int k = 3; k < 6; k++) {
+          R cd[6]; cross_motion(cd, vb, s.cdof[k]);
+          const R qd = s.qvel[k];
+          for (int r = 0; r < 6; r++) { a[r] += cd[r] * qd; v[r] += s.cdof[k][r] * qd; }
+        }
+      } else {
+        for (int k = 0; k < nd; k++) {
+          R cd[6]; cross_motion(cd, v, s.cdof[da + k]);
+          const R qd = s.qvel[da + k];
+          for (int r = 0; r < 6; r++) { a[r] += cd[r] * qd; v[r] += s.cdof[da + k][r] * qd; }
+        }
+      }
+      for (int r = 0; r < 6; r++) { s.u.v.cvel[b][r] = v[r]; s.u.v.cacc[b][r] = a[r]; }
+      R Ia[6], Iv[6], x[6];
+      sinert_mul(Ia, s.sin[b], a); sinert_mul(Iv, s.sin[b], v); cross_force(x, v, Iv);
+      for (int r = 0; r < 6; r++) s.u.v.cfrc[b][r] = Ia[r] + x[r];
+    }
+    dmw::sync();
+  }
+  if (isbody) {
+    R acc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned msk = TOPO.subtree[b];
+    for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int r = 0; r < 6; r++) acc[r] += s.u.v.cfrc[c][r];
+    for (int r = 0; r < 6; r++) s.u.v.csub[b][r] = acc[r];
+  }
+  dmw::sync();
+  if (lane < NV) {
+    const R bias = dot6(s.cdof[lane], s.u.v.csub[TOPO.dof_body[lane]]);
+    s.tau[lane] = -M.dof_damping[lane] * s.qvel[lane] - bias + s.act[lane];
+  }
+  dmw::sync();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// collision: narrow phase for one candidate pair.  Contacts of a pair share the frame (normal n, tangent hint h).
+template <class R>
+struct PairContacts {
+  int n;
+  R nrm[3], hint[3];
+  R dist[4], pos[4][3];
+};
+
+template <class R>
+DM_DEV void plane_sphere(PairContacts<R>& pc, const R* p0, const R* n, const R* c, R r, R margin) {
+  R t[3] = {c[0] - p0[0], c[1] - p0[1], c[2] - p0[2]};
+  const R cd = dot3(t, n);
+  if (cd > margin + r) return;
+  const int k = pc.n++;
+  pc.dist[k] = cd - r;
+  const R sc = -pc.dist[k] / 2 - r;
+  pc.pos[k][0] = c[0] + n[0] * sc; pc.pos[k][1] = c[1] + n[1] * sc; pc.pos[k][2] = c[2] + n[2] * sc;
+}
+template <class R>
+DM_DEV void sphere_sphere(PairContacts<R>& pc, const R* c1, R r1, const R* c2, R r2, R margin) {
+  R dif[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+  const R bound = margin + r1 + r2;
+  if (dot3(dif, dif) > bound * bound) return;
+  const R nn = normalize3(dif);
+  pc.n = 1;
+  pc.nrm[0] = dif[0]; pc.nrm[1] = dif[1]; pc.nrm[2] = dif[2];
+  pc.dist[0] = nn - r1 - r2;
+  const R sc = r1 + R(0.5) * pc.dist[0];
+  pc.pos[0][0] = c1[0] + dif[0] * sc; pc.pos[0][1] = c1[1] + dif[1] * sc; pc.pos[0][2] = c1[2] + dif[2] * sc;
+}
+
+template <class R>
+DM_DEV void narrowphase(const DevModel<R>& M, const Shared<R>& s, int g1, int g2, R margin, PairContacts<R>& pc) {
+  pc.n = 0;
+  pc.hint[0] = pc.hint[1] = pc.hint[2] = 0;
+  pc.nrm[0] = pc.nrm[1] = 0; pc.nrm[2] = 1;
+  const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
+  const R* p1 = s.gpos[g1]; const R* p2 = s.gpos[g2];
+  const R* m1 = s.gmat[g1]; const R* m2 = s.gmat[g2];
+  const R* s1 = M.geom_size[g1]; const R* s2 = M.geom_size[g2];
+  if (t1 == GEOM_PLANE) {
+    const R n[3] = {m1[2], m1[5], m1[8]};
+    pc.nrm[0] = n[0]; pc.nrm[1] = n[1]; pc.nrm[2] = n[2];
+    if (t2 == GEOM_SPHERE) {
+      plane_sphere(pc, p1, n, p2, s2[0], margin);
+    } else if (t2 == GEOM_CAPSULE) {   // [MJ mjc_PlaneCapsule] +axis end first, tangent hint = axis
+      const R ax[3] = {m2[2], m2[5], m2[8]};
+      R c[3] = {p2[0] + ax[0] * s2[1], p2[1] + ax[1] * s2[1], p2[2] + ax[2] * s2[1]};
+      plane_sphere(pc, p1, n, c, s2[0], margin);
+      c[0] = p2[0] - ax[0] * s2[1]; c[1] = p2[1] - ax[1] * s2[1]; c[2] = p2[2] - ax[2] * s2[1];
+      plane_sphere(pc, p1, n, c, s2[0], margin);
+      pc.hint[0] = ax[0]; pc.hint[1] = ax[1]; pc.hint[2] = ax[2];
+    } else if (t2 == GEOM_BOX) {       // [MJ mjc_PlaneBox] corners below the margin, at most 4
+      const R dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+      const R dist = dot3(dif, n);
+      for (int i = 0; i < 8 && pc.n < 4; i++) {
+        const R vec[3] = {(i & 1) ? s2[0] : -s2[0], (i & 2) ? s2[1] : -s2[1], (i & 4) ? s2[2] : -s2[2]};
+        R corner[3];
+        mat_vec(corner, m2, vec);
+        const R ld = dot3(n, corner);
+        if (dist + ld > margin || ld > 0) continue;
+        const int k = pc.n++;
+        pc.dist[k] = dist + ld;
+        const R sc = -pc.dist[k] / 2;
+        pc.pos[k][0] = corner[0] + p2[0] + n[0] * sc; pc.pos[k][1] = corner[1] + p2[1] + n[1] * sc; pc.pos[k][2] = corner[2] + p2[2] + n[2] * sc;
+      }
+    }
+    return;
+  }
+  if (t2 <= GEOM_CAPSULE) {  // sphere/capsule family: closest points of two (possibly degenerate) segments
+    R c1[3] = {p1[0], p1[1], p1[2]}, c2[3] = {p2[0], p2[1], p2[2]};
+    if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) {        // [MJ mjc_SphereCapsule]
+      const R ax[3] = {m2[2], m2[5], m2[8]};
+      const R v[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+      const R x = clampr(dot3(ax, v), -s2[1], s2[1]);
+      c2[0] += ax[0] * x; c2[1] += ax[1] * x; c2[2] += ax[2] * x;
+    } else if (t1 == GEOM_CAPSULE) {                       // [MJ mjc_CapsuleCapsule], non-parallel branch
+      const R a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
+      const R dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+      const R ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
+      const R det = ma * mc - mb * mb;
+      R x1, x2;
+      if (fabs(det) >= R(DM_MINVAL)) {
+        x1 = (mc * u - mb * v) / det; x2 = (ma * v - mb * u) / det;
+        if (x1 > s1[1]) { x1 = s1[1]; x2 = (v - mb * s1[1]) / mc; } else if (x1 < -s1[1]) { x1 = -s1[1]; x2 = (v + mb * s1[1]) / mc; }
+        if (x2 > s2[1]) { x2 = s2[1]; x1 = (u - mb * s2[1]) / ma; } else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = (u + mb * s2[1]) / ma; }
+        if (x1 > s1[1]) x1 = s1[1]; else if (x1 < -s1[1]) x1 = -s1[1];
+      } else {  // parallel axes (measure zero): first end of capsule 1 against segment 2
+        x1 = s1[1];
+        const R t[3] = {p1[0] + a1[0] * x1 - p2[0], p1[1] + a1[1] * x1 - p2[1], p1[2] + a1[2] * x1 - p2[2]};
+        x2 = clampr(dot3(t, a2), -s2[1], s2[1]);
+      }
+      c1[0] += a1[0] * x1; c1[1] += a1[1] * x1; c1[2] += a1[2] * x1;
+      c2[0] += a2[0] * x2; c2[1] += a2[1] * x2; c2[2] += a2[2] * x2;
+    }
+    sphere_sphere(pc, c1, s1[0], c2, s2[0], margin);
+    return;
+  }
+  if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) {  // [MJ mjc_SphereBox]
+    R t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, center[3], clamped[3], nrm[3], pl[3];
+    matT_vec(center, m2, t);
+    for (int i = 0; i < 3; i++) clamped[i] = clampr(center[i], -s2[i], s2[i]);
+    t[0] = center[0] - clamped[0]; t[1] = center[1] - clamped[1]; t[2] = center[2] - clamped[2];
+    const R dist = sqrt(dot3(t, t));
+    if (dist - s1[0] > margin) return;
+    if (dist <= R(DM_MINVAL)) {
+      R closest = 2 * fmax(s2[0], fmax(s2[1], s2[2]));
+      int k = 0;
+      for (int i = 0; i < 6; i++) { const R fd = fabs(((i % 2) ? R(1) : R(-1)) * s2[i / 2] - center[i / 2]); if (closest > fd) { closest = fd; k = i; } }
+      nrm[0] = nrm[1] = nrm[2] = 0; nrm[k / 2] = (k % 2) ? R(-1) : R(1);
+      const R sc = (s1[0] - closest) / 2;
+      pl[0] = center[0] + nrm[0] * sc; pl[1] = center[1] + nrm[1] * sc; pl[2] = center[2] + nrm[2] * sc;
+      pc.dist[0] = -closest - s1[0];
+    } else {
+      for (int i = 0; i < 3; i++) nrm[i] = -t[i] / dist;
+      const R sc = s1[0] + R(0.5) * (dist - s1[0]);
+      pl[0] = center[0] + nrm[0] * sc; pl[1] = center[1] + nrm[1] * sc; pl[2] = center[2] + nrm[2] * sc;
+      pc.dist[0] = dist - s1[0];
+    }
+    pc.n = 1;
+    mat_vec(pc.nrm, m2, nrm);
+    mat_vec(pc.pos[0], m2, pl);
+    pc.pos[0][0] += p2[0]; pc.pos[0][1] += p2[1]; pc.pos[0][2] += p2[2];
+    return;
+  }
+  // capsule-box, box-box: not handled this round (the oracle returns no contact for them as well)
+}
+
+// [MJ mju_makeFrame] rows of f: normal, tangent 1, tangent 2
+template <class R>
+DM_DEV void make_frame(R* f, const R* nrm, const R* hint) {
+  f[0] = nrm[0]; f[1] = nrm[1]; f[2] = nrm[2];
+  f[3] = hint[0]; f[4] = hint[1]; f[5] = hint[2];
+  normalize3(f);
+  if (sqrt(dot3(f + 3, f + 3)) < R(0.5)) {
+    f[3] = f[4] = f[5] = 0;
+    if (f[1] < R(0.5) && f[1] > R(-0.5)) f[4] = 1; else f[5] = 1;
+  }
+  const R dp = dot3(f, f + 3);
+  f[3] -= f[0] * dp; f[4] -= f[1] * dp; f[5] -= f[2] * dp;
+  normalize3(f + 3);
+  cross3(f + 6, f, f + 3);
+}
+
+// constraint rows: joint limits first (joint order), then contacts (pair-list order)  [MJ mj_collision, mj_makeConstraint]
+template <class R>
+DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane) {
+  int nrow = 0;
+  // ---- joint limits: hinge j = lane + 1, dof = lane + 6
+  {
+    bool viol = false;
+    R dist = 0, sgn = 0;
+    if (M.enable_limit && lane < NU && M.jnt_limited[lane + 1]) {
+      const R q = s.qpos[lane + 7];
+      const R dlo = q - M.jnt_lo[lane + 1], dhi = M.jnt_hi[lane + 1] - q;
+      if (dlo < 0) { viol = true; dist = dlo; sgn = 1; }
+      else if (dhi < 0) { viol = true; dist = dhi; sgn = -1; }
+    }
+    const unsigned long long mask = dmw::ballot(viol);
+    if (viol) {
+      const int r = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+      s.rowd[r][0] = sgn; s.rowd[r][6] = dist; s.rowd[r][7] = 0;
+      s.rowd[r][8] = M.dof_invw[lane + 6]; s.rowd[r][9] = 1;
+      s.rowi[r] = ROW_LIMIT | ((lane + 6) << 8);
+    }
+    nrow = __builtin_popcountll(mask);
+  }
+  // ---- contacts: lanes over candidate pairs, two passes of 64
+  int ncon = 0, firstdrop = 1 << 20;
+  if (M.enable_contact) {
+    for (int pass = 0; pass * 64 < M.npair; pass++) {
+      const int pidx = pass * 64 + lane;
+      PairContacts<R> pc;
+      pc.n = 0;
+      int g1 = 0, g2 = 0, dim = 1;
+      R margin = 0, mu = 0;
+      if (pidx < M.npair) {
+        g1 = M.pair_g1[pidx]; g2 = M.pair_g2[pidx];
+        margin = fmax(M.geom_margin[g1], M.geom_margin[g2]);
+        // bounding-sphere rejection (conservative; [MJ mj_collideGeoms] does the same before the narrow phase)
+        bool maybe = true;
+        if (M.geom_type[g1] == GEOM_PLANE) {
+          const R* m1 = s.gmat[g1];
+          const R dz = (s.gpos[g2][0] - s.gpos[g1][0]) * m1[2] + (s.gpos[g2][1] - s.gpos[g1][1]) * m1[5] + (s.gpos[g2][2] - s.gpos[g1][2]) * m1[8];
+          maybe = dz <= M.geom_rbound[g2] + margin;
+        } else {
+          const R d[3] = {s.gpos[g2][0] - s.gpos[g1][0], s.gpos[g2][1] - s.gpos[g1][1], s.gpos[g2][2] - s.gpos[g1][2]};
+          const R bound = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
+          maybe = dot3(d, d) <= bound * bound;
+        }
+        if (maybe) narrowphase(M, s, g1, g2, margin, pc);
+        dim = M.geom_condim[g1] > M.geom_condim[g2] ? M.geom_condim[g1] : M.geom_condim[g2];
+        mu = fmax(M.geom_mu[g1], M.geom_mu[g2]);
+      }
+      const int rows_per = dim == 1 ? 1 : 2 * (dim - 1);
+      int tot_rows, tot_con;
+      const int r0 = nrow + dmw::wave_exclusive_scan(pc.n * rows_per, lane, &tot_rows);
+      const int c0 = ncon + dmw::wave_exclusive_scan(pc.n, lane, &tot_con);
+      if (pc.n > 0) {
+        R fr[9];
+        make_frame(fr, pc.nrm, pc.hint);
+        const int b1 = M.geom_body[g1], b2 = M.geom_body[g2];
+        const R tran = M.body_invw[b1] + M.body_invw[b2];
+        for (int k = 0; k < pc.n; k++) {
+          const int rk = r0 + k * rows_per;
+          if (c0 + k < MAXEFC) { s.cong[c0 + k][0] = g1; s.cong[c0 + k][1] = g2; }
+          // rows past the on-chip capacity are dropped contact-wise, in list order (status bit 0)
+          if (rk + rows_per > MAXROWS) { if (rk < firstdrop) firstdrop = rk; continue; }
+          for (int q = 0; q < rows_per; q++) {
+            R dir[3];
+            if (dim == 1) { dir[0] = fr[0]; dir[1] = fr[1]; dir[2] = fr[2]; }
+            else {
+              const int t = 1 + q / 2;
+              const R sg = (q & 1) ? -mu : mu;
+              dir[0] = fr[0] + sg * fr[3 * t]; dir[1] = fr[1] + sg * fr[3 * t + 1]; dir[2] = fr[2] + sg * fr[3 * t + 2];
+            }
+            R* rd = s.rowd[rk + q];
+            cross3(rd, pc.pos[k], dir);
+            rd[3] = dir[0]; rd[4] = dir[1]; rd[5] = dir[2];
+            rd[6] = pc.dist[k]; rd[7] = margin;
+            rd[8] = dim == 1 ? tran : tran + mu * mu * tran;
+            rd[9] = dim == 1 ? R(1) : 2 * mu * mu;
+            s.rowi[rk + q] = ROW_CONTACT | (b1 << 8) | (b2 << 16);
+          }
+        }
+      }
+      nrow += tot_rows; ncon += tot_con;
+    }
+  }
+  // first dropped row index over the wave (min), if any
+  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 32)); firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 16));
+  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 8));  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 4));
+  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 2));  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 1));
+  int status = 0;
+  if (firstdrop < nrow) { status = 1; nrow = firstdrop; }
+  if (lane == 0) { s.nefc = nrow; s.ncon = ncon; s.status |= status; }
+  dmw::sync();
+}
+
+// [MJ getimpedance]
+template <class R>
+DM_DEV R impedance(const R* si, R x) {
+  if (si[0] == si[1] || si[2] <= R(DM_MINVAL)) return R(0.5) * (si[0] + si[1]);
+  x = fabs(x / si[2]);
+  if (x >= 1) return si[1];
+  if (x <= 0) return si[0];
+  R y;
+  if (si[4] == R(1)) y = x;
+  else if (x <= si[3]) y = pow(x, si[4]) / pow(si[3], si[4] - 1);
+  else y = 1 - pow(1 - x, si[4]) / pow(1 - si[3], si[4] - 1);
+  return si[0] + y * (si[1] - si[0]);
+}
+
+// sum_l fsel_l * Y_l over the lanes (transpose-reduce through LDS, 8 dofs at a time), then the back half of the
+// solve: out = L^-1 D^-1/2 (.)  — every lane ends up with the full 34-vector in registers (uniform values).
+template <class R>
+DM_DEV void reduce_and_backsolve(Shared<R>& s, int lane, const R* y, R fsel, R* out) {
+#pragma unroll
+  for (int c = 0; c < (NV + 7) / 8; c++) {
+    dmw::sync();
+#pragma unroll
+    for (int dd = 0; dd < 8; dd++) {
+      const int d = c * 8 + dd;
+      if (d < NV) s.u.tbuf[dd][lane] = y[d] * fsel;
+    }
+    dmw::sync();
+    R part = 0;
+    {
+      const int dd = lane >> 3, p = lane & 7;
+#pragma unroll
+      for (int t = 0; t < 8; t++) part += s.u.tbuf[dd][p * 8 + t];
+      part += dmw::shfl_xor(part, 1); part += dmw::shfl_xor(part, 2); part += dmw::shfl_xor(part, 4);
+    }
+#pragma unroll
+    for (int dd = 0; dd < 8; dd++) {
+      const int d = c * 8 + dd;
+      if (d < NV) out[d] = dmw::bcast(part, dd * 8);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < NV; d++) out[d] *= s.dsq[d];
+  dmw::sync();
+  solve_L(out, s.qLD);
+}
+
+// constraint solve.  Lane r < nefc owns constraint row r; lane 63 carries the smooth force tau through the same
+// half solve, so that  qacc = L^-1 D^-1/2 ( y_tau + sum_r f_r Y_r )  needs a single back-substitution.
+//   [MJ mj_fwdAcceleration, mj_projectConstraint, mj_fwdConstraint (warmstart, mj_solPGS)]
+template <class R>
+DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg) {
+  const int nefc = s.nefc;            // <= MAXEFC - 1 = 63
+  const bool active = lane < nefc;
+  const bool taulane = lane == 63;
+  R y[NV];
+  R Rr = 1, aref = 0, bb = 0, f = 0, pos = 0, margin = 0;
+  {
+    const int info = active ? s.rowi[lane] : 0;
+    const int type = info & 0xff;
+    R w[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long mplus = 0, mminus = 0;
+    int ldof = -1;
+    R lsgn = 0, dA = 0, rscale = 1;
+    if (active) {
+      const R* rd = s.rowd[lane];
+      pos = rd[6]; margin = rd[7]; dA = rd[8]; rscale = rd[9];
+      if (type == ROW_LIMIT) { ldof = (info >> 8) & 0xff; lsgn = rd[0]; }
+      else {
+        for (int r = 0; r < 6; r++) w[r] = rd[r];
+        mminus = TOPO.chain[(info >> 8) & 0xff]; mplus = TOPO.chain[(info >> 16) & 0xff];
+      }
+    }
+    R vel = 0, jws = 0;
+    int z = 0;
+#pragma unroll
+    for (int d = 0; d < NV; d++) {
+      if ((d & 3) == 0) z = dmw::pin_zero();
+      const R sg = R((int)((mplus >> d) & 1ull) - (int)((mminus >> d) & 1ull));
+      R j = sg * dot6(s.cdof[d + z], w);
+      if (d == ldof) j = lsgn;
+      vel += j * s.qvel[d + z]; jws += j * s.qws[d + z];
+      y[d] = taulane ? s.tau[d + z] : j;
+      if ((d & 3) == 3) dmw::pin_value(vel);
+    }
+    if (dbg && active) {
+      double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + lane * (34 + 6);
+#pragma unroll
+      for (int d = 0; d < NV; d++) o[d] = (double)y[d];
+    }
+    const R imp = impedance(M.solimp, pos - margin);
+    Rr = fmax(R(DM_MINVAL), (1 - imp) * dA / imp);
+    if (rscale != R(1)) Rr = fmax(R(DM_MINVAL), rscale * Rr);
+    aref = -M.B * vel - M.K * imp * (pos - margin);
+    const R jar = jws - aref;
+    f = (active && jar < 0) ? -jar / Rr : R(0);
+    // half solve: y <- D^-1/2 L^-T y
+    solve_LT(y, s.qLD);
+#pragma unroll
+    for (int d = 0; d < NV; d++) y[d] *= s.dsq[d];
+  }
+  if (lane == 0) s.solver_iter = 0;
+  int iter = 0;
+  if (nefc > 0) {
+    // ---- b = J qacc_smooth - aref = Y . y_tau - aref : y_tau broadcast through LDS ----------------------------
+    if (taulane) {
+#pragma unroll
+      for (int d = 0; d < NV; d++) s.qaccs[d] = y[d];
+    }
+    dmw::sync();
+    {
+      R acc = 0;
+#pragma unroll
+      for (int d = 0; d < NV; d++) acc += y[d] * s.qaccs[d];
+      bb = active ? acc - aref : R(0);
+    }
+    // ---- A = Y Y^T + diag(R): rows of Y broadcast through LDS, 16 at a time ---------------------------------
+    R AR[MAXEFC];
+    R diag = 1;
+#pragma unroll
+    for (int c = 0; c < MAXEFC / 16; c++) {
+      if (c * 16 < nefc) {
+        dmw::sync();
+        if ((lane >> 4) == c) {
+#pragma unroll
+          for (int d = 0; d < NV; d++) s.u.ybuf[lane & 15][d] = y[d];
+        }
+        dmw::sync();
+#pragma unroll
+        for (int ii = 0; ii < 16; ii++) {
+          const int i = c * 16 + ii;
+          R acc = 0;
+          if (i < nefc) {
+            const int z = dmw::pin_zero();
+#pragma unroll
+            for (int d = 0; d < NV; d++) acc += y[d] * s.u.ybuf[ii][d + z];
+            dmw::pin_value(acc);
+          }
+          if (lane == i) { acc += Rr; diag = acc; }
+          AR[i] = acc;
+        }
+      } else {
+#pragma unroll
+        for (int ii = 0; ii < 16; ii++) AR[c * 16 + ii] = 0;
+      }
+    }
+    const R dinvr = R(1) / diag;
+    // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ------------------------------
+    R res = bb;  // residual r_j = b_j + sum_i A_ji f_i, maintained incrementally
+#pragma unroll
+    for (int i = 0; i < MAXEFC; i++) {
+      if (i < nefc) res += AR[i] * dmw::bcast(f, i);
+    }
+    {
+      const R cost = dmw::wave_sum(active ? f * (R(0.5) * (res - bb) + bb) : R(0));
+      if (cost > 0) { f = 0; res = bb; }
+    }
+    // ---- projected Gauss-Seidel, rows in order; one broadcast + one FMA per row -----------------------------
+    while (iter < M.iterations) {
+      R myimp = 0;
+#pragma unroll
+      for (int i = 0; i < MAXEFC; i++) {
+        if (i < nefc) {
+          // every lane evaluates its own candidate update; only lane i's is taken
+          R fn = f - res * dinvr;
+          fn = fn < 0 ? R(0) : fn;
+          R delta = fn - f;
+          R change = delta * (R(0.5) * delta * diag + res);
+          if (change > R(1e-10)) { delta = 0; change = 0; }
+          const R di = dmw::bcast(delta, i);
+          if (lane == i) { f += delta; myimp -= change; }
+          res += AR[i] * di;
+        }
+      }
+      const R improvement = dmw::wave_sum(active ? myimp : R(0)) * M.pgs_scale;
+      iter++;
+      if (improvement < M.tolerance) break;
+    }
+    if (dbg && active) {
+      double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + lane * (34 + 6) + 34;
+      o[0] = (double)pos; o[1] = (double)margin; o[2] = (double)Rr; o[3] = (double)aref; o[4] = (double)bb; o[5] = (double)f;
+    }
+  }
+  // ---- qacc = L^-1 D^-1/2 ( y_tau + sum_r f_r Y_r ) -------------------------------------------------------------
+  R acc_out[NV];
+  reduce_and_backsolve(s, lane, y, taulane ? R(1) : (active ? f : R(0)), acc_out);
+  dmw::sync();
+  if (lane == 0) {
+    s.solver_iter = iter;
+#pragma unroll
+    for (int d = 0; d < NV; d++) s.qacc[d] = acc_out[d];
+  }
+  if (dbg) {   // qacc_smooth for the stage-by-stage parity dump (debug kernel only)
+    R sm[NV];
+    reduce_and_backsolve(s, lane, y, taulane ? R(1) : R(0), sm);
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < NV; d++) dbg->out[34 * 34 + 34 + d] = (double)sm[d];
+    }
+  }
+  dmw::sync();
+}
+
+// one forward-dynamics evaluation: s.qpos, s.qvel, s.act, s.qws  ->  s.qacc (+ s.xipos, contact bookkeeping)
+template <class R>
+DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg) {
+  stage_kinematics(M, s, lane);
+  if (dbg) { for (int e = lane; e < NV * NV; e += 64) dbg->out[e] = 0; dmw::sync(); }
+  stage_mass_matrix(M, s, lane, dbg);
+  stage_bias(M, s, lane);
+  if (dbg && lane < NV) {
+    const double bias = (double)(-M.dof_damping[lane] * s.qvel[lane] + s.act[lane] - s.tau[lane]);
+    dbg->out[34 * 34 + lane] = bias;
+  }
+  stage_rows(M, s, lane);
+  stage_constraint(M, s, lane, dbg);
+  if (dbg) {
+    if (lane < NV) dbg->out[34 * 34 + 68 + lane] = (double)s.qacc[lane];
+    if (lane < NB * 3) dbg->out[34 * 34 + 102 + lane] = (double)s.xipos[lane / 3][lane % 3];
+    if (lane == 0) { dbg->out[34 * 34 + 144] = s.nefc; dbg->out[34 * 34 + 145] = s.ncon; dbg->out[34 * 34 + 146] = s.solver_iter; }
+  }
+}
+
+}  // namespace dm

@@ -1,0 +1,172 @@
+/* dmenv.h — C ABI of libdmenv.so: the MI355X-native batched DeepMimic humanoid environment.
+ *
+ * This is the drop-in boundary for the hot path of mingfeisun/DeepMimic_mujoco.  In the reference the
+ * path sits behind mujoco-py's Cython API (third-party, EXTERNAL) as used by gym's MujocoEnv and by
+ * src/dp_env_v3.py; each entry point below names the reference interface it replaces.  Plain C types
+ * only (no torch / numpy types); every function returns 0 on success or a negative DM_E* code, and
+ * dm_last_error() returns a thread-local message.  A dm_batch is confined to one host thread and one
+ * HIP stream; different batches (e.g. one per GPU) may be driven from different threads/processes.
+ *
+ * All per-environment state (qpos, qvel, time, qacc_warmstart, mocap frame indices) lives in device
+ * memory owned by the library, as [N, 35] / [N, 34] row-major float64 arrays: one wavefront per
+ * environment loads its row with one coalesced access.  Caller buffers (actions in, obs / reward /
+ * done out) may be host or device memory (DM_PTR_HOST / DM_PTR_DEVICE).
+ */
+#ifndef DMENV_H
+#define DMENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_ABI_VERSION 1
+
+/* fixed sizes of the DeepMimic humanoid (dp_env_v3.xml:21-156): the kernels are specialised to this tree */
+#define DM_NBODY 14
+#define DM_NJNT 29
+#define DM_NQ 35
+#define DM_NV 34
+#define DM_NU 28
+#define DM_NGEOM 16
+#define DM_NOBS 56
+#define DM_MAXPAIR 128
+#define DM_MAXEFC 64   /* constraint rows per environment held on chip; overflow is reported, not silent */
+
+enum { DM_OK = 0, DM_EINVAL = -1, DM_EHIP = -2, DM_ENOMEM = -3, DM_EUNSUPPORTED = -4, DM_ENODEVICE = -5 };
+enum { DM_PTR_HOST = 0, DM_PTR_DEVICE = 1 };
+
+typedef struct dm_model dm_model;
+typedef struct dm_mocap dm_mocap;
+typedef struct dm_batch dm_batch;
+
+/* Compiled model tables (host pointers, float64 / int32, read once by dm_model_create).
+ * Replaces: mujoco_py.load_model_from_path(xml) -> PyMjModel, called from gym MujocoEnv.__init__
+ * (reference call site src/dp_env_v3.py:59).  Filled by deepmimic_mujoco_amd/model.py. */
+typedef struct {
+  int32_t abi_version;
+  int32_t nbody, njnt, nq, nv, nu, ngeom, npair, iterations;
+  const int32_t* body_parentid;   /* [nbody] */
+  const int32_t* body_dofnum;     /* [nbody] */
+  const double* body_pos;         /* [nbody,3] */
+  const double* body_ipos;        /* [nbody,3] */
+  const double* body_mass;        /* [nbody] */
+  const double* body_inertia;     /* [nbody,9] about COM, body axes */
+  const double* body_invweight0;  /* [nbody,2] */
+  const int32_t* jnt_type;        /* [njnt] 0 free, 3 hinge */
+  const int32_t* jnt_bodyid;      /* [njnt] */
+  const int32_t* jnt_limited;     /* [njnt] */
+  const double* jnt_axis;         /* [njnt,3] */
+  const double* jnt_range;        /* [njnt,2] */
+  const double* dof_armature;     /* [nv] */
+  const double* dof_damping;      /* [nv] */
+  const double* dof_invweight0;   /* [nv] */
+  const int32_t* geom_type;       /* [ngeom] mjtGeom */
+  const int32_t* geom_bodyid;     /* [ngeom] */
+  const int32_t* geom_condim;     /* [ngeom] */
+  const double* geom_pos;         /* [ngeom,3] in body frame */
+  const double* geom_mat;         /* [ngeom,9] in body frame */
+  const double* geom_size;        /* [ngeom,3] */
+  const double* geom_margin;      /* [ngeom] */
+  const double* geom_friction;    /* [ngeom,3] */
+  const int32_t* pair_geom;       /* [npair,2] candidate pairs in contact-list order, geom1 = lower type */
+  const int32_t* actuator_dofid;  /* [nu] */
+  const double* actuator_gear;    /* [nu] */
+  const double* actuator_ctrlrange; /* [nu,2] */
+  double timestep, gravity[3], tolerance, solref[2], solimp[5], meaninertia;
+} dm_model_desc;
+
+int dm_model_create(const dm_model_desc* desc, dm_model** out);
+void dm_model_destroy(dm_model* m);
+
+/* Mocap reference tables (MocapDM.data_config [F,35], .data_vel [F,34]; src/mujoco/mocap_v2.py:78-149).
+ * Replaces: the Python-list lookups `self.mocap.data_config[idx]`, `.data_vel[idx]` at
+ * src/dp_env_v3.py:93,150-151 — the tables become device-resident. */
+int dm_mocap_create(const double* data_config, const double* data_vel, int32_t n_frames, double dt,
+                    dm_mocap** out);
+void dm_mocap_destroy(dm_mocap* mc);
+
+/* flags for dm_batch_create */
+#define DM_FLAG_NO_CONTACT (1u << 0) /* BASELINE.json config 2: collision off   */
+#define DM_FLAG_NO_LIMIT   (1u << 1) /* BASELINE.json config 2: joint limits off */
+
+/* Replaces: mujoco_py.MjSim(model) (gym MujocoEnv.__init__), once per environment; here once per batch.
+ * device_id: HIP device ordinal.  There is no CPU backend: no device -> DM_ENODEVICE. */
+int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n_envs, int32_t device_id, uint32_t flags,
+                    dm_batch** out);
+void dm_batch_destroy(dm_batch* b);
+int dm_batch_set_stream(dm_batch* b, void* hip_stream); /* default: a stream owned by the batch */
+
+/* options */
+enum {
+  DM_OPT_REWARD_MODE = 1, /* 0 alive=1.0 (dp_env_v3.py:117-128, default), 1 v3-config (:89-104), 2 v2-pose (dp_env_v2.py:116-183) */
+  DM_OPT_AUTORESET = 2,   /* 0 off (default), 1 RSI on done, 2 noisy-init on done (DummyVecEnv convention) */
+  DM_OPT_ACTION_MODE = 3, /* 0 raw ctrl (dp_env_v3.py:112, default), 1 P-control 0.8*(mocap_cfg - q) + action (env_torque_test.py:20) */
+  DM_OPT_SEED = 4
+};
+int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t value);
+
+/* Replaces: MujocoEnv.set_state(qpos, qvel) = sim.set_state(...) + sim.forward() (src/dp_env_v3.py:153,160):
+ * qpos/qvel replaced for the masked envs (mask NULL = all), time and qacc_warmstart kept, derived
+ * quantities (xipos ...) recomputed.  frame_idx may be NULL (unchanged). */
+int dm_batch_set_state(dm_batch* b, const double* qpos, const double* qvel, const int32_t* frame_idx,
+                       const uint8_t* mask, int32_t ptr_kind);
+
+/* Replaces: MujocoEnv.reset() = sim.reset() + DPEnv.reset_model() (src/dp_env_v3.py:148-156), or
+ * DPEnv.reset_model_init() (:158-164).  mode 0 = RSI (frame ~ U{0..F-1}), 1 = noisy init pose
+ * (init_qpos/init_qvel + U(-0.01, 0.01)), both from a counter-based per-env RNG keyed by (seed, env, episode);
+ * mode 2 = sim.reset() only (qpos0, zero velocity).  time and qacc_warmstart are zeroed for modes 0/1 only when
+ * `hard` is nonzero (sim.reset() semantics); reset_model_init() called on its own keeps them. */
+int dm_batch_reset(dm_batch* b, int32_t mode, int32_t hard, const uint8_t* mask, int32_t ptr_kind);
+
+/* Replaces: DPEnv.step(action) (src/dp_env_v3.py:106-132) = do_simulation(action, n) [ctrl <- action; n x mj_step]
+ * + _get_obs() + reward + is_done(), for every environment of the batch in one launch.
+ * action [N,28], obs [N,56], reward [N] float64; done [N] uint8. */
+int dm_batch_step(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done,
+                  int32_t n_substeps, int32_t ptr_kind);
+/* Replaces: DPEnv._get_obs() (src/dp_env_v3.py:62-65) without stepping. */
+int dm_batch_get_obs(dm_batch* b, double* obs, int32_t ptr_kind);
+
+/* state / diagnostics access.  Replaces reads and writes of sim.data.<field> (numpy views in mujoco-py). */
+enum {
+  DM_F_QPOS = 1,        /* double [N,35] */
+  DM_F_QVEL = 2,        /* double [N,34] */
+  DM_F_QACC_WARMSTART = 3, /* double [N,34] */
+  DM_F_TIME = 4,        /* double [N] */
+  DM_F_FRAME_IDX = 5,   /* int32 [N]  (DPEnv.idx_curr) */
+  DM_F_FRAME_INIT = 6,  /* int32 [N]  (DPEnv.idx_init) */
+  DM_F_XIPOS = 7,       /* double [N,14,3] body COM positions of the last forward evaluation */
+  DM_F_COM_Z = 8,       /* double [N] */
+  DM_F_NCON = 9,        /* int32 [N] contacts of the last forward evaluation */
+  DM_F_NEFC = 10,       /* int32 [N] constraint rows */
+  DM_F_CONTACT_GEOMS = 11, /* int32 [N,DM_MAXEFC,2] (geom1, geom2) per contact, -1 padded */
+  DM_F_STATUS = 12,     /* int32 [N] bit0: constraint rows overflowed DM_MAXEFC, bit1: non-finite state */
+  DM_F_SOLVER_ITER = 13,/* int32 [N] PGS sweeps of the last forward evaluation */
+  DM_F_CTRL = 14,       /* double [N,28] last (unclamped) ctrl */
+  DM_F_EPISODE = 15     /* int32 [N] episode counter used by the reset RNG */
+};
+int dm_batch_get(dm_batch* b, int32_t field, void* out, size_t bytes, int32_t ptr_kind);
+int dm_batch_set(dm_batch* b, int32_t field, const void* in, size_t bytes, int32_t ptr_kind);
+
+/* One forward evaluation (mj_forward = sim.forward()) of environment `env` with every intermediate dumped:
+ * used by the parity tests to compare stage by stage with the oracle.  Layout of `out` (float64):
+ *   M[34*34] | qfrc_bias[34] | qacc_smooth[34] | qacc[34] | xipos[14*3] | nefc | ncon | solver_iter |
+ *   per row r < DM_MAXEFC: J[34] , then pos, margin, R, aref, b, force   (DM_DEBUG_DOUBLES in total) */
+#define DM_DEBUG_DOUBLES (34 * 34 + 34 * 3 + 42 + 3 + DM_MAXEFC * (34 + 6))
+int dm_batch_debug_forward(dm_batch* b, int32_t env, double* out_host);
+
+/* kernel timing of the last dm_batch_step launch, measured with HIP events on the batch's stream (ms) */
+int dm_batch_last_step_ms(dm_batch* b, float* ms);
+int dm_batch_enable_timing(dm_batch* b, int32_t on);
+
+int dm_batch_sync(dm_batch* b);
+const char* dm_last_error(void);
+int dm_abi_version(void);
+int dm_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMENV_H */

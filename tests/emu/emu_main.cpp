@@ -1,0 +1,151 @@
+// emu_main.cpp — TEST INFRASTRUCTURE: C entry points that run the HIP kernel source on the fibre wave testbench.
+// Mirrors the subset of include/dmenv.h the parity tests use, one environment after another.
+#include <ucontext.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "wave_testbench.h"
+// kernel source, unmodified
+#include "env_step.h"
+#include "model_host.h"
+
+namespace dmw {
+static WaveBench g_bench;
+WaveBench& bench() { return g_bench; }
+}  // namespace dmw
+
+namespace {
+constexpr size_t STACK = 1 << 20;
+ucontext_t g_main, g_fib[64];
+bool g_done[64];
+std::function<void(int)>* g_body;
+char* g_stacks;
+
+void yield_to_main() { swapcontext(&g_fib[dmw::g_bench.cur_lane], &g_main); }
+void fibre_entry() {
+  const int l = dmw::g_bench.cur_lane;
+  (*g_body)(l);
+  g_done[l] = true;
+  swapcontext(&g_fib[l], &g_main);
+}
+// run body(lane) on 64 fibres to completion
+void run_wave(std::function<void(int)> body) {
+  if (!g_stacks) g_stacks = (char*)malloc(STACK * 64);
+  g_body = &body;
+  dmw::g_bench.arrived = 0; dmw::g_bench.gen = 0; dmw::g_bench.yield_fn = yield_to_main;
+  for (int l = 0; l < 64; l++) {
+    g_done[l] = false;
+    getcontext(&g_fib[l]);
+    g_fib[l].uc_stack.ss_sp = g_stacks + STACK * l; g_fib[l].uc_stack.ss_size = STACK; g_fib[l].uc_link = &g_main;
+    makecontext(&g_fib[l], fibre_entry, 0);
+  }
+  for (;;) {
+    bool all = true;
+    for (int l = 0; l < 64; l++) if (!g_done[l]) { all = false; dmw::g_bench.cur_lane = l; swapcontext(&g_main, &g_fib[l]); }
+    if (all) break;
+  }
+}
+
+using namespace dm;
+struct EmuBatch {
+  DevModel<double> M;
+  Batch<double> B;
+  std::vector<double> qpos, qvel, qws, time, ctrl, xipos, comz, cfg, vel;
+  std::vector<int> fidx, finit, ncon, nefc, cong, status, siter, episode;
+  Shared<double> sh;
+  StepScratch<double> xs;
+};
+}  // namespace
+
+extern "C" {
+void* emu_create(const dm_model_desc* d, const double* cfg, const double* vel, int F, int n, unsigned flags) {
+  EmuBatch* e = new EmuBatch();
+  std::string err;
+  if (build_dev_model(d, &e->M, &err) != 0) { fprintf(stderr, "emu_create: %s\n", err.c_str()); delete e; return nullptr; }
+  e->M.enable_contact = (flags & DM_FLAG_NO_CONTACT) ? 0 : 1;
+  e->M.enable_limit = (flags & DM_FLAG_NO_LIMIT) ? 0 : 1;
+  e->qpos.assign((size_t)n * NQ, 0); e->qvel.assign((size_t)n * NV, 0); e->qws.assign((size_t)n * NV, 0);
+  e->time.assign(n, 0); e->ctrl.assign((size_t)n * NU, 0); e->xipos.assign((size_t)n * NB * 3, 0); e->comz.assign(n, 0);
+  e->cfg.assign(cfg, cfg + (size_t)F * NQ); e->vel.assign(vel, vel + (size_t)F * NV);
+  e->fidx.assign(n, 0); e->finit.assign(n, 0); e->ncon.assign(n, 0); e->nefc.assign(n, 0); e->cong.assign((size_t)n * MAXEFC * 2, -1);
+  e->status.assign(n, 0); e->siter.assign(n, 0); e->episode.assign(n, 0);
+  for (int i = 0; i < n; i++) for (int k = 0; k < NQ; k++) e->qpos[(size_t)i * NQ + k] = e->M.qpos0[k];
+  Batch<double>& B = e->B;
+  B.qpos = e->qpos.data(); B.qvel = e->qvel.data(); B.qws = e->qws.data(); B.time = e->time.data(); B.ctrl = e->ctrl.data();
+  B.xipos = e->xipos.data(); B.comz = e->comz.data(); B.frame_idx = e->fidx.data(); B.frame_init = e->finit.data();
+  B.ncon = e->ncon.data(); B.nefc = e->nefc.data(); B.cong = e->cong.data(); B.status = e->status.data();
+  B.solver_iter = e->siter.data(); B.episode = e->episode.data(); B.mocap_cfg = e->cfg.data(); B.mocap_vel = e->vel.data();
+  B.n_frames = F; B.n_envs = n; B.env_offset = 0; B.reward_mode = 0; B.autoreset = 0; B.action_mode = 0; B.seed = 0;
+  return e;
+}
+void emu_destroy(void* h) { delete (EmuBatch*)h; }
+void emu_set_option(void* h, int opt, long long v) {
+  EmuBatch* e = (EmuBatch*)h;
+  if (opt == DM_OPT_REWARD_MODE) e->B.reward_mode = (int)v;
+  else if (opt == DM_OPT_AUTORESET) e->B.autoreset = (int)v;
+  else if (opt == DM_OPT_ACTION_MODE) e->B.action_mode = (int)v;
+  else if (opt == DM_OPT_SEED) e->B.seed = (unsigned long long)v;
+  else if (opt == 100) e->B.env_offset = (int)v;
+}
+void* emu_field(void* h, int field) {
+  EmuBatch* e = (EmuBatch*)h;
+  switch (field) {
+    case DM_F_QPOS: return e->qpos.data(); case DM_F_QVEL: return e->qvel.data(); case DM_F_QACC_WARMSTART: return e->qws.data();
+    case DM_F_TIME: return e->time.data(); case DM_F_FRAME_IDX: return e->fidx.data(); case DM_F_FRAME_INIT: return e->finit.data();
+    case DM_F_XIPOS: return e->xipos.data(); case DM_F_COM_Z: return e->comz.data(); case DM_F_NCON: return e->ncon.data();
+    case DM_F_NEFC: return e->nefc.data(); case DM_F_CONTACT_GEOMS: return e->cong.data(); case DM_F_STATUS: return e->status.data();
+    case DM_F_SOLVER_ITER: return e->siter.data(); case DM_F_CTRL: return e->ctrl.data(); case DM_F_EPISODE: return e->episode.data();
+  }
+  return nullptr;
+}
+void emu_step(void* h, const double* action, double* obs, double* reward, unsigned char* done, int nsub) {
+  EmuBatch* e = (EmuBatch*)h;
+  for (int env = 0; env < e->B.n_envs; env++)
+    run_wave([&](int lane) { env_step(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); });
+}
+void emu_set_state(void* h, const double* qpos, const double* qvel, const int* fidx, const unsigned char* mask) {
+  EmuBatch* e = (EmuBatch*)h;
+  for (int env = 0; env < e->B.n_envs; env++) {
+    if (mask && !mask[env]) continue;
+    run_wave([&](int lane) {
+      load_env(e->M, e->B, e->sh, env, lane, (const double*)0);
+      if (lane < NQ) e->sh.qpos[lane] = qpos[(size_t)env * NQ + lane];
+      if (lane < NV) e->sh.qvel[lane] = qvel[(size_t)env * NV + lane];
+      if (fidx && lane == 0) { e->B.frame_idx[env] = fidx[env]; e->B.frame_init[env] = fidx[env]; }
+      dmw::sync();
+      store_state(e->B, e->sh, env, lane);
+      forward(e->M, e->sh, lane, (const DebugOut*)0);
+      store_derived(e->B, e->M, e->sh, env, lane);
+    });
+  }
+}
+void emu_reset(void* h, int mode, int hard, const unsigned char* mask) {
+  EmuBatch* e = (EmuBatch*)h;
+  for (int env = 0; env < e->B.n_envs; env++) {
+    if (mask && !mask[env]) continue;
+    run_wave([&](int lane) {
+      load_env(e->M, e->B, e->sh, env, lane, (const double*)0);
+      reset_env(e->M, e->B, e->sh, env, lane, mode, hard);
+      store_state(e->B, e->sh, env, lane);
+      forward(e->M, e->sh, lane, (const DebugOut*)0);
+      store_derived(e->B, e->M, e->sh, env, lane);
+    });
+  }
+}
+void emu_debug_forward(void* h, int env, double* out) {
+  EmuBatch* e = (EmuBatch*)h;
+  for (int i = 0; i < DM_DEBUG_DOUBLES; i++) out[i] = 0;
+  run_wave([&](int lane) {
+    load_env(e->M, e->B, e->sh, env, lane, (const double*)0);
+    if (lane < NU) { const int d = lane + 6; e->sh.act[d] = e->M.gear[d] * clampr(e->B.ctrl[(size_t)env * NU + lane], e->M.ctrl_lo[d], e->M.ctrl_hi[d]); }
+    dmw::sync();
+    DebugOut dbg{out};
+    forward(e->M, e->sh, lane, &dbg);
+    store_derived(e->B, e->M, e->sh, env, lane);
+  });
+}
+}

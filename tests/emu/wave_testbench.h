@@ -1,0 +1,74 @@
+// wave_testbench.h — TEST INFRASTRUCTURE.  Runs the unmodified kernel source (deepmimic_mujoco_amd/csrc/env_*.h)
+// on the CPU of the GPU-less build container by giving each of the 64 lanes of a wavefront its own cooperative
+// fibre (ucontext).  Cross-lane primitives (sync / shfl / ballot / bcast) are rendezvous points; between them a
+// fibre runs alone, so any missing barrier or divergent collective in the kernel shows up as a wrong result or a
+// deadlock here, before GPU time is spent.  Never linked into libdmenv.so; the product has no CPU path.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#define DM_DEV inline
+#define DM_DEV_NOINLINE inline
+#define DM_CONSTANT constexpr
+
+namespace dmw {
+
+struct WaveBench {
+  int cur_lane;
+  int arrived;
+  unsigned long long gen;
+  unsigned long long slot[2][64];
+  void (*yield_fn)(void);
+};
+WaveBench& bench();
+
+inline int lane() { return bench().cur_lane; }
+
+inline void rendezvous() {
+  WaveBench& b = bench();
+  const unsigned long long g = b.gen;
+  if (++b.arrived == 64) { b.arrived = 0; b.gen++; }
+  else while (b.gen == g) b.yield_fn();
+}
+inline void sync() { rendezvous(); }
+
+template <class T> inline unsigned long long to_bits(T v) { unsigned long long u = 0; std::memcpy(&u, &v, sizeof(T)); return u; }
+template <class T> inline T from_bits(unsigned long long u) { T v; std::memcpy(&v, &u, sizeof(T)); return v; }
+
+template <class T> inline T exchange(T v, int src) {
+  WaveBench& b = bench();
+  const int p = (int)(b.gen & 1ull);
+  b.slot[p][b.cur_lane] = to_bits(v);
+  rendezvous();
+  return from_bits<T>(bench().slot[p][src & 63]);
+}
+inline unsigned long long ballot(bool pr) {
+  WaveBench& b = bench();
+  const int p = (int)(b.gen & 1ull);
+  b.slot[p][b.cur_lane] = pr ? 1ull : 0ull;
+  rendezvous();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; l++) m |= (bench().slot[p][l] & 1ull) << l;
+  return m;
+}
+inline int shfl_i(int v, int src) { return exchange(v, src); }
+inline double shfl(double v, int src) { return exchange(v, src); }
+inline float shfl(float v, int src) { return exchange(v, src); }
+inline double shfl_xor(double v, int m) { return exchange(v, lane() ^ m); }
+inline float shfl_xor(float v, int m) { return exchange(v, lane() ^ m); }
+inline int shfl_xor_i(int v, int m) { return exchange(v, lane() ^ m); }
+inline int shfl_up_i(int v, int d) { const int l = lane(); return exchange(v, l >= d ? l - d : l); }
+inline double bcast(double v, int src) { return exchange(v, src); }
+inline float bcast(float v, int src) { return exchange(v, src); }
+inline int bcast_i(int v, int src) { return exchange(v, src); }
+inline void sched_fence() {}
+inline void reload_fence() {}
+inline int pin_zero() { return 0; }
+inline void pin_value(double&) {}
+inline void pin_value(float&) {}
+
+}  // namespace dmw
+
+using std::fabs; using std::fmax; using std::sqrt; using std::sin; using std::cos; using std::pow; using std::exp;
