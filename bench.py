@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched DeepMimic humanoid step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (config.workload): BASELINE.json configs[2] — 'walk' clip, 4096 envs per GPU, full contact + joint-limit
+solve (PGS 50), imitation reward `v3-config`, RSI auto-reset on done, actions ~ N(0, 0.9^2) i.i.d. (pre-generated on
+the device).  One "step" = one `dm_batch_step` launch = one DPEnv.step (one RK4 mj_step, h = 0.0166 s) of every env
+of the rank.  With N > 1 the env index range is sharded over ranks (weak scaling, no per-step collective) and every
+256 steps the [256, 4096, 87] f32 rollout block is all-gathered over RCCL, as the learner would consume it.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+HORIZON = 256
+ALGO_BYTES_PER_STEP = 2353      # fp64 state/action in + state/obs/reward/done out, per env-step
+ALGO_FLOP_PER_STEP = 1.5e6      # SURVEY.md section 8(d) estimate with ~8 floor contacts + limits
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X fp64 vector peak (public spec)
+
+
+def cpu_baseline(clip, budget_s=12.0):
+    """Time the CPU oracle (oracle/, float64 C, OpenMP over envs) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from deepmimic_mujoco_amd import MocapDM
+    cores = os.cpu_count() or 1
+    mc = MocapDM(); mc.load_mocap(clip)
+    F = mc.data_config.shape[0]
+    n = max(8, cores * 4)
+    om = O.Model()
+    ds = [O.Data(om) for _ in range(n)]
+    rng = np.random.RandomState(0)
+    for e, d in enumerate(ds):
+        d.reset(); d.set_state(mc.data_config[e % F], mc.data_vel[e % F])
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        a = rng.randn(n, 28) * 0.9
+        _o, _r, done = O.batch_step(om, ds, a, 1, cores)
+        steps += 1
+        for e in np.nonzero(done)[0]:
+            k = rng.randint(F)
+            ds[e].reset(); ds[e].set_state(mc.data_config[k], mc.data_vel[k])
+        el = time.perf_counter() - t0
+        if el > budget_s and steps >= 4:
+            break
+    return {"value": round(n * steps / el, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d steps of the same workload (walk, contacts+limits, N(0,0.9^2) actions, RSI reset on done), "
+                      "oracle/dm_oracle.c fp64 with OpenMP over envs, %.1f s" % (n, steps, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3"])
+    ap.add_argument("--clip", default="walk")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from deepmimic_mujoco_amd import DPVecEnv, _abi as A
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = args.envs
+    full = args.workload == "cfg3"
+    env = DPVecEnv(n, motion=args.clip, device=local_rank, reward="v3-config" if full else "alive",
+                   autoreset="rsi", seed=0, contacts=full, limits=full,
+                   action_mode="raw" if full else "p-control", env_offset=rank * n)
+    stream = torch.cuda.Stream(device=dev)
+    env.batch.set_stream(stream.cuda_stream)
+
+    with torch.cuda.stream(stream):
+        gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+        pool = 32
+        if full:
+            actions = torch.randn((pool, n, A.NU), generator=gen, device=dev, dtype=torch.float64) * 0.9
+        else:
+            actions = torch.zeros((pool, n, A.NU), device=dev, dtype=torch.float64)   # cfg2: pure P-controller
+        obs = torch.empty((n, A.NOBS), dtype=torch.float64, device=dev)
+        rew = torch.empty(n, dtype=torch.float64, device=dev)
+        done = torch.empty(n, dtype=torch.uint8, device=dev)
+        block = torch.zeros((HORIZON, n, 87), dtype=torch.float32, device=dev)   # obs 56 + act 28 + rew + done + vpred
+        gathered = torch.empty((world * HORIZON, n, 87), dtype=torch.float32, device=dev) if world > 1 else None
+        env.reset("rsi")
+
+        def one_step(t):
+            a = actions[t % pool]
+            env.batch.step(a, 1, (obs, rew, done))
+            row = block[t % HORIZON]
+            row[:, :56] = obs; row[:, 56:84] = a; row[:, 84] = rew; row[:, 85] = done
+            if world > 1 and (t + 1) % HORIZON == 0:
+                dist.all_gather_into_tensor(gathered, block)
+
+        for t in range(args.warmup):
+            one_step(t)
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        done_count = torch.zeros((), dtype=torch.int64, device=dev)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for t in range(args.steps):
+            one_step(t)
+        ev1.record(stream)
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    gpu_ms = ev0.elapsed_time(ev1)
+    status = env.batch.get(A.F_STATUS)
+    nefc = env.batch.get(A.F_NEFC)
+
+    if rank == 0:
+        total_steps = world * n * args.steps
+        value = total_steps / elapsed
+        kernel_ms = gpu_ms / args.steps       # per-launch duration on the launch stream (incl. the 4 tiny rollout-copy ops)
+        ach_gbs = ALGO_BYTES_PER_STEP * n / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("BASELINE.json configs[2]: 'walk' mocap, %d envs/GPU, full contact + joint-limit PGS solve, "
+                                    "v3-config imitation reward, RSI auto-reset" % n) if full else
+                                   ("BASELINE.json configs[1]: 'walk' mocap, %d envs/GPU, P-controller torque, contacts and limits off" % n),
+                       "envs_per_gpu": n, "global_envs": world * n, "clip": args.clip, "parallelism": "env-shard x%d" % world,
+                       "rollout_allgather_every": HORIZON if world > 1 else None,
+                       "mean_nefc": round(float(nefc.mean()), 2), "overflow_envs": int((status & 1).sum())},
+            "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel": "k_step", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
+                         "note": "latency/ALU-bound path: see fp64 fraction",
+                         "fp64_est_tflops": round(ALGO_FLOP_PER_STEP * n / (kernel_ms * 1e-3) / 1e12, 3),
+                         "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.clip)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+"""`Batch`: thin Python owner of a `dm_batch` (include/dmenv.h) — N lock-step environments on one GPU.
+
+Buffers may be numpy arrays (host pointers; the library stages them) or torch tensors on the batch's device
+(device pointers, zero-copy, stream-ordered).  Nothing here computes physics: every call lands in a HIP kernel.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Batch(object):
+    def __init__(self, compiled_model, data_config, data_vel, n_envs, device=0, flags=0, mocap_dt=0.0):
+        L = A.load()
+        self._L = L
+        self.n = int(n_envs)
+        self.device = int(device)
+        md, self._keep = A.make_model_desc(compiled_model)
+        self._model = C.c_void_p(); self._mocap = C.c_void_p(); self._h = C.c_void_p()
+        A.check(L.dm_model_create(C.byref(md), C.byref(self._model)), L)
+        cfg = np.ascontiguousarray(data_config, dtype=np.float64); vel = np.ascontiguousarray(data_vel, dtype=np.float64)
+        if cfg.ndim != 2 or cfg.shape[1] != A.NQ or vel.shape != (cfg.shape[0], A.NV):
+            raise ValueError("mocap tables must be [F,35] and [F,34]")
+        self.n_frames = cfg.shape[0]
+        A.check(L.dm_mocap_create(cfg.ctypes.data_as(A._dp), vel.ctypes.data_as(A._dp), cfg.shape[0], float(mocap_dt),
+                                  C.byref(self._mocap)), L)
+        A.check(L.dm_batch_create(self._model, self._mocap, self.n, self.device, int(flags), C.byref(self._h)), L)
+
+    def close(self):
+        L = getattr(self, "_L", None)
+        if L is None:
+            return
+        if getattr(self, "_h", None):
+            L.dm_batch_destroy(self._h); self._h = None
+        if getattr(self, "_mocap", None):
+            L.dm_mocap_destroy(self._mocap); self._mocap = None
+        if getattr(self, "_model", None):
+            L.dm_model_destroy(self._model); self._model = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers ------------------------------------------------------------------------------------
+    def _ptr(self, x, dtype, shape, out=False):
+        """-> (pointer, kind, keepalive)"""
+        if x is None:
+            return None, A.PTR_HOST, None
+        if _is_torch(x):
+            import torch
+            want = {np.float64: torch.float64, np.int32: torch.int32, np.uint8: torch.uint8}[dtype]
+            if x.dtype != want or not x.is_contiguous() or tuple(x.shape) != tuple(shape):
+                raise ValueError("tensor must be contiguous %s of shape %s" % (want, shape))
+            if x.device.type != "cuda" or (x.device.index or 0) != self.device:
+                raise ValueError("tensor must live on cuda:%d" % self.device)
+            return C.c_void_p(x.data_ptr()), A.PTR_DEVICE, x
+        a = x if out else np.ascontiguousarray(x, dtype=dtype)
+        if a.dtype != dtype or not a.flags.c_contiguous or a.shape != tuple(shape):
+            raise ValueError("array must be C-contiguous %s of shape %s" % (np.dtype(dtype), shape))
+        return C.c_void_p(a.ctypes.data), A.PTR_HOST, a
+
+    def set_option(self, opt, value):
+        A.check(self._L.dm_batch_set_option(self._h, int(opt), int(value)), self._L)
+
+    def set_stream(self, stream_handle):
+        A.check(self._L.dm_batch_set_stream(self._h, C.c_void_p(int(stream_handle))), self._L)
+
+    # ---- the hot path -------------------------------------------------------------------------------
+    def step(self, action, n_substeps=1, out=None):
+        n = self.n
+        ap, kind, _ka = self._ptr(action, np.float64, (n, A.NU))
+        if out is None:
+            if kind == A.PTR_DEVICE:
+                import torch
+                dev = action.device
+                out = (torch.empty((n, A.NOBS), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
+                       torch.empty(n, dtype=torch.uint8, device=dev))
+            else:
+                out = (np.empty((n, A.NOBS)), np.empty(n), np.empty(n, dtype=np.uint8))
+        obs, rew, done = out
+        op, k1, _ = self._ptr(obs, np.float64, (n, A.NOBS), out=True)
+        rp, k2, _ = self._ptr(rew, np.float64, (n,), out=True)
+        dp, k3, _ = self._ptr(done, np.uint8, (n,), out=True)
+        if not (kind == k1 == k2 == k3):
+            raise ValueError("action and output buffers must all be host arrays or all be device tensors")
+        A.check(self._L.dm_batch_step(self._h, ap, op, rp, dp, int(n_substeps), kind), self._L)
+        return obs, rew, done
+
+    def get_obs(self, out=None):
+        if out is None:
+            out = np.empty((self.n, A.NOBS))
+        p, kind, _ = self._ptr(out, np.float64, (self.n, A.NOBS), out=True)
+        A.check(self._L.dm_batch_get_obs(self._h, p, kind), self._L)
+        return out
+
+    def set_state(self, qpos, qvel, frame_idx=None, mask=None):
+        n = self.n
+        qp, k, _a = self._ptr(qpos, np.float64, (n, A.NQ)); vp, k2, _b = self._ptr(qvel, np.float64, (n, A.NV))
+        fp, k3, _c = self._ptr(frame_idx, np.int32, (n,)); mp, k4, _d = self._ptr(mask, np.uint8, (n,))
+        kinds = {k, k2} | ({k3} if frame_idx is not None else set()) | ({k4} if mask is not None else set())
+        if len(kinds) != 1:
+            raise ValueError("mixed host/device buffers")
+        A.check(self._L.dm_batch_set_state(self._h, qp, vp, fp, mp, k), self._L)
+
+    def reset(self, mode=0, hard=1, mask=None):
+        mp, k, _ = self._ptr(mask, np.uint8, (self.n,))
+        A.check(self._L.dm_batch_reset(self._h, int(mode), int(hard), mp, k), self._L)
+
+    def get(self, field, out=None):
+        dt, shp = A.FIELD_SPEC[field]
+        if out is None:
+            out = np.empty((self.n,) + shp, dtype=dt)
+        p, kind, _ = self._ptr(out, dt, (self.n,) + shp, out=True)
+        nbytes = int(np.prod((self.n,) + shp)) * np.dtype(dt).itemsize
+        A.check(self._L.dm_batch_get(self._h, int(field), p, nbytes, kind), self._L)
+        return out
+
+    def set(self, field, value):
+        dt, shp = A.FIELD_SPEC[field]
+        if not _is_torch(value):
+            value = np.ascontiguousarray(np.asarray(value, dtype=dt).reshape((self.n,) + shp))
+        p, kind, _ka = self._ptr(value, dt, (self.n,) + shp)
+        nbytes = int(np.prod((self.n,) + shp)) * np.dtype(dt).itemsize
+        A.check(self._L.dm_batch_set(self._h, int(field), p, nbytes, kind), self._L)
+
+    def debug_forward(self, env=0):
+        buf = np.zeros(A.DEBUG_DOUBLES)
+        A.check(self._L.dm_batch_debug_forward(self._h, int(env), buf.ctypes.data_as(A._dp)), self._L)
+        return A.parse_debug(buf)
+
+    def enable_timing(self, on=True):
+        A.check(self._L.dm_batch_enable_timing(self._h, 1 if on else 0), self._L)
+
+    def last_step_ms(self):
+        ms = C.c_float(0)
+        A.check(self._L.dm_batch_last_step_ms(self._h, C.byref(ms)), self._L)
+        return float(ms.value)
+
+    def sync(self):
+        A.check(self._L.dm_batch_sync(self._h), self._L)

@@ -1,0 +1,296 @@
+"""`DPEnv` / `DPVecEnv`: the reference's environment API on top of the HIP batch.
+
+`DPEnv` keeps the surface `trpo.py` consumes from `dp_env_v3.DPEnv` (src/dp_env_v3.py:34-171; callers at
+src/trpo.py:30-32,66,78-79,343,403-404,461-463): `reset() -> ob[56]`, `step(ac[28]) -> (ob, reward, done, {})`,
+`seed`, `close`, `action_space`, `observation_space`, `reset_model`, `reset_model_init`, `load_mocap`,
+`calc_config_reward`, `is_done`, `goto`, `get_time`, `set_state`, and the attributes `sim.data.qpos/qvel/xipos/ctrl/
+time`, `model.{nq,nv,nu,body_mass,opt.timestep}`, `mocap`, `idx_curr`, `idx_init`, `mocap_dt`, `mocap_data_len`,
+`init_qpos`, `init_qvel`, `np_random`.  It is one environment of a `Batch` of size 1; every physics call is a HIP
+kernel launch (there is no CPU path — constructing it without a GPU raises).
+
+`DPVecEnv` is the batched form (N envs in lock step, one wavefront each), following the vendored VecEnv contract
+(src/utils/vec_env/__init__.py:26-100) and DummyVecEnv's auto-reset-on-done convention
+(src/utils/vec_env/dummy_vec_env.py:45-56).  It accepts numpy arrays or torch CUDA tensors.
+
+Semantics kept from the reference: reward is the constant 1.0 unless another reward mode
+is selected; `frame_skip=6` is stored but `step` runs ONE mj_step; `done` is the whole-body COM height outside
+[0.7, 2.0] evaluated on the derived data of the last RK4 stage; actions are not clipped in Python; the constructor
+performs gym's warm-up `step(zeros)`; `reset()` = sim.reset() + reference-state-init from Python's global `random`;
+`reset_model_init()` perturbs the init pose with `self.np_random` and keeps time / warm-start.
+"""
+import math
+import random
+
+import numpy as np
+
+from . import _abi as A
+from .batch import Batch
+from .config import Config
+from .humanoid import humanoid_spec
+from .mjcf import load_mjcf
+from .mocap import MocapDM
+from .model import CompiledModel
+from .spaces import Box
+
+REWARD_MODES = {"alive": 0, "v3-config": 1, "v2-pose": 2}
+
+
+def _load_model(xml_path=None):
+    import os
+    if xml_path and os.path.isfile(xml_path):
+        return CompiledModel(load_mjcf(xml_path))
+    return CompiledModel(humanoid_spec())
+
+
+class _Opt(object):
+    def __init__(self, timestep):
+        self.timestep = timestep
+
+
+class _ModelView(object):
+    """The handful of `sim.model` attributes the reference's scripts read."""
+
+    def __init__(self, cm):
+        self.nq, self.nv, self.nu, self.nbody = cm.nq, cm.nv, cm.nu, cm.nbody
+        self.body_mass = cm.body_mass.copy()
+        self.actuator_ctrlrange = cm.actuator_ctrlrange.copy()
+        self.opt = _Opt(cm.timestep)
+
+
+class _DataView(object):
+    """`sim.data` look-alike for env 0 of a batch: attribute reads fetch from the device (copies)."""
+
+    def __init__(self, batch, env=0):
+        self._b, self._e = batch, env
+
+    qpos = property(lambda self: self._b.get(A.F_QPOS)[self._e])
+    qvel = property(lambda self: self._b.get(A.F_QVEL)[self._e])
+    xipos = property(lambda self: self._b.get(A.F_XIPOS)[self._e])
+    ctrl = property(lambda self: self._b.get(A.F_CTRL)[self._e])
+    time = property(lambda self: float(self._b.get(A.F_TIME)[self._e]))
+    qacc_warmstart = property(lambda self: self._b.get(A.F_QACC_WARMSTART)[self._e])
+    ncon = property(lambda self: int(self._b.get(A.F_NCON)[self._e]))
+
+
+class _SimView(object):
+    def __init__(self, env):
+        self._env = env
+        self.data = _DataView(env._batch)
+        self.model = env.model
+
+    def forward(self):   # sim.forward(): recompute derived quantities from the current state
+        b = self._env._batch
+        b.set_state(b.get(A.F_QPOS), b.get(A.F_QVEL))
+
+    def step(self):      # sim.step() with the stored ctrl
+        b = self._env._batch
+        b.step(b.get(A.F_CTRL))
+
+    def reset(self):     # mj_resetData
+        self._env._batch.reset(mode=2, hard=1)
+
+
+class DPEnv(object):
+    metadata = {"render.modes": []}
+    reward_range = (-float("inf"), float("inf"))
+    spec = None
+
+    def __init__(self, motion=None, mocap_path=None, xml_path=None, device=0, reward="alive", batch_factory=None):
+        self.mocap = MocapDM()
+        self._cm = _load_model(xml_path if xml_path is not None else Config.xml_path)
+        self.model = _ModelView(self._cm)
+        self._device = device
+        self._batch_factory = batch_factory or (lambda cm, cfg, vel, n, dt: Batch(cm, cfg, vel, n, device=device, mocap_dt=dt))
+        self._batch = None
+        self._reward_mode = REWARD_MODES[reward]
+        # reward weights / scales (src/dp_env_v3.py:42-53; unused by the default reward)
+        self.weight_pose, self.weight_vel, self.weight_root, self.weight_end_eff, self.weight_com = 0.5, 0.05, 0.2, 0.15, 0.1
+        self.scale_pose, self.scale_vel, self.scale_end_eff, self.scale_root, self.scale_com, self.scale_err = 2.0, 0.1, 40.0, 5.0, 10.0, 1.0
+        if mocap_path is None:
+            mocap_path = motion if motion is not None else Config.mocap_path
+        self.load_mocap(mocap_path)
+        self.reference_state_init()
+        self.idx_curr = -1
+        self.idx_tmp_count = -1
+        # --- gym MujocoEnv.__init__(xml, 6) ---------------------------------------------------------------
+        self.frame_skip = 6
+        self.init_qpos = self._cm.qpos0.copy()
+        self.init_qvel = np.zeros(self._cm.nv)
+        self.sim = _SimView(self)
+        self.data = self.sim.data
+        observation, _r, done, _i = self.step(np.zeros(self._cm.nu))   # the base class's warm-up step
+        assert not done
+        cr = self._cm.actuator_ctrlrange
+        self.action_space = Box(low=cr[:, 0], high=cr[:, 1], dtype=np.float32)
+        self.observation_space = Box(low=-np.inf, high=np.inf, shape=(observation.size,), dtype=np.float32)
+        self.seed()
+
+    # ---- plumbing ----------------------------------------------------------------------------------------
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def dt(self):
+        return self._cm.timestep * self.frame_skip
+
+    def seed(self, seed=None):
+        self.np_random = np.random.RandomState(seed)
+        return [seed]
+
+    def close(self):
+        if self._batch is not None:
+            self._batch.close(); self._batch = None
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is outside the accelerated path")
+
+    def viewer_setup(self):
+        pass
+
+    def _sync_frame_idx(self):
+        self._batch.set(A.F_FRAME_IDX, np.array([max(self.idx_curr, 0)], dtype=np.int32))
+        self._batch.set(A.F_FRAME_INIT, np.array([self.idx_init], dtype=np.int32))
+
+    # ---- reference API -------------------------------------------------------------------------------------
+    def load_mocap(self, filepath):
+        self.mocap.load_mocap(filepath)
+        self.mocap_dt = self.mocap.dt
+        self.mocap_data_len = len(self.mocap.data)
+        if self._batch is not None:
+            self._batch.close()
+        self._batch = self._batch_factory(self._cm, self.mocap.data_config, self.mocap.data_vel, 1, float(self.mocap_dt))
+        self._batch.set_option(A.OPT_REWARD_MODE, self._reward_mode)
+        if hasattr(self, "sim"):
+            self.sim = _SimView(self); self.data = self.sim.data
+
+    def _get_obs(self):
+        return self._batch.get_obs()[0].copy()
+
+    def reference_state_init(self):
+        self.idx_init = random.randint(0, self.mocap_data_len - 1)
+        self.idx_curr = self.idx_init
+        self.idx_tmp_count = 0
+
+    def early_termination(self):
+        pass
+
+    def get_joint_configs(self):
+        return self.sim.data.qpos[7:]
+
+    def calc_config_errs(self, env_config, mocap_config):
+        assert len(env_config) == len(mocap_config)
+        return np.sum(np.abs(env_config - mocap_config))
+
+    def calc_config_reward(self):
+        assert len(self.mocap.data) != 0
+        target_config = self.mocap.data_config[self.idx_curr][7:]
+        self.curr_frame = target_config
+        err_configs = self.calc_config_errs(self.get_joint_configs(), target_config)
+        reward_config = math.exp(-err_configs)
+        self.idx_curr += 1
+        self.idx_curr = self.idx_curr % self.mocap_data_len
+        return reward_config
+
+    def do_simulation(self, ctrl, n_frames):
+        a = np.ascontiguousarray(np.asarray(ctrl, dtype=np.float64).reshape(1, self._cm.nu))
+        return self._batch.step(a, n_substeps=int(n_frames))
+
+    def step(self, action):
+        self.step_len = 1
+        if self._reward_mode != 0:
+            self._sync_frame_idx()
+        obs, rew, done = self.do_simulation(action, 1)
+        if self._reward_mode != 0:
+            self.idx_curr = int(self._batch.get(A.F_FRAME_IDX)[0])
+        return obs[0].copy(), float(rew[0]), bool(done[0]), dict()
+
+    def is_done(self):
+        z_com = float(self._batch.get(A.F_COM_Z)[0])
+        return bool((z_com < 0.7) or (z_com > 2.0))
+
+    def goto(self, pos):
+        self._batch.set_state(np.asarray(pos, dtype=np.float64).reshape(1, -1), self._batch.get(A.F_QVEL))
+
+    def get_time(self):
+        return self.sim.data.time
+
+    def set_state(self, qpos, qvel):
+        qpos = np.asarray(qpos, dtype=np.float64); qvel = np.asarray(qvel, dtype=np.float64)
+        assert qpos.shape == (self._cm.nq,) and qvel.shape == (self._cm.nv,)
+        self._batch.set_state(qpos.reshape(1, -1), qvel.reshape(1, -1))
+
+    def reset(self):
+        self._batch.reset(mode=2, hard=1)          # sim.reset()
+        return self.reset_model()
+
+    def reset_model(self):
+        self.reference_state_init()
+        qpos = self.mocap.data_config[self.idx_init]
+        qvel = self.mocap.data_vel[self.idx_init]
+        self.set_state(qpos, qvel)
+        observation = self._get_obs()
+        self.idx_tmp_count = -self.step_len
+        return observation
+
+    def reset_model_init(self):
+        c = 0.01
+        self.set_state(self.init_qpos + self.np_random.uniform(low=-c, high=c, size=self.model.nq),
+                       self.init_qvel + self.np_random.uniform(low=-c, high=c, size=self.model.nv))
+        return self._get_obs()
+
+
+class DPVecEnv(object):
+    """N DeepMimic humanoids in lock step on one GPU (one wavefront per environment)."""
+
+    def __init__(self, num_envs, motion="walk", xml_path=None, device=0, reward="alive", autoreset="rsi", seed=0,
+                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None):
+        self.num_envs = int(num_envs)
+        self.mocap = MocapDM()
+        self.mocap.load_mocap(motion)
+        self.mocap_dt = self.mocap.dt
+        self.mocap_data_len = len(self.mocap.data)
+        self._cm = _load_model(xml_path)
+        self.model = _ModelView(self._cm)
+        flags = (0 if contacts else A.FLAG_NO_CONTACT) | (0 if limits else A.FLAG_NO_LIMIT)
+        if batch_factory is None:
+            self._batch = Batch(self._cm, self.mocap.data_config, self.mocap.data_vel, self.num_envs, device=device,
+                                flags=flags, mocap_dt=float(self.mocap_dt))
+        else:
+            self._batch = batch_factory(self._cm, self.mocap.data_config, self.mocap.data_vel, self.num_envs, flags)
+        b = self._batch
+        b.set_option(A.OPT_REWARD_MODE, REWARD_MODES[reward])
+        b.set_option(A.OPT_AUTORESET, {"none": 0, None: 0, "rsi": 1, "init": 2}[autoreset])
+        b.set_option(A.OPT_ACTION_MODE, {"raw": 0, "p-control": 1}[action_mode])
+        b.set_option(A.OPT_SEED, int(seed))
+        b.set_option(A.OPT_ENV_OFFSET, int(env_offset))
+        cr = self._cm.actuator_ctrlrange
+        self.action_space = Box(low=cr[:, 0], high=cr[:, 1], dtype=np.float32)
+        self.observation_space = Box(low=-np.inf, high=np.inf, shape=(A.NOBS,), dtype=np.float32)
+        self._pending = None
+
+    @property
+    def batch(self):
+        return self._batch
+
+    def seed(self, seed):
+        self._batch.set_option(A.OPT_SEED, int(seed))
+
+    def reset(self, mode="rsi", out=None):
+        self._batch.reset(mode={"rsi": 0, "init": 1, "qpos0": 2}[mode], hard=1)
+        return self._batch.get_obs(out)
+
+    def step_async(self, actions):
+        self._pending = actions
+
+    def step_wait(self, out=None):
+        obs, rew, done = self._batch.step(self._pending, 1, out)
+        self._pending = None
+        return obs, rew, done, [{} for _ in range(0)]
+
+    def step(self, actions, out=None):
+        self.step_async(actions)
+        return self.step_wait(out)
+
+    def close(self):
+        self._batch.close()

@@ -334,7 +334,7 @@ int dmo_compile(const dmo_spec* sp, dmo_model* m) {
   m->s = *sp;
   const dmo_spec* s = &m->s;
   m->enable_contact = 1; m->enable_limit = 1;
-  m->pyramid_diag_mu2 = 1; m->pyramid_r_rescale = 1;
+  m->pyramid_diag_mu2 = 1; m->pyramid_r_rescale = 1; m->max_efc = DMO_MAXEFC;
   if (s->nbody > DMO_MAXBODY || s->njnt > DMO_MAXJNT || s->ngeom > DMO_MAXGEOM || s->nu > DMO_MAXU) return -1;
   /* address tables */
   int nq = 0, nv = 0;
@@ -660,7 +660,7 @@ static void make_constraint(const dmo_model* m, dmo_data* d) {
     double value = d->qpos[m->jnt_qposadr[j]];
     for (int side = -1; side <= 1; side += 2) {
       double dist = side * (s->jnt_range[j][(side + 1) / 2] - value);
-      if (dist < 0 && n < DMO_MAXEFC) { /* jnt_margin = 0 */
+      if (dist < 0 && n < m->max_efc) { /* jnt_margin = 0 */
         for (int k = 0; k < nv; k++) d->efc_J[n][k] = 0;
         d->efc_J[n][m->jnt_dofadr[j]] = -(double)side;
         d->efc_pos[n] = dist; d->efc_margin[n] = 0;
@@ -682,11 +682,11 @@ static void make_constraint(const dmo_model* m, dmo_data* d) {
     }
     double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
     if (c->dim == 1) {
-      if (n >= DMO_MAXEFC) break;
+      if (n >= m->max_efc) break;
       for (int k = 0; k < nv; k++) d->efc_J[n][k] = jc[0][k];
       d->efc_pos[n] = c->dist; d->efc_margin[n] = c->includemargin; d->efc_diagApprox[n] = tran; n++;
     } else {
-      if (n + 2 * (c->dim - 1) > DMO_MAXEFC) break;
+      if (n + 2 * (c->dim - 1) > m->max_efc) break;
       for (int t = 1; t < c->dim; t++) for (int sg = 0; sg < 2; sg++) {
         double mu = c->friction[t - 1];
         for (int k = 0; k < nv; k++) d->efc_J[n][k] = jc[0][k] + (sg == 0 ? mu : -mu) * jc[t][k];
@@ -975,6 +975,7 @@ int dmo_model_set(dmo_model* m, const char* field, double v) {
   if (!strcmp(field, "pyramid_diag_mu2")) { m->pyramid_diag_mu2 = (int)v; return 0; }
   if (!strcmp(field, "pyramid_r_rescale")) { m->pyramid_r_rescale = (int)v; return 0; }
   if (!strcmp(field, "iterations")) { m->s.iterations = (int)v; return 0; }
+  if (!strcmp(field, "max_efc")) { m->max_efc = (int)v > DMO_MAXEFC ? DMO_MAXEFC : (int)v; return 0; }
   if (!strcmp(field, "timestep")) { m->s.timestep = v; return 0; }
   if (!strcmp(field, "tolerance")) { m->s.tolerance = v; return 0; }
   if (!strcmp(field, "gravity_z")) { m->s.gravity[2] = v; return 0; }

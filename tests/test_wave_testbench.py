@@ -1,0 +1,86 @@
+"""The HIP kernel source (deepmimic_mujoco_amd/csrc/env_*.h), executed lane-for-lane on the fibre wave testbench
+(tests/emu), against the CPU oracle.  Runs in the GPU-less container; the same comparisons run on the real device
+in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from deepmimic_mujoco_amd import _abi as A
+from tests import helpers as H
+from tests.emu.emu import EmuBatch
+
+
+def make(n, flags=0):
+    mc = H.mocap()
+    return EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, flags)
+
+
+def test_forward_stages_match_oracle_on_testbench():
+    n = 12
+    worst = H.compare_forward(make(n), H.oracle_model(), *H.varied_states(n, seed=3))
+    assert max(worst.values()) < 1e-11
+
+
+def test_rollout_matches_oracle_on_testbench():
+    n = 6
+    idx, q, v, _w, _c = H.varied_states(n, seed=5)
+    worst, ndone = H.compare_rollout(make(n), H.oracle_model(), idx, q, v, steps=15, seed=1)
+    assert worst < 1e-10
+
+
+def test_no_contact_config_on_testbench():
+    n = 3
+    idx, q, v, _w, _c = H.varied_states(n, seed=7)
+    b = make(n, A.FLAG_NO_CONTACT | A.FLAG_NO_LIMIT)
+    H.compare_rollout(b, H.oracle_model(enable_contact=0, enable_limit=0), idx, q, v, steps=8, seed=2)
+    assert np.all(b.get(A.F_NEFC) == 0)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_reward_modes_on_testbench(mode):
+    n = 2
+    b = make(n)
+    b.set_option(A.OPT_REWARD_MODE, mode)
+    idx, q, v, _w, _c = H.varied_states(n, seed=11)
+    H.compare_rollout(b, H.oracle_model(), idx, q, v, steps=5, seed=3, reward_mode=mode)
+
+
+def test_row_capacity_overflow_is_reported_and_mirrors_oracle():
+    """A humanoid pressed flat into the floor produces more than 63 constraint rows: contacts past the on-chip capacity
+    are dropped in list order, status bit 0 is set, and the kept rows still match the oracle with the same cap."""
+    mc = H.mocap()
+    q = mc.data_config[0:1].copy(); v = np.zeros((1, 34))
+    q[0, 2] = 0.02; q[0, 3:7] = [np.sqrt(0.5), 0, np.sqrt(0.5), 0]; q[0, 7:] = 0.0
+    b = make(1)
+    ws = np.zeros((1, 34)); ctrl = np.zeros((1, 28))
+    H.compare_forward(b, H.oracle_model(), np.zeros(1, dtype=np.int32), q, v, ws, ctrl)
+    assert b.get(A.F_NEFC)[0] <= 63
+    if b.get(A.F_NCON)[0] * 4 > 63:
+        assert b.get(A.F_STATUS)[0] & 1
+
+
+def test_reset_and_autoreset_on_testbench():
+    n = 4
+    mc = H.mocap()
+    b = make(n)
+    b.set_option(A.OPT_SEED, 9)
+    b.reset(0, 1)
+    fi = b.get(A.F_FRAME_IDX)
+    assert np.array_equal(b.get(A.F_QPOS), mc.data_config[fi]) and np.array_equal(b.get(A.F_QVEL), mc.data_vel[fi])
+    assert np.all(b.get(A.F_EPISODE) == 1)
+    b2 = make(n); b2.set_option(A.OPT_SEED, 9); b2.set_option(A.OPT_ENV_OFFSET, 0); b2.reset(0, 1)
+    assert np.array_equal(b2.get(A.F_FRAME_IDX), fi), "reset RNG must be a pure function of (seed, env, episode)"
+    b3 = make(2); b3.set_option(A.OPT_SEED, 9); b3.set_option(A.OPT_ENV_OFFSET, 2); b3.reset(0, 1)
+    assert np.array_equal(b3.get(A.F_FRAME_IDX), fi[2:]), "sharding must not change per-env RNG streams"
+    b.reset(1, 1)
+    q = b.get(A.F_QPOS)
+    assert np.all(np.abs(q - H.compiled_model().qpos0) <= 0.01) and np.all(b.get(A.F_TIME) == 0)
+    # auto-reset: start below the termination height so the first step reports done and re-initialises
+    b.set_option(A.OPT_AUTORESET, 1)
+    qq = mc.data_config[[0, 1, 2, 3]].copy(); qq[:2, 2] = 0.3
+    b.set_state(qq, mc.data_vel[[0, 1, 2, 3]].copy())
+    obs, rew, done = b.step(np.zeros((n, 28)))
+    assert list(done[:2]) == [1, 1]
+    fi = b.get(A.F_FRAME_IDX)
+    for e in np.nonzero(done)[0]:
+        assert np.array_equal(b.get(A.F_QPOS)[e], mc.data_config[fi[e]]) and b.get(A.F_TIME)[e] == 0
+        assert np.array_equal(obs[e][:28], mc.data_config[fi[e]][7:])
