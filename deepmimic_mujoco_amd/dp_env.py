@@ -286,7 +286,7 @@ class DPVecEnv(object):
     def step_wait(self, out=None):
         obs, rew, done = self._batch.step(self._pending, 1, out)
         self._pending = None
-        return obs, rew, done, [{} for _ in range(0)]
+        return obs, rew, done, [{} for _ in range(self.num_envs)]
 
     def step(self, actions, out=None):
         self.step_async(actions)

@@ -1012,5 +1012,6 @@ int dmo_data_set(const dmo_model* m, dmo_data* d, const char* field, const doubl
   if (!strcmp(field, "ctrl")) { memcpy(d->ctrl, in, sizeof(double) * (n < m->s.nu ? n : m->s.nu)); return 0; }
   if (!strcmp(field, "qacc_warmstart")) { memcpy(d->qacc_warmstart, in, sizeof(double) * (n < m->nv ? n : m->nv)); return 0; }
   if (!strcmp(field, "time")) { d->time = in[0]; return 0; }
+  if (!strcmp(field, "xipos")) { memcpy(&d->xipos[0][0], in, sizeof(double) * (n < 3 * m->s.nbody ? n : 3 * m->s.nbody)); return 0; }
   return -1;
 }

@@ -59,7 +59,7 @@ class EmuBatch(object):
     def set(self, field, value):
         self._view(field)[...] = np.asarray(value).reshape(self._view(field).shape)
 
-    def step(self, action, n_substeps=1):
+    def step(self, action, n_substeps=1, out=None):
         a = np.ascontiguousarray(action, dtype=np.float64).reshape(self.n, A.NU)
         obs = np.zeros((self.n, A.NOBS)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.uint8)
         lib().emu_step(self.h, a.ctypes.data_as(A._dp), obs.ctypes.data_as(A._dp), rew.ctypes.data_as(A._dp),
@@ -78,6 +78,13 @@ class EmuBatch(object):
     def reset(self, mode=0, hard=1, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         lib().emu_reset(self.h, mode, hard, None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)))
+
+    def get_obs(self, out=None):
+        q = self.get(A.F_QPOS); v = self.get(A.F_QVEL)
+        return np.concatenate([q[:, 7:], v[:, 6:]], 1)
+
+    def close(self):
+        pass
 
     def debug_forward(self, env=0):
         buf = np.zeros(A.DEBUG_DOUBLES)

