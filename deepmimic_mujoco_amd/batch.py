@@ -60,6 +60,11 @@ class Batch(object):
                 raise ValueError("tensor must be contiguous %s of shape %s" % (want, shape))
             if x.device.type != "cuda" or (x.device.index or 0) != self.device:
                 raise ValueError("tensor must live on cuda:%d" % self.device)
+            # device buffers are ordered on the batch's stream: follow torch's current stream so that kernels producing
+            # the tensor (e.g. the policy, torch.randn) and our launch are serialised without extra synchronisation
+            cur = torch.cuda.current_stream(x.device).cuda_stream
+            if cur != getattr(self, "_stream_handle", None):
+                self.set_stream(cur)
             return C.c_void_p(x.data_ptr()), A.PTR_DEVICE, x
         a = x if out else np.ascontiguousarray(x, dtype=dtype)
         if a.dtype != dtype or not a.flags.c_contiguous or a.shape != tuple(shape):
@@ -71,6 +76,7 @@ class Batch(object):
 
     def set_stream(self, stream_handle):
         A.check(self._L.dm_batch_set_stream(self._h, C.c_void_p(int(stream_handle))), self._L)
+        self._stream_handle = int(stream_handle)
 
     # ---- the hot path -------------------------------------------------------------------------------
     def step(self, action, n_substeps=1, out=None):
@@ -142,6 +148,12 @@ class Batch(object):
         ms = C.c_float(0)
         A.check(self._L.dm_batch_last_step_ms(self._h, C.byref(ms)), self._L)
         return float(ms.value)
+
+    def read_profile(self):
+        """[N,8] int64 shader-clock cycles of the last step: kin, mass, bias, rows, constraint, total, nefc, sweeps."""
+        out = np.zeros((self.n, 16), dtype=np.int64)
+        A.check(self._L.dm_batch_read_profile(self._h, out.ctypes.data_as(C.POINTER(C.c_longlong))), self._L)
+        return out
 
     def sync(self):
         A.check(self._L.dm_batch_sync(self._h), self._L)

@@ -31,6 +31,17 @@ __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ 
   env_step(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
 }
 
+// same step with per-stage shader-clock accounting (DM_OPT 101); not used on the timed path
+__global__ __launch_bounds__(64) void k_step_prof(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ action,
+                                                  Real* __restrict__ obs, Real* __restrict__ reward, unsigned char* __restrict__ done,
+                                                  int n_substeps, long long* prof) {
+  __shared__ Shared<Real> s;
+  __shared__ StepScratch<Real> x;
+  const int env = blockIdx.x;
+  if (env >= B.n_envs) return;
+  env_step<Real, true>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps, prof);
+}
+
 __global__ __launch_bounds__(64) void k_set_state(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ qpos,
                                                   const Real* __restrict__ qvel, const int* __restrict__ frame_idx,
                                                   const unsigned char* __restrict__ mask) {
@@ -44,7 +55,7 @@ __global__ __launch_bounds__(64) void k_set_state(const DevModel<Real>* __restri
   if (frame_idx && lane == 0) { B.frame_idx[env] = frame_idx[env]; B.frame_init[env] = frame_idx[env]; }
   dmw::sync();
   store_state(B, s, env, lane);
-  forward(*Mp, s, lane, (const DebugOut*)0);   // sim.forward()
+  { const LaneTopo lt = lane_topo(lane); stage_tables(s, lane); dmw::sync(); forward(*Mp, s, lane, lt, (const DebugOut*)0); }   // sim.forward()
   store_derived(B, *Mp, s, env, lane);
 }
 
@@ -57,7 +68,7 @@ __global__ __launch_bounds__(64) void k_reset(const DevModel<Real>* __restrict__
   load_env(*Mp, B, s, env, lane, (const Real*)0);
   reset_env(*Mp, B, s, env, lane, mode, hard);
   store_state(B, s, env, lane);
-  forward(*Mp, s, lane, (const DebugOut*)0);
+  { const LaneTopo lt = lane_topo(lane); stage_tables(s, lane); dmw::sync(); forward(*Mp, s, lane, lt, (const DebugOut*)0); }
   store_derived(B, *Mp, s, env, lane);
 }
 
@@ -76,7 +87,7 @@ __global__ __launch_bounds__(64) void k_debug_forward(const DevModel<Real>* __re
   if (lane < NU) { const int d = lane + 6; s.act[d] = Mp->gear[d] * clampr(B.ctrl[(size_t)env * NU + lane], Mp->ctrl_lo[d], Mp->ctrl_hi[d]); }
   dmw::sync();
   DebugOut dbg{out};
-  forward(*Mp, s, lane, &dbg);
+  { const LaneTopo lt = lane_topo(lane); stage_tables(s, lane); dmw::sync(); forward(*Mp, s, lane, lt, &dbg); }
   store_derived(B, *Mp, s, env, lane);
 }
 
@@ -97,6 +108,7 @@ struct dm_batch {
   Real *d_action = nullptr, *d_obs = nullptr, *d_reward = nullptr; unsigned char *d_done = nullptr, *d_mask = nullptr;
   Real *d_qpos_in = nullptr, *d_qvel_in = nullptr; int* d_fidx_in = nullptr;
   double* d_debug = nullptr;
+  long long* d_prof = nullptr; bool prof = false;
   bool timing = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f; bool ev_pending = false;
 };
 
@@ -134,7 +146,7 @@ extern "C" void dm_batch_destroy(dm_batch* b) {
   if (b->stream) hipStreamSynchronize(b->stream);
   void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
                   b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
-                  b->d_reward, b->d_done, b->d_mask, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug};
+                  b->d_reward, b->d_done, b->d_mask, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof};
   for (void* p : ptrs) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
@@ -185,7 +197,8 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
 
 extern "C" int dm_batch_set_stream(dm_batch* b, void* s) {
   if (!b) return fail(DM_EINVAL, "null batch");
-  if (b->own_stream && b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
+  hipStreamSynchronize(b->stream);   /* keep ordering with work already queued on the previous stream */
+  if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
   b->stream = (hipStream_t)s; b->own_stream = false;
   return DM_OK;
 }
@@ -198,6 +211,10 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
     case DM_OPT_ACTION_MODE: if (v < 0 || v > 1) return fail(DM_EINVAL, "action mode must be 0..1"); b->B.action_mode = (int)v; break;
     case DM_OPT_SEED: b->B.seed = (unsigned long long)v; break;
     case 100: b->B.env_offset = (int)v; break;  /* global id of env 0 (multi-GPU sharding) */
+    case 101:                                   /* per-stage cycle profile on/off (diagnostic) */
+      b->prof = v != 0;
+      if (b->prof && !b->d_prof) { if (hipMalloc((void**)&b->d_prof, (size_t)b->n * 16 * sizeof(long long)) != hipSuccess) return fail(DM_ENOMEM, "prof alloc"); }
+      break;
     default: return fail(DM_EINVAL, "unknown option");
   }
   return DM_OK;
@@ -245,7 +262,8 @@ extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, dou
   Real* r = kind == DM_PTR_DEVICE ? reward : b->d_reward;
   unsigned char* dn = kind == DM_PTR_DEVICE ? done : b->d_done;
   if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } HIPCHK(hipEventRecord(b->ev0, b->stream)); }
-  hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub);
+  if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, b->d_prof);
+  else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub);
   HIPCHK(hipGetLastError());
   if (b->timing) { HIPCHK(hipEventRecord(b->ev1, b->stream)); b->ev_pending = true; }
   if (kind == DM_PTR_HOST) {
@@ -324,6 +342,12 @@ extern "C" int dm_batch_debug_forward(dm_batch* b, int32_t env, double* out_host
   return DM_OK;
 }
 
+extern "C" int dm_batch_read_profile(dm_batch* b, long long* out_host) {   /* [N,8]: kin, mass, bias, rows, constraint, total, nefc, iters */
+  if (!b || !out_host || !b->d_prof) return fail(DM_EINVAL, "profile not enabled");
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out_host, b->d_prof, (size_t)b->n * 16 * sizeof(long long), hipMemcpyDeviceToHost));
+  return DM_OK;
+}
 extern "C" int dm_batch_enable_timing(dm_batch* b, int32_t on) { if (!b) return fail(DM_EINVAL, "null batch"); b->timing = on != 0; b->ev_pending = false; return DM_OK; }
 extern "C" int dm_batch_last_step_ms(dm_batch* b, float* ms) {
   if (!b || !ms) return fail(DM_EINVAL, "null argument");

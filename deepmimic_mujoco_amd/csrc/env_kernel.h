@@ -75,7 +75,31 @@ struct Shared {
   int rowi[MAXEFC];    // type | b1<<8 | b2<<16   (limit: type | dof<<8)
   int cong[MAXEFC][2]; // contact geom ids
   int nefc, ncon, status, solver_iter;
+  // static index tables staged from the compile-time topology once per kernel (LDS lookups instead of global loads)
+  unsigned short tab_dst[NV][14];   // tab_dst[k][a] = madr[anc_a(k)]: first stored entry of the row of k's a-th ancestor
+  unsigned short tab_ent[312];      // entry e of the sparse M -> (i << 8) | j
 };
+
+// per-lane topology constants, read once per kernel
+struct LaneTopo {
+  int parent, dofadr, dofnum, depth;
+  unsigned subtree;
+};
+DM_DEV LaneTopo lane_topo(int lane) {
+  LaneTopo t;
+  const int b = lane < NB - 1 ? lane + 1 : 0;
+  t.parent = TOPO.body_parent[b]; t.dofadr = TOPO.body_dofadr[b]; t.dofnum = TOPO.body_dofnum[b];
+  t.depth = lane < NB - 1 ? TOPO.body_depth[b] : 0; t.subtree = TOPO.subtree[b];
+  return t;
+}
+template <class R>
+DM_DEV void stage_tables(Shared<R>& s, int lane) {
+  for (int e = lane; e < TOPO.nM; e += 64) s.tab_ent[e] = (unsigned short)((TOPO.ent_i[e] << 8) | TOPO.ent_j[e]);
+  for (int t = lane; t < NV * 14; t += 64) {
+    const int k = t / 14, a = t % 14, i = TOPO.dof_anc[k][a];
+    s.tab_dst[k][a] = (unsigned short)(i >= 0 ? TOPO.madr[i] : 0);
+  }
+}
 
 // optional dump of one forward evaluation (parity tests)
 struct DebugOut {
@@ -188,10 +212,10 @@ template <class R> DM_DEV void solve_L(R* x, const R* qLD) {  // x <- L^-1 x
 // ---------------------------------------------------------------------------------------------------------
 // position stage: kinematics, geom poses, motion axes, spatial inertias   [MJ mj_kinematics, mj_comPos]
 template <class R>
-DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane) {
+DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) {
   const int b = lane + 1;
   const bool isbody = lane < NB - 1;
-  const int depth = isbody ? TOPO.body_depth[b] : 0;
+  const int depth = lt.depth;
   if (lane == 0) {
     s.xpos[0][0] = s.xpos[0][1] = s.xpos[0][2] = 0; s.xipos[0][0] = s.xipos[0][1] = s.xipos[0][2] = 0;
     s.xquat[0][0] = 1; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0;
@@ -200,13 +224,13 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane) {
   for (int L = 1; L <= MAXDEPTH_BODY; L++) {
     if (isbody && depth == L) {
       R xp[3], q[4], mat[9];
-      const int da = TOPO.body_dofadr[b], nd = TOPO.body_dofnum[b];
+      const int da = lt.dofadr, nd = lt.dofnum;
       if (b == 1) {
         xp[0] = s.qpos[0]; xp[1] = s.qpos[1]; xp[2] = s.qpos[2];
         q[0] = s.qpos[3]; q[1] = s.qpos[4]; q[2] = s.qpos[5]; q[3] = s.qpos[6];
         normalize4(q);
       } else {
-        const int p = TOPO.body_parent[b];
+        const int p = lt.parent;
         R v[3];
         mat_vec(v, s.xmat[p], M.body_pos[b]);
         xp[0] = s.xpos[p][0] + v[0]; xp[1] = s.xpos[p][1] + v[1]; xp[2] = s.xpos[p][2] + v[2];
@@ -267,7 +291,7 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane) {
   if (isbody) {
     R acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0;
-    const unsigned msk = TOPO.subtree[b];
+    const unsigned msk = lt.subtree;
     for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int k = 0; k < 10; k++) acc[k] += s.sin[c][k];
     for (int k = 0; k < 10; k++) s.crb[b][k] = acc[k];
   }
@@ -275,6 +299,36 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane) {
 }
 
 // mass matrix (tree-sparse, MuJoCo qM order) and its L^T D L factor   [MJ mj_crb, mj_factorM]
+template <int K, class R>
+DM_DEV void eliminate_dof(Shared<R>& s, int lane) {
+  // column K of the elimination: for every ancestor pair (a, c), row i = anc_a(K):
+  //   M(i, anc_c(i)) -= M(K, anc_{a+c}(K)) * M(K, i) / M(K, K)
+  // Row K itself is left unscaled (nothing reads it again during the factorisation); all rows are scaled at the end.
+  constexpr int nk = TOPO.dof_depth[K] - 1;   // proper ancestors
+  constexpr int base = TOPO.madr[K];
+  if (nk > 0) {
+    const R inv = R(1) / s.qLD[base];
+#pragma unroll
+    for (int t0 = 0; t0 < nk * nk; t0 += 64) {
+      const int t = t0 + lane;
+      const int a = t / nk + 1, c = t % nk;
+      if (t < nk * nk && c <= nk - a) {
+        const int dst = s.tab_dst[K][a] + c;
+        s.qLD[dst] -= s.qLD[base + a + c] * (s.qLD[base + a] * inv);
+      }
+    }
+    dmw::sync();
+  }
+}
+template <int K, class R>
+struct EliminateFrom {
+  static DM_DEV void run(Shared<R>& s, int lane) { eliminate_dof<K>(s, lane); EliminateFrom<K - 1, R>::run(s, lane); }
+};
+template <class R>
+struct EliminateFrom<0, R> {
+  static DM_DEV void run(Shared<R>&, int) {}
+};
+
 template <class R>
 DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg) {
   if (lane < NV) {
@@ -284,44 +338,30 @@ DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane, cons
   }
   dmw::sync();
   for (int e = lane; e < TOPO.nM; e += 64) {
-    const int i = TOPO.ent_i[e], j = TOPO.ent_j[e];
+    const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
     R v = dot6(s.cdof[j], s.u.fdof[i]);
     if (i == j) v += M.dof_armature[i];
     s.qLD[e] = v;
     if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
   }
   dmw::sync();
-  // elimination, one dof k per step (last to first); lanes over the rank-1 update pairs (a, c):
-  //   row i = anc_a(k):  M(i, anc_c(i)) -= M(k, anc_{a+c}(k)) * M(k, i) / M(k, k)
-  for (int k = NV - 1; k >= 0; k--) {
-    const int nk = TOPO.dof_depth[k] - 1;  // proper ancestors (wave-uniform)
-    const int base = TOPO.madr[k];
-    const R mkk = s.qLD[base];
-    const R inv = R(1) / mkk;
-    if (nk > 0) {
-      const int npairs = nk * (nk + 1) / 2;
-      for (int t = lane; t < npairs; t += 64) {
-        // t -> (a, c), a = 1..nk, c = 0..nk-a : rows of lengths nk, nk-1, ..., 1
-        int a = 1, rem = t;
-        while (rem >= nk - a + 1) { rem -= nk - a + 1; a++; }
-        const int c = rem;
-        const int i = TOPO.dof_anc[k][a];
-        s.qLD[TOPO.madr[i] + c] -= s.qLD[base + a + c] * (s.qLD[base + a] * inv);
-      }
-      dmw::sync();
-      if (lane >= 1 && lane <= nk) s.qLD[base + lane] *= inv;
-    }
-    if (lane == 0) { s.dinv[k] = inv; s.dsq[k] = sqrt(inv); }
-    dmw::sync();
+  EliminateFrom<NV - 1, R>::run(s, lane);      // dofs 33 .. 1, one barrier each (fully unrolled, compile-time shapes)
+  // D^-1, D^-1/2 and the unit-triangular scaling L(k, j) = M(k, j) / D_k, all entries at once
+  if (lane < NV) { const R inv = R(1) / s.qLD[TOPO.madr[lane]]; s.dinv[lane] = inv; s.dsq[lane] = sqrt(inv); }
+  dmw::sync();
+  for (int e = lane; e < TOPO.nM; e += 64) {
+    const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
+    if (i != j) s.qLD[e] *= s.dinv[i];
   }
+  dmw::sync();
 }
 
 // velocity stage: bias forces C(q, v) incl. gravity; smooth generalized force   [MJ mj_comVel, mj_rne, mj_passive]
 template <class R>
-DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane) {
+DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) {
   const int b = lane + 1;
   const bool isbody = lane < NB - 1;
-  const int depth = isbody ? TOPO.body_depth[b] : 0;
+  const int depth = lt.depth;
   if (lane == 0) {
     for (int r = 0; r < 6; r++) { s.u.v.cvel[0][r] = 0; s.u.v.cacc[0][r] = 0; }
     s.u.v.cacc[0][3] = -M.gravity[0]; s.u.v.cacc[0][4] = -M.gravity[1]; s.u.v.cacc[0][5] = -M.gravity[2];
@@ -329,7 +369,7 @@ DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane) {
   dmw::sync();
   for (int L = 1; L <= MAXDEPTH_BODY; L++) {
     if (isbody && depth == L) {
-      const int p = TOPO.body_parent[b], da = TOPO.body_dofadr[b], nd = TOPO.body_dofnum[b];
+      const int p = lt.parent, da = lt.dofadr, nd = lt.dofnum;
       R v[6], a[6];
       for (int r = 0; r < 6; r++) { v[r] = s.u.v.cvel[p][r]; a[r] = s.u.v.cacc[p][r]; }
       if (b == 1) {
@@ -357,7 +397,7 @@ DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane) {
   }
   if (isbody) {
     R acc[6] = {0, 0, 0, 0, 0, 0};
-    const unsigned msk = TOPO.subtree[b];
+    const unsigned msk = lt.subtree;
     for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int r = 0; r < 6; r++) acc[r] += s.u.v.cfrc[c][r];
     for (int r = 0; r < 6; r++) s.u.v.csub[b][r] = acc[r];
   }
@@ -540,13 +580,14 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane) {
   // ---- contacts: lanes over candidate pairs, two passes of 64
   int ncon = 0, firstdrop = 1 << 20;
   if (M.enable_contact) {
-    for (int pass = 0; pass * 64 < M.npair; pass++) {
+    const int npair = dmw::uniform(M.npair);
+    for (int pass = 0; pass * 64 < npair; pass++) {
       const int pidx = pass * 64 + lane;
       PairContacts<R> pc;
       pc.n = 0;
       int g1 = 0, g2 = 0, dim = 1;
       R margin = 0, mu = 0;
-      if (pidx < M.npair) {
+      if (pidx < npair) {
         g1 = M.pair_g1[pidx]; g2 = M.pair_g2[pidx];
         margin = fmax(M.geom_margin[g1], M.geom_margin[g2]);
         // bounding-sphere rejection (conservative; [MJ mj_collideGeoms] does the same before the narrow phase)
@@ -658,9 +699,12 @@ DM_DEV void reduce_and_backsolve(Shared<R>& s, int lane, const R* y, R fsel, R* 
 // constraint solve.  Lane r < nefc owns constraint row r; lane 63 carries the smooth force tau through the same
 // half solve, so that  qacc = L^-1 D^-1/2 ( y_tau + sum_r f_r Y_r )  needs a single back-substitution.
 //   [MJ mj_fwdAcceleration, mj_projectConstraint, mj_fwdConstraint (warmstart, mj_solPGS)]
-template <class R>
-DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg) {
-  const int nefc = s.nefc;            // <= MAXEFC - 1 = 63
+template <class R, bool PROF = false>
+DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg, long long* prof = 0) {
+  long long pt0 = 0, pt1 = 0;
+  if (PROF) pt0 = dmw::clk();
+#define DM_STAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
+  const int nefc = dmw::uniform(s.nefc);   // <= MAXEFC - 1 = 63; in an SGPR so that the row loops branch scalar
   const bool active = lane < nefc;
   const bool taulane = lane == 63;
   R y[NV];
@@ -698,6 +742,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
 #pragma unroll
       for (int d = 0; d < NV; d++) o[d] = (double)y[d];
     }
+    DM_STAMP(8)
     const R imp = impedance(M.solimp, pos - margin);
     Rr = fmax(R(DM_MINVAL), (1 - imp) * dA / imp);
     if (rscale != R(1)) Rr = fmax(R(DM_MINVAL), rscale * Rr);
@@ -709,6 +754,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
 #pragma unroll
     for (int d = 0; d < NV; d++) y[d] *= s.dsq[d];
   }
+  DM_STAMP(9)
   if (lane == 0) s.solver_iter = 0;
   int iter = 0;
   if (nefc > 0) {
@@ -755,37 +801,53 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
       }
     }
     const R dinvr = R(1) / diag;
+    DM_STAMP(10)
     // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ------------------------------
     R res = bb;  // residual r_j = b_j + sum_i A_ji f_i, maintained incrementally
 #pragma unroll
-    for (int i = 0; i < MAXEFC; i++) {
-      if (i < nefc) res += AR[i] * dmw::bcast(f, i);
+    for (int blk = 0; blk < MAXEFC / 8; blk++) {
+      if (blk * 8 < nefc) {
+#pragma unroll
+        for (int ii = 0; ii < 8; ii++) {
+          const int i = blk * 8 + ii;
+          if (i < nefc) res += AR[i] * dmw::bcast(f, i);
+        }
+      }
     }
     {
       const R cost = dmw::wave_sum(active ? f * (R(0.5) * (res - bb) + bb) : R(0));
       if (cost > 0) { f = 0; res = bb; }
     }
+    DM_STAMP(11)
     // ---- projected Gauss-Seidel, rows in order; one broadcast + one FMA per row -----------------------------
-    while (iter < M.iterations) {
+    const int maxiter = dmw::uniform(M.iterations);
+    while (iter < maxiter) {
       R myimp = 0;
 #pragma unroll
-      for (int i = 0; i < MAXEFC; i++) {
-        if (i < nefc) {
-          // every lane evaluates its own candidate update; only lane i's is taken
-          R fn = f - res * dinvr;
-          fn = fn < 0 ? R(0) : fn;
-          R delta = fn - f;
-          R change = delta * (R(0.5) * delta * diag + res);
-          if (change > R(1e-10)) { delta = 0; change = 0; }
-          const R di = dmw::bcast(delta, i);
-          if (lane == i) { f += delta; myimp -= change; }
-          res += AR[i] * di;
+      for (int blk = 0; blk < MAXEFC / 8; blk++) {
+        if (blk * 8 < nefc) {          // scalar branch per block of 8 rows; rows past nefc cost one scalar compare each
+#pragma unroll
+          for (int ii = 0; ii < 8; ii++) {
+            const int i = blk * 8 + ii;
+            if (i < nefc) {
+              // every lane evaluates its own candidate update; only lane i's is taken
+              R fn = f - res * dinvr;
+              fn = fn < 0 ? R(0) : fn;
+              R delta = fn - f;
+              R change = delta * (R(0.5) * delta * diag + res);
+              if (change > R(1e-10)) { delta = 0; change = 0; }
+              const R di = dmw::bcast(delta, i);
+              if (lane == i) { f += delta; myimp -= change; }
+              res += AR[i] * di;
+            }
+          }
         }
       }
       const R improvement = dmw::wave_sum(active ? myimp : R(0)) * M.pgs_scale;
       iter++;
-      if (improvement < M.tolerance) break;
+      if (dmw::uniform(improvement < M.tolerance)) break;
     }
+    DM_STAMP(12)
     if (dbg && active) {
       double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + lane * (34 + 6) + 34;
       o[0] = (double)pos; o[1] = (double)margin; o[2] = (double)Rr; o[3] = (double)aref; o[4] = (double)bb; o[5] = (double)f;
@@ -800,6 +862,8 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
 #pragma unroll
     for (int d = 0; d < NV; d++) s.qacc[d] = acc_out[d];
   }
+  DM_STAMP(13)
+#undef DM_STAMP
   if (dbg) {   // qacc_smooth for the stage-by-stage parity dump (debug kernel only)
     R sm[NV];
     reduce_and_backsolve(s, lane, y, taulane ? R(1) : R(0), sm);
@@ -812,18 +876,26 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
 }
 
 // one forward-dynamics evaluation: s.qpos, s.qvel, s.act, s.qws  ->  s.qacc (+ s.xipos, contact bookkeeping)
-template <class R>
-DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg) {
-  stage_kinematics(M, s, lane);
+// PROF: accumulate shader-clock cycles per stage into prof[0..4] (profiling kernel only).
+template <class R, bool PROF = false>
+DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt, const DebugOut* dbg, long long* prof = 0) {
+  long long t0 = 0, t1 = 0;
+  if (PROF) t0 = dmw::clk();
+  stage_kinematics(M, s, lane, lt);
+  if (PROF) { t1 = dmw::clk(); prof[0] += t1 - t0; t0 = t1; }
   if (dbg) { for (int e = lane; e < NV * NV; e += 64) dbg->out[e] = 0; dmw::sync(); }
   stage_mass_matrix(M, s, lane, dbg);
-  stage_bias(M, s, lane);
+  if (PROF) { t1 = dmw::clk(); prof[1] += t1 - t0; t0 = t1; }
+  stage_bias(M, s, lane, lt);
+  if (PROF) { t1 = dmw::clk(); prof[2] += t1 - t0; t0 = t1; }
   if (dbg && lane < NV) {
     const double bias = (double)(-M.dof_damping[lane] * s.qvel[lane] + s.act[lane] - s.tau[lane]);
     dbg->out[34 * 34 + lane] = bias;
   }
   stage_rows(M, s, lane);
-  stage_constraint(M, s, lane, dbg);
+  if (PROF) { t1 = dmw::clk(); prof[3] += t1 - t0; t0 = t1; }
+  stage_constraint<R, PROF>(M, s, lane, dbg, prof);
+  if (PROF) { t1 = dmw::clk(); prof[4] += t1 - t0; t0 = t1; }
   if (dbg) {
     if (lane < NV) dbg->out[34 * 34 + 68 + lane] = (double)s.qacc[lane];
     if (lane < NB * 3) dbg->out[34 * 34 + 102 + lane] = (double)s.xipos[lane / 3][lane % 3];

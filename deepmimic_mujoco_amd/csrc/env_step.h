@@ -69,8 +69,8 @@ struct StepScratch {
 
 // [MJ mj_step, integrator RK4] on the state in s.qpos / s.qvel / s.qws / s.act.  Returns with the new state in
 // s.qpos / s.qvel / s.qws and the derived quantities of the 4th stage evaluation in `s` (as sim.data after sim.step()).
-template <class R>
-DM_DEV void rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int lane) {
+template <class R, bool PROF = false>
+DM_DEV void rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int lane, const LaneTopo& lt, long long* prof = 0) {
   const R h = M.timestep;
   const R A[3] = {R(0.5), R(0.5), R(1)};
   const R Bw[4] = {R(1) / 6, R(1) / 3, R(1) / 3, R(1) / 6};
@@ -88,7 +88,7 @@ DM_DEV void rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int 
       if (lane < NV) { vprev = v0 + h * (c * aprev); s.qvel[lane] = vprev; }
       dmw::sync();
     }
-    forward(M, s, lane, (const DebugOut*)0);
+    forward<R, PROF>(M, s, lane, lt, (const DebugOut*)0, prof);
     if (lane < NV) { aprev = s.qacc[lane]; sumv += Bw[i] * vprev; suma += Bw[i] * aprev; }
   }
   if (lane < NV) s.tau[lane] = sumv;
@@ -172,11 +172,16 @@ DM_DEV void reset_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int
 }
 
 // DPEnv.step for one environment
-template <class R>
+template <class R, bool PROF = false>
 DM_DEV void env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, StepScratch<R>& x, int env, int lane,
-                     const R* action, R* obs, R* reward, unsigned char* done, int n_substeps) {
+                     const R* action, R* obs, R* reward, unsigned char* done, int n_substeps, long long* prof_out = 0) {
+  long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tstart = 0;
+  if (PROF) tstart = dmw::clk();
+  const LaneTopo lt = lane_topo(lane);
+  stage_tables(s, lane);
   load_env(M, B, s, env, lane, action);
-  for (int k = 0; k < n_substeps; k++) rk4_step(M, s, x, lane);   // do_simulation(action, n)
+  for (int k = 0; k < n_substeps; k++) rk4_step<R, PROF>(M, s, x, lane, lt, prof);   // do_simulation(action, n)
   const R z = com_z(M, s);
   const bool dn = (z < R(0.7)) || (z > R(2.0));
   // reward
@@ -208,6 +213,11 @@ DM_DEV void env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
   if (lane < 28) obs[(size_t)env * NOBS + lane] = s.qpos[7 + lane];
   else if (lane < NOBS) obs[(size_t)env * NOBS + lane] = s.qvel[6 + (lane - 28)];
   store_state(B, s, env, lane);
+  if (PROF && lane == 0) {
+    prof[5] = dmw::clk() - tstart;
+    prof[6] = s.nefc; prof[7] = s.solver_iter;
+    for (int k = 0; k < 16; k++) prof_out[(size_t)env * 16 + k] = prof[k];
+  }
 }
 
 }  // namespace dm

@@ -39,6 +39,12 @@ DM_DEV double bcast(double v, int src) {
 }
 DM_DEV float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 DM_DEV int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// assert wave-uniformity to the compiler: the value moves to an SGPR, so loops / branches on it are scalar
+// (s_cmp + s_cbranch) instead of exec-masked.  Only for values that ARE identical in all lanes.
+DM_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+DM_DEV bool uniform(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+// shader clock (s_memtime), for the optional per-stage profile
+DM_DEV long long clk() { return (long long)__builtin_readcyclecounter(); }
 // compiler scheduling fence: nothing moves across it (no instruction is emitted)
 DM_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // compiler-only memory fence: values loaded from LDS before it are not kept live / reused after it.

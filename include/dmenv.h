@@ -161,6 +161,10 @@ int dm_batch_debug_forward(dm_batch* b, int32_t env, double* out_host);
 int dm_batch_last_step_ms(dm_batch* b, float* ms);
 int dm_batch_enable_timing(dm_batch* b, int32_t on);
 
+/* diagnostic: per-env shader-clock cycles of the last step by stage (enable with dm_batch_set_option(b, 101, 1)):
+ * out [N,8] int64 = kinematics, mass matrix+factor, bias, rows(collision), constraint, whole step, nefc, PGS sweeps */
+int dm_batch_read_profile(dm_batch* b, long long* out_host);
+
 int dm_batch_sync(dm_batch* b);
 const char* dm_last_error(void);
 int dm_abi_version(void);

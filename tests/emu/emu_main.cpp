@@ -118,7 +118,7 @@ void emu_set_state(void* h, const double* qpos, const double* qvel, const int* f
       if (fidx && lane == 0) { e->B.frame_idx[env] = fidx[env]; e->B.frame_init[env] = fidx[env]; }
       dmw::sync();
       store_state(e->B, e->sh, env, lane);
-      forward(e->M, e->sh, lane, (const DebugOut*)0);
+      { const LaneTopo lt = lane_topo(lane); stage_tables(e->sh, lane); dmw::sync(); forward(e->M, e->sh, lane, lt, (const DebugOut*)0); }
       store_derived(e->B, e->M, e->sh, env, lane);
     });
   }
@@ -131,7 +131,7 @@ void emu_reset(void* h, int mode, int hard, const unsigned char* mask) {
       load_env(e->M, e->B, e->sh, env, lane, (const double*)0);
       reset_env(e->M, e->B, e->sh, env, lane, mode, hard);
       store_state(e->B, e->sh, env, lane);
-      forward(e->M, e->sh, lane, (const DebugOut*)0);
+      { const LaneTopo lt = lane_topo(lane); stage_tables(e->sh, lane); dmw::sync(); forward(e->M, e->sh, lane, lt, (const DebugOut*)0); }
       store_derived(e->B, e->M, e->sh, env, lane);
     });
   }
@@ -144,7 +144,7 @@ void emu_debug_forward(void* h, int env, double* out) {
     if (lane < NU) { const int d = lane + 6; e->sh.act[d] = e->M.gear[d] * clampr(e->B.ctrl[(size_t)env * NU + lane], e->M.ctrl_lo[d], e->M.ctrl_hi[d]); }
     dmw::sync();
     DebugOut dbg{out};
-    forward(e->M, e->sh, lane, &dbg);
+    { const LaneTopo lt = lane_topo(lane); stage_tables(e->sh, lane); dmw::sync(); forward(e->M, e->sh, lane, lt, &dbg); }
     store_derived(e->B, e->M, e->sh, env, lane);
   });
 }

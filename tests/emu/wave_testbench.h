@@ -63,6 +63,9 @@ inline int shfl_up_i(int v, int d) { const int l = lane(); return exchange(v, l 
 inline double bcast(double v, int src) { return exchange(v, src); }
 inline float bcast(float v, int src) { return exchange(v, src); }
 inline int bcast_i(int v, int src) { return exchange(v, src); }
+inline long long clk() { return 0; }
+inline int uniform(int v) { return v; }
+inline bool uniform(bool v) { return v; }
 inline void sched_fence() {}
 inline void reload_fence() {}
 inline int pin_zero() { return 0; }

@@ -1,0 +1,39 @@
+"""Diagnostic: per-stage shader-clock profile of k_step on the GPU (uses DM_OPT 101)."""
+import os
+import sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from deepmimic_mujoco_amd import DPVecEnv, _abi as A
+
+for wl in ("cfg3", "cfg2"):
+    full = wl == "cfg3"
+    n = 4096
+    env = DPVecEnv(n, motion="walk", device=0, reward="v3-config" if full else "alive", autoreset="rsi", seed=0,
+                   contacts=full, limits=full, action_mode="raw" if full else "p-control")
+    env.reset("rsi")
+    rng = np.random.RandomState(0)
+    for t in range(40):
+        env.step(rng.randn(n, 28) * (0.9 if full else 0.0))
+    env.batch.set_option(101, 1)
+    acc = np.zeros(6); nefc = []; its = []
+    K = 5
+    for t in range(K):
+        env.step(rng.randn(n, 28) * (0.9 if full else 0.0))
+        p = env.batch.read_profile()
+        acc += p[:, :6].mean(0); nefc.append(p[:, 6].mean()); its.append(p[:, 7].mean())
+    acc /= K
+    names = ["kinematics", "mass+factor", "bias(RNE)", "rows(collision)", "constraint", "total step"]
+    print(wl, "mean cycles per env-step (4 evaluations):")
+    for nme, v in zip(names, acc):
+        print("   %-16s %10.0f  (%.1f%%)" % (nme, v, 100 * v / acc[5]))
+    print("   mean nefc(last eval) %.2f  mean PGS sweeps %.2f" % (np.mean(nefc), np.mean(its)))
+    p = env.batch.read_profile()
+    sub = ["y-build", "half-solve(+imp)", "b + A build", "warm start", "PGS", "reduce+backsolve"]
+    for k, nme in enumerate(sub):
+        print("      constraint/%-18s %9.0f" % (nme, p[:, 8 + k].mean()))
+    for lo, hi in [(0, 1), (1, 8), (8, 16), (16, 32), (32, 64)]:
+        m = (p[:, 6] >= lo) & (p[:, 6] < hi)
+        if m.any():
+            print("   nefc [%d,%d): %5d envs, constraint %8.0f rows %8.0f total %8.0f | sweeps %.1f ybuild %6.0f half %6.0f A %6.0f ws %6.0f pgs %7.0f fin %6.0f" % (
+                lo, hi, m.sum(), p[m, 4].mean(), p[m, 3].mean(), p[m, 5].mean(), p[m, 7].mean(), *[p[m, 8 + k].mean() for k in range(6)]))
+    env.close()
