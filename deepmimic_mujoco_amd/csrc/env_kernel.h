@@ -55,23 +55,31 @@ struct DevModel {
   int iterations, enable_contact, enable_limit;
 };
 
-// per-wave LDS working set
+// per-wave LDS working set.  Regions whose lifetimes do not overlap inside one forward evaluation share storage:
+//   ua: body quaternions (kinematics only)            | smooth force / y_tau / qacc (bias .. constraint, RK driver)
+//   ub: spatial inertias (kinematics .. bias)          | geom world poses (collision)
+//   u : M-build scratch | RNE scratch | row descriptors (collision -> row registers) | broadcast / reduce buffers
 template <class R>
 struct Shared {
   R qpos[36], qvel[NV], act[NV], qws[NV];
-  R xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3];
+  R xpos[NB][3], xmat[NB][9], xipos[NB][3];
   R cdof[NV][6];
-  R sin[NB][10], crb[NB][10];
   R qLD[312], dinv[NV], dsq[NV];
-  R tau[NV], qaccs[NV], qacc[NV];
-  R gpos[NG][3], gmat[NG][9];
+  union {
+    R xquat[NB][4];
+    struct { R tau[NV], qaccs[NV], qacc[NV]; } f;
+  } ua;
+  union {
+    struct { R sin[NB][10], crb[NB][10]; } i;
+    struct { R gpos[NG][3], gmat[NG][9]; } g;
+  } ub;
   union {
     R fdof[NV][6];
     struct { R cvel[NB][6], cacc[NB][6], cfrc[NB][6], csub[NB][6]; } v;
+    R rowd[MAXEFC][10];  // w[6], dist, margin, dA, rscale
     R ybuf[16][NV];
-    R tbuf[8][65];
+    struct { R rowf[MAXEFC][6], G[NB][6], Gsub[NB][6]; } c;   // constraint forces as body wrenches (end of the solve)
   } u;
-  R rowd[MAXEFC][10];  // w[6], dist, margin, dA, rscale
   int rowi[MAXEFC];    // type | b1<<8 | b2<<16   (limit: type | dof<<8)
   int cong[MAXEFC][2]; // contact geom ids
   int nefc, ncon, status, solver_iter;
@@ -180,33 +188,53 @@ template <class R> DM_DEV void sinert_mul(R* f, const R* S, const R* v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// tree-sparse L^T D L solves with a vector held in registers (static indices once unrolled).
-// Factor entries are read from LDS at wave-uniform addresses (broadcast).
-template <class R> DM_DEV void solve_LT(R* x, const R* qLD) {  // x <- L^-T x
-  int z = 0;
+// tree-sparse L^T D L solves with a vector held in registers (static indices: everything below is unrolled at compile
+// time from TOPO).  Factor entries are read from LDS at wave-uniform addresses (broadcast).  The loops are software
+// pipelined by hand: the entries of the NEXT row are loaded while the current row is applied, and the order pins
+// (wave.h) keep the compiler from either hoisting all 310 loads to the top (>500 VGPRs) or issuing each load just
+// before its use (every LDS round trip exposed).
+template <int I, class R>
+DM_DEV void load_factor_row(R* dst, const R* qLD) {
+  if constexpr (I >= 0 && I < NV) {
 #pragma unroll
-  for (int i = NV - 1; i >= 0; i--) {
-    if ((i & 3) == 1) z = dmw::pin_zero();
-#pragma unroll
-    for (int a = 1; a < 16; a++) {
-      const int j = TOPO.dof_anc[i][a];
-      if (j >= 0) x[j] -= qLD[TOPO.madr[i] + a + z] * x[i];
-    }
-    if ((i & 3) == 2 && i > 0) dmw::pin_value(x[TOPO.dof_anc[i][1] >= 0 ? TOPO.dof_anc[i][1] : 0]);
+    for (int a = 1; a < 14; a++) if (TOPO.dof_anc[I][a] >= 0) dst[a] = qLD[TOPO.madr[I] + a];
   }
 }
-template <class R> DM_DEV void solve_L(R* x, const R* qLD) {  // x <- L^-1 x
-  int z = 0;
+template <int I, class R>
+struct SolveLTStep {   // x <- L^-T x, rows NV-1 .. 1:  x[anc] -= L(I, anc) * x[I]
+  static DM_DEV void run(R* x, const R* qLD, const R* cur) {
+    R nxt[14];
+    load_factor_row<I - 1>(nxt, qLD + dmw::pin_zero());
+    dmw::sched_fence();
 #pragma unroll
-  for (int i = 0; i < NV; i++) {
-    if ((i & 3) == 0) z = dmw::pin_zero();
-#pragma unroll
-    for (int a = 1; a < 16; a++) {
-      const int j = TOPO.dof_anc[i][a];
-      if (j >= 0) x[i] -= qLD[TOPO.madr[i] + a + z] * x[j];
-    }
-    if ((i & 3) == 3) dmw::pin_value(x[i]);
+    for (int a = 1; a < 14; a++) { const int j = TOPO.dof_anc[I][a]; if (j >= 0) x[j] -= cur[a] * x[I]; }
+    dmw::pin_value(x[TOPO.dof_anc[I][1]]);
+    SolveLTStep<I - 1, R>::run(x, qLD, nxt);
   }
+};
+template <class R> struct SolveLTStep<0, R> { static DM_DEV void run(R*, const R*, const R*) {} };
+template <class R> DM_DEV void solve_LT(R* x, const R* qLD) {
+  R cur[14];
+  load_factor_row<NV - 1>(cur, qLD + dmw::pin_zero());
+  SolveLTStep<NV - 1, R>::run(x, qLD, cur);
+}
+template <int I, class R>
+struct SolveLStep {    // x <- L^-1 x, rows 1 .. NV-1:  x[I] -= L(I, anc) * x[anc]
+  static DM_DEV void run(R* x, const R* qLD, const R* cur) {
+    R nxt[14];
+    load_factor_row<I + 1>(nxt, qLD + dmw::pin_zero());
+    dmw::sched_fence();
+#pragma unroll
+    for (int a = 1; a < 14; a++) { const int j = TOPO.dof_anc[I][a]; if (j >= 0) x[I] -= cur[a] * x[j]; }
+    dmw::pin_value(x[I]);
+    SolveLStep<I + 1, R>::run(x, qLD, nxt);
+  }
+};
+template <class R> struct SolveLStep<NV, R> { static DM_DEV void run(R*, const R*, const R*) {} };
+template <class R> DM_DEV void solve_L(R* x, const R* qLD) {
+  R cur[14];
+  load_factor_row<1>(cur, qLD + dmw::pin_zero());
+  SolveLStep<1, R>::run(x, qLD, cur);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -218,7 +246,7 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane, const
   const int depth = lt.depth;
   if (lane == 0) {
     s.xpos[0][0] = s.xpos[0][1] = s.xpos[0][2] = 0; s.xipos[0][0] = s.xipos[0][1] = s.xipos[0][2] = 0;
-    s.xquat[0][0] = 1; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0;
+    s.ua.xquat[0][0] = 1; s.ua.xquat[0][1] = s.ua.xquat[0][2] = s.ua.xquat[0][3] = 0;
     for (int k = 0; k < 9; k++) s.xmat[0][k] = (k % 4 == 0) ? R(1) : R(0);
   }
   for (int L = 1; L <= MAXDEPTH_BODY; L++) {
@@ -234,7 +262,7 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane, const
         R v[3];
         mat_vec(v, s.xmat[p], M.body_pos[b]);
         xp[0] = s.xpos[p][0] + v[0]; xp[1] = s.xpos[p][1] + v[1]; xp[2] = s.xpos[p][2] + v[2];
-        q[0] = s.xquat[p][0]; q[1] = s.xquat[p][1]; q[2] = s.xquat[p][2]; q[3] = s.xquat[p][3];
+        q[0] = s.ua.xquat[p][0]; q[1] = s.ua.xquat[p][1]; q[2] = s.ua.xquat[p][2]; q[3] = s.ua.xquat[p][3];
         for (int k = 0; k < nd; k++) {
           const int d = da + k, j = d - 5;
           R axl[3] = {M.jnt_axis[j][0], M.jnt_axis[j][1], M.jnt_axis[j][2]}, axw[3], ql[4], qm[9];
@@ -249,7 +277,7 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane, const
       normalize4(q);
       quat2mat(mat, q);
       for (int k = 0; k < 3; k++) s.xpos[b][k] = xp[k];
-      for (int k = 0; k < 4; k++) s.xquat[b][k] = q[k];
+      for (int k = 0; k < 4; k++) s.ua.xquat[b][k] = q[k];
       for (int k = 0; k < 9; k++) s.xmat[b][k] = mat[k];
       R ip[3] = {M.body_ipos[b][0], M.body_ipos[b][1], M.body_ipos[b][2]}, v[3];
       mat_vec(v, mat, ip);
@@ -271,29 +299,20 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane, const
         const R m = M.body_mass[b];
         const R c[3] = {s.xipos[b][0], s.xipos[b][1], s.xipos[b][2]};
         const R cc = dot3(c, c);
-        s.sin[b][0] = Iw[0] + m * (cc - c[0] * c[0]); s.sin[b][1] = Iw[4] + m * (cc - c[1] * c[1]); s.sin[b][2] = Iw[8] + m * (cc - c[2] * c[2]);
-        s.sin[b][3] = Iw[1] - m * c[0] * c[1]; s.sin[b][4] = Iw[2] - m * c[0] * c[2]; s.sin[b][5] = Iw[5] - m * c[1] * c[2];
-        s.sin[b][6] = m * c[0]; s.sin[b][7] = m * c[1]; s.sin[b][8] = m * c[2]; s.sin[b][9] = m;
+        s.ub.i.sin[b][0] = Iw[0] + m * (cc - c[0] * c[0]); s.ub.i.sin[b][1] = Iw[4] + m * (cc - c[1] * c[1]); s.ub.i.sin[b][2] = Iw[8] + m * (cc - c[2] * c[2]);
+        s.ub.i.sin[b][3] = Iw[1] - m * c[0] * c[1]; s.ub.i.sin[b][4] = Iw[2] - m * c[0] * c[2]; s.ub.i.sin[b][5] = Iw[5] - m * c[1] * c[2];
+        s.ub.i.sin[b][6] = m * c[0]; s.ub.i.sin[b][7] = m * c[1]; s.ub.i.sin[b][8] = m * c[2]; s.ub.i.sin[b][9] = m;
       }
     }
     dmw::sync();
-  }
-  // geom world poses
-  if (lane < NG) {
-    const int g = lane, gb = M.geom_body[g];
-    R v[3];
-    mat_vec(v, s.xmat[gb], M.geom_pos[g]);
-    s.gpos[g][0] = s.xpos[gb][0] + v[0]; s.gpos[g][1] = s.xpos[gb][1] + v[1]; s.gpos[g][2] = s.xpos[gb][2] + v[2];
-    const R* a = s.xmat[gb]; const R* bm = M.geom_mat[g];
-    for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) s.gmat[g][3 * i + jx] = a[3 * i] * bm[jx] + a[3 * i + 1] * bm[3 + jx] + a[3 * i + 2] * bm[6 + jx];
   }
   // composite inertias: sum over the (static) subtree   [MJ mj_crb backward pass]
   if (isbody) {
     R acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0;
     const unsigned msk = lt.subtree;
-    for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int k = 0; k < 10; k++) acc[k] += s.sin[c][k];
-    for (int k = 0; k < 10; k++) s.crb[b][k] = acc[k];
+    for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int k = 0; k < 10; k++) acc[k] += s.ub.i.sin[c][k];
+    for (int k = 0; k < 10; k++) s.ub.i.crb[b][k] = acc[k];
   }
   dmw::sync();
 }
@@ -333,7 +352,7 @@ template <class R>
 DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg) {
   if (lane < NV) {
     R f[6];
-    sinert_mul(f, s.crb[TOPO.dof_body[lane]], s.cdof[lane]);
+    sinert_mul(f, s.ub.i.crb[TOPO.dof_body[lane]], s.cdof[lane]);
     for (int r = 0; r < 6; r++) s.u.fdof[lane][r] = f[r];
   }
   dmw::sync();
@@ -390,7 +409,7 @@ DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane, const LaneT
       }
       for (int r = 0; r < 6; r++) { s.u.v.cvel[b][r] = v[r]; s.u.v.cacc[b][r] = a[r]; }
       R Ia[6], Iv[6], x[6];
-      sinert_mul(Ia, s.sin[b], a); sinert_mul(Iv, s.sin[b], v); cross_force(x, v, Iv);
+      sinert_mul(Ia, s.ub.i.sin[b], a); sinert_mul(Iv, s.ub.i.sin[b], v); cross_force(x, v, Iv);
       for (int r = 0; r < 6; r++) s.u.v.cfrc[b][r] = Ia[r] + x[r];
     }
     dmw::sync();
@@ -404,7 +423,7 @@ DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane, const LaneT
   dmw::sync();
   if (lane < NV) {
     const R bias = dot6(s.cdof[lane], s.u.v.csub[TOPO.dof_body[lane]]);
-    s.tau[lane] = -M.dof_damping[lane] * s.qvel[lane] - bias + s.act[lane];
+    s.ua.f.tau[lane] = -M.dof_damping[lane] * s.qvel[lane] - bias + s.act[lane];
   }
   dmw::sync();
 }
@@ -447,8 +466,8 @@ DM_DEV void narrowphase(const DevModel<R>& M, const Shared<R>& s, int g1, int g2
   pc.hint[0] = pc.hint[1] = pc.hint[2] = 0;
   pc.nrm[0] = pc.nrm[1] = 0; pc.nrm[2] = 1;
   const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
-  const R* p1 = s.gpos[g1]; const R* p2 = s.gpos[g2];
-  const R* m1 = s.gmat[g1]; const R* m2 = s.gmat[g2];
+  const R* p1 = s.ub.g.gpos[g1]; const R* p2 = s.ub.g.gpos[g2];
+  const R* m1 = s.ub.g.gmat[g1]; const R* m2 = s.ub.g.gmat[g2];
   const R* s1 = M.geom_size[g1]; const R* s2 = M.geom_size[g2];
   if (t1 == GEOM_PLANE) {
     const R n[3] = {m1[2], m1[5], m1[8]};
@@ -558,6 +577,18 @@ DM_DEV void make_frame(R* f, const R* nrm, const R* hint) {
 template <class R>
 DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane) {
   int nrow = 0;
+  if (M.enable_contact) {   // (the inertia region these poses overwrite is dead by now)
+    // geom world poses
+    if (lane < NG) {
+      const int g = lane, gb = M.geom_body[g];
+      R v[3];
+      mat_vec(v, s.xmat[gb], M.geom_pos[g]);
+      s.ub.g.gpos[g][0] = s.xpos[gb][0] + v[0]; s.ub.g.gpos[g][1] = s.xpos[gb][1] + v[1]; s.ub.g.gpos[g][2] = s.xpos[gb][2] + v[2];
+      const R* a = s.xmat[gb]; const R* bm = M.geom_mat[g];
+      for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) s.ub.g.gmat[g][3 * i + jx] = a[3 * i] * bm[jx] + a[3 * i + 1] * bm[3 + jx] + a[3 * i + 2] * bm[6 + jx];
+    }
+  }
+  dmw::sync();
   // ---- joint limits: hinge j = lane + 1, dof = lane + 6
   {
     bool viol = false;
@@ -571,8 +602,8 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane) {
     const unsigned long long mask = dmw::ballot(viol);
     if (viol) {
       const int r = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-      s.rowd[r][0] = sgn; s.rowd[r][6] = dist; s.rowd[r][7] = 0;
-      s.rowd[r][8] = M.dof_invw[lane + 6]; s.rowd[r][9] = 1;
+      s.u.rowd[r][0] = sgn; s.u.rowd[r][6] = dist; s.u.rowd[r][7] = 0;
+      s.u.rowd[r][8] = M.dof_invw[lane + 6]; s.u.rowd[r][9] = 1;
       s.rowi[r] = ROW_LIMIT | ((lane + 6) << 8);
     }
     nrow = __builtin_popcountll(mask);
@@ -593,11 +624,11 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane) {
         // bounding-sphere rejection (conservative; [MJ mj_collideGeoms] does the same before the narrow phase)
         bool maybe = true;
         if (M.geom_type[g1] == GEOM_PLANE) {
-          const R* m1 = s.gmat[g1];
-          const R dz = (s.gpos[g2][0] - s.gpos[g1][0]) * m1[2] + (s.gpos[g2][1] - s.gpos[g1][1]) * m1[5] + (s.gpos[g2][2] - s.gpos[g1][2]) * m1[8];
+          const R* m1 = s.ub.g.gmat[g1];
+          const R dz = (s.ub.g.gpos[g2][0] - s.ub.g.gpos[g1][0]) * m1[2] + (s.ub.g.gpos[g2][1] - s.ub.g.gpos[g1][1]) * m1[5] + (s.ub.g.gpos[g2][2] - s.ub.g.gpos[g1][2]) * m1[8];
           maybe = dz <= M.geom_rbound[g2] + margin;
         } else {
-          const R d[3] = {s.gpos[g2][0] - s.gpos[g1][0], s.gpos[g2][1] - s.gpos[g1][1], s.gpos[g2][2] - s.gpos[g1][2]};
+          const R d[3] = {s.ub.g.gpos[g2][0] - s.ub.g.gpos[g1][0], s.ub.g.gpos[g2][1] - s.ub.g.gpos[g1][1], s.ub.g.gpos[g2][2] - s.ub.g.gpos[g1][2]};
           const R bound = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
           maybe = dot3(d, d) <= bound * bound;
         }
@@ -618,7 +649,7 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane) {
           const int rk = r0 + k * rows_per;
           if (c0 + k < MAXEFC) { s.cong[c0 + k][0] = g1; s.cong[c0 + k][1] = g2; }
           // rows past the on-chip capacity are dropped contact-wise, in list order (status bit 0)
-          if (rk + rows_per > MAXROWS) { if (rk < firstdrop) firstdrop = rk; continue; }
+          if (rk + rows_per > MAXEFC) { if (rk < firstdrop) firstdrop = rk; continue; }
           for (int q = 0; q < rows_per; q++) {
             R dir[3];
             if (dim == 1) { dir[0] = fr[0]; dir[1] = fr[1]; dir[2] = fr[2]; }
@@ -627,7 +658,7 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane) {
               const R sg = (q & 1) ? -mu : mu;
               dir[0] = fr[0] + sg * fr[3 * t]; dir[1] = fr[1] + sg * fr[3 * t + 1]; dir[2] = fr[2] + sg * fr[3 * t + 2];
             }
-            R* rd = s.rowd[rk + q];
+            R* rd = s.u.rowd[rk + q];
             cross3(rd, pc.pos[k], dir);
             rd[3] = dir[0]; rd[4] = dir[1]; rd[5] = dir[2];
             rd[6] = pc.dist[k]; rd[7] = margin;
@@ -664,60 +695,95 @@ DM_DEV R impedance(const R* si, R x) {
   return si[0] + y * (si[1] - si[0]);
 }
 
-// sum_l fsel_l * Y_l over the lanes (transpose-reduce through LDS, 8 dofs at a time), then the back half of the
-// solve: out = L^-1 D^-1/2 (.)  — every lane ends up with the full 34-vector in registers (uniform values).
+// x <- M^-1 x for a vector held identically by every lane (uniform operands: no divergence, no reduction).
 template <class R>
-DM_DEV void reduce_and_backsolve(Shared<R>& s, int lane, const R* y, R fsel, R* out) {
+DM_DEV void uniform_solve(const Shared<R>& s, R* x) {
+  solve_LT(x, s.qLD);
 #pragma unroll
-  for (int c = 0; c < (NV + 7) / 8; c++) {
-    dmw::sync();
-#pragma unroll
-    for (int dd = 0; dd < 8; dd++) {
-      const int d = c * 8 + dd;
-      if (d < NV) s.u.tbuf[dd][lane] = y[d] * fsel;
-    }
-    dmw::sync();
-    R part = 0;
-    {
-      const int dd = lane >> 3, p = lane & 7;
-#pragma unroll
-      for (int t = 0; t < 8; t++) part += s.u.tbuf[dd][p * 8 + t];
-      part += dmw::shfl_xor(part, 1); part += dmw::shfl_xor(part, 2); part += dmw::shfl_xor(part, 4);
-    }
-#pragma unroll
-    for (int dd = 0; dd < 8; dd++) {
-      const int d = c * 8 + dd;
-      if (d < NV) out[d] = dmw::bcast(part, dd * 8);
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < NV; d++) out[d] *= s.dsq[d];
-  dmw::sync();
-  solve_L(out, s.qLD);
+  for (int d = 0; d < NV; d++) x[d] *= s.dinv[d];
+  solve_L(x, s.qLD);
 }
 
-// constraint solve.  Lane r < nefc owns constraint row r; lane 63 carries the smooth force tau through the same
-// half solve, so that  qacc = L^-1 D^-1/2 ( y_tau + sum_r f_r Y_r )  needs a single back-substitution.
+// Jacobian row of one constraint, one dof per step, operands of the next dof prefetched (see solve_LT above).
+template <class R>
+struct RowAcc {
+  R w[6];
+  unsigned plus_lo, plus_hi, minus_lo, minus_hi;   // ancestor-chain masks of body2 (+) and body1 (-)
+  int ldof;
+  R lsgn, vel, jsm, jws;
+};
+template <int D, class R>
+DM_DEV void load_dof_operands(R* dst, const Shared<R>& s, int z) {
+  if constexpr (D < NV) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) dst[r] = s.cdof[D + z][r];
+    dst[6] = s.qvel[D + z]; dst[7] = s.ua.f.qaccs[D + z]; dst[8] = s.qws[D + z];
+  }
+}
+template <int D, class R>
+struct RowStep {
+  static DM_DEV void run(R* y, RowAcc<R>& ra, const Shared<R>& s, const R* cur) {
+    R nxt[9];
+    load_dof_operands<D + 1>(nxt, s, dmw::pin_zero());
+    dmw::sched_fence();
+    const unsigned pb = D < 32 ? (ra.plus_lo >> D) & 1u : (ra.plus_hi >> (D - 32)) & 1u;
+    const unsigned mb = D < 32 ? (ra.minus_lo >> D) & 1u : (ra.minus_hi >> (D - 32)) & 1u;
+    R j = ra.w[0] * cur[0] + ra.w[1] * cur[1] + ra.w[2] * cur[2] + ra.w[3] * cur[3] + ra.w[4] * cur[4] + ra.w[5] * cur[5];
+    j = (pb == mb) ? R(0) : (pb ? j : -j);   // a dof that moves both bodies (common ancestor) cancels exactly
+    if (D == ra.ldof) j = ra.lsgn;
+    ra.vel += j * cur[6]; ra.jsm += j * cur[7]; ra.jws += j * cur[8];
+    y[D] = j;
+    dmw::pin_value(ra.vel);
+    RowStep<D + 1, R>::run(y, ra, s, nxt);
+  }
+};
+template <class R> struct RowStep<NV, R> { static DM_DEV void run(R*, RowAcc<R>&, const Shared<R>&, const R*) {} };
+
+// constraint solve.  Lane r < nefc owns constraint row r (limits first, then contacts in list order).
 //   [MJ mj_fwdAcceleration, mj_projectConstraint, mj_fwdConstraint (warmstart, mj_solPGS)]
 template <class R, bool PROF = false>
 DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg, long long* prof = 0) {
   long long pt0 = 0, pt1 = 0;
   if (PROF) pt0 = dmw::clk();
 #define DM_STAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
-  const int nefc = dmw::uniform(s.nefc);   // <= MAXEFC - 1 = 63; in an SGPR so that the row loops branch scalar
+  const int nefc = dmw::uniform(s.nefc);   // in an SGPR so that the row loops branch scalar
   const bool active = lane < nefc;
-  const bool taulane = lane == 63;
-  R y[NV];
-  R Rr = 1, aref = 0, bb = 0, f = 0, pos = 0, margin = 0;
+  // ---- qacc_smooth = M^-1 tau --------------------------------------------------------------------------------
   {
-    const int info = active ? s.rowi[lane] : 0;
-    const int type = info & 0xff;
-    R w[6] = {0, 0, 0, 0, 0, 0};
+    R x[NV];
+#pragma unroll
+    for (int d = 0; d < NV; d++) x[d] = s.ua.f.tau[d];
+    uniform_solve(s, x);
+    dmw::sync();
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < NV; d++) { s.ua.f.qaccs[d] = x[d]; s.ua.f.qacc[d] = x[d]; }
+      s.solver_iter = 0;
+    }
+    if (dbg && lane == 0) {
+#pragma unroll
+      for (int d = 0; d < NV; d++) dbg->out[34 * 34 + 34 + d] = (double)x[d];
+    }
+  }
+  dmw::sync();
+  DM_STAMP(8)
+  if (nefc == 0) return;
+
+  // ---- this lane's row: Jacobian from the contact wrench, reference acceleration, warm-start force -----------------
+  const int info = active ? s.rowi[lane] : 0;
+  const int type = info & 0xff;
+  R w[6] = {0, 0, 0, 0, 0, 0};
+  int ldof = -1;
+  R lsgn = 0;
+  R Rr = 1, aref = 0, bb = 0, f = 0, pos = 0, margin = 0;
+  R AR[MAXEFC];
+  R diag = 1;
+  {
+    R y[NV];
     unsigned long long mplus = 0, mminus = 0;
-    int ldof = -1;
-    R lsgn = 0, dA = 0, rscale = 1;
+    R dA = 0, rscale = 1;
     if (active) {
-      const R* rd = s.rowd[lane];
+      const R* rd = s.u.rowd[lane];
       pos = rd[6]; margin = rd[7]; dA = rd[8]; rscale = rd[9];
       if (type == ROW_LIMIT) { ldof = (info >> 8) & 0xff; lsgn = rd[0]; }
       else {
@@ -725,54 +791,35 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
         mminus = TOPO.chain[(info >> 8) & 0xff]; mplus = TOPO.chain[(info >> 16) & 0xff];
       }
     }
-    R vel = 0, jws = 0;
-    int z = 0;
-#pragma unroll
-    for (int d = 0; d < NV; d++) {
-      if ((d & 3) == 0) z = dmw::pin_zero();
-      const R sg = R((int)((mplus >> d) & 1ull) - (int)((mminus >> d) & 1ull));
-      R j = sg * dot6(s.cdof[d + z], w);
-      if (d == ldof) j = lsgn;
-      vel += j * s.qvel[d + z]; jws += j * s.qws[d + z];
-      y[d] = taulane ? s.tau[d + z] : j;
-      if ((d & 3) == 3) dmw::pin_value(vel);
+    RowAcc<R> ra;
+    for (int r = 0; r < 6; r++) ra.w[r] = w[r];
+    ra.plus_lo = (unsigned)mplus; ra.plus_hi = (unsigned)(mplus >> 32); ra.minus_lo = (unsigned)mminus; ra.minus_hi = (unsigned)(mminus >> 32);
+    ra.ldof = ldof; ra.lsgn = lsgn; ra.vel = 0; ra.jsm = 0; ra.jws = 0;
+    {
+      R cur[9];
+      load_dof_operands<0>(cur, s, dmw::pin_zero());
+      RowStep<0, R>::run(y, ra, s, cur);
     }
+    const R vel = ra.vel, jsm = ra.jsm, jws = ra.jws;
     if (dbg && active) {
       double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + lane * (34 + 6);
 #pragma unroll
       for (int d = 0; d < NV; d++) o[d] = (double)y[d];
     }
-    DM_STAMP(8)
+    DM_STAMP(9)
     const R imp = impedance(M.solimp, pos - margin);
     Rr = fmax(R(DM_MINVAL), (1 - imp) * dA / imp);
     if (rscale != R(1)) Rr = fmax(R(DM_MINVAL), rscale * Rr);
     aref = -M.B * vel - M.K * imp * (pos - margin);
+    bb = active ? jsm - aref : R(0);
     const R jar = jws - aref;
     f = (active && jar < 0) ? -jar / Rr : R(0);
-    // half solve: y <- D^-1/2 L^-T y
+    // half solve: y <- D^-1/2 L^-T J^T, so that A = Y Y^T
     solve_LT(y, s.qLD);
 #pragma unroll
     for (int d = 0; d < NV; d++) y[d] *= s.dsq[d];
-  }
-  DM_STAMP(9)
-  if (lane == 0) s.solver_iter = 0;
-  int iter = 0;
-  if (nefc > 0) {
-    // ---- b = J qacc_smooth - aref = Y . y_tau - aref : y_tau broadcast through LDS ----------------------------
-    if (taulane) {
-#pragma unroll
-      for (int d = 0; d < NV; d++) s.qaccs[d] = y[d];
-    }
-    dmw::sync();
-    {
-      R acc = 0;
-#pragma unroll
-      for (int d = 0; d < NV; d++) acc += y[d] * s.qaccs[d];
-      bb = active ? acc - aref : R(0);
-    }
+    DM_STAMP(10)
     // ---- A = Y Y^T + diag(R): rows of Y broadcast through LDS, 16 at a time ---------------------------------
-    R AR[MAXEFC];
-    R diag = 1;
 #pragma unroll
     for (int c = 0; c < MAXEFC / 16; c++) {
       if (c * 16 < nefc) {
@@ -787,9 +834,18 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
           const int i = c * 16 + ii;
           R acc = 0;
           if (i < nefc) {
-            const int z = dmw::pin_zero();
+            R h0[17], h1[17];
+            const int z0 = dmw::pin_zero();
 #pragma unroll
-            for (int d = 0; d < NV; d++) acc += y[d] * s.u.ybuf[ii][d + z];
+            for (int d = 0; d < 17; d++) h0[d] = s.u.ybuf[ii][d + z0];
+            const int z1 = dmw::pin_zero();
+#pragma unroll
+            for (int d = 0; d < 17; d++) h1[d] = s.u.ybuf[ii][17 + d + z1];
+            dmw::sched_fence();
+#pragma unroll
+            for (int d = 0; d < 17; d++) acc += y[d] * h0[d];
+#pragma unroll
+            for (int d = 0; d < 17; d++) acc += y[17 + d] * h1[d];
             dmw::pin_value(acc);
           }
           if (lane == i) { acc += Rr; diag = acc; }
@@ -800,82 +856,111 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
         for (int ii = 0; ii < 16; ii++) AR[c * 16 + ii] = 0;
       }
     }
-    const R dinvr = R(1) / diag;
-    DM_STAMP(10)
-    // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ------------------------------
-    R res = bb;  // residual r_j = b_j + sum_i A_ji f_i, maintained incrementally
+  }
+  const R dinvr = R(1) / diag;
+  DM_STAMP(11)
+  // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ------------------------------------
+  R res = bb;  // residual r_j = b_j + sum_i A_ji f_i, maintained incrementally
+#pragma unroll
+  for (int blk = 0; blk < MAXEFC / 8; blk++) {
+    if (blk * 8 < nefc) {
+#pragma unroll
+      for (int ii = 0; ii < 8; ii++) {
+        const int i = blk * 8 + ii;
+        if (i < nefc) res += AR[i] * dmw::bcast(f, i);
+      }
+    }
+  }
+  {
+    const R cost = dmw::wave_sum(active ? f * (R(0.5) * (res - bb) + bb) : R(0));
+    if (cost > 0) { f = 0; res = bb; }
+  }
+  // ---- projected Gauss-Seidel, rows in order; one broadcast + one FMA per row, no memory ------------------------
+  int iter = 0;
+  const int maxiter = dmw::uniform(M.iterations);
+  while (iter < maxiter) {
+    R myimp = 0;
 #pragma unroll
     for (int blk = 0; blk < MAXEFC / 8; blk++) {
-      if (blk * 8 < nefc) {
+      if (blk * 8 < nefc) {          // scalar branch per block of 8 rows; rows past nefc cost one scalar compare each
 #pragma unroll
         for (int ii = 0; ii < 8; ii++) {
           const int i = blk * 8 + ii;
-          if (i < nefc) res += AR[i] * dmw::bcast(f, i);
-        }
-      }
-    }
-    {
-      const R cost = dmw::wave_sum(active ? f * (R(0.5) * (res - bb) + bb) : R(0));
-      if (cost > 0) { f = 0; res = bb; }
-    }
-    DM_STAMP(11)
-    // ---- projected Gauss-Seidel, rows in order; one broadcast + one FMA per row -----------------------------
-    const int maxiter = dmw::uniform(M.iterations);
-    while (iter < maxiter) {
-      R myimp = 0;
-#pragma unroll
-      for (int blk = 0; blk < MAXEFC / 8; blk++) {
-        if (blk * 8 < nefc) {          // scalar branch per block of 8 rows; rows past nefc cost one scalar compare each
-#pragma unroll
-          for (int ii = 0; ii < 8; ii++) {
-            const int i = blk * 8 + ii;
-            if (i < nefc) {
-              // every lane evaluates its own candidate update; only lane i's is taken
-              R fn = f - res * dinvr;
-              fn = fn < 0 ? R(0) : fn;
-              R delta = fn - f;
-              R change = delta * (R(0.5) * delta * diag + res);
-              if (change > R(1e-10)) { delta = 0; change = 0; }
-              const R di = dmw::bcast(delta, i);
-              if (lane == i) { f += delta; myimp -= change; }
-              res += AR[i] * di;
-            }
+          if (i < nefc) {
+            // every lane evaluates its own candidate update; only lane i's is taken
+            R fn = f - res * dinvr;
+            fn = fn < 0 ? R(0) : fn;
+            R delta = fn - f;
+            R change = delta * (R(0.5) * delta * diag + res);
+            if (change > R(1e-10)) { delta = 0; change = 0; }
+            const R di = dmw::bcast(delta, i);
+            if (lane == i) { f += delta; myimp -= change; }
+            res += AR[i] * di;
           }
         }
       }
-      const R improvement = dmw::wave_sum(active ? myimp : R(0)) * M.pgs_scale;
-      iter++;
-      if (dmw::uniform(improvement < M.tolerance)) break;
     }
-    DM_STAMP(12)
-    if (dbg && active) {
-      double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + lane * (34 + 6) + 34;
-      o[0] = (double)pos; o[1] = (double)margin; o[2] = (double)Rr; o[3] = (double)aref; o[4] = (double)bb; o[5] = (double)f;
-    }
+    const R improvement = dmw::wave_sum(active ? myimp : R(0)) * M.pgs_scale;
+    iter++;
+    if (dmw::uniform(improvement < M.tolerance)) break;
   }
-  // ---- qacc = L^-1 D^-1/2 ( y_tau + sum_r f_r Y_r ) -------------------------------------------------------------
-  R acc_out[NV];
-  reduce_and_backsolve(s, lane, y, taulane ? R(1) : (active ? f : R(0)), acc_out);
+  DM_STAMP(12)
+  if (dbg && active) {
+    double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + lane * (34 + 6) + 34;
+    o[0] = (double)pos; o[1] = (double)margin; o[2] = (double)Rr; o[3] = (double)aref; o[4] = (double)bb; o[5] = (double)f;
+  }
+  // ---- qfrc_constraint = J^T f, assembled as body wrenches like the RNE backward pass; qacc = qacc_smooth + M^-1 (.) --
   dmw::sync();
-  if (lane == 0) {
-    s.solver_iter = iter;
+  if (lane < NV) s.ua.f.tau[lane] = 0;          // tau is dead: reuse it for qfrc_constraint
+  dmw::sync();
+  {
 #pragma unroll
-    for (int d = 0; d < NV; d++) s.qacc[d] = acc_out[d];
+    for (int r = 0; r < 6; r++) s.u.c.rowf[lane][r] = f * w[r];      // zero for limit rows and idle lanes
+    if (active && type == ROW_LIMIT) s.ua.f.tau[ldof] = lsgn * f;    // at most one limit row per hinge: no conflict
   }
+  dmw::sync();
+  if (lane < NB - 1) {
+    const int b = lane + 1;
+    R g[6] = {0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < nefc; r++) {
+      const int inf = s.rowi[r];
+      if ((inf & 0xff) == ROW_CONTACT) {
+        const int b1 = (inf >> 8) & 0xff, b2 = (inf >> 16) & 0xff;
+        const R sg = (b2 == b ? R(1) : R(0)) - (b1 == b ? R(1) : R(0));
+        if (sg != R(0)) for (int k = 0; k < 6; k++) g[k] += sg * s.u.c.rowf[r][k];
+      }
+    }
+    for (int k = 0; k < 6; k++) s.u.c.G[b][k] = g[k];
+  }
+  dmw::sync();
+  if (lane < NB - 1) {
+    const int b = lane + 1;
+    R acc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned msk = TOPO.subtree[b];
+    for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int k = 0; k < 6; k++) acc[k] += s.u.c.G[c][k];
+    for (int k = 0; k < 6; k++) s.u.c.Gsub[b][k] = acc[k];
+  }
+  dmw::sync();
+  if (lane < NV) s.ua.f.tau[lane] += dot6(s.cdof[lane], s.u.c.Gsub[TOPO.dof_body[lane]]);
+  dmw::sync();
+  {
+    R x[NV];
+#pragma unroll
+    for (int d = 0; d < NV; d++) x[d] = s.ua.f.tau[d];
+    uniform_solve(s, x);
+    dmw::sync();
+    if (lane == 0) {
+      s.solver_iter = iter;
+#pragma unroll
+      for (int d = 0; d < NV; d++) s.ua.f.qacc[d] = s.ua.f.qaccs[d] + x[d];
+    }
+  }
+  dmw::sync();
   DM_STAMP(13)
 #undef DM_STAMP
-  if (dbg) {   // qacc_smooth for the stage-by-stage parity dump (debug kernel only)
-    R sm[NV];
-    reduce_and_backsolve(s, lane, y, taulane ? R(1) : R(0), sm);
-    if (lane == 0) {
-#pragma unroll
-      for (int d = 0; d < NV; d++) dbg->out[34 * 34 + 34 + d] = (double)sm[d];
-    }
-  }
-  dmw::sync();
 }
 
-// one forward-dynamics evaluation: s.qpos, s.qvel, s.act, s.qws  ->  s.qacc (+ s.xipos, contact bookkeeping)
+// one forward-dynamics evaluation: s.qpos, s.qvel, s.act, s.qws  ->  s.ua.f.qacc (+ s.xipos, contact bookkeeping)
 // PROF: accumulate shader-clock cycles per stage into prof[0..4] (profiling kernel only).
 template <class R, bool PROF = false>
 DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt, const DebugOut* dbg, long long* prof = 0) {
@@ -889,7 +974,7 @@ DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo
   stage_bias(M, s, lane, lt);
   if (PROF) { t1 = dmw::clk(); prof[2] += t1 - t0; t0 = t1; }
   if (dbg && lane < NV) {
-    const double bias = (double)(-M.dof_damping[lane] * s.qvel[lane] + s.act[lane] - s.tau[lane]);
+    const double bias = (double)(-M.dof_damping[lane] * s.qvel[lane] + s.act[lane] - s.ua.f.tau[lane]);
     dbg->out[34 * 34 + lane] = bias;
   }
   stage_rows(M, s, lane);
@@ -897,7 +982,7 @@ DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo
   stage_constraint<R, PROF>(M, s, lane, dbg, prof);
   if (PROF) { t1 = dmw::clk(); prof[4] += t1 - t0; t0 = t1; }
   if (dbg) {
-    if (lane < NV) dbg->out[34 * 34 + 68 + lane] = (double)s.qacc[lane];
+    if (lane < NV) dbg->out[34 * 34 + 68 + lane] = (double)s.ua.f.qacc[lane];
     if (lane < NB * 3) dbg->out[34 * 34 + 102 + lane] = (double)s.xipos[lane / 3][lane % 3];
     if (lane == 0) { dbg->out[34 * 34 + 144] = s.nefc; dbg->out[34 * 34 + 145] = s.ncon; dbg->out[34 * 34 + 146] = s.solver_iter; }
   }

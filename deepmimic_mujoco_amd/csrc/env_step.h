@@ -47,18 +47,18 @@ DM_DEV double rng_uniform(unsigned long long seed, int genv, int episode, int k)
   return (double)(h >> 11) * (1.0 / 9007199254740992.0);
 }
 
-// [MJ mj_integratePos] s.qpos <- x0q (+) h * dv, with dv read from s.tau (scratch).  Caller syncs before and after.
+// [MJ mj_integratePos] s.qpos <- x0q (+) h * dv, with dv read from s.ua.f.tau (scratch).  Caller syncs before and after.
 template <class R>
 DM_DEV void integrate_pos(Shared<R>& s, const R* x0q, int lane, R h) {
-  if (lane < 3) s.qpos[lane] = x0q[lane] + h * s.tau[lane];
+  if (lane < 3) s.qpos[lane] = x0q[lane] + h * s.ua.f.tau[lane];
   else if (lane == 3) {
-    R ax[3] = {s.tau[3], s.tau[4], s.tau[5]}, q[4] = {x0q[3], x0q[4], x0q[5], x0q[6]}, qr[4];
+    R ax[3] = {s.ua.f.tau[3], s.ua.f.tau[4], s.ua.f.tau[5]}, q[4] = {x0q[3], x0q[4], x0q[5], x0q[6]}, qr[4];
     const R angle = h * normalize3(ax);
     if (angle == R(0)) { qr[0] = 1; qr[1] = qr[2] = qr[3] = 0; } else axisangle2quat(qr, ax, angle);
     normalize4(q);
     quat_mul(q, q, qr);
     s.qpos[3] = q[0]; s.qpos[4] = q[1]; s.qpos[5] = q[2]; s.qpos[6] = q[3];
-  } else if (lane >= 7 && lane < NQ) s.qpos[lane] = x0q[lane] + h * s.tau[lane - 1];
+  } else if (lane >= 7 && lane < NQ) s.qpos[lane] = x0q[lane] + h * s.ua.f.tau[lane - 1];
 }
 
 // x0q/x0v: LDS copies of the state at the start of the step (kept outside `Shared`'s scratch regions)
@@ -82,16 +82,16 @@ DM_DEV void rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int 
   for (int i = 0; i < 4; i++) {   // single call site of forward(): the four evaluations share one copy of the code
     if (i > 0) {
       const R c = A[i - 1];
-      if (lane < NV) s.tau[lane] = c * vprev;   // dX (position part)
+      if (lane < NV) s.ua.f.tau[lane] = c * vprev;   // dX (position part)
       dmw::sync();
       integrate_pos(s, x.x0q, lane, h);
       if (lane < NV) { vprev = v0 + h * (c * aprev); s.qvel[lane] = vprev; }
       dmw::sync();
     }
     forward<R, PROF>(M, s, lane, lt, (const DebugOut*)0, prof);
-    if (lane < NV) { aprev = s.qacc[lane]; sumv += Bw[i] * vprev; suma += Bw[i] * aprev; }
+    if (lane < NV) { aprev = s.ua.f.qacc[lane]; sumv += Bw[i] * vprev; suma += Bw[i] * aprev; }
   }
-  if (lane < NV) s.tau[lane] = sumv;
+  if (lane < NV) s.ua.f.tau[lane] = sumv;
   dmw::sync();
   integrate_pos(s, x.x0q, lane, h);
   if (lane < NV) { s.qvel[lane] = v0 + h * suma; s.qws[lane] = aprev; }

@@ -10,7 +10,7 @@
 namespace dmt {
 
 constexpr int NB = 14, NV = 34, NQ = 35, NJ = 29, NG = 16, NU = 28, NOBS = 56;
-constexpr int MAXPAIR = 128, MAXEFC = 64;   // rows 0..62 usable: lane 63 carries the smooth force
+constexpr int MAXPAIR = 128, MAXEFC = 64;   // one constraint row per lane
 constexpr int MAXROWS = MAXEFC - 1;
 constexpr int MAXDEPTH_BODY = 4;
 

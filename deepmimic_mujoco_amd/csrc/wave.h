@@ -39,6 +39,18 @@ DM_DEV double bcast(double v, int src) {
 }
 DM_DEV float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 DM_DEV int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// DPP lane permutations on doubles (two 32-bit DPP moves; ~8 cycles instead of a ~100-cycle ds_bpermute round trip)
+template <int CTRL>
+DM_DEV double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+DM_DEV double perm_xor1(double v) { return dpp_f64<0xB1>(v); }         // quad_perm [1,0,3,2]
+DM_DEV double perm_xor2(double v) { return dpp_f64<0x4E>(v); }         // quad_perm [2,3,0,1]
+DM_DEV double perm_half_mirror(double v) { return dpp_f64<0x141>(v); } // lane i <-> 7-i within each 8
+DM_DEV double perm_row_mirror(double v) { return dpp_f64<0x140>(v); }  // lane i <-> 15-i within each 16
 // assert wave-uniformity to the compiler: the value moves to an SGPR, so loops / branches on it are scalar
 // (s_cmp + s_cbranch) instead of exec-masked.  Only for values that ARE identical in all lanes.
 DM_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -61,12 +73,12 @@ DM_DEV void reload_fence() { asm volatile("" ::: "memory"); }
 #endif
 
 namespace dmw {
-// sum over the 64 lanes, result in every lane (butterfly: 6 exchange steps)
-template <class R>
-DM_DEV R wave_sum(R v) {
-  v += shfl_xor(v, 32); v += shfl_xor(v, 16); v += shfl_xor(v, 8);
-  v += shfl_xor(v, 4);  v += shfl_xor(v, 2);  v += shfl_xor(v, 1);
-  return v;
+// sums over lane groups, result in every lane of the group (no LDS traffic)
+DM_DEV double sum8(double v) { v += perm_xor1(v); v += perm_xor2(v); v += perm_half_mirror(v); return v; }
+DM_DEV double sum16(double v) { v = sum8(v); v += perm_row_mirror(v); return v; }
+DM_DEV double wave_sum(double v) {
+  v = sum16(v);
+  return ((bcast(v, 0) + bcast(v, 16)) + bcast(v, 32)) + bcast(v, 48);
 }
 // exclusive prefix sum of small non-negative ints over lanes (Hillis-Steele on shfl_up)
 DM_DEV int wave_exclusive_scan(int v, int lane_id, int* total) {

@@ -66,6 +66,10 @@ inline int bcast_i(int v, int src) { return exchange(v, src); }
 inline long long clk() { return 0; }
 inline int uniform(int v) { return v; }
 inline bool uniform(bool v) { return v; }
+inline double perm_xor1(double v) { return exchange(v, lane() ^ 1); }
+inline double perm_xor2(double v) { return exchange(v, lane() ^ 2); }
+inline double perm_half_mirror(double v) { const int l = lane(); return exchange(v, (l & ~7) | (7 - (l & 7))); }
+inline double perm_row_mirror(double v) { const int l = lane(); return exchange(v, (l & ~15) | (15 - (l & 15))); }
 inline void sched_fence() {}
 inline void reload_fence() {}
 inline int pin_zero() { return 0; }

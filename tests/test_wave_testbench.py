@@ -53,8 +53,8 @@ def test_row_capacity_overflow_is_reported_and_mirrors_oracle():
     b = make(1)
     ws = np.zeros((1, 34)); ctrl = np.zeros((1, 28))
     H.compare_forward(b, H.oracle_model(), np.zeros(1, dtype=np.int32), q, v, ws, ctrl)
-    assert b.get(A.F_NEFC)[0] <= 63
-    if b.get(A.F_NCON)[0] * 4 > 63:
+    assert b.get(A.F_NEFC)[0] <= 64
+    if b.get(A.F_NCON)[0] * 4 > 64:
         assert b.get(A.F_STATUS)[0] & 1
 
 
