@@ -45,7 +45,7 @@ struct DevModel {
   int jnt_limited[NJ];
   R dof_armature[NV], dof_damping[NV], dof_invw[NV];
   R gear[NV], ctrl_lo[NV], ctrl_hi[NV];  // per dof (0 for the free joint)
-  int geom_type[NG], geom_body[NG], geom_condim[NG];
+  int geom_type[NG], geom_body[NG], geom_condim[NG], geom_boxslot[NG];   // boxslot: index among box geoms (< 4) or -1
   R geom_pos[NG][3], geom_mat[NG][9], geom_size[NG][3], geom_margin[NG], geom_mu[NG], geom_rbound[NG];
   int npair;
   short pair_g1[MAXPAIR], pair_g2[MAXPAIR];
@@ -80,6 +80,7 @@ struct Shared {
     R ybuf[16][NV];
     struct { R rowf[MAXEFC][6], G[NB][6], Gsub[NB][6]; } c;   // constraint forces as body wrenches (end of the solve)
   } u;
+  R boxc[4][4][4];     // plane-box corner contacts (dist, pos) staged per box: the only pair type with > 2 contacts
   int rowi[MAXEFC];    // type | b1<<8 | b2<<16   (limit: type | dof<<8)
   int cong[MAXEFC][2]; // contact geom ids
   int nefc, ncon, status, solver_iter;
@@ -240,7 +241,8 @@ template <class R> DM_DEV void solve_L(R* x, const R* qLD) {
 // ---------------------------------------------------------------------------------------------------------
 // position stage: kinematics, geom poses, motion axes, spatial inertias   [MJ mj_kinematics, mj_comPos]
 template <class R>
-DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) {
+DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt) {
+  const int lane = dmw::launder(lane_in);
   const int b = lane + 1;
   const bool isbody = lane < NB - 1;
   const int depth = lt.depth;
@@ -319,7 +321,8 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane, const
 
 // mass matrix (tree-sparse, MuJoCo qM order) and its L^T D L factor   [MJ mj_crb, mj_factorM]
 template <int K, class R>
-DM_DEV void eliminate_dof(Shared<R>& s, int lane) {
+DM_DEV void eliminate_dof(Shared<R>& s, int lane_in) {
+  const int lane = dmw::launder(lane_in);
   // column K of the elimination: for every ancestor pair (a, c), row i = anc_a(K):
   //   M(i, anc_c(i)) -= M(K, anc_{a+c}(K)) * M(K, i) / M(K, K)
   // Row K itself is left unscaled (nothing reads it again during the factorisation); all rows are scaled at the end.
@@ -349,7 +352,8 @@ struct EliminateFrom<0, R> {
 };
 
 template <class R>
-DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg) {
+DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane_in, const DebugOut* dbg) {
+  const int lane = dmw::launder(lane_in);
   if (lane < NV) {
     R f[6];
     sinert_mul(f, s.ub.i.crb[TOPO.dof_body[lane]], s.cdof[lane]);
@@ -377,7 +381,8 @@ DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane, cons
 
 // velocity stage: bias forces C(q, v) incl. gravity; smooth generalized force   [MJ mj_comVel, mj_rne, mj_passive]
 template <class R>
-DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) {
+DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt) {
+  const int lane = dmw::launder(lane_in);
   const int b = lane + 1;
   const bool isbody = lane < NB - 1;
   const int depth = lt.depth;
@@ -430,22 +435,23 @@ DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane, const LaneT
 
 // ---------------------------------------------------------------------------------------------------------
 // collision: narrow phase for one candidate pair.  Contacts of a pair share the frame (normal n, tangent hint h).
+// Up to two contacts live in registers (static slots); plane-box corners (up to 4) are staged in LDS (s.boxc).
 template <class R>
 struct PairContacts {
-  int n;
+  int n, boxslot;
   R nrm[3], hint[3];
-  R dist[4], pos[4][3];
+  R d0, p0[3], d1, p1[3];
 };
 
+// plane through p0 with unit normal n vs sphere (c, r): returns hit, distance and contact position  [MJ mjc_PlaneSphere]
 template <class R>
-DM_DEV void plane_sphere(PairContacts<R>& pc, const R* p0, const R* n, const R* c, R r, R margin) {
+DM_DEV bool plane_sphere(const R* p0, const R* n, const R* c, R r, R margin, R& dist, R* pos) {
   R t[3] = {c[0] - p0[0], c[1] - p0[1], c[2] - p0[2]};
   const R cd = dot3(t, n);
-  if (cd > margin + r) return;
-  const int k = pc.n++;
-  pc.dist[k] = cd - r;
-  const R sc = -pc.dist[k] / 2 - r;
-  pc.pos[k][0] = c[0] + n[0] * sc; pc.pos[k][1] = c[1] + n[1] * sc; pc.pos[k][2] = c[2] + n[2] * sc;
+  dist = cd - r;
+  const R sc = -dist / 2 - r;
+  pos[0] = c[0] + n[0] * sc; pos[1] = c[1] + n[1] * sc; pos[2] = c[2] + n[2] * sc;
+  return !(cd > margin + r);
 }
 template <class R>
 DM_DEV void sphere_sphere(PairContacts<R>& pc, const R* c1, R r1, const R* c2, R r2, R margin) {
@@ -455,16 +461,17 @@ DM_DEV void sphere_sphere(PairContacts<R>& pc, const R* c1, R r1, const R* c2, R
   const R nn = normalize3(dif);
   pc.n = 1;
   pc.nrm[0] = dif[0]; pc.nrm[1] = dif[1]; pc.nrm[2] = dif[2];
-  pc.dist[0] = nn - r1 - r2;
-  const R sc = r1 + R(0.5) * pc.dist[0];
-  pc.pos[0][0] = c1[0] + dif[0] * sc; pc.pos[0][1] = c1[1] + dif[1] * sc; pc.pos[0][2] = c1[2] + dif[2] * sc;
+  pc.d0 = nn - r1 - r2;
+  const R sc = r1 + R(0.5) * pc.d0;
+  pc.p0[0] = c1[0] + dif[0] * sc; pc.p0[1] = c1[1] + dif[1] * sc; pc.p0[2] = c1[2] + dif[2] * sc;
 }
 
 template <class R>
-DM_DEV void narrowphase(const DevModel<R>& M, const Shared<R>& s, int g1, int g2, R margin, PairContacts<R>& pc) {
-  pc.n = 0;
+DM_DEV void narrowphase(const DevModel<R>& M, Shared<R>& s, int g1, int g2, R margin, PairContacts<R>& pc) {
+  pc.n = 0; pc.boxslot = -1;
   pc.hint[0] = pc.hint[1] = pc.hint[2] = 0;
   pc.nrm[0] = pc.nrm[1] = 0; pc.nrm[2] = 1;
+  pc.d0 = pc.d1 = 0; pc.p0[0] = pc.p0[1] = pc.p0[2] = 0; pc.p1[0] = pc.p1[1] = pc.p1[2] = 0;
   const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
   const R* p1 = s.ub.g.gpos[g1]; const R* p2 = s.ub.g.gpos[g2];
   const R* m1 = s.ub.g.gmat[g1]; const R* m2 = s.ub.g.gmat[g2];
@@ -473,17 +480,21 @@ DM_DEV void narrowphase(const DevModel<R>& M, const Shared<R>& s, int g1, int g2
     const R n[3] = {m1[2], m1[5], m1[8]};
     pc.nrm[0] = n[0]; pc.nrm[1] = n[1]; pc.nrm[2] = n[2];
     if (t2 == GEOM_SPHERE) {
-      plane_sphere(pc, p1, n, p2, s2[0], margin);
+      if (plane_sphere(p1, n, p2, s2[0], margin, pc.d0, pc.p0)) pc.n = 1;
     } else if (t2 == GEOM_CAPSULE) {   // [MJ mjc_PlaneCapsule] +axis end first, tangent hint = axis
       const R ax[3] = {m2[2], m2[5], m2[8]};
       R c[3] = {p2[0] + ax[0] * s2[1], p2[1] + ax[1] * s2[1], p2[2] + ax[2] * s2[1]};
-      plane_sphere(pc, p1, n, c, s2[0], margin);
+      const bool ha = plane_sphere(p1, n, c, s2[0], margin, pc.d0, pc.p0);
       c[0] = p2[0] - ax[0] * s2[1]; c[1] = p2[1] - ax[1] * s2[1]; c[2] = p2[2] - ax[2] * s2[1];
-      plane_sphere(pc, p1, n, c, s2[0], margin);
+      const bool hb = plane_sphere(p1, n, c, s2[0], margin, pc.d1, pc.p1);
+      if (!ha && hb) { pc.d0 = pc.d1; pc.p0[0] = pc.p1[0]; pc.p0[1] = pc.p1[1]; pc.p0[2] = pc.p1[2]; }
+      pc.n = (ha ? 1 : 0) + (hb ? 1 : 0);
       pc.hint[0] = ax[0]; pc.hint[1] = ax[1]; pc.hint[2] = ax[2];
-    } else if (t2 == GEOM_BOX) {       // [MJ mjc_PlaneBox] corners below the margin, at most 4
+    } else if (t2 == GEOM_BOX) {       // [MJ mjc_PlaneBox] corners below the margin, at most 4, staged in LDS
       const R dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
       const R dist = dot3(dif, n);
+      const int slot = M.geom_boxslot[g2];
+      pc.boxslot = slot;
       for (int i = 0; i < 8 && pc.n < 4; i++) {
         const R vec[3] = {(i & 1) ? s2[0] : -s2[0], (i & 2) ? s2[1] : -s2[1], (i & 4) ? s2[2] : -s2[2]};
         R corner[3];
@@ -491,9 +502,9 @@ DM_DEV void narrowphase(const DevModel<R>& M, const Shared<R>& s, int g1, int g2
         const R ld = dot3(n, corner);
         if (dist + ld > margin || ld > 0) continue;
         const int k = pc.n++;
-        pc.dist[k] = dist + ld;
-        const R sc = -pc.dist[k] / 2;
-        pc.pos[k][0] = corner[0] + p2[0] + n[0] * sc; pc.pos[k][1] = corner[1] + p2[1] + n[1] * sc; pc.pos[k][2] = corner[2] + p2[2] + n[2] * sc;
+        const R dk = dist + ld, sc = -dk / 2;
+        R* o = s.boxc[slot][k];
+        o[0] = dk; o[1] = corner[0] + p2[0] + n[0] * sc; o[2] = corner[1] + p2[1] + n[1] * sc; o[3] = corner[2] + p2[2] + n[2] * sc;
       }
     }
     return;
@@ -541,17 +552,17 @@ DM_DEV void narrowphase(const DevModel<R>& M, const Shared<R>& s, int g1, int g2
       nrm[0] = nrm[1] = nrm[2] = 0; nrm[k / 2] = (k % 2) ? R(-1) : R(1);
       const R sc = (s1[0] - closest) / 2;
       pl[0] = center[0] + nrm[0] * sc; pl[1] = center[1] + nrm[1] * sc; pl[2] = center[2] + nrm[2] * sc;
-      pc.dist[0] = -closest - s1[0];
+      pc.d0 = -closest - s1[0];
     } else {
       for (int i = 0; i < 3; i++) nrm[i] = -t[i] / dist;
       const R sc = s1[0] + R(0.5) * (dist - s1[0]);
       pl[0] = center[0] + nrm[0] * sc; pl[1] = center[1] + nrm[1] * sc; pl[2] = center[2] + nrm[2] * sc;
-      pc.dist[0] = dist - s1[0];
+      pc.d0 = dist - s1[0];
     }
     pc.n = 1;
     mat_vec(pc.nrm, m2, nrm);
-    mat_vec(pc.pos[0], m2, pl);
-    pc.pos[0][0] += p2[0]; pc.pos[0][1] += p2[1]; pc.pos[0][2] += p2[2];
+    mat_vec(pc.p0, m2, pl);
+    pc.p0[0] += p2[0]; pc.p0[1] += p2[1]; pc.p0[2] += p2[2];
     return;
   }
   // capsule-box, box-box: not handled this round (the oracle returns no contact for them as well)
@@ -574,8 +585,9 @@ DM_DEV void make_frame(R* f, const R* nrm, const R* hint) {
 }
 
 // constraint rows: joint limits first (joint order), then contacts (pair-list order)  [MJ mj_collision, mj_makeConstraint]
-template <class R>
-DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane) {
+template <class R, int ROWS>
+DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
+  const int lane = dmw::launder(lane_in);
   int nrow = 0;
   if (M.enable_contact) {   // (the inertia region these poses overwrite is dead by now)
     // geom world poses
@@ -646,10 +658,14 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane) {
         const int b1 = M.geom_body[g1], b2 = M.geom_body[g2];
         const R tran = M.body_invw[b1] + M.body_invw[b2];
         for (int k = 0; k < pc.n; k++) {
+          R cdist, cpos[3];
+          if (pc.boxslot >= 0) { const R* o = s.boxc[pc.boxslot][k]; cdist = o[0]; cpos[0] = o[1]; cpos[1] = o[2]; cpos[2] = o[3]; }
+          else if (k == 0) { cdist = pc.d0; cpos[0] = pc.p0[0]; cpos[1] = pc.p0[1]; cpos[2] = pc.p0[2]; }
+          else { cdist = pc.d1; cpos[0] = pc.p1[0]; cpos[1] = pc.p1[1]; cpos[2] = pc.p1[2]; }
           const int rk = r0 + k * rows_per;
           if (c0 + k < MAXEFC) { s.cong[c0 + k][0] = g1; s.cong[c0 + k][1] = g2; }
           // rows past the on-chip capacity are dropped contact-wise, in list order (status bit 0)
-          if (rk + rows_per > MAXEFC) { if (rk < firstdrop) firstdrop = rk; continue; }
+          if (rk + rows_per > ROWS) { if (rk < firstdrop) firstdrop = rk; continue; }
           for (int q = 0; q < rows_per; q++) {
             R dir[3];
             if (dim == 1) { dir[0] = fr[0]; dir[1] = fr[1]; dir[2] = fr[2]; }
@@ -659,9 +675,9 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane) {
               dir[0] = fr[0] + sg * fr[3 * t]; dir[1] = fr[1] + sg * fr[3 * t + 1]; dir[2] = fr[2] + sg * fr[3 * t + 2];
             }
             R* rd = s.u.rowd[rk + q];
-            cross3(rd, pc.pos[k], dir);
+            cross3(rd, cpos, dir);
             rd[3] = dir[0]; rd[4] = dir[1]; rd[5] = dir[2];
-            rd[6] = pc.dist[k]; rd[7] = margin;
+            rd[6] = cdist; rd[7] = margin;
             rd[8] = dim == 1 ? tran : tran + mu * mu * tran;
             rd[9] = dim == 1 ? R(1) : 2 * mu * mu;
             s.rowi[rk + q] = ROW_CONTACT | (b1 << 8) | (b2 << 16);
@@ -741,8 +757,9 @@ template <class R> struct RowStep<NV, R> { static DM_DEV void run(R*, RowAcc<R>&
 
 // constraint solve.  Lane r < nefc owns constraint row r (limits first, then contacts in list order).
 //   [MJ mj_fwdAcceleration, mj_projectConstraint, mj_fwdConstraint (warmstart, mj_solPGS)]
-template <class R, bool PROF = false>
-DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const DebugOut* dbg, long long* prof = 0) {
+template <class R, int ROWS, bool PROF = false>
+DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, const DebugOut* dbg, long long* prof = 0) {
+  const int lane = dmw::launder(lane_in);
   long long pt0 = 0, pt1 = 0;
   if (PROF) pt0 = dmw::clk();
 #define DM_STAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
@@ -776,7 +793,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
   int ldof = -1;
   R lsgn = 0;
   R Rr = 1, aref = 0, bb = 0, f = 0, pos = 0, margin = 0;
-  R AR[MAXEFC];
+  R AR[ROWS];
   R diag = 1;
   {
     R y[NV];
@@ -821,7 +838,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
     DM_STAMP(10)
     // ---- A = Y Y^T + diag(R): rows of Y broadcast through LDS, 16 at a time ---------------------------------
 #pragma unroll
-    for (int c = 0; c < MAXEFC / 16; c++) {
+    for (int c = 0; c < ROWS / 16; c++) {
       if (c * 16 < nefc) {
         dmw::sync();
         if ((lane >> 4) == c) {
@@ -834,18 +851,33 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
           const int i = c * 16 + ii;
           R acc = 0;
           if (i < nefc) {
-            R h0[17], h1[17];
-            const int z0 = dmw::pin_zero();
+            // dot(Y_lane, Y_i) in four quarter rows, the next quarter loaded while the current one is multiplied
+            R qa[9], qb[9];
+            { const int z0 = dmw::pin_zero();
 #pragma unroll
-            for (int d = 0; d < 17; d++) h0[d] = s.u.ybuf[ii][d + z0];
-            const int z1 = dmw::pin_zero();
+              for (int d = 0; d < 9; d++) qa[d] = s.u.ybuf[ii][d + z0]; }
+            { const int z1 = dmw::pin_zero();
 #pragma unroll
-            for (int d = 0; d < 17; d++) h1[d] = s.u.ybuf[ii][17 + d + z1];
+              for (int d = 0; d < 9; d++) qb[d] = s.u.ybuf[ii][9 + d + z1]; }
             dmw::sched_fence();
 #pragma unroll
-            for (int d = 0; d < 17; d++) acc += y[d] * h0[d];
+            for (int d = 0; d < 9; d++) acc += y[d] * qa[d];
+            dmw::pin_value(acc);
+            { const int z2 = dmw::pin_zero();
 #pragma unroll
-            for (int d = 0; d < 17; d++) acc += y[17 + d] * h1[d];
+              for (int d = 0; d < 8; d++) qa[d] = s.u.ybuf[ii][18 + d + z2]; }
+            dmw::sched_fence();
+#pragma unroll
+            for (int d = 0; d < 9; d++) acc += y[9 + d] * qb[d];
+            dmw::pin_value(acc);
+            { const int z3 = dmw::pin_zero();
+#pragma unroll
+              for (int d = 0; d < 8; d++) qb[d] = s.u.ybuf[ii][26 + d + z3]; }
+            dmw::sched_fence();
+#pragma unroll
+            for (int d = 0; d < 8; d++) acc += y[18 + d] * qa[d];
+#pragma unroll
+            for (int d = 0; d < 8; d++) acc += y[26 + d] * qb[d];
             dmw::pin_value(acc);
           }
           if (lane == i) { acc += Rr; diag = acc; }
@@ -862,7 +894,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
   // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ------------------------------------
   R res = bb;  // residual r_j = b_j + sum_i A_ji f_i, maintained incrementally
 #pragma unroll
-  for (int blk = 0; blk < MAXEFC / 8; blk++) {
+  for (int blk = 0; blk < ROWS / 8; blk++) {
     if (blk * 8 < nefc) {
 #pragma unroll
       for (int ii = 0; ii < 8; ii++) {
@@ -880,21 +912,25 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
   const int maxiter = dmw::uniform(M.iterations);
   while (iter < maxiter) {
     R myimp = 0;
+    // fresh opaque copies per sweep: otherwise the 64 row-exists tests and 64 lane==row masks are hoisted out of the
+    // sweep loop as 128 SGPR pairs, spilled to VGPR lanes and read back with v_readlane on every row
+    const int ne = dmw::launder_uniform(nefc);
+    const int ln = dmw::launder(lane);
 #pragma unroll
-    for (int blk = 0; blk < MAXEFC / 8; blk++) {
-      if (blk * 8 < nefc) {          // scalar branch per block of 8 rows; rows past nefc cost one scalar compare each
+    for (int blk = 0; blk < ROWS / 8; blk++) {
+      if (blk * 8 < ne) {          // scalar branch per block of 8 rows; rows past nefc cost one scalar compare each
 #pragma unroll
         for (int ii = 0; ii < 8; ii++) {
           const int i = blk * 8 + ii;
-          if (i < nefc) {
-            // every lane evaluates its own candidate update; only lane i's is taken
-            R fn = f - res * dinvr;
-            fn = fn < 0 ? R(0) : fn;
+          if (i < ne) {
+            // every lane evaluates its own candidate update; only lane i's is taken (v_readlane broadcast of delta)
+            const R fn = fmax(f - res * dinvr, R(0));
             R delta = fn - f;
-            R change = delta * (R(0.5) * delta * diag + res);
-            if (change > R(1e-10)) { delta = 0; change = 0; }
+            const R change = delta * (R(0.5) * delta * diag + res);
+            const bool rej = change > R(1e-10);          // [MJ costChange]: never accept an increase
+            if (rej) delta = 0;
             const R di = dmw::bcast(delta, i);
-            if (lane == i) { f += delta; myimp -= change; }
+            if (ln == i && !rej) { f = fn; myimp -= change; }
             res += AR[i] * di;
           }
         }
@@ -962,7 +998,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane, const
 
 // one forward-dynamics evaluation: s.qpos, s.qvel, s.act, s.qws  ->  s.ua.f.qacc (+ s.xipos, contact bookkeeping)
 // PROF: accumulate shader-clock cycles per stage into prof[0..4] (profiling kernel only).
-template <class R, bool PROF = false>
+template <class R, int ROWS = MAXEFC, bool PROF = false>
 DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt, const DebugOut* dbg, long long* prof = 0) {
   long long t0 = 0, t1 = 0;
   if (PROF) t0 = dmw::clk();
@@ -977,9 +1013,10 @@ DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo
     const double bias = (double)(-M.dof_damping[lane] * s.qvel[lane] + s.act[lane] - s.ua.f.tau[lane]);
     dbg->out[34 * 34 + lane] = bias;
   }
-  stage_rows(M, s, lane);
+  stage_rows<R, ROWS>(M, s, lane);
   if (PROF) { t1 = dmw::clk(); prof[3] += t1 - t0; t0 = t1; }
-  stage_constraint<R, PROF>(M, s, lane, dbg, prof);
+  if (ROWS < MAXEFC && (dmw::uniform(s.status) & 1)) return;   // capacity tier exceeded: the caller re-runs this env on the wide tier
+  stage_constraint<R, ROWS, PROF>(M, s, lane, dbg, prof);
   if (PROF) { t1 = dmw::clk(); prof[4] += t1 - t0; t0 = t1; }
   if (dbg) {
     if (lane < NV) dbg->out[34 * 34 + 68 + lane] = (double)s.ua.f.qacc[lane];

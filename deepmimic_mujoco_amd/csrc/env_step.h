@@ -69,8 +69,8 @@ struct StepScratch {
 
 // [MJ mj_step, integrator RK4] on the state in s.qpos / s.qvel / s.qws / s.act.  Returns with the new state in
 // s.qpos / s.qvel / s.qws and the derived quantities of the 4th stage evaluation in `s` (as sim.data after sim.step()).
-template <class R, bool PROF = false>
-DM_DEV void rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int lane, const LaneTopo& lt, long long* prof = 0) {
+template <class R, int ROWS = MAXEFC, bool PROF = false>
+DM_DEV bool rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int lane, const LaneTopo& lt, long long* prof = 0) {
   const R h = M.timestep;
   const R A[3] = {R(0.5), R(0.5), R(1)};
   const R Bw[4] = {R(1) / 6, R(1) / 3, R(1) / 3, R(1) / 6};
@@ -88,7 +88,8 @@ DM_DEV void rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int 
       if (lane < NV) { vprev = v0 + h * (c * aprev); s.qvel[lane] = vprev; }
       dmw::sync();
     }
-    forward<R, PROF>(M, s, lane, lt, (const DebugOut*)0, prof);
+    forward<R, ROWS, PROF>(M, s, lane, lt, (const DebugOut*)0, prof);
+    if (ROWS < MAXEFC && (dmw::uniform(s.status) & 1)) return false;   // needs the wide tier
     if (lane < NV) { aprev = s.ua.f.qacc[lane]; sumv += Bw[i] * vprev; suma += Bw[i] * aprev; }
   }
   if (lane < NV) s.ua.f.tau[lane] = sumv;
@@ -96,6 +97,7 @@ DM_DEV void rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int 
   integrate_pos(s, x.x0q, lane, h);
   if (lane < NV) { s.qvel[lane] = v0 + h * suma; s.qws[lane] = aprev; }
   dmw::sync();
+  return true;
 }
 
 // load one env's row from HBM (coalesced: lane k reads element k) and turn the action into actuator forces
@@ -172,8 +174,10 @@ DM_DEV void reset_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int
 }
 
 // DPEnv.step for one environment
-template <class R, bool PROF = false>
-DM_DEV void env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, StepScratch<R>& x, int env, int lane,
+// ROWS = constraint-row capacity of this instantiation.  The narrow tier (ROWS < MAXEFC) returns false, leaving the env's
+// state untouched, when an evaluation needs more rows; the host then runs the wide tier for exactly those envs.
+template <class R, int ROWS = MAXEFC, bool PROF = false>
+DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, StepScratch<R>& x, int env, int lane,
                      const R* action, R* obs, R* reward, unsigned char* done, int n_substeps, long long* prof_out = 0) {
   long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tstart = 0;
@@ -181,7 +185,8 @@ DM_DEV void env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
   const LaneTopo lt = lane_topo(lane);
   stage_tables(s, lane);
   load_env(M, B, s, env, lane, action);
-  for (int k = 0; k < n_substeps; k++) rk4_step<R, PROF>(M, s, x, lane, lt, prof);   // do_simulation(action, n)
+  for (int k = 0; k < n_substeps; k++)   // do_simulation(action, n)
+    if (!rk4_step<R, ROWS, PROF>(M, s, x, lane, lt, prof)) return false;
   const R z = com_z(M, s);
   const bool dn = (z < R(0.7)) || (z > R(2.0));
   // reward
@@ -218,6 +223,7 @@ DM_DEV void env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     prof[6] = s.nefc; prof[7] = s.solver_iter;
     for (int k = 0; k < 16; k++) prof_out[(size_t)env * 16 + k] = prof[k];
   }
+  return true;
 }
 
 }  // namespace dm

@@ -57,6 +57,8 @@ inline int build_dev_model(const dm_model_desc* d, DevModel<double>* hp, std::st
     else if (h.geom_type[g] == GEOM_BOX) rb = std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
     h.geom_rbound[g] = rb;
   }
+  { int nbox = 0; for (int g = 0; g < NG; g++) h.geom_boxslot[g] = (h.geom_type[g] == GEOM_BOX) ? nbox++ : -1;
+    if (nbox > 4) return mfail(err, DM_EUNSUPPORTED, "dm_model_create: at most 4 box geoms are supported"); }
   h.npair = d->npair;
   for (int p = 0; p < d->npair; p++) { h.pair_g1[p] = (short)d->pair_geom[2 * p]; h.pair_g2[p] = (short)d->pair_geom[2 * p + 1]; }
   h.qpos0[0] = d->body_pos[3]; h.qpos0[1] = d->body_pos[4]; h.qpos0[2] = d->body_pos[5]; h.qpos0[3] = 1;

@@ -68,6 +68,11 @@ DM_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 DM_DEV int pin_zero() { int z = 0; asm volatile("" : "+s"(z)); return z; }
 DM_DEV void pin_value(double& v) { asm volatile("" : "+v"(v)); }
 DM_DEV void pin_value(float& v) { asm volatile("" : "+v"(v)); }
+// opaque copy of a per-lane integer: index arithmetic derived from it cannot be hoisted out of the enclosing loop or
+// shared across stages (LICM/GVN otherwise precompute every stage's lane->index maps at kernel entry and keep them
+// live across the whole step: hundreds of VGPRs)
+DM_DEV int launder(int v) { asm volatile("" : "+v"(v)); return v; }
+DM_DEV int launder_uniform(int v) { asm volatile("" : "+s"(v)); return v; }   // same for a wave-uniform (SGPR) value
 DM_DEV void reload_fence() { asm volatile("" ::: "memory"); }
 }  // namespace dmw
 #endif

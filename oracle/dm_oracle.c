@@ -762,7 +762,7 @@ static void solve_constraint(const dmo_model* m, dmo_data* d) {
       double res = d->efc_b[i];
       for (int j = 0; j < n; j++) res += d->efc_AR[i][j] * d->efc_force[j];
       double old = d->efc_force[i];
-      double f = old - res / d->efc_AR[i][i];
+      double f = old - res * (1.0 / d->efc_AR[i][i]); /* MuJoCo multiplies by the precomputed inverse diagonal */
       if (f < 0) f = 0;
       double delta = f - old, change = 0.5 * delta * delta * d->efc_AR[i][i] + delta * res;
       if (change > 1e-10) { f = old; change = 0; } /* [MJ costChange] never accept an increase */

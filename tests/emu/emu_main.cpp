@@ -105,7 +105,12 @@ void* emu_field(void* h, int field) {
 void emu_step(void* h, const double* action, double* obs, double* reward, unsigned char* done, int nsub) {
   EmuBatch* e = (EmuBatch*)h;
   for (int env = 0; env < e->B.n_envs; env++)
-    run_wave([&](int lane) { env_step(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); });
+  {
+    // same two-tier scheme as the device: narrow (32 rows) first, wide (64) for the envs that report overflow
+    bool ok = true;
+    run_wave([&](int lane) { bool r = env_step<double, 32>(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); if (lane == 0) ok = r; });
+    if (!ok) run_wave([&](int lane) { env_step<double, MAXEFC>(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); });
+  }
 }
 void emu_set_state(void* h, const double* qpos, const double* qvel, const int* fidx, const unsigned char* mask) {
   EmuBatch* e = (EmuBatch*)h;

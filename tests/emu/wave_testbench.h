@@ -73,6 +73,8 @@ inline double perm_row_mirror(double v) { const int l = lane(); return exchange(
 inline void sched_fence() {}
 inline void reload_fence() {}
 inline int pin_zero() { return 0; }
+inline int launder(int v) { return v; }
+inline int launder_uniform(int v) { return v; }
 inline void pin_value(double&) {}
 inline void pin_value(float&) {}
 
