@@ -225,8 +225,13 @@ struct SolveLStep {    // x <- L^-1 x, rows 1 .. NV-1:  x[I] -= L(I, anc) * x[an
     R nxt[14];
     load_factor_row<I + 1>(nxt, qLD + dmw::pin_zero());
     dmw::sched_fence();
+    R acc0 = 0, acc1 = 0;   // two partial sums: halves the dependent FMA chain of a 13-entry row
 #pragma unroll
-    for (int a = 1; a < 14; a++) { const int j = TOPO.dof_anc[I][a]; if (j >= 0) x[I] -= cur[a] * x[j]; }
+    for (int a = 1; a < 14; a++) {
+      const int j = TOPO.dof_anc[I][a];
+      if (j >= 0) { if (a & 1) acc0 += cur[a] * x[j]; else acc1 += cur[a] * x[j]; }
+    }
+    x[I] -= acc0 + acc1;
     dmw::pin_value(x[I]);
     SolveLStep<I + 1, R>::run(x, qLD, nxt);
   }
@@ -239,76 +244,97 @@ template <class R> DM_DEV void solve_L(R* x, const R* qLD) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// position stage: kinematics, geom poses, motion axes, spatial inertias   [MJ mj_kinematics, mj_comPos]
+// position stage: kinematics, motion axes, spatial inertias   [MJ mj_kinematics, mj_comPos]
+// Only the composition of a body's frame with its parent's is serial in the tree depth, so the work is split:
+//   1. per body (parallel): the product of its own hinge rotations q_loc and each hinge axis in the parent frame;
+//   2. four levels (serial): xpos = xpos_p + R_p pos,  xquat = normalize(xquat_p * q_loc),  xmat;
+//   3. per body (parallel): world joint axes -> cdof (about the world origin), xipos, spatial inertia;
+//   4. composite inertias as static subtree sums.
 template <class R>
 DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt) {
   const int lane = dmw::launder(lane_in);
   const int b = lane + 1;
   const bool isbody = lane < NB - 1;
-  const int depth = lt.depth;
+  const int depth = lt.depth, da = lt.dofadr, nd = lt.dofnum, p = lt.parent;
+  R qloc[4] = {1, 0, 0, 0}, aloc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   if (lane == 0) {
     s.xpos[0][0] = s.xpos[0][1] = s.xpos[0][2] = 0; s.xipos[0][0] = s.xipos[0][1] = s.xipos[0][2] = 0;
     s.ua.xquat[0][0] = 1; s.ua.xquat[0][1] = s.ua.xquat[0][2] = s.ua.xquat[0][3] = 0;
     for (int k = 0; k < 9; k++) s.xmat[0][k] = (k % 4 == 0) ? R(1) : R(0);
   }
+  // 1. local hinge chain (bodies 2..13)
+  if (isbody && b > 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (k < nd) {
+      const int d = da + k, j = d - 5;
+      const R axl[3] = {M.jnt_axis[j][0], M.jnt_axis[j][1], M.jnt_axis[j][2]};
+      R qm[9], ql[4];
+      quat2mat(qm, qloc);
+      mat_vec(aloc[k], qm, axl);                       // axis of hinge k before its own rotation, in the parent frame
+      axisangle2quat(ql, axl, s.qpos[d + 1] - M.qpos0[d + 1]);
+      quat_mul(qloc, qloc, ql);
+    }
+  }
+  // 2. compose down the tree
   for (int L = 1; L <= MAXDEPTH_BODY; L++) {
     if (isbody && depth == L) {
       R xp[3], q[4], mat[9];
-      const int da = lt.dofadr, nd = lt.dofnum;
       if (b == 1) {
         xp[0] = s.qpos[0]; xp[1] = s.qpos[1]; xp[2] = s.qpos[2];
         q[0] = s.qpos[3]; q[1] = s.qpos[4]; q[2] = s.qpos[5]; q[3] = s.qpos[6];
-        normalize4(q);
       } else {
-        const int p = lt.parent;
         R v[3];
         mat_vec(v, s.xmat[p], M.body_pos[b]);
         xp[0] = s.xpos[p][0] + v[0]; xp[1] = s.xpos[p][1] + v[1]; xp[2] = s.xpos[p][2] + v[2];
-        q[0] = s.ua.xquat[p][0]; q[1] = s.ua.xquat[p][1]; q[2] = s.ua.xquat[p][2]; q[3] = s.ua.xquat[p][3];
-        for (int k = 0; k < nd; k++) {
-          const int d = da + k, j = d - 5;
-          R axl[3] = {M.jnt_axis[j][0], M.jnt_axis[j][1], M.jnt_axis[j][2]}, axw[3], ql[4], qm[9];
-          quat2mat(qm, q);
-          mat_vec(axw, qm, axl);
-          s.cdof[d][0] = axw[0]; s.cdof[d][1] = axw[1]; s.cdof[d][2] = axw[2];
-          cross3(&s.cdof[d][3], xp, axw);
-          axisangle2quat(ql, axl, s.qpos[d + 1] - M.qpos0[d + 1]);
-          quat_mul(q, q, ql);
-        }
+        quat_mul(q, s.ua.xquat[p], qloc);
       }
       normalize4(q);
       quat2mat(mat, q);
       for (int k = 0; k < 3; k++) s.xpos[b][k] = xp[k];
       for (int k = 0; k < 4; k++) s.ua.xquat[b][k] = q[k];
       for (int k = 0; k < 9; k++) s.xmat[b][k] = mat[k];
-      R ip[3] = {M.body_ipos[b][0], M.body_ipos[b][1], M.body_ipos[b][2]}, v[3];
-      mat_vec(v, mat, ip);
-      s.xipos[b][0] = xp[0] + v[0]; s.xipos[b][1] = xp[1] + v[1]; s.xipos[b][2] = xp[2] + v[2];
-      if (b == 1) {
-        for (int k = 0; k < 3; k++) {
-          for (int r = 0; r < 6; r++) s.cdof[k][r] = (r == 3 + k) ? R(1) : R(0);
-          R ax[3] = {mat[k], mat[3 + k], mat[6 + k]};
-          s.cdof[3 + k][0] = ax[0]; s.cdof[3 + k][1] = ax[1]; s.cdof[3 + k][2] = ax[2];
-          cross3(&s.cdof[3 + k][3], xp, ax);
-        }
-      }
-      // own spatial inertia about the origin: Iw = R Ib R^T, then parallel-axis shift to the origin
-      {
-        const R* Ib = M.body_inertia[b];
-        R A[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]}, T[9], Iw[9];
-        for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) T[3 * i + jx] = mat[3 * i] * A[jx] + mat[3 * i + 1] * A[3 + jx] + mat[3 * i + 2] * A[6 + jx];
-        for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) Iw[3 * i + jx] = T[3 * i] * mat[3 * jx] + T[3 * i + 1] * mat[3 * jx + 1] + T[3 * i + 2] * mat[3 * jx + 2];
-        const R m = M.body_mass[b];
-        const R c[3] = {s.xipos[b][0], s.xipos[b][1], s.xipos[b][2]};
-        const R cc = dot3(c, c);
-        s.ub.i.sin[b][0] = Iw[0] + m * (cc - c[0] * c[0]); s.ub.i.sin[b][1] = Iw[4] + m * (cc - c[1] * c[1]); s.ub.i.sin[b][2] = Iw[8] + m * (cc - c[2] * c[2]);
-        s.ub.i.sin[b][3] = Iw[1] - m * c[0] * c[1]; s.ub.i.sin[b][4] = Iw[2] - m * c[0] * c[2]; s.ub.i.sin[b][5] = Iw[5] - m * c[1] * c[2];
-        s.ub.i.sin[b][6] = m * c[0]; s.ub.i.sin[b][7] = m * c[1]; s.ub.i.sin[b][8] = m * c[2]; s.ub.i.sin[b][9] = m;
-      }
     }
     dmw::sync();
   }
-  // composite inertias: sum over the (static) subtree   [MJ mj_crb backward pass]
+  // 3. motion axes, inertial frame position, own spatial inertia about the origin
+  if (isbody) {
+    const R xp[3] = {s.xpos[b][0], s.xpos[b][1], s.xpos[b][2]};
+    const R* mat = s.xmat[b];
+    if (b == 1) {
+      for (int k = 0; k < 3; k++) {
+        for (int r = 0; r < 6; r++) s.cdof[k][r] = (r == 3 + k) ? R(1) : R(0);
+        const R ax[3] = {mat[k], mat[3 + k], mat[6 + k]};
+        s.cdof[3 + k][0] = ax[0]; s.cdof[3 + k][1] = ax[1]; s.cdof[3 + k][2] = ax[2];
+        cross3(&s.cdof[3 + k][3], xp, ax);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; k++) if (k < nd) {
+        R axw[3];
+        mat_vec(axw, s.xmat[p], aloc[k]);
+        s.cdof[da + k][0] = axw[0]; s.cdof[da + k][1] = axw[1]; s.cdof[da + k][2] = axw[2];
+        cross3(&s.cdof[da + k][3], xp, axw);
+      }
+    }
+    const R ip[3] = {M.body_ipos[b][0], M.body_ipos[b][1], M.body_ipos[b][2]};
+    R c[3];
+    mat_vec(c, mat, ip);
+    c[0] += xp[0]; c[1] += xp[1]; c[2] += xp[2];
+    s.xipos[b][0] = c[0]; s.xipos[b][1] = c[1]; s.xipos[b][2] = c[2];
+    // Iw = R Ib R^T, then parallel-axis shift to the origin
+    const R* Ib = M.body_inertia[b];
+    const R A[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]};
+    R T[9], Iw[9];
+    for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) T[3 * i + jx] = mat[3 * i] * A[jx] + mat[3 * i + 1] * A[3 + jx] + mat[3 * i + 2] * A[6 + jx];
+    for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) Iw[3 * i + jx] = T[3 * i] * mat[3 * jx] + T[3 * i + 1] * mat[3 * jx + 1] + T[3 * i + 2] * mat[3 * jx + 2];
+    const R m = M.body_mass[b];
+    const R cc = dot3(c, c);
+    s.ub.i.sin[b][0] = Iw[0] + m * (cc - c[0] * c[0]); s.ub.i.sin[b][1] = Iw[4] + m * (cc - c[1] * c[1]); s.ub.i.sin[b][2] = Iw[8] + m * (cc - c[2] * c[2]);
+    s.ub.i.sin[b][3] = Iw[1] - m * c[0] * c[1]; s.ub.i.sin[b][4] = Iw[2] - m * c[0] * c[2]; s.ub.i.sin[b][5] = Iw[5] - m * c[1] * c[2];
+    s.ub.i.sin[b][6] = m * c[0]; s.ub.i.sin[b][7] = m * c[1]; s.ub.i.sin[b][8] = m * c[2]; s.ub.i.sin[b][9] = m;
+  }
+  dmw::sync();
+  // 4. composite inertias: sum over the (static) subtree   [MJ mj_crb backward pass]
   if (isbody) {
     R acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0;
@@ -627,7 +653,8 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
     for (int pass = 0; pass * 64 < npair; pass++) {
       const int pidx = pass * 64 + lane;
       PairContacts<R> pc;
-      pc.n = 0;
+      pc.n = 0; pc.boxslot = -1;
+      bool cand = false;
       int g1 = 0, g2 = 0, dim = 1;
       R margin = 0, mu = 0;
       if (pidx < npair) {
@@ -644,10 +671,13 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
           const R bound = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
           maybe = dot3(d, d) <= bound * bound;
         }
-        if (maybe) narrowphase(M, s, g1, g2, margin, pc);
+        cand = maybe;
         dim = M.geom_condim[g1] > M.geom_condim[g2] ? M.geom_condim[g1] : M.geom_condim[g2];
         mu = fmax(M.geom_mu[g1], M.geom_mu[g2]);
       }
+      if (dmw::ballot(cand) == 0ull) continue;        // nothing near anything in this pass (the common case for body-body pairs)
+      if (cand) narrowphase(M, s, g1, g2, margin, pc);
+      if (dmw::ballot(pc.n > 0) == 0ull) continue;
       const int rows_per = dim == 1 ? 1 : 2 * (dim - 1);
       int tot_rows, tot_con;
       const int r0 = nrow + dmw::wave_exclusive_scan(pc.n * rows_per, lane, &tot_rows);

@@ -85,15 +85,18 @@ DM_DEV double wave_sum(double v) {
   v = sum16(v);
   return ((bcast(v, 0) + bcast(v, 16)) + bcast(v, 32)) + bcast(v, 48);
 }
-// exclusive prefix sum of small non-negative ints over lanes (Hillis-Steele on shfl_up)
+// exclusive prefix sum over lanes of a small non-negative int (< 32): one ballot + popcount per bit instead of a
+// 6-step shuffle scan (each shuffle is an LDS-crossbar round trip)
 DM_DEV int wave_exclusive_scan(int v, int lane_id, int* total) {
-  int x = v;
+  const unsigned long long below = (1ull << lane_id) - 1ull;
+  int pre = 0, tot = 0;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int y = shfl_up_i(x, d);
-    if (lane_id >= d) x += y;
+  for (int b = 0; b < 5; b++) {
+    const unsigned long long m = ballot(((v >> b) & 1) != 0);
+    pre += __builtin_popcountll(m & below) << b;
+    tot += __builtin_popcountll(m) << b;
   }
-  *total = shfl_i(x, 63);
-  return x - v;
+  *total = tot;
+  return pre;
 }
 }  // namespace dmw
