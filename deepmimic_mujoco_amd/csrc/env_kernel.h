@@ -779,7 +779,9 @@ struct RowStep {
     if (D == ra.ldof) j = ra.lsgn;
     ra.vel += j * cur[6]; ra.jsm += j * cur[7]; ra.jws += j * cur[8];
     y[D] = j;
-    dmw::pin_value(ra.vel);
+    // pin all three running sums: an unpinned one is sunk to the end of the loop by the optimiser, which keeps its 34
+    // operands (loaded here) alive — and spilled — until then
+    dmw::pin_value(ra.vel); dmw::pin_value(ra.jsm); dmw::pin_value(ra.jws);
     RowStep<D + 1, R>::run(y, ra, s, nxt);
   }
 };
@@ -867,55 +869,38 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     for (int d = 0; d < NV; d++) y[d] *= s.dsq[d];
     DM_STAMP(10)
     // ---- A = Y Y^T + diag(R): rows of Y broadcast through LDS, 16 at a time ---------------------------------
+    // (every AR[i] is defined exactly here — no early zero-initialisation that would keep the array live during the
+    //  row build and the half solve)
 #pragma unroll
     for (int c = 0; c < ROWS / 16; c++) {
-      if (c * 16 < nefc) {
+      const bool chunk_live = c * 16 < nefc;
+      if (chunk_live) {
         dmw::sync();
         if ((lane >> 4) == c) {
 #pragma unroll
           for (int d = 0; d < NV; d++) s.u.ybuf[lane & 15][d] = y[d];
         }
         dmw::sync();
+      }
 #pragma unroll
-        for (int ii = 0; ii < 16; ii++) {
-          const int i = c * 16 + ii;
-          R acc = 0;
-          if (i < nefc) {
-            // dot(Y_lane, Y_i) in four quarter rows, the next quarter loaded while the current one is multiplied
-            R qa[9], qb[9];
-            { const int z0 = dmw::pin_zero();
+      for (int ii = 0; ii < 16; ii++) {
+        const int i = c * 16 + ii;
+        R acc = 0;
+        if (i < nefc) {
+          // dot(Y_lane, Y_i) in chunks of 6 entries read at a wave-uniform LDS address
+          R qa[6];
 #pragma unroll
-              for (int d = 0; d < 9; d++) qa[d] = s.u.ybuf[ii][d + z0]; }
-            { const int z1 = dmw::pin_zero();
+          for (int c0 = 0; c0 < NV; c0 += 6) {
+            const int zc = dmw::pin_zero();
 #pragma unroll
-              for (int d = 0; d < 9; d++) qb[d] = s.u.ybuf[ii][9 + d + z1]; }
-            dmw::sched_fence();
+            for (int d = 0; d < 6; d++) if (c0 + d < NV) qa[d] = s.u.ybuf[ii][c0 + d + zc];
 #pragma unroll
-            for (int d = 0; d < 9; d++) acc += y[d] * qa[d];
-            dmw::pin_value(acc);
-            { const int z2 = dmw::pin_zero();
-#pragma unroll
-              for (int d = 0; d < 8; d++) qa[d] = s.u.ybuf[ii][18 + d + z2]; }
-            dmw::sched_fence();
-#pragma unroll
-            for (int d = 0; d < 9; d++) acc += y[9 + d] * qb[d];
-            dmw::pin_value(acc);
-            { const int z3 = dmw::pin_zero();
-#pragma unroll
-              for (int d = 0; d < 8; d++) qb[d] = s.u.ybuf[ii][26 + d + z3]; }
-            dmw::sched_fence();
-#pragma unroll
-            for (int d = 0; d < 8; d++) acc += y[18 + d] * qa[d];
-#pragma unroll
-            for (int d = 0; d < 8; d++) acc += y[26 + d] * qb[d];
+            for (int d = 0; d < 6; d++) if (c0 + d < NV) acc += y[c0 + d] * qa[d];
             dmw::pin_value(acc);
           }
-          if (lane == i) { acc += Rr; diag = acc; }
-          AR[i] = acc;
         }
-      } else {
-#pragma unroll
-        for (int ii = 0; ii < 16; ii++) AR[c * 16 + ii] = 0;
+        if (lane == i) { acc += Rr; diag = acc; }
+        AR[i] = acc;
       }
     }
   }
@@ -940,6 +925,9 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   // ---- projected Gauss-Seidel, rows in order; one broadcast + one FMA per row, no memory ------------------------
   int iter = 0;
   const int maxiter = dmw::uniform(M.iterations);
+  // loop constants pinned in VGPRs: left to itself the compiler re-loads them from memory (s_load + wait) every sweep
+  R pgs_scale = M.pgs_scale, pgs_tol = M.tolerance;
+  dmw::pin_value(pgs_scale); dmw::pin_value(pgs_tol);
   while (iter < maxiter) {
     R myimp = 0;
     // fresh opaque copies per sweep: otherwise the 64 row-exists tests and 64 lane==row masks are hoisted out of the
@@ -966,9 +954,9 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
         }
       }
     }
-    const R improvement = dmw::wave_sum(active ? myimp : R(0)) * M.pgs_scale;
+    const R improvement = dmw::wave_sum(active ? myimp : R(0)) * pgs_scale;
     iter++;
-    if (dmw::uniform(improvement < M.tolerance)) break;
+    if (dmw::uniform(improvement < pgs_tol)) break;
   }
   DM_STAMP(12)
   if (dbg && active) {

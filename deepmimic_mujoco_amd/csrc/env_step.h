@@ -65,6 +65,7 @@ DM_DEV void integrate_pos(Shared<R>& s, const R* x0q, int lane, R h) {
 template <class R>
 struct StepScratch {
   R x0q[36], x0v[NV];
+  R vprev[NV], aprev[NV], sumv[NV], suma[NV];   // RK accumulators parked in LDS while forward() needs the registers
 };
 
 // [MJ mj_step, integrator RK4] on the state in s.qpos / s.qvel / s.qws / s.act.  Returns with the new state in
@@ -75,27 +76,28 @@ DM_DEV bool rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int 
   const R A[3] = {R(0.5), R(0.5), R(1)};
   const R Bw[4] = {R(1) / 6, R(1) / 3, R(1) / 3, R(1) / 6};
   if (lane < NQ) x.x0q[lane] = s.qpos[lane];
-  if (lane < NV) x.x0v[lane] = s.qvel[lane];
+  if (lane < NV) { const R v0 = s.qvel[lane]; x.x0v[lane] = v0; x.vprev[lane] = v0; x.sumv[lane] = 0; x.suma[lane] = 0; }
   dmw::sync();
-  R v0 = 0, vprev = 0, aprev = 0, sumv = 0, suma = 0;
-  if (lane < NV) { v0 = x.x0v[lane]; vprev = v0; }
   for (int i = 0; i < 4; i++) {   // single call site of forward(): the four evaluations share one copy of the code
     if (i > 0) {
       const R c = A[i - 1];
-      if (lane < NV) s.ua.f.tau[lane] = c * vprev;   // dX (position part)
+      if (lane < NV) s.ua.f.tau[lane] = c * x.vprev[lane];   // dX (position part)
       dmw::sync();
       integrate_pos(s, x.x0q, lane, h);
-      if (lane < NV) { vprev = v0 + h * (c * aprev); s.qvel[lane] = vprev; }
+      if (lane < NV) { const R vi = x.x0v[lane] + h * (c * x.aprev[lane]); x.vprev[lane] = vi; s.qvel[lane] = vi; }
       dmw::sync();
     }
     forward<R, ROWS, PROF>(M, s, lane, lt, (const DebugOut*)0, prof);
     if (ROWS < MAXEFC && (dmw::uniform(s.status) & 1)) return false;   // needs the wide tier
-    if (lane < NV) { aprev = s.ua.f.qacc[lane]; sumv += Bw[i] * vprev; suma += Bw[i] * aprev; }
+    if (lane < NV) {
+      const R a = s.ua.f.qacc[lane];
+      x.aprev[lane] = a; x.sumv[lane] += Bw[i] * x.vprev[lane]; x.suma[lane] += Bw[i] * a;
+    }
   }
-  if (lane < NV) s.ua.f.tau[lane] = sumv;
+  if (lane < NV) s.ua.f.tau[lane] = x.sumv[lane];
   dmw::sync();
   integrate_pos(s, x.x0q, lane, h);
-  if (lane < NV) { s.qvel[lane] = v0 + h * suma; s.qws[lane] = aprev; }
+  if (lane < NV) { s.qvel[lane] = x.x0v[lane] + h * x.suma[lane]; s.qws[lane] = x.aprev[lane]; }
   dmw::sync();
   return true;
 }
