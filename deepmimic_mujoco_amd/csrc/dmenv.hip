@@ -225,7 +225,7 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
   switch (opt) {
     case DM_OPT_REWARD_MODE: if (v < 0 || v > 2) return fail(DM_EINVAL, "reward mode must be 0..2"); b->B.reward_mode = (int)v; break;
     case DM_OPT_AUTORESET: if (v < 0 || v > 2) return fail(DM_EINVAL, "autoreset must be 0..2"); b->B.autoreset = (int)v; break;
-    case DM_OPT_ACTION_MODE: if (v < 0 || v > 1) return fail(DM_EINVAL, "action mode must be 0..1"); b->B.action_mode = (int)v; break;
+    case DM_OPT_ACTION_MODE: if (v < 0 || v > 2) return fail(DM_EINVAL, "action mode must be 0..2"); b->B.action_mode = (int)v; break;
     case DM_OPT_SEED: b->B.seed = (unsigned long long)v; break;
     case 100: b->B.env_offset = (int)v; break;  /* global id of env 0 (multi-GPU sharding) */
     case 102: b->two_tier = v != 0; break;       /* 1 (default): narrow 32-row kernel + wide 64-row kernel for the envs that need it */

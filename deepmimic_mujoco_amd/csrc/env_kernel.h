@@ -45,6 +45,7 @@ struct DevModel {
   int jnt_limited[NJ];
   R dof_armature[NV], dof_damping[NV], dof_invw[NV];
   R gear[NV], ctrl_lo[NV], ctrl_hi[NV];  // per dof (0 for the free joint)
+  R kp[NV], kd[NV];                      // PD gains per dof (PARAMS_KP_KD, src/mujoco/mocap_util.py:22-24), action mode 2
   int geom_type[NG], geom_body[NG], geom_condim[NG], geom_boxslot[NG];   // boxslot: index among box geoms (< 4) or -1
   R geom_pos[NG][3], geom_mat[NG][9], geom_size[NG][3], geom_margin[NG], geom_mu[NG], geom_rbound[NG];
   int npair;
@@ -591,7 +592,56 @@ DM_DEV void narrowphase(const DevModel<R>& M, Shared<R>& s, int g1, int g2, R ma
     pc.p0[0] += p2[0]; pc.p0[1] += p2[1]; pc.p0[2] += p2[2];
     return;
   }
-  // capsule-box, box-box: not handled this round (the oracle returns no contact for them as well)
+  if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) {
+    // closest point of the capsule segment to the box by a fixed 48-step golden-section search on the convex point-box
+    // distance, then one sphere-box contact there (own algorithm, identical to the oracle's; MuJoCo's mjc_CapsuleBox is a
+    // case analysis that is not restated)
+    const R ax[3] = {m1[2], m1[5], m1[8]};
+    R t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, c0[3], u[3];
+    matT_vec(c0, m2, t); matT_vec(u, m2, ax);
+    R lo = -s1[1], hi = s1[1];
+    const R gr = R(0.6180339887498949);
+    auto d2 = [&](R tt) { R acc = 0; for (int k = 0; k < 3; k++) { const R pk = c0[k] + tt * u[k]; const R ck = clampr(pk, -s2[k], s2[k]); acc += (pk - ck) * (pk - ck); } return acc; };
+    R x1 = hi - gr * (hi - lo), x2 = lo + gr * (hi - lo), f1 = d2(x1), f2 = d2(x2);
+    for (int it = 0; it < 48; it++) {
+      if (f1 <= f2) { hi = x2; x2 = x1; f2 = f1; x1 = hi - gr * (hi - lo); f1 = d2(x1); }
+      else { lo = x1; x1 = x2; f1 = f2; x2 = lo + gr * (hi - lo); f2 = d2(x2); }
+    }
+    R ts = R(0.5) * (lo + hi);
+    {  // closed-form refinement with the clamping pattern the search found (the search alone is only sqrt(eps)-accurate)
+      R num = 0, den = 0;
+      for (int k = 0; k < 3; k++) {
+        const R pk = c0[k] + ts * u[k];
+        if (pk > s2[k]) { num += u[k] * (c0[k] - s2[k]); den += u[k] * u[k]; }
+        else if (pk < -s2[k]) { num += u[k] * (c0[k] + s2[k]); den += u[k] * u[k]; }
+      }
+      if (den > R(1e-12)) ts = clampr(-num / den, -s1[1], s1[1]);
+    }
+    R center[3], clamped[3], nrm[3], pl[3];
+    for (int k = 0; k < 3; k++) { center[k] = c0[k] + ts * u[k]; clamped[k] = clampr(center[k], -s2[k], s2[k]); t[k] = center[k] - clamped[k]; }
+    const R dist = sqrt(dot3(t, t));
+    if (dist - s1[0] > margin) return;
+    if (dist <= R(DM_MINVAL)) {
+      R closest = 2 * fmax(s2[0], fmax(s2[1], s2[2]));
+      int k = 0;
+      for (int i = 0; i < 6; i++) { const R fd = fabs(((i % 2) ? R(1) : R(-1)) * s2[i / 2] - center[i / 2]); if (closest > fd) { closest = fd; k = i; } }
+      nrm[0] = nrm[1] = nrm[2] = 0; nrm[k / 2] = (k % 2) ? R(-1) : R(1);
+      const R sc = (s1[0] - closest) / 2;
+      pl[0] = center[0] + nrm[0] * sc; pl[1] = center[1] + nrm[1] * sc; pl[2] = center[2] + nrm[2] * sc;
+      pc.d0 = -closest - s1[0];
+    } else {
+      for (int i = 0; i < 3; i++) nrm[i] = -t[i] / dist;
+      const R sc = s1[0] + R(0.5) * (dist - s1[0]);
+      pl[0] = center[0] + nrm[0] * sc; pl[1] = center[1] + nrm[1] * sc; pl[2] = center[2] + nrm[2] * sc;
+      pc.d0 = dist - s1[0];
+    }
+    pc.n = 1;
+    mat_vec(pc.nrm, m2, nrm);
+    mat_vec(pc.p0, m2, pl);
+    pc.p0[0] += p2[0]; pc.p0[1] += p2[1]; pc.p0[2] += p2[2];
+    return;
+  }
+  // box-box (foot against foot): not handled this round (the oracle returns no contact for it as well)
 }
 
 // [MJ mju_makeFrame] rows of f: normal, tangent 1, tangent 2

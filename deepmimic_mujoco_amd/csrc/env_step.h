@@ -114,6 +114,10 @@ DM_DEV void load_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int 
     if (B.action_mode == 1) {  // P-control towards the current mocap frame (src/env_torque_test.py:14-20)
       const int idx = B.frame_idx[env];
       a += R(0.8) * (B.mocap_cfg[(size_t)idx * NQ + 7 + lane] - s.qpos[7 + lane]);
+    } else if (B.action_mode == 2) {  // PD torque kp*dq + kd*dv written to ctrl (src/mujoco/setting_states.py:207-226)
+      const int idx = B.frame_idx[env];
+      a += M.kp[lane + 6] * (B.mocap_cfg[(size_t)idx * NQ + 7 + lane] - s.qpos[7 + lane]) +
+           M.kd[lane + 6] * (B.mocap_vel[(size_t)idx * NV + 6 + lane] - s.qvel[6 + lane]);
     }
     B.ctrl[(size_t)env * NU + lane] = a;  // data.ctrl keeps the unclamped value
     const int d = lane + 6;

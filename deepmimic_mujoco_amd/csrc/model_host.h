@@ -59,6 +59,12 @@ inline int build_dev_model(const dm_model_desc* d, DevModel<double>* hp, std::st
   }
   { int nbox = 0; for (int g = 0; g < NG; g++) h.geom_boxslot[g] = (h.geom_type[g] == GEOM_BOX) ? nbox++ : -1;
     if (nbox > 4) return mfail(err, DM_EUNSUPPORTED, "dm_model_create: at most 4 box geoms are supported"); }
+  { // Kp / Kd per hinge dof, joint order chest, neck, r_shoulder, r_elbow, l_shoulder, l_elbow, r_hip, r_knee, r_ankle, l_hip, l_knee, l_ankle
+    // (PARAMS_KP_KD, src/mujoco/mocap_util.py:22-24; assembled like MujocoInterface.__init__, src/mujoco/mujoco_interface.py:66-72)
+    static const double kp_j[12] = {1000, 100, 400, 300, 400, 300, 500, 500, 400, 500, 500, 400};
+    static const double kd_j[12] = {100, 10, 40, 30, 40, 30, 50, 50, 40, 50, 50, 40};
+    for (int dd = 6; dd < NV; dd++) { const int jb = dm::make_topo().dof_body[dd] - 2; h.kp[dd] = kp_j[jb]; h.kd[dd] = kd_j[jb]; }
+  }
   h.npair = d->npair;
   for (int p = 0; p < d->npair; p++) { h.pair_g1[p] = (short)d->pair_geom[2 * p]; h.pair_g2[p] = (short)d->pair_geom[2 * p + 1]; }
   h.qpos0[0] = d->body_pos[3]; h.qpos0[1] = d->body_pos[4]; h.qpos0[2] = d->body_pos[5]; h.qpos0[3] = 1;

@@ -261,7 +261,7 @@ class DPVecEnv(object):
         b = self._batch
         b.set_option(A.OPT_REWARD_MODE, REWARD_MODES[reward])
         b.set_option(A.OPT_AUTORESET, {"none": 0, None: 0, "rsi": 1, "init": 2}[autoreset])
-        b.set_option(A.OPT_ACTION_MODE, {"raw": 0, "p-control": 1}[action_mode])
+        b.set_option(A.OPT_ACTION_MODE, {"raw": 0, "p-control": 1, "pd": 2}[action_mode])
         b.set_option(A.OPT_SEED, int(seed))
         b.set_option(A.OPT_ENV_OFFSET, int(env_offset))
         cr = self._cm.actuator_ctrlrange

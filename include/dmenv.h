@@ -103,7 +103,8 @@ int dm_batch_set_stream(dm_batch* b, void* hip_stream); /* default: a stream own
 enum {
   DM_OPT_REWARD_MODE = 1, /* 0 alive=1.0 (dp_env_v3.py:117-128, default), 1 v3-config (:89-104), 2 v2-pose (dp_env_v2.py:116-183) */
   DM_OPT_AUTORESET = 2,   /* 0 off (default), 1 RSI on done, 2 noisy-init on done (DummyVecEnv convention) */
-  DM_OPT_ACTION_MODE = 3, /* 0 raw ctrl (dp_env_v3.py:112, default), 1 P-control 0.8*(mocap_cfg - q) + action (env_torque_test.py:20) */
+  DM_OPT_ACTION_MODE = 3, /* 0 raw ctrl (dp_env_v3.py:112, default), 1 P-control 0.8*(mocap_cfg - q) + action (env_torque_test.py:20),
+                             2 PD kp*(mocap_cfg - q) + kd*(mocap_vel - v) + action (setting_states.py:207-226, gains mocap_util.py:22-24) */
   DM_OPT_SEED = 4
 };
 int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t value);

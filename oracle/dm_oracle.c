@@ -599,8 +599,54 @@ static int narrowphase(const dmo_model* m, const dmo_data* d, int g1, int g2, do
     mat_vec(con->pos, m2, pl); add3(con->pos, con->pos, p2);
     return 1;
   }
-  /* capsule-box and box-box (feet against shins / each other): NOT YET RESTATED — returns no contact.
-   * Documented gap (DESIGN.md "out of scope this round"); the HIP path mirrors the same behaviour. */
+  if (t1 == DMO_GEOM_CAPSULE && t2 == DMO_GEOM_BOX) {
+    /* OWN ALGORITHM (MuJoCo's mjc_CapsuleBox is a long case analysis that is not restated): the point of the capsule
+     * segment closest to the box is found by a fixed 48-step golden-section search on the (convex) point-box distance,
+     * and one sphere-box contact [MJ mjc_SphereBox] is generated there.  The HIP kernel runs the identical search. */
+    double ax[3] = {m1[2], m1[5], m1[8]}, t[3], c0[3], u[3];
+    sub3(t, p1, p2); matT_vec(c0, m2, t); matT_vec(u, m2, ax);
+    double lo = -s1[1], hi = s1[1];
+    const double gr = 0.6180339887498949;
+    double x1 = hi - gr * (hi - lo), x2 = lo + gr * (hi - lo), f1, f2;
+#define SEGBOX_D2(tt, out) do { double d2_ = 0; for (int k_ = 0; k_ < 3; k_++) { double pk_ = c0[k_] + (tt) * u[k_]; \
+      double ck_ = clampd(pk_, -s2[k_], s2[k_]); d2_ += (pk_ - ck_) * (pk_ - ck_); } (out) = d2_; } while (0)
+    SEGBOX_D2(x1, f1); SEGBOX_D2(x2, f2);
+    for (int it = 0; it < 48; it++) {
+      if (f1 <= f2) { hi = x2; x2 = x1; f2 = f1; x1 = hi - gr * (hi - lo); SEGBOX_D2(x1, f1); }
+      else { lo = x1; x1 = x2; f1 = f2; x2 = lo + gr * (hi - lo); SEGBOX_D2(x2, f2); }
+    }
+#undef SEGBOX_D2
+    double ts = 0.5 * (lo + hi), center[3], clamped[3], nrm[3], pl[3];
+    { /* the search locates the minimiser only to ~sqrt(eps); with the clamping pattern it found, the distance is an exact
+       * quadratic in t: one closed-form refinement makes the result reproducible to rounding */
+      double num = 0, den = 0;
+      for (int k = 0; k < 3; k++) {
+        double pk = c0[k] + ts * u[k];
+        if (pk > s2[k]) { num += u[k] * (c0[k] - s2[k]); den += u[k] * u[k]; }
+        else if (pk < -s2[k]) { num += u[k] * (c0[k] + s2[k]); den += u[k] * u[k]; }
+      }
+      if (den > 1e-12) ts = clampd(-num / den, -s1[1], s1[1]);
+    }
+    for (int k = 0; k < 3; k++) { center[k] = c0[k] + ts * u[k]; clamped[k] = clampd(center[k], -s2[k], s2[k]); t[k] = center[k] - clamped[k]; }
+    double dist = norm3(t);
+    if (dist - s1[0] > margin) return 0;
+    if (dist <= MINVAL) {
+      double closest = 2 * fmax(s2[0], fmax(s2[1], s2[2])); int kk = 0;
+      for (int i = 0; i < 6; i++) { double fd = fabs((i % 2 ? 1 : -1) * s2[i / 2] - center[i / 2]); if (closest > fd) { closest = fd; kk = i; } }
+      zero3(nrm); nrm[kk / 2] = (kk % 2 ? -1 : 1);
+      addscl3(pl, center, nrm, (s1[0] - closest) / 2);
+      con->dist = -closest - s1[0];
+    } else {
+      for (int i = 0; i < 3; i++) nrm[i] = -t[i] / dist;
+      addscl3(pl, center, nrm, s1[0] + 0.5 * (dist - s1[0]));
+      con->dist = dist - s1[0];
+    }
+    mat_vec(con->frame, m2, nrm); zero3(con->frame + 3);
+    mat_vec(con->pos, m2, pl); add3(con->pos, con->pos, p2);
+    return 1;
+  }
+  /* box-box (foot against foot): NOT YET RESTATED — returns no contact.  Documented gap; the HIP path
+   * mirrors the same behaviour. */
   return 0;
 }
 /* [MJ mju_makeFrame] complete (normal, tangent hint) into a right-handed orthonormal frame, rows = axes */

