@@ -50,6 +50,7 @@ struct DevModel {
   R geom_pos[NG][3], geom_mat[NG][9], geom_size[NG][3], geom_margin[NG], geom_mu[NG], geom_rbound[NG];
   int npair;
   short pair_g1[MAXPAIR], pair_g2[MAXPAIR];
+  short pair_stage[MAXPAIR];   // LDS staging slot of a pair that can yield > 2 contacts (plane-box 0..3, box-box 4..5), else -1
   R qpos0[NQ];
   R timestep, gravity[3], tolerance, solref[2], solimp[5], meaninertia, total_mass;
   R K, B, pgs_scale;  // constraint stiffness / damping (refsafe applied), 1/(meaninertia*nv)
@@ -72,7 +73,7 @@ struct Shared {
   } ua;
   union {
     struct { R sin[NB][10], crb[NB][10]; } i;
-    struct { R gpos[NG][3], gmat[NG][9]; } g;
+    struct { R gpos[NG][3], gmat[NG][9], poly[2][8][3], axes[2][3][3]; } g;   // poly / axes: box-box scratch (dynamically indexed)
   } ub;
   union {
     R fdof[NV][6];
@@ -81,7 +82,7 @@ struct Shared {
     R ybuf[16][NV];
     struct { R rowf[MAXEFC][6], G[NB][6], Gsub[NB][6]; } c;   // constraint forces as body wrenches (end of the solve)
   } u;
-  R boxc[4][4][4];     // plane-box corner contacts (dist, pos) staged per box: the only pair type with > 2 contacts
+  R boxc[6][4][4];     // contacts (dist, pos) of the pair types with > 2 contacts: plane-box (slots 0..3), box-box (4..5)
   int rowi[MAXEFC];    // type | b1<<8 | b2<<16   (limit: type | dof<<8)
   int cong[MAXEFC][2]; // contact geom ids
   int nefc, ncon, status, solver_iter;
@@ -263,16 +264,23 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     s.ua.xquat[0][0] = 1; s.ua.xquat[0][1] = s.ua.xquat[0][2] = s.ua.xquat[0][3] = 0;
     for (int k = 0; k < 9; k++) s.xmat[0][k] = (k % 4 == 0) ? R(1) : R(0);
   }
-  // 1. local hinge chain (bodies 2..13)
+  // 1a. half-angle sine / cosine of every hinge, one lane per hinge (one sincos evaluation deep instead of three)
+  if (lane < NU) {
+    const R half = (s.qpos[lane + 7] - M.qpos0[lane + 7]) * R(0.5);
+    s.u.fdof[lane][0] = cos(half); s.u.fdof[lane][1] = sin(half);     // (u.fdof is free until the mass-matrix stage)
+  }
+  dmw::sync();
+  // 1b. local hinge chain (bodies 2..13)
   if (isbody && b > 1) {
 #pragma unroll
     for (int k = 0; k < 3; k++) if (k < nd) {
       const int d = da + k, j = d - 5;
       const R axl[3] = {M.jnt_axis[j][0], M.jnt_axis[j][1], M.jnt_axis[j][2]};
-      R qm[9], ql[4];
+      R qm[9];
       quat2mat(qm, qloc);
       mat_vec(aloc[k], qm, axl);                       // axis of hinge k before its own rotation, in the parent frame
-      axisangle2quat(ql, axl, s.qpos[d + 1] - M.qpos0[d + 1]);
+      const R c = s.u.fdof[d - 6][0], sn = s.u.fdof[d - 6][1];
+      const R ql[4] = {c, axl[0] * sn, axl[1] * sn, axl[2] * sn};
       quat_mul(qloc, qloc, ql);
     }
   }
@@ -493,8 +501,123 @@ DM_DEV void sphere_sphere(PairContacts<R>& pc, const R* c1, R r1, const R* c2, R
   pc.p0[0] = c1[0] + dif[0] * sc; pc.p0[1] = c1[1] + dif[1] * sc; pc.p0[2] = c1[2] + dif[2] * sc;
 }
 
+// box-box: separating-axis test (6 face normals + 9 edge cross products); least-penetration axis -> either a face
+// contact (incident face clipped against the reference face, the 4 deepest clipped vertices within the margin) or one
+// edge-edge contact.  Own algorithm, identical to the oracle's box_box (MuJoCo's mjc_BoxBox is not restated).  Runs in a
+// single lane (the feet pair); the clipping polygons and the contacts are staged in LDS.
 template <class R>
-DM_DEV void narrowphase(const DevModel<R>& M, Shared<R>& s, int g1, int g2, R margin, PairContacts<R>& pc) {
+DM_DEV void box_box(Shared<R>& s, const R* p1, const R* m1, const R* s1, const R* p2, const R* m2, const R* s2, int slot, R margin,
+                    PairContacts<R>& pc) {
+  // box axes live in LDS: they are indexed with run-time axis numbers below (register arrays would go to scratch)
+  R (*A)[3] = s.ub.g.axes[0];
+  R (*B)[3] = s.ub.g.axes[1];
+  R aR[3][3];
+  for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = m1[3 * k + i]; B[i][k] = m2[3 * k + i]; }
+  const R d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) aR[i][j] = fabs(dot3(A[i], B[j]));
+  R best = R(-1e300);
+  int code = -1;
+  for (int i = 0; i < 3; i++) {
+    const R sep = fabs(dot3(d, A[i])) - (s1[i] + s2[0] * aR[i][0] + s2[1] * aR[i][1] + s2[2] * aR[i][2]);
+    if (sep > margin) return;
+    if (sep > best) { best = sep; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    const R sep = fabs(dot3(d, B[j])) - (s2[j] + s1[0] * aR[0][j] + s1[1] * aR[1][j] + s1[2] * aR[2][j]);
+    if (sep > margin) return;
+    if (sep > best) { best = sep; code = 3 + j; }
+  }
+  R ebest = R(-1e300), en[3] = {0, 0, 0};
+  int ei = -1, ej = -1;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    R L[3];
+    cross3(L, A[i], B[j]);
+    const R len = sqrt(dot3(L, L));
+    if (len < R(1e-6)) continue;
+    L[0] /= len; L[1] /= len; L[2] /= len;
+    const R rA = s1[0] * fabs(dot3(A[0], L)) + s1[1] * fabs(dot3(A[1], L)) + s1[2] * fabs(dot3(A[2], L));
+    const R rB = s2[0] * fabs(dot3(B[0], L)) + s2[1] * fabs(dot3(B[1], L)) + s2[2] * fabs(dot3(B[2], L));
+    const R dl = dot3(d, L), sep = fabs(dl) - rA - rB;
+    if (sep > margin) return;
+    if (sep > ebest) { ebest = sep; ei = i; ej = j; const R sg = dl < 0 ? R(-1) : R(1); en[0] = sg * L[0]; en[1] = sg * L[1]; en[2] = sg * L[2]; }
+  }
+  pc.boxslot = slot;
+  if (ei >= 0 && ebest > best + R(1e-6)) {
+    R ca[3] = {p1[0], p1[1], p1[2]}, cb[3] = {p2[0], p2[1], p2[2]};
+    for (int k = 0; k < 3; k++) if (k != ei) { const R sg = (dot3(en, A[k]) > 0 ? R(1) : R(-1)) * s1[k]; ca[0] += A[k][0] * sg; ca[1] += A[k][1] * sg; ca[2] += A[k][2] * sg; }
+    for (int k = 0; k < 3; k++) if (k != ej) { const R sg = (dot3(en, B[k]) > 0 ? R(-1) : R(1)) * s2[k]; cb[0] += B[k][0] * sg; cb[1] += B[k][1] * sg; cb[2] += B[k][2] * sg; }
+    const R w[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+    const R ab = dot3(A[ei], B[ej]), aw = dot3(A[ei], w), bw = dot3(B[ej], w), den = 1 - ab * ab;
+    R ta = den > R(1e-12) ? (ab * bw - aw) / den : R(0), tb = den > R(1e-12) ? (bw - ab * aw) / den : R(0);
+    ta = clampr(ta, -s1[ei], s1[ei]); tb = clampr(tb, -s2[ej], s2[ej]);
+    R* o = s.boxc[slot][0];
+    o[0] = ebest;
+    for (int k = 0; k < 3; k++) o[1 + k] = R(0.5) * ((ca[k] + A[ei][k] * ta) + (cb[k] + B[ej][k] * tb));
+    pc.nrm[0] = en[0]; pc.nrm[1] = en[1]; pc.nrm[2] = en[2];
+    pc.n = 1;
+    return;
+  }
+  const bool refB = code >= 3;
+  const int ax = refB ? code - 3 : code;
+  const R* pr = refB ? p2 : p1; const R* pi = refB ? p1 : p2; const R* sr = refB ? s2 : s1; const R* si = refB ? s1 : s2;
+  R (*Rr)[3] = refB ? B : A; R (*Ri)[3] = refB ? A : B;
+  const R dr[3] = {pi[0] - pr[0], pi[1] - pr[1], pi[2] - pr[2]};
+  const R sgn = dot3(dr, Rr[ax]) < 0 ? R(-1) : R(1);
+  const R n[3] = {sgn * Rr[ax][0], sgn * Rr[ax][1], sgn * Rr[ax][2]};
+  int k = 0;
+  R bestdot = -1;
+  for (int j = 0; j < 3; j++) { const R dd = fabs(dot3(n, Ri[j])); if (dd > bestdot) { bestdot = dd; k = j; } }
+  const R fs = dot3(n, Ri[k]) > 0 ? R(-1) : R(1);
+  const int k1 = (k + 1) % 3, k2 = (k + 2) % 3, u = (ax + 1) % 3, v = (ax + 2) % 3;
+  int np = 4, cur = 0;
+  for (int c = 0; c < 4; c++) {
+    const R a1 = (c == 0 || c == 3) ? R(1) : R(-1), a2 = (c < 2) ? R(1) : R(-1);
+    R rel[3];
+    for (int t = 0; t < 3; t++) rel[t] = pi[t] + fs * si[k] * Ri[k][t] + a1 * si[k1] * Ri[k1][t] + a2 * si[k2] * Ri[k2][t] - pr[t];
+    s.ub.g.poly[0][c][0] = dot3(rel, Rr[u]); s.ub.g.poly[0][c][1] = dot3(rel, Rr[v]); s.ub.g.poly[0][c][2] = sgn * dot3(rel, Rr[ax]);
+  }
+  for (int e = 0; e < 4 && np > 0; e++) {
+    const int cdim = e / 2;
+    const R sg = (e % 2) ? R(-1) : R(1), lim = cdim == 0 ? sr[u] : sr[v];
+    int nn = 0;
+    for (int a = 0; a < np; a++) {
+      const R* P = s.ub.g.poly[cur][a]; const R* Q = s.ub.g.poly[cur][(a + 1) % np];
+      const R P0 = P[0], P1 = P[1], P2 = P[2], Q0 = Q[0], Q1 = Q[1], Q2 = Q[2];
+      const R dp = lim - sg * (cdim == 0 ? P0 : P1), dq = lim - sg * (cdim == 0 ? Q0 : Q1);
+      if (dp >= 0 && nn < 8) { R* o = s.ub.g.poly[1 - cur][nn]; o[0] = P0; o[1] = P1; o[2] = P2; nn++; }
+      if ((dp >= 0) != (dq >= 0) && nn < 8) {
+        const R tt = dp / (dp - dq);
+        R* o = s.ub.g.poly[1 - cur][nn];
+        o[0] = P0 + tt * (Q0 - P0); o[1] = P1 + tt * (Q1 - P1); o[2] = P2 + tt * (Q2 - P2); nn++;
+      }
+    }
+    np = nn; cur = 1 - cur;
+  }
+  // keep the (up to) 4 deepest candidates within the margin, in polygon order (bit mask instead of an array)
+  unsigned keep = 0;
+  int nk = 0;
+  for (int a = 0; a < np; a++) if (s.ub.g.poly[cur][a][2] - sr[ax] < margin) { keep |= 1u << a; nk++; }
+  while (nk > 4) {
+    int worst = -1;
+    R wd = 0;
+    for (int a = 0; a < np; a++) if ((keep >> a) & 1u) { const R da = s.ub.g.poly[cur][a][2] - sr[ax]; if (worst < 0 || da > wd) { worst = a; wd = da; } }
+    keep &= ~(1u << worst); nk--;
+  }
+  int cnt = 0;
+  for (int a = 0; a < np; a++) if ((keep >> a) & 1u) {
+    const R* P = s.ub.g.poly[cur][a];
+    const R da = P[2] - sr[ax];
+    R* o = s.boxc[slot][cnt];
+    o[0] = da;
+    for (int t = 0; t < 3; t++) o[1 + t] = (pr[t] + P[0] * Rr[u][t] + P[1] * Rr[v][t] + sgn * P[2] * Rr[ax][t]) - n[t] * da / 2;
+    cnt++;
+  }
+  pc.nrm[0] = refB ? -n[0] : n[0]; pc.nrm[1] = refB ? -n[1] : n[1]; pc.nrm[2] = refB ? -n[2] : n[2];
+  pc.n = cnt;
+}
+
+template <class R>
+DM_DEV void narrowphase(const DevModel<R>& M, Shared<R>& s, int g1, int g2, int stage_slot, R margin, PairContacts<R>& pc) {
   pc.n = 0; pc.boxslot = -1;
   pc.hint[0] = pc.hint[1] = pc.hint[2] = 0;
   pc.nrm[0] = pc.nrm[1] = 0; pc.nrm[2] = 1;
@@ -520,7 +643,7 @@ DM_DEV void narrowphase(const DevModel<R>& M, Shared<R>& s, int g1, int g2, R ma
     } else if (t2 == GEOM_BOX) {       // [MJ mjc_PlaneBox] corners below the margin, at most 4, staged in LDS
       const R dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
       const R dist = dot3(dif, n);
-      const int slot = M.geom_boxslot[g2];
+      const int slot = stage_slot;
       pc.boxslot = slot;
       for (int i = 0; i < 8 && pc.n < 4; i++) {
         const R vec[3] = {(i & 1) ? s2[0] : -s2[0], (i & 2) ? s2[1] : -s2[1], (i & 4) ? s2[2] : -s2[2]};
@@ -641,7 +764,7 @@ DM_DEV void narrowphase(const DevModel<R>& M, Shared<R>& s, int g1, int g2, R ma
     pc.p0[0] += p2[0]; pc.p0[1] += p2[1]; pc.p0[2] += p2[2];
     return;
   }
-  // box-box (foot against foot): not handled this round (the oracle returns no contact for it as well)
+  if (t1 == GEOM_BOX && t2 == GEOM_BOX) box_box(s, p1, m1, s1, p2, m2, s2, stage_slot, margin, pc);
 }
 
 // [MJ mju_makeFrame] rows of f: normal, tangent 1, tangent 2
@@ -726,7 +849,7 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
         mu = fmax(M.geom_mu[g1], M.geom_mu[g2]);
       }
       if (dmw::ballot(cand) == 0ull) continue;        // nothing near anything in this pass (the common case for body-body pairs)
-      if (cand) narrowphase(M, s, g1, g2, margin, pc);
+      if (cand) narrowphase(M, s, g1, g2, M.pair_stage[pidx], margin, pc);
       if (dmw::ballot(pc.n > 0) == 0ull) continue;
       const int rows_per = dim == 1 ? 1 : 2 * (dim - 1);
       int tot_rows, tot_con;
@@ -937,15 +1060,27 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
         const int i = c * 16 + ii;
         R acc = 0;
         if (i < nefc) {
-          // dot(Y_lane, Y_i) in chunks of 6 entries read at a wave-uniform LDS address
-          R qa[6];
+          // dot(Y_lane, Y_i) in chunks of 6 entries read at a wave-uniform LDS address, double-buffered: the next chunk
+          // is loaded while the current one is multiplied
+          R qa[6], qb[6];
+          { const int zc = dmw::pin_zero();
 #pragma unroll
-          for (int c0 = 0; c0 < NV; c0 += 6) {
-            const int zc = dmw::pin_zero();
+            for (int d = 0; d < 6; d++) qa[d] = s.u.ybuf[ii][d + zc]; }
 #pragma unroll
-            for (int d = 0; d < 6; d++) if (c0 + d < NV) qa[d] = s.u.ybuf[ii][c0 + d + zc];
+          for (int c0 = 0; c0 < NV; c0 += 12) {
+            { const int zc = dmw::pin_zero();
+#pragma unroll
+              for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) qb[d] = s.u.ybuf[ii][c0 + 6 + d + zc]; }
+            dmw::sched_fence();
 #pragma unroll
             for (int d = 0; d < 6; d++) if (c0 + d < NV) acc += y[c0 + d] * qa[d];
+            dmw::pin_value(acc);
+            { const int zc = dmw::pin_zero();
+#pragma unroll
+              for (int d = 0; d < 6; d++) if (c0 + 12 + d < NV) qa[d] = s.u.ybuf[ii][c0 + 12 + d + zc]; }
+            dmw::sched_fence();
+#pragma unroll
+            for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) acc += y[c0 + 6 + d] * qb[d];
             dmw::pin_value(acc);
           }
         }

@@ -66,7 +66,17 @@ inline int build_dev_model(const dm_model_desc* d, DevModel<double>* hp, std::st
     for (int dd = 6; dd < NV; dd++) { const int jb = dm::make_topo().dof_body[dd] - 2; h.kp[dd] = kp_j[jb]; h.kd[dd] = kd_j[jb]; }
   }
   h.npair = d->npair;
-  for (int p = 0; p < d->npair; p++) { h.pair_g1[p] = (short)d->pair_geom[2 * p]; h.pair_g2[p] = (short)d->pair_geom[2 * p + 1]; }
+  { int nbb = 0;
+    for (int p = 0; p < d->npair; p++) {
+      const int a = d->pair_geom[2 * p], b = d->pair_geom[2 * p + 1];
+      h.pair_g1[p] = (short)a; h.pair_g2[p] = (short)b; h.pair_stage[p] = -1;
+      if (h.geom_type[a] == GEOM_PLANE && h.geom_type[b] == GEOM_BOX) h.pair_stage[p] = (short)h.geom_boxslot[b];
+      else if (h.geom_type[a] == GEOM_BOX && h.geom_type[b] == GEOM_BOX) {
+        if (nbb >= 2) return mfail(err, DM_EUNSUPPORTED, "dm_model_create: at most 2 box-box candidate pairs are supported");
+        h.pair_stage[p] = (short)(4 + nbb++);
+      }
+    }
+  }
   h.qpos0[0] = d->body_pos[3]; h.qpos0[1] = d->body_pos[4]; h.qpos0[2] = d->body_pos[5]; h.qpos0[3] = 1;
   h.timestep = d->timestep; h.tolerance = d->tolerance; h.meaninertia = d->meaninertia; h.iterations = d->iterations;
   for (int k = 0; k < 3; k++) h.gravity[k] = d->gravity[k];

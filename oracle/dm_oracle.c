@@ -501,6 +501,102 @@ static int sphere_sphere(rawcon* con, const double* c1, double r1, const double*
   addscl3(con->pos, c1, con->frame, r1 + 0.5 * con->dist);
   return 1;
 }
+/* OWN ALGORITHM for box-box (MuJoCo's mjc_BoxBox, ~700 lines derived from ODE, is not restated): separating-axis test
+ * over the 6 face normals and 9 edge cross products; the axis of least penetration decides between
+ *   - face contact: the incident face of the other box is clipped (Sutherland-Hodgman) against the side planes of the
+ *     reference face; clipped vertices within `margin` of the reference face become contacts (the 4 deepest are kept);
+ *   - edge contact: one contact at the midpoint of the closest points of the two supporting edges.
+ * All contacts share the normal (from geom1 to geom2).  The HIP kernel runs the identical procedure. */
+static int box_box(rawcon* con, const double* p1, const double* m1, const double* s1, const double* p2, const double* m2,
+                   const double* s2, double margin) {
+  double A[3][3], B[3][3], d[3], Rm[3][3], aR[3][3];
+  for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = m1[3 * k + i]; B[i][k] = m2[3 * k + i]; }
+  sub3(d, p2, p1);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Rm[i][j] = dot3(A[i], B[j]); aR[i][j] = fabs(Rm[i][j]); }
+  double best = -1e300; int code = -1;
+  for (int i = 0; i < 3; i++) {
+    double sep = fabs(dot3(d, A[i])) - (s1[i] + s2[0] * aR[i][0] + s2[1] * aR[i][1] + s2[2] * aR[i][2]);
+    if (sep > margin) return 0;
+    if (sep > best) { best = sep; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    double sep = fabs(dot3(d, B[j])) - (s2[j] + s1[0] * aR[0][j] + s1[1] * aR[1][j] + s1[2] * aR[2][j]);
+    if (sep > margin) return 0;
+    if (sep > best) { best = sep; code = 3 + j; }
+  }
+  double ebest = -1e300, en[3] = {0, 0, 0}; int ei = -1, ej = -1;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double L[3]; cross3(L, A[i], B[j]);
+    double len = norm3(L);
+    if (len < 1e-6) continue;
+    L[0] /= len; L[1] /= len; L[2] /= len;
+    double rA = s1[0] * fabs(dot3(A[0], L)) + s1[1] * fabs(dot3(A[1], L)) + s1[2] * fabs(dot3(A[2], L));
+    double rB = s2[0] * fabs(dot3(B[0], L)) + s2[1] * fabs(dot3(B[1], L)) + s2[2] * fabs(dot3(B[2], L));
+    double dl = dot3(d, L), sep = fabs(dl) - rA - rB;
+    if (sep > margin) return 0;
+    if (sep > ebest) { ebest = sep; ei = i; ej = j; double sg = dl < 0 ? -1 : 1; en[0] = sg * L[0]; en[1] = sg * L[1]; en[2] = sg * L[2]; }
+  }
+  if (ei >= 0 && ebest > best + 1e-6) {
+    /* edge-edge: supporting edges, closest points of the two lines */
+    double ca[3], cb[3];
+    copy3(ca, p1); copy3(cb, p2);
+    for (int k = 0; k < 3; k++) if (k != ei) { double sg = dot3(en, A[k]) > 0 ? 1 : -1; addscl3(ca, ca, A[k], sg * s1[k]); }
+    for (int k = 0; k < 3; k++) if (k != ej) { double sg = dot3(en, B[k]) > 0 ? -1 : 1; addscl3(cb, cb, B[k], sg * s2[k]); }
+    double w[3]; sub3(w, ca, cb);
+    double ab = dot3(A[ei], B[ej]), aw = dot3(A[ei], w), bw = dot3(B[ej], w), den = 1 - ab * ab;
+    double ta = den > 1e-12 ? (ab * bw - aw) / den : 0, tb = den > 1e-12 ? (bw - ab * aw) / den : 0;
+    ta = clampd(ta, -s1[ei], s1[ei]); tb = clampd(tb, -s2[ej], s2[ej]);
+    double qa[3], qb[3];
+    addscl3(qa, ca, A[ei], ta); addscl3(qb, cb, B[ej], tb);
+    con->dist = ebest;
+    copy3(con->frame, en); zero3(con->frame + 3);
+    for (int k = 0; k < 3; k++) con->pos[k] = 0.5 * (qa[k] + qb[k]);
+    return 1;
+  }
+  /* face contact: reference box owns the axis */
+  const int refB = code >= 3, ax = refB ? code - 3 : code;
+  const double *pr = refB ? p2 : p1, *pi = refB ? p1 : p2, *sr = refB ? s2 : s1, *si = refB ? s1 : s2;
+  double (*Rr)[3] = refB ? B : A, (*Ri)[3] = refB ? A : B;
+  double dr[3]; sub3(dr, pi, pr);
+  double sgn = dot3(dr, Rr[ax]) < 0 ? -1 : 1, n[3] = {sgn * Rr[ax][0], sgn * Rr[ax][1], sgn * Rr[ax][2]}; /* ref -> inc */
+  int k = 0; double bestdot = -1;
+  for (int j = 0; j < 3; j++) { double dd = fabs(dot3(n, Ri[j])); if (dd > bestdot) { bestdot = dd; k = j; } }
+  double fs = dot3(n, Ri[k]) > 0 ? -1 : 1; /* incident face = the one facing the reference box */
+  int k1 = (k + 1) % 3, k2 = (k + 2) % 3, u = (ax + 1) % 3, v = (ax + 2) % 3;
+  double poly[2][8][3]; int np = 4, cur = 0;
+  for (int c = 0; c < 4; c++) {
+    double vert[3], rel[3];
+    double a1 = (c == 0 || c == 3) ? 1 : -1, a2 = (c < 2) ? 1 : -1;
+    for (int t = 0; t < 3; t++) vert[t] = pi[t] + fs * si[k] * Ri[k][t] + a1 * si[k1] * Ri[k1][t] + a2 * si[k2] * Ri[k2][t];
+    sub3(rel, vert, pr);
+    poly[0][c][0] = dot3(rel, Rr[u]); poly[0][c][1] = dot3(rel, Rr[v]); poly[0][c][2] = sgn * dot3(rel, Rr[ax]);
+  }
+  for (int e = 0; e < 4 && np > 0; e++) { /* clip against  +u, -u, +v, -v  */
+    const int cdim = e / 2; const double sg = (e % 2) ? -1 : 1, lim = cdim == 0 ? sr[u] : sr[v];
+    int nn = 0;
+    for (int a = 0; a < np; a++) {
+      const double* P = poly[cur][a]; const double* Q = poly[cur][(a + 1) % np];
+      double dp = lim - sg * P[cdim], dq = lim - sg * Q[cdim]; /* >= 0 inside */
+      if (dp >= 0 && nn < 8) { copy3(poly[1 - cur][nn], P); nn++; }
+      if ((dp >= 0) != (dq >= 0) && nn < 8) { double tt = dp / (dp - dq); for (int t = 0; t < 3; t++) poly[1 - cur][nn][t] = P[t] + tt * (Q[t] - P[t]); nn++; }
+    }
+    np = nn; cur = 1 - cur;
+  }
+  /* candidates within the margin of the reference face; keep the (up to) 4 deepest, in polygon order */
+  double dist[8]; int keep[8], nk = 0;
+  for (int a = 0; a < np; a++) { dist[a] = poly[cur][a][2] - sr[ax]; keep[a] = dist[a] < margin; nk += keep[a]; }
+  while (nk > 4) { int worst = -1; for (int a = 0; a < np; a++) if (keep[a] && (worst < 0 || dist[a] > dist[worst])) worst = a; keep[worst] = 0; nk--; }
+  int cnt = 0;
+  for (int a = 0; a < np; a++) if (keep[a]) {
+    double wv[3];
+    for (int t = 0; t < 3; t++) wv[t] = pr[t] + poly[cur][a][0] * Rr[u][t] + poly[cur][a][1] * Rr[v][t] + sgn * poly[cur][a][2] * Rr[ax][t];
+    con[cnt].dist = dist[a];
+    for (int t = 0; t < 3; t++) { con[cnt].frame[t] = refB ? -n[t] : n[t]; con[cnt].frame[3 + t] = 0; con[cnt].pos[t] = wv[t] - n[t] * dist[a] / 2; }
+    cnt++;
+  }
+  return cnt;
+}
+
 static int narrowphase(const dmo_model* m, const dmo_data* d, int g1, int g2, double margin, rawcon* con) {
   const dmo_spec* s = &m->s;
   int t1 = s->geom_type[g1], t2 = s->geom_type[g2];
@@ -645,8 +741,7 @@ static int narrowphase(const dmo_model* m, const dmo_data* d, int g1, int g2, do
     mat_vec(con->pos, m2, pl); add3(con->pos, con->pos, p2);
     return 1;
   }
-  /* box-box (foot against foot): NOT YET RESTATED — returns no contact.  Documented gap; the HIP path
-   * mirrors the same behaviour. */
+  if (t1 == DMO_GEOM_BOX && t2 == DMO_GEOM_BOX) return box_box(con, p1, m1, s1, p2, m2, s2, margin);
   return 0;
 }
 /* [MJ mju_makeFrame] complete (normal, tangent hint) into a right-handed orthonormal frame, rows = axes */

@@ -37,6 +37,16 @@ def test_capsule_box_contacts_match_oracle():
     b.close()
 
 
+def test_box_box_contacts_match_oracle():
+    qs = np.load(H.GOLDEN + "/box_box_poses.npy")
+    n = len(qs)
+    b = make_batch(n)
+    H.compare_forward(b, H.oracle_model(), np.zeros(n, dtype=np.int32), qs, np.zeros((n, 34)), np.zeros((n, 34)), np.zeros((n, 28)))
+    idx = np.zeros(n, dtype=np.int32)
+    H.compare_rollout(b, H.oracle_model(), idx, qs, np.zeros((n, 34)), steps=6, seed=9, action_scale=0.2)
+    b.close()
+
+
 def test_action_front_ends_match_host_formula():
     mc = H.mocap()
     n = 16

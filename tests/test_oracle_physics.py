@@ -185,3 +185,36 @@ def test_warmstart_and_time_semantics():
     assert abs(d.get("time")[0] - 0.0166) < 1e-15 and np.abs(d.get("qacc_warmstart")).max() > 0
     d.reset()                                                       # sim.reset() zeroes them
     assert d.get("time")[0] == 0 and np.abs(d.get("qacc_warmstart")).max() == 0 and np.array_equal(d.get("qpos"), m.get("qpos0"))
+
+
+def two_box_spec():
+    s = box_on_floor_spec(50.0)
+    s.geom_size[1][0] = 0.3; s.geom_size[1][1] = 0.2; s.geom_size[1][2] = 0.1
+    s.body_pos[1][2] = 0.1
+    s.nbody = 3; s.body_parent[2] = 0; s.body_pos[2][2] = 0.2 + 0.05
+    s.njnt = 2; s.jnt_type[1] = O.JNT_FREE; s.jnt_body[1] = 2; s.jnt_axis[1][2] = 1
+    s.ngeom = 3
+    s.geom_type[2] = O.GEOM_BOX; s.geom_body[2] = 2; s.geom_condim[2] = 3; s.geom_contype[2] = 1; s.geom_conaffinity[2] = 1
+    s.geom_size[2][0] = 0.1; s.geom_size[2][1] = 0.08; s.geom_size[2][2] = 0.05; s.geom_mass[2] = 2.0
+    s.geom_friction[2][0] = 1; s.geom_friction[2][1] = 0.005; s.geom_friction[2][2] = 0.0001; s.geom_margin[2] = 0.001
+    return s
+
+
+def test_box_box_stack_rests_and_overhang_is_clipped():
+    m = O.Model(two_box_spec()); d = O.Data(m)
+    for _ in range(300):
+        d.step()
+    d.forward()
+    cg = d.get("contact_geom").reshape(-1, 2).astype(int).tolist()
+    assert cg == [[0, 1]] * 4 + [[1, 2]] * 4                       # floor first, then the box pair: 4 face contacts each
+    assert np.abs(d.get("qvel")).max() < 1e-3 and abs(d.get("qpos")[9] - 0.25) < 3e-3
+    f = d.get("efc_force")
+    assert abs(f[16:].sum() - 2.0 * 9.81) / (2.0 * 9.81) < 1e-3    # the upper box is carried by the lower one
+    # overhang + yaw: the incident face is clipped against the reference face -> contacts stay inside the lower box's top
+    q = d.get("qpos").copy(); ang = 0.6
+    q[7] = 0.28; q[8] = 0.17; q[10:14] = [np.cos(ang / 2), 0, 0, np.sin(ang / 2)]
+    d.set("qpos", q); d.set("qvel", np.zeros(12)); d.forward()
+    pos = d.get("contact_pos").reshape(-1, 3)[4:]
+    assert len(pos) == 4 and np.all(np.abs(pos[:, 0]) <= 0.3 + 1e-6) and np.all(np.abs(pos[:, 1]) <= 0.2 + 1e-6)
+    fr = d.get("contact_frame").reshape(-1, 9)[4:]
+    assert np.allclose(fr[:, :3], [0, 0, 1], atol=1e-4)             # normal from geom1 (lower box) to geom2 (upper box)

@@ -122,3 +122,13 @@ def test_capsule_box_contacts_on_testbench():
     H.compare_forward(b, H.oracle_model(), np.zeros(n, dtype=np.int32), qs, np.zeros((n, 34)), np.zeros((n, 34)), np.zeros((n, 28)))
     cg = b.get(A.F_CONTACT_GEOMS)
     assert all(any((c[0] in (10, 11, 13, 14)) and (c[1] in (12, 15)) for c in cg[e] if c[0] >= 0) for e in range(n))
+
+
+def test_box_box_contacts_on_testbench():
+    """Foot box against foot box (face contacts with 2-4 clipped vertices and edge-edge contacts; seeded poses)."""
+    qs = np.load(H.GOLDEN + "/box_box_poses.npy")[[0, 1, 2]]
+    n = len(qs)
+    b = make(n)
+    H.compare_forward(b, H.oracle_model(), np.zeros(n, dtype=np.int32), qs, np.zeros((n, 34)), np.zeros((n, 34)), np.zeros((n, 28)))
+    cg = b.get(A.F_CONTACT_GEOMS)
+    assert all(any(tuple(c) == (12, 15) for c in cg[e]) for e in range(n))
