@@ -1,0 +1,174 @@
+"""Batched MLP policy + value function of the reference's TRPO learner, as plain torch tensors on the env's device.
+
+Mirror of `src/mlp_policy_trpo.py:13-79` (class MlpPolicy) and `src/utils/misc_util.py:32-70` (RunningMeanStd):
+
+    obz   = clip((ob - ob_rms.mean) / ob_rms.std, -5, 5)                    (mlp_policy_trpo.py:35)
+    vpred = vffinal(tanh(vffc2(tanh(vffc1(obz)))))[:, 0]                    (:37-39)
+    mean  = polfinal(tanh(polfc2(tanh(polfc1(obz)))))                       (:41-46)
+    ac    = mean + exp(logstd) * N(0, 1)   if stochastic else mean          (:57-58, distributions.py DiagGaussianPd)
+
+`act(stochastic, ob)` takes the whole [N, 56] observation batch that `dm_batch_step` wrote on the device and returns
+([N, 28] float64 actions ready for the next `dm_batch_step`, [N] vpred) without leaving the device or the stream.
+The network arithmetic is float32 like the reference's TF graph; the two 100-wide GEMMs are library GEMMs (rocBLAS
+through torch) — they are ~1% of a rollout step next to the physics kernel, so no hand-written kernel is warranted.
+
+Weights are interchangeable with the reference's checkpoints: `MlpPolicy.from_tf_checkpoint(prefix)` reads a
+`tf.train.Saver` bundle (scope 'pi'), `state_dict()/load_state_dict()` use the reference's variable names.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .tf_checkpoint import load_checkpoint
+
+
+class RunningMeanStd:
+    """src/utils/misc_util.py:32-70.  Sums in float64; count and sumsq start at epsilon = 1e-2; the variance is floored
+    at 1e-2 before the sqrt.  `update` all-reduces (sum, sumsq, count) over the process group like the reference's
+    MPI.Allreduce (:69) when torch.distributed is initialised."""
+
+    def __init__(self, shape, device="cpu", epsilon=1e-2):
+        self.shape = tuple(shape) if not isinstance(shape, int) else (shape,)
+        self.sum = torch.zeros(self.shape, dtype=torch.float64, device=device)
+        self.sumsq = torch.full(self.shape, epsilon, dtype=torch.float64, device=device)
+        self.count = torch.full((), epsilon, dtype=torch.float64, device=device)
+        self._refresh()
+
+    def _refresh(self):
+        self.mean = (self.sum / self.count).to(torch.float32)
+        var = (self.sumsq / self.count).to(torch.float32) - self.mean * self.mean
+        self.std = torch.sqrt(torch.clamp(var, min=1e-2))
+
+    def update(self, x, group=None):
+        x = x.reshape(-1, *self.shape).to(torch.float64)
+        n = self.sum.numel()
+        add = torch.cat([x.sum(0).reshape(-1), (x * x).sum(0).reshape(-1),
+                         torch.tensor([float(x.shape[0])], dtype=torch.float64, device=x.device)])
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(add, op=dist.ReduceOp.SUM, group=group)
+        self.sum += add[:n].reshape(self.shape)
+        self.sumsq += add[n:2 * n].reshape(self.shape)
+        self.count += add[2 * n]
+        self._refresh()
+
+
+def _normc(gen, fan_in, fan_out, std, device):
+    """U.normc_initializer (src/utils/tf_util.py:98-103): Gaussian columns rescaled to L2 norm `std`."""
+    w = torch.randn((fan_in, fan_out), generator=gen, dtype=torch.float32)
+    w *= std / torch.sqrt((w * w).sum(0, keepdim=True))
+    return w.to(device)
+
+
+_LAYERS = ("vffc1", "vffc2", "vffinal", "polfc1", "polfc2", "polfinal")
+
+
+class MlpPolicy:
+    """`MlpPolicy(name, ob_space, ac_space, hid_size=100, num_hid_layers=2)` of the reference, for N envs at once."""
+
+    recurrent = False
+
+    def __init__(self, ob_dim=56, ac_dim=28, hid_size=100, num_hid_layers=2, device="cpu", seed=0):
+        if num_hid_layers != 2:
+            raise ValueError("the reference trains 2 hidden layers (src/trpo.py:436); got %d" % num_hid_layers)
+        self.ob_dim, self.ac_dim, self.hid_size = ob_dim, ac_dim, hid_size
+        self.device = torch.device(device)
+        gen = torch.Generator(); gen.manual_seed(seed)
+        self.ob_rms = RunningMeanStd((ob_dim,), device=self.device)
+        p = {}
+        dims = {"vffc1": (ob_dim, hid_size, 1.0), "vffc2": (hid_size, hid_size, 1.0), "vffinal": (hid_size, 1, 1.0),
+                "polfc1": (ob_dim, hid_size, 1.0), "polfc2": (hid_size, hid_size, 1.0), "polfinal": (hid_size, ac_dim, 0.01)}
+        for name in _LAYERS:
+            i, o, s = dims[name]
+            p[name + "/w"] = _normc(gen, i, o, s, self.device)
+            p[name + "/b"] = torch.zeros(o, dtype=torch.float32, device=self.device)
+        p["logstd"] = torch.zeros((1, ac_dim), dtype=torch.float32, device=self.device)
+        self.params = p
+        self._noise_gen = None
+
+    # ---- weights ----------------------------------------------------------------------------------------------------
+    def state_dict(self):
+        d = {k: v.detach().cpu().numpy() for k, v in self.params.items()}
+        d["obfilter/runningsum"] = self.ob_rms.sum.cpu().numpy()
+        d["obfilter/runningsumsq"] = self.ob_rms.sumsq.cpu().numpy()
+        d["obfilter/count"] = self.ob_rms.count.cpu().numpy()
+        return d
+
+    def load_state_dict(self, d):
+        for k in self.params:
+            v = np.asarray(d[k])
+            if tuple(v.shape) != tuple(self.params[k].shape):
+                raise ValueError("%s: shape %s != %s" % (k, v.shape, tuple(self.params[k].shape)))
+            self.params[k] = torch.as_tensor(v, dtype=torch.float32).to(self.device).contiguous()
+        self.ob_rms.sum = torch.as_tensor(np.asarray(d["obfilter/runningsum"]), dtype=torch.float64).to(self.device)
+        self.ob_rms.sumsq = torch.as_tensor(np.asarray(d["obfilter/runningsumsq"]), dtype=torch.float64).to(self.device)
+        self.ob_rms.count = torch.as_tensor(np.asarray(d["obfilter/count"]), dtype=torch.float64).to(self.device)
+        self.ob_rms._refresh()
+        return self
+
+    @classmethod
+    def from_tf_checkpoint(cls, prefix, scope="pi", device="cpu"):
+        """`U.load_state(load_model_path)` (src/trpo.py:365): restore the 'pi' scope of a tf.train.Saver bundle."""
+        d = load_checkpoint(prefix, scope=scope)
+        pol = cls(ob_dim=d["polfc1/w"].shape[0], ac_dim=d["polfinal/w"].shape[1], hid_size=d["polfc1/w"].shape[1], device=device)
+        return pol.load_state_dict(d)
+
+    @classmethod
+    def from_npz(cls, path, device="cpu"):
+        d = dict(np.load(path))
+        pol = cls(ob_dim=d["polfc1/w"].shape[0], ac_dim=d["polfinal/w"].shape[1], hid_size=d["polfc1/w"].shape[1], device=device)
+        return pol.load_state_dict(d)
+
+    def save_npz(self, path):
+        np.savez(path, **self.state_dict())
+
+    # ---- forward ----------------------------------------------------------------------------------------------------
+    def _obz(self, ob):
+        ob = ob.to(torch.float32)
+        return torch.clamp((ob - self.ob_rms.mean) / self.ob_rms.std, -5.0, 5.0)
+
+    def forward(self, ob):
+        """ob [N, ob_dim] -> (mean [N, ac_dim] f32, vpred [N] f32)."""
+        p = self.params
+        z = self._obz(ob)
+        h = torch.tanh(torch.addmm(p["vffc1/b"], z, p["vffc1/w"]))
+        h = torch.tanh(torch.addmm(p["vffc2/b"], h, p["vffc2/w"]))
+        vpred = torch.addmm(p["vffinal/b"], h, p["vffinal/w"])[:, 0]
+        h = torch.tanh(torch.addmm(p["polfc1/b"], z, p["polfc1/w"]))
+        h = torch.tanh(torch.addmm(p["polfc2/b"], h, p["polfc2/w"]))
+        mean = torch.addmm(p["polfinal/b"], h, p["polfinal/w"])
+        return mean, vpred
+
+    def seed(self, seed):
+        self._noise_gen = torch.Generator(device=self.device)
+        self._noise_gen.manual_seed(int(seed))
+
+    def act(self, stochastic, ob, out=None):
+        """mlp_policy_trpo.py:63-65 for a batch: returns (ac [N, ac_dim] float64, vpred [N] float32).
+        `out` (float64 [N, ac_dim]) receives the action in place when given (the buffer handed to dm_batch_step)."""
+        single = ob.dim() == 1
+        if single:
+            ob = ob[None]
+        mean, vpred = self.forward(ob)
+        if stochastic:
+            noise = torch.randn(mean.shape, dtype=torch.float32, device=mean.device, generator=self._noise_gen)
+            ac = mean + torch.exp(self.params["logstd"]) * noise
+        else:
+            ac = mean
+        if out is not None:
+            out.copy_(ac)
+            ac = out
+        else:
+            ac = ac.to(torch.float64)
+        return (ac[0], vpred[0]) if single else (ac, vpred)
+
+    # ---- distribution (src/distributions.py:220-243 DiagGaussianPd) ---------------------------------------------------
+    def neglogp(self, ob, ac):
+        mean, _ = self.forward(ob)
+        logstd = self.params["logstd"]
+        z = (ac.to(torch.float32) - mean) / torch.exp(logstd)
+        return 0.5 * (z * z).sum(-1) + 0.5 * math.log(2.0 * math.pi) * self.ac_dim + logstd.sum(-1)
+
+    def entropy(self):
+        return float((self.params["logstd"] + 0.5 * math.log(2.0 * math.pi * math.e)).sum())

@@ -101,7 +101,7 @@ class Model(object):
         self.nbody = int(self.get("nbody")[0]); self.ngeom = int(self.get("ngeom")[0])
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:      # `lib` is None during interpreter shutdown
             lib().dmo_model_free(self.h); self.h = None
 
     def get(self, field, maxn=8192):
@@ -124,7 +124,7 @@ class Data(object):
         self.h = lib().dmo_data_create(model.h)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:      # `lib` is None during interpreter shutdown
             lib().dmo_data_destroy(self.h); self.h = None
 
     def get(self, field, maxn=70000):

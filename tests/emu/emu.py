@@ -61,7 +61,12 @@ class EmuBatch(object):
 
     def step(self, action, n_substeps=1, out=None):
         a = np.ascontiguousarray(action, dtype=np.float64).reshape(self.n, A.NU)
-        obs = np.zeros((self.n, A.NOBS)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.uint8)
+        if out is None:
+            obs = np.zeros((self.n, A.NOBS)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.uint8)
+        else:
+            obs, rew, done = out
+            assert obs.dtype == np.float64 and rew.dtype == np.float64 and done.dtype == np.uint8
+            assert obs.flags.c_contiguous and obs.shape == (self.n, A.NOBS)
         lib().emu_step(self.h, a.ctypes.data_as(A._dp), obs.ctypes.data_as(A._dp), rew.ctypes.data_as(A._dp),
                        done.ctypes.data_as(C.POINTER(C.c_uint8)), n_substeps)
         return obs, rew, done
@@ -81,7 +86,11 @@ class EmuBatch(object):
 
     def get_obs(self, out=None):
         q = self.get(A.F_QPOS); v = self.get(A.F_QVEL)
-        return np.concatenate([q[:, 7:], v[:, 6:]], 1)
+        o = np.concatenate([q[:, 7:], v[:, 6:]], 1)
+        if out is not None:
+            out[...] = o
+            return out
+        return o
 
     def close(self):
         pass

@@ -1,0 +1,70 @@
+"""GPU tests of the device-resident rollout (policy + env kernel + GAE on one stream) and the statistical anchor of the
+physics on the HIP path: the reference's shipped policy must live as long in the kernel's physics as in its own
+training log (real MuJoCo)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from deepmimic_mujoco_amd import DPVecEnv, MlpPolicy, traj_segment_generator, add_vtarg_and_adv
+from tests.test_policy import CKPT, GOLD, _gae_reference_loop
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(pol, stochastic, n, steps, seed=0):
+    env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=seed)
+    pol.seed(seed)
+    gen = traj_segment_generator(pol, env, steps, stochastic=stochastic)
+    seg = next(gen)
+    env.close()
+    return seg
+
+
+def test_rollout_segment_is_consistent_and_gae_matches_reference_loop():
+    pol = MlpPolicy.from_tf_checkpoint(CKPT, device=DEV)
+    T, n = 300, 64
+    seg = _run(pol, True, n, T, seed=2)
+    assert seg["ob"].shape == (T, n, 56) and seg["ac"].shape == (T, n, 28) and seg["ob"].device.type == "cuda"
+    assert bool(torch.isfinite(seg["ob"]).all()) and bool((seg["new"][0] == 1).all())
+    assert float(seg["rew"].min()) == 1.0 and float(seg["rew"].max()) == 1.0          # alive reward of dp_env_v3.py:117-128
+    # vpred / ac are the policy's outputs on the stored observations (float32 storage of float64 obs costs ~1e-6)
+    mean, vpred = pol.forward(seg["ob"].reshape(-1, 56))
+    assert float((vpred.reshape(T, n) - seg["vpred"]).abs().max()) < 1e-3 * max(1.0, float(seg["vpred"].abs().max()))
+    # episodes: every new[t]=1 (t>0) closes an episode whose length was logged
+    starts = seg["new"].cpu().numpy()
+    assert int(starts[1:].sum()) == len(seg["ep_lens"]) and len(seg["ep_lens"]) > 0
+    assert abs(sum(seg["ep_rets"]) - sum(seg["ep_lens"])) < 1e-9
+    add_vtarg_and_adv(seg, 0.995, 0.97)
+    rew, vp, nw, nxt = (seg[k].cpu().numpy() for k in ("rew", "vpred", "new", "nextvpred"))
+    for e in range(0, n, 7):
+        adv, ret = _gae_reference_loop(rew[:, e], vp[:, e], nw[:, e], nxt[e], 0.995, 0.97)
+        assert np.allclose(seg["adv"][:, e].cpu().numpy(), adv, rtol=1e-4, atol=1e-3)
+        assert np.allclose(seg["tdlamret"][:, e].cpu().numpy(), ret, rtol=1e-4, atol=1e-3)
+
+
+def test_shipped_policy_episode_lengths_on_gpu_match_training_log():
+    log = np.load(os.path.join(GOLD, "trpo_walk0_log.npz"))["EpLenMean"]
+    n = 2048
+    seg = _run(MlpPolicy(device=DEV, seed=0), True, n, 160, seed=1)
+    first = _first_lengths(seg, 160)
+    print("untrained policy: first-episode length mean %.1f (reference log, first 5 iterations: %.1f)" % (first.mean(), log[:5].mean()))
+    assert abs(first.mean() - log[:5].mean()) < 4
+    seg = _run(MlpPolicy.from_tf_checkpoint(CKPT, device=DEV), True, n, 2000, seed=1)
+    first = _first_lengths(seg, 2000)
+    print("shipped policy: first-episode length mean %.1f median %.0f (reference log, last 100 iterations: %.1f, range %.0f-%.0f)"
+          % (first.mean(), np.median(first), log[-100:].mean(), log[-100:].min(), log[-100:].max()))
+    assert 0.8 * log[-100:].mean() < first.mean() < 1.35 * log[-100:].mean()
+    seg = _run(MlpPolicy.from_tf_checkpoint(CKPT, device=DEV), False, 512, 1000, seed=1)
+    alive = float((_first_lengths(seg, 1000) == 1000).mean())
+    print("deterministic shipped policy: %.1f%% of envs still up after 1000 steps" % (100 * alive))
+    assert alive > 0.9
+
+
+def _first_lengths(seg, cap):
+    new = seg["new"].cpu().numpy()[1:]                       # new[t]=1: the episode ended at step t
+    T, n = new.shape
+    first = np.where(new.any(0), new.argmax(0) + 1, cap)
+    return first

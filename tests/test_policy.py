@@ -1,0 +1,204 @@
+"""Policy / rollout / GAE host logic and the statistical anchor of the physics restatement:
+the reference's shipped TRPO policy (trained inside real MuJoCo) replayed in the oracle reproduces the episode lengths its
+own training log reports."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from deepmimic_mujoco_amd import _abi as A
+from deepmimic_mujoco_amd.policy import MlpPolicy, RunningMeanStd
+from deepmimic_mujoco_amd.rollout import add_vtarg_and_adv, traj_segment_generator, flatten_segment
+from deepmimic_mujoco_amd.tf_checkpoint import load_checkpoint, read_index, crc32c
+from tests import helpers as H
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CKPT = os.path.join(GOLD, "ckpt", "trpo-walk-0")
+
+
+def test_crc32c_known_answers():
+    assert crc32c(b"") == 0
+    assert crc32c(b"123456789") == 0xE3069283          # the standard CRC-32C check value
+    assert crc32c(bytes(32)) == 0x8A9136AA             # RFC 3720 B.4: 32 zero bytes
+
+
+def test_tf_checkpoint_reader_shipped_bundle(tmp_path):
+    idx = read_index(CKPT)
+    assert len(idx) == 32 and sorted(k.split("/")[0] for k in idx)[0] == "oldpi"
+    assert idx["pi/polfc1/w"][:2] == (np.dtype("<f4"), (56, 100))
+    assert idx["pi/obfilter/count"][:2] == (np.dtype("<f8"), ())
+    d = load_checkpoint(CKPT, scope="pi")                # verifies every tensor's crc32c
+    assert set(d) == {"logstd", "obfilter/count", "obfilter/runningsum", "obfilter/runningsumsq"} | {
+        "%s/%s" % (l, p) for l in ("polfc1", "polfc2", "polfinal", "vffc1", "vffc2", "vffinal") for p in ("w", "b")}
+    assert d["polfinal/w"].shape == (100, 28) and d["vffinal/w"].shape == (100, 1) and d["logstd"].shape == (1, 28)
+    # a flipped data byte is caught by the checksum
+    for ext in (".index", ".data-00000-of-00001"):
+        shutil.copyfile(CKPT + ext, str(tmp_path / ("c" + ext)))
+    p = str(tmp_path / "c.data-00000-of-00001")
+    raw = bytearray(open(p, "rb").read()); raw[200000] ^= 0x40
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="crc32c"):
+        load_checkpoint(str(tmp_path / "c"))
+
+
+def test_policy_forward_matches_numpy_restatement():
+    g = np.load(os.path.join(GOLD, "policy_forward_golden.npz"))
+    pol = MlpPolicy.from_tf_checkpoint(CKPT)
+    mean, vpred = pol.forward(torch.from_numpy(g["ob"]))
+    assert np.abs(mean.numpy() - g["mean"]).max() < 2e-5 * max(1.0, np.abs(g["mean"]).max())
+    assert np.abs(vpred.numpy() - g["vpred"]).max() < 2e-5 * max(1.0, np.abs(g["vpred"]).max())
+    ac, vp = pol.act(False, torch.from_numpy(g["ob"]))
+    assert ac.dtype == torch.float64 and torch.equal(ac, mean.to(torch.float64)) and torch.equal(vp, vpred)
+    a1, v1 = pol.act(False, torch.from_numpy(g["ob"][3]))            # single observation like the reference's act()
+    assert a1.shape == (28,) and abs(float(v1) - float(vpred[3])) < 1e-5
+
+
+def test_policy_entropy_matches_training_log():
+    log = np.load(os.path.join(GOLD, "trpo_walk0_log.npz"))
+    pol = MlpPolicy.from_tf_checkpoint(CKPT)
+    assert abs(pol.entropy() - log["entropy"][-1]) < 0.05           # 35.72 in the checkpoint vs 35.73 logged at the last iteration
+
+
+def test_policy_sampling_and_neglogp():
+    pol = MlpPolicy.from_tf_checkpoint(CKPT)
+    pol.seed(3)
+    ob = torch.zeros((20000, 56), dtype=torch.float64)
+    ac, _ = pol.act(True, ob)
+    mean, _ = pol.forward(ob)
+    resid = (ac.to(torch.float32) - mean) / torch.exp(pol.params["logstd"])
+    assert abs(float(resid.mean())) < 0.01 and abs(float(resid.std()) - 1.0) < 0.01
+    nl = pol.neglogp(ob[:5], mean[:5])                                # at the mode: 0.5*k*log(2 pi) + sum(logstd)
+    assert torch.allclose(nl, torch.full((5,), 0.5 * np.log(2 * np.pi) * 28 + float(pol.params["logstd"].sum())), atol=1e-4)
+    fresh = MlpPolicy(seed=1)                                          # reference initialisation
+    for name, s in (("polfc1/w", 1.0), ("vffc2/w", 1.0), ("polfinal/w", 0.01)):
+        assert torch.allclose(torch.sqrt((fresh.params[name] ** 2).sum(0)), torch.full((fresh.params[name].shape[1],), s), atol=1e-5)
+    assert float(fresh.params["logstd"].abs().max()) == 0.0
+    rt = MlpPolicy().load_state_dict(pol.state_dict())
+    assert torch.equal(rt.forward(ob[:3])[0], pol.forward(ob[:3])[0])
+
+
+def test_running_mean_std():
+    rms = RunningMeanStd((5,))
+    rng = np.random.RandomState(0)
+    xs = [rng.randn(17, 5) * 3 + 1, rng.randn(40, 5) * 0.01]
+    for x in xs:
+        rms.update(torch.from_numpy(x))
+    allx = np.concatenate(xs)
+    cnt = 1e-2 + len(allx)
+    mean = (allx.sum(0) / cnt).astype(np.float32)
+    std = np.sqrt(np.maximum(((allx ** 2).sum(0) + 1e-2) / cnt - mean.astype(np.float64) ** 2, 1e-2))
+    assert np.allclose(rms.mean.numpy(), mean, atol=1e-6) and np.allclose(rms.std.numpy(), std, atol=1e-5)
+    assert float(RunningMeanStd((3,)).std[0]) == pytest.approx(1.0)   # sqrt(max(eps/eps - 0, 1e-2))
+
+
+def _gae_reference_loop(rew, vpred, new, nextvpred, gamma, lam):
+    """numpy restatement of src/trpo.py:83-94 for ONE environment."""
+    new = np.append(new, 0)
+    vpred = np.append(vpred, nextvpred)
+    T = len(rew)
+    gaelam = np.empty(T, "float32")
+    last = 0
+    for t in reversed(range(T)):
+        nonterminal = 1 - new[t + 1]
+        delta = rew[t] + gamma * vpred[t + 1] * nonterminal - vpred[t]
+        gaelam[t] = last = delta + gamma * lam * nonterminal * last
+    return gaelam, gaelam + vpred[:-1]
+
+
+def test_gae_matches_reference_loop():
+    rng = np.random.RandomState(1)
+    T, N = 64, 9
+    rew = rng.rand(T, N).astype(np.float32)
+    vpred = rng.randn(T, N).astype(np.float32) * 5
+    new = (rng.rand(T, N) < 0.1).astype(np.int32); new[0] = 1
+    nxt = rng.randn(N).astype(np.float32)
+    seg = {"rew": torch.from_numpy(rew), "vpred": torch.from_numpy(vpred), "new": torch.from_numpy(new), "nextvpred": torch.from_numpy(nxt)}
+    add_vtarg_and_adv(seg, 0.995, 0.97)
+    for e in range(N):
+        adv, ret = _gae_reference_loop(rew[:, e], vpred[:, e], new[:, e], nxt[e], 0.995, 0.97)
+        assert np.allclose(seg["adv"][:, e].numpy(), adv, rtol=2e-5, atol=2e-5)
+        assert np.allclose(seg["tdlamret"][:, e].numpy(), ret, rtol=2e-5, atol=2e-5)
+    flat = flatten_segment(seg)
+    assert flat["adv"].shape == (T * N,) and torch.equal(flat["adv"][T:2 * T], seg["adv"][:, 1])
+
+
+def _emu_vec_env(n, seed):
+    from deepmimic_mujoco_amd import DPVecEnv
+    from tests.emu.emu import EmuBatch
+    return DPVecEnv(n, motion="walk", reward="alive", autoreset="init", seed=seed,
+                    batch_factory=lambda cm, cfg, vel, ne, flags: EmuBatch(cm, cfg, vel, ne, flags))
+
+
+def test_segment_generator_equals_per_step_loop_on_testbench():
+    """The batched generator (kernel source on the wave testbench) against the reference's loop written out by hand."""
+    n, T = 3, 4
+    pol = MlpPolicy.from_tf_checkpoint(CKPT)
+    env = _emu_vec_env(n, 5)
+    pol.seed(11)
+    gen = traj_segment_generator(pol, env, T, stochastic=True)
+    seg1 = {k: (v.clone() if torch.is_tensor(v) else list(v)) for k, v in next(gen).items()}
+    seg2 = next(gen)
+
+    env2 = _emu_vec_env(n, 5)
+    pol.seed(11)
+    ob = torch.from_numpy(env2.reset("rsi"))
+    new = np.ones(n, np.int32)
+    rows = []
+    for t in range(2 * T + 1):
+        ac, vpred = pol.act(True, ob)
+        rows.append((ob.clone(), ac.clone(), vpred.clone(), new.copy()))
+        o, r, d = env2.batch.step(ac.numpy(), 1)
+        rows[-1] += (r.copy(),)
+        ob = torch.from_numpy(o); new = d.astype(np.int32)
+    for k, seg in enumerate((seg1, seg2)):
+        for i in range(T):
+            ob_i, ac_i, vp_i, new_i, r_i = rows[k * T + i]
+            assert torch.equal(seg["ob"][i], ob_i.to(torch.float32))
+            assert torch.equal(seg["ac"][i], ac_i.to(torch.float32))
+            assert torch.equal(seg["vpred"][i], vp_i)
+            assert np.array_equal(seg["new"][i].numpy(), new_i)
+            assert np.array_equal(seg["rew"][i].numpy(), r_i.astype(np.float32))
+        nxt = rows[(k + 1) * T]
+        assert torch.allclose(seg["nextvpred"], nxt[2] * torch.from_numpy(1 - nxt[3]).to(torch.float32))
+    assert torch.equal(seg2["prevac"][1], seg2["ac"][0]) and torch.equal(seg2["prevac"][0], seg1["ac"][T - 1])
+    assert seg1["new"][0].tolist() == [1] * n
+
+
+def _first_episode_lengths(pol, stochastic, n, cap, seed):
+    """Protocol of src/trpo.py:27-80 on the oracle: noisy default pose (reset_model_init), one env.step per policy action,
+    until is_done.  Returns the first-episode length per env (cap = censored)."""
+    from oracle import oracle as O
+    om = O.Model()
+    ds = [O.Data(om) for _ in range(n)]
+    rng = np.random.RandomState(seed)
+    for d in ds:
+        d.reset()
+        d.set_state(d.get("qpos") + rng.uniform(-0.01, 0.01, 35), d.get("qvel") + rng.uniform(-0.01, 0.01, 34))
+    length = np.zeros(n, int)
+    alive = np.ones(n, bool)
+    pol.seed(seed)
+    for t in range(cap):
+        ob = np.stack([np.concatenate([d.get("qpos")[7:], d.get("qvel")[6:]]) for d in ds])
+        ac, _ = pol.act(stochastic, torch.from_numpy(ob))
+        _o, _r, done = O.batch_step(om, ds, ac.numpy(), 1, min(n, os.cpu_count() or 1))
+        fin = alive & (done != 0)
+        length[fin] = t + 1
+        alive &= ~fin
+        if not alive.any():
+            break
+    length[alive] = cap
+    return length
+
+
+def test_shipped_policy_reproduces_training_log_episode_lengths():
+    """Statistical anchor: the run that produced the shipped checkpoint logged EpLenMean ~ 33-37 for
+    the untrained policy and ~ 235-287 over its last 100 iterations (real MuJoCo 2.0).  The same policies in the oracle's
+    physics: 34 and ~ 290.  A wrong contact / limit / actuator model cannot balance a policy trained against the real one."""
+    log = np.load(os.path.join(GOLD, "trpo_walk0_log.npz"))["EpLenMean"]
+    assert 30 < log[:5].mean() < 40 and 230 < log[-100:].mean() < 290
+    untrained = _first_episode_lengths(MlpPolicy(seed=0), True, 32, 200, 0)
+    assert abs(untrained.mean() - log[:5].mean()) < 6, untrained.mean()
+    trained = _first_episode_lengths(MlpPolicy.from_tf_checkpoint(CKPT), True, 48, 1500, 0)
+    assert 0.7 * log[-100:].mean() < trained.mean() < 1.5 * log[-100:].mean(), trained.mean()
