@@ -21,28 +21,29 @@ typedef double Real;
 
 // ============================================ kernels ======================================================
 // one 64-lane workgroup (= one wavefront) per environment.
-// Two capacity tiers: the narrow kernel keeps 32 constraint rows per env in registers (fewer VGPRs -> more waves per
-// SIMD) and flags the envs that need more; the wide kernel (64 rows) then steps exactly those envs.  Both tiers perform
-// identical arithmetic on the rows that exist, so results do not depend on which tier ran.
+// k_step_narrow (the timed path) keeps NARROW_ROWS columns of the constraint matrix A per env in registers, which fits
+// 256 VGPRs -> 2 waves per SIMD; evaluations with more rows (up to MAXEFC = 64; < 1% in practice) keep the remaining
+// columns in a per-env global-memory strip.  k_step holds all 64 columns in registers (512 VGPRs, 1 wave per SIMD) and is
+// the single-tier fallback (DM option 102 = 0) and the profiling / debug instantiation.  Both perform identical
+// arithmetic on the rows that exist.
 constexpr int NARROW_ROWS = 32;
+static_assert(NARROW_ROWS + AOVF_COLS >= MAXEFC, "overflow strip too small");
 __global__ __launch_bounds__(64, 2) void k_step_narrow(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ action,
                                                     Real* __restrict__ obs, Real* __restrict__ reward, unsigned char* __restrict__ done,
-                                                    int n_substeps, unsigned char* __restrict__ retry) {
+                                                    int n_substeps) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
   const int env = blockIdx.x;
   if (env >= B.n_envs) return;
-  const bool ok = env_step<Real, NARROW_ROWS>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
-  if (dmw::lane() == 0) retry[env] = ok ? 0 : 1;
+  env_step<Real, NARROW_ROWS>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
 }
 __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ action,
                                              Real* __restrict__ obs, Real* __restrict__ reward, unsigned char* __restrict__ done,
-                                             int n_substeps, const unsigned char* __restrict__ retry) {
+                                             int n_substeps) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
   const int env = blockIdx.x;
   if (env >= B.n_envs) return;
-  if (retry && !retry[env]) return;
   env_step<Real, MAXEFC>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
 }
 
@@ -124,7 +125,7 @@ struct dm_batch {
   Real *d_qpos_in = nullptr, *d_qvel_in = nullptr; int* d_fidx_in = nullptr;
   double* d_debug = nullptr;
   long long* d_prof = nullptr; bool prof = false;
-  unsigned char* d_retry = nullptr; bool two_tier = true;
+  bool two_tier = true;
   bool timing = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f; bool ev_pending = false;
 };
 
@@ -162,7 +163,7 @@ extern "C" void dm_batch_destroy(dm_batch* b) {
   if (b->stream) hipStreamSynchronize(b->stream);
   void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
                   b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
-                  b->d_reward, b->d_done, b->d_mask, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->d_retry};
+                  b->d_reward, b->d_done, b->d_mask, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf};
   for (void* p : ptrs) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
@@ -193,7 +194,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   A(b->B.cong, (size_t)n * MAXEFC * 2); A(b->B.status, n); A(b->B.solver_iter, n); A(b->B.episode, n);
   A(b->d_cfg, (size_t)mc->n_frames * NQ); A(b->d_vel, (size_t)mc->n_frames * NV);
   A(b->d_action, (size_t)n * NU); A(b->d_obs, (size_t)n * NOBS); A(b->d_reward, n); A(b->d_done, n); A(b->d_mask, n);
-  A(b->d_retry, n);
+  A(b->B.aovf, (size_t)n * AOVF_COLS * 64);
   A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
 #undef A
   if (!ok) { dm_batch_destroy(b); return fail(DM_ENOMEM, "dm_batch_create: hipMalloc failed"); }
@@ -228,7 +229,7 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
     case DM_OPT_ACTION_MODE: if (v < 0 || v > 2) return fail(DM_EINVAL, "action mode must be 0..2"); b->B.action_mode = (int)v; break;
     case DM_OPT_SEED: b->B.seed = (unsigned long long)v; break;
     case 100: b->B.env_offset = (int)v; break;  /* global id of env 0 (multi-GPU sharding) */
-    case 102: b->two_tier = v != 0; break;       /* 1 (default): narrow 32-row kernel + wide 64-row kernel for the envs that need it */
+    case 102: b->two_tier = v != 0; break;       /* 1 (default): register tier of NARROW_ROWS columns + overflow strip; 0: all 64 columns in registers */
     case 101:                                   /* per-stage cycle profile on/off (diagnostic) */
       b->prof = v != 0;
       if (b->prof && !b->d_prof) { if (hipMalloc((void**)&b->d_prof, (size_t)b->n * 16 * sizeof(long long)) != hipSuccess) return fail(DM_ENOMEM, "prof alloc"); }
@@ -282,9 +283,8 @@ extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, dou
   if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } HIPCHK(hipEventRecord(b->ev0, b->stream)); }
   if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, b->d_prof);
   else if (b->two_tier) {
-    hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, b->d_retry);
-    hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, (const unsigned char*)b->d_retry);
-  } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, (const unsigned char*)nullptr);
+    hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub);
+  } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub);
   HIPCHK(hipGetLastError());
   if (b->timing) { HIPCHK(hipEventRecord(b->ev1, b->stream)); b->ev_pending = true; }
   if (kind == DM_PTR_HOST) {

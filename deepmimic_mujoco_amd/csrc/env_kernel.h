@@ -86,6 +86,7 @@ struct Shared {
   int rowi[MAXEFC];    // type | b1<<8 | b2<<16   (limit: type | dof<<8)
   int cong[MAXEFC][2]; // contact geom ids
   int nefc, ncon, status, solver_iter;
+  R* aovf;   // this env's overflow columns of A (rows >= the register tier's capacity), [MAXEFC - ROWS][64] in global memory
   // static index tables staged from the compile-time topology once per kernel (LDS lookups instead of global loads)
   unsigned short tab_dst[NV][14];   // tab_dst[k][a] = madr[anc_a(k)]: first stored entry of the row of k's a-th ancestor
   unsigned short tab_ent[312];      // entry e of the sparse M -> (i << 8) | j
@@ -868,7 +869,7 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
           const int rk = r0 + k * rows_per;
           if (c0 + k < MAXEFC) { s.cong[c0 + k][0] = g1; s.cong[c0 + k][1] = g2; }
           // rows past the on-chip capacity are dropped contact-wise, in list order (status bit 0)
-          if (rk + rows_per > ROWS) { if (rk < firstdrop) firstdrop = rk; continue; }
+          if (rk + rows_per > MAXEFC) { if (rk < firstdrop) firstdrop = rk; continue; }
           for (int q = 0; q < rows_per; q++) {
             R dir[3];
             if (dim == 1) { dir[0] = fr[0]; dir[1] = fr[1]; dir[2] = fr[2]; }
@@ -1041,11 +1042,34 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
 #pragma unroll
     for (int d = 0; d < NV; d++) y[d] *= s.dsq[d];
     DM_STAMP(10)
+    // overflow tier first (while AR is not live yet): columns ROWS.. of A do not fit the register budget of this
+    // instantiation; they go to a per-env global-memory strip [col - ROWS][lane] that only this lane ever reads back
+    // (rare: < 1% of evaluations).
+    if (ROWS < MAXEFC && nefc > ROWS) {
+      R* const aov = (&s.aovf)[dmw::pin_zero()];      // (re-read where needed: a live pointer would cost registers on the hot path)
+      for (int c = ROWS / 16; c * 16 < nefc; c++) {
+        dmw::sync();
+        if ((lane >> 4) == c) {
+#pragma unroll
+          for (int d = 0; d < NV; d++) s.u.ybuf[lane & 15][d] = y[d];
+        }
+        dmw::sync();
+        for (int ii = 0; ii < 16; ii++) {
+          const int i = c * 16 + ii;
+          if (i < ROWS || i >= nefc) continue;
+          R acc = 0;
+#pragma unroll
+          for (int d = 0; d < NV; d++) acc += y[d] * s.u.ybuf[ii][d];
+          if (lane == i) { acc += Rr; diag = acc; }
+          aov[(i - ROWS) * 64 + lane] = acc;
+        }
+      }
+    }
     // ---- A = Y Y^T + diag(R): rows of Y broadcast through LDS, 16 at a time ---------------------------------
     // (every AR[i] is defined exactly here — no early zero-initialisation that would keep the array live during the
     //  row build and the half solve)
 #pragma unroll
-    for (int c = 0; c < ROWS / 16; c++) {
+    for (int c = 0; c < (ROWS + 15) / 16; c++) {
       const bool chunk_live = c * 16 < nefc;
       if (chunk_live) {
         dmw::sync();
@@ -1058,6 +1082,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
 #pragma unroll
       for (int ii = 0; ii < 16; ii++) {
         const int i = c * 16 + ii;
+        if (i >= ROWS) continue;
         R acc = 0;
         if (i < nefc) {
           // dot(Y_lane, Y_i) in chunks of 6 entries read at a wave-uniform LDS address, double-buffered: the next chunk
@@ -1103,6 +1128,10 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       }
     }
   }
+  if (ROWS < MAXEFC && nefc > ROWS) {
+    const R* const aov = (&s.aovf)[dmw::pin_zero()];
+    for (int i = ROWS; i < nefc; i++) res += aov[(i - ROWS) * 64 + lane] * dmw::bcast(f, i);
+  }
   {
     const R cost = dmw::wave_sum(active ? f * (R(0.5) * (res - bb) + bb) : R(0));
     if (cost > 0) { f = 0; res = bb; }
@@ -1138,6 +1167,17 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
           }
         }
       }
+    }
+    if (ROWS < MAXEFC && ne > ROWS) for (int i = ROWS; i < ne; i++) {      // overflow rows: same update, column of A from memory
+      const R a = ((const R*)(&s.aovf)[dmw::pin_zero()])[(i - ROWS) * 64 + ln];
+      const R fn = fmax(f - res * dinvr, R(0));
+      R delta = fn - f;
+      const R change = delta * (R(0.5) * delta * diag + res);
+      const bool rej = change > R(1e-10);
+      if (rej) delta = 0;
+      const R di = dmw::bcast(delta, i);
+      if (ln == i && !rej) { f = fn; myimp -= change; }
+      res += a * di;
     }
     const R improvement = dmw::wave_sum(active ? myimp : R(0)) * pgs_scale;
     iter++;
@@ -1218,7 +1258,6 @@ DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo
   }
   stage_rows<R, ROWS>(M, s, lane);
   if (PROF) { t1 = dmw::clk(); prof[3] += t1 - t0; t0 = t1; }
-  if (ROWS < MAXEFC && (dmw::uniform(s.status) & 1)) return;   // capacity tier exceeded: the caller re-runs this env on the wide tier
   stage_constraint<R, ROWS, PROF>(M, s, lane, dbg, prof);
   if (PROF) { t1 = dmw::clk(); prof[4] += t1 - t0; t0 = t1; }
   if (dbg) {

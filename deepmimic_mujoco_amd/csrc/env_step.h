@@ -22,6 +22,7 @@ struct Batch {
   int* ncon;        // [N]
   int* nefc;        // [N]
   int* cong;        // [N,MAXEFC,2]
+  R* aovf;          // [N, AOVF_COLS, 64] overflow columns of A for the register-tier kernel (nullptr if unused)
   int* status;      // [N]
   int* solver_iter; // [N]
   int* episode;     // [N]
@@ -88,7 +89,6 @@ DM_DEV bool rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int 
       dmw::sync();
     }
     forward<R, ROWS, PROF>(M, s, lane, lt, (const DebugOut*)0, prof);
-    if (ROWS < MAXEFC && (dmw::uniform(s.status) & 1)) return false;   // needs the wide tier
     if (lane < NV) {
       const R a = s.ua.f.qacc[lane];
       x.aprev[lane] = a; x.sumv[lane] += Bw[i] * x.vprev[lane]; x.suma[lane] += Bw[i] * a;
@@ -107,7 +107,7 @@ template <class R>
 DM_DEV void load_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int env, int lane, const R* action) {
   if (lane < NQ) s.qpos[lane] = B.qpos[(size_t)env * NQ + lane];
   if (lane < NV) { s.qvel[lane] = B.qvel[(size_t)env * NV + lane]; s.qws[lane] = B.qws[(size_t)env * NV + lane]; s.act[lane] = 0; }
-  if (lane == 0) { s.status = 0; s.nefc = 0; s.ncon = 0; s.solver_iter = 0; }
+  if (lane == 0) { s.status = 0; s.nefc = 0; s.ncon = 0; s.solver_iter = 0; s.aovf = B.aovf ? B.aovf + (size_t)env * AOVF_COLS * 64 : (R*)0; }
   dmw::sync();
   if (action && lane < NU) {
     R a = action[(size_t)env * NU + lane];
@@ -180,8 +180,8 @@ DM_DEV void reset_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int
 }
 
 // DPEnv.step for one environment
-// ROWS = constraint-row capacity of this instantiation.  The narrow tier (ROWS < MAXEFC) returns false, leaving the env's
-// state untouched, when an evaluation needs more rows; the host then runs the wide tier for exactly those envs.
+// ROWS = columns of A = J M^-1 J^T + R that this instantiation keeps in registers; an evaluation with more constraint rows
+// (up to MAXEFC) keeps the remaining columns in the env's global-memory strip s.aovf (see stage_constraint).
 template <class R, int ROWS = MAXEFC, bool PROF = false>
 DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, StepScratch<R>& x, int env, int lane,
                      const R* action, R* obs, R* reward, unsigned char* done, int n_substeps, long long* prof_out = 0) {

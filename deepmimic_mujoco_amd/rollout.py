@@ -75,7 +75,7 @@ def add_vtarg_and_adv(seg, gamma, lam):
     return seg
 
 
-def traj_segment_generator(pi, env, horizon, stochastic=True, device=None):
+def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first_reset="rsi"):
     """Batched `traj_segment_generator` (src/trpo.py:27-80): N envs advance in lock step on the device.
 
     pi: policy.MlpPolicy; env: DPVecEnv created with autoreset="init" — the kernel then applies, on `done`, exactly what
@@ -108,7 +108,7 @@ def traj_segment_generator(pi, env, horizon, stochastic=True, device=None):
     cur_len = torch.zeros(n, dtype=torch.int32, device=device)
     as_buf = (lambda x: x) if torch.device(device).type == "cuda" else (lambda x: x.numpy())   # host tensors: shared-memory views
     step_out = (as_buf(ob), as_buf(rew), as_buf(done))
-    env.reset("rsi", out=as_buf(ob))                                      # trpo.py:32 `ob = env.reset()`
+    env.reset(first_reset, out=as_buf(ob))                                # trpo.py:32 `ob = env.reset()` (RSI); later episodes: noisy init
     t = 0
     while True:
         prevac.copy_(ac)

@@ -54,7 +54,8 @@ using namespace dm;
 struct EmuBatch {
   DevModel<double> M;
   Batch<double> B;
-  std::vector<double> qpos, qvel, qws, time, ctrl, xipos, comz, cfg, vel;
+  std::vector<double> qpos, qvel, qws, time, ctrl, xipos, comz, cfg, vel, aovf;
+  bool two_tier = true;
   std::vector<int> fidx, finit, ncon, nefc, cong, status, siter, episode;
   Shared<double> sh;
   StepScratch<double> xs;
@@ -72,12 +73,13 @@ void* emu_create(const dm_model_desc* d, const double* cfg, const double* vel, i
   e->time.assign(n, 0); e->ctrl.assign((size_t)n * NU, 0); e->xipos.assign((size_t)n * NB * 3, 0); e->comz.assign(n, 0);
   e->cfg.assign(cfg, cfg + (size_t)F * NQ); e->vel.assign(vel, vel + (size_t)F * NV);
   e->fidx.assign(n, 0); e->finit.assign(n, 0); e->ncon.assign(n, 0); e->nefc.assign(n, 0); e->cong.assign((size_t)n * MAXEFC * 2, -1);
-  e->status.assign(n, 0); e->siter.assign(n, 0); e->episode.assign(n, 0);
+  e->status.assign(n, 0); e->siter.assign(n, 0); e->episode.assign(n, 0); e->aovf.assign((size_t)n * AOVF_COLS * 64, 0);
   for (int i = 0; i < n; i++) for (int k = 0; k < NQ; k++) e->qpos[(size_t)i * NQ + k] = e->M.qpos0[k];
   Batch<double>& B = e->B;
   B.qpos = e->qpos.data(); B.qvel = e->qvel.data(); B.qws = e->qws.data(); B.time = e->time.data(); B.ctrl = e->ctrl.data();
   B.xipos = e->xipos.data(); B.comz = e->comz.data(); B.frame_idx = e->fidx.data(); B.frame_init = e->finit.data();
   B.ncon = e->ncon.data(); B.nefc = e->nefc.data(); B.cong = e->cong.data(); B.status = e->status.data();
+  B.aovf = e->aovf.data();
   B.solver_iter = e->siter.data(); B.episode = e->episode.data(); B.mocap_cfg = e->cfg.data(); B.mocap_vel = e->vel.data();
   B.n_frames = F; B.n_envs = n; B.env_offset = 0; B.reward_mode = 0; B.autoreset = 0; B.action_mode = 0; B.seed = 0;
   return e;
@@ -90,6 +92,7 @@ void emu_set_option(void* h, int opt, long long v) {
   else if (opt == DM_OPT_ACTION_MODE) e->B.action_mode = (int)v;
   else if (opt == DM_OPT_SEED) e->B.seed = (unsigned long long)v;
   else if (opt == 100) e->B.env_offset = (int)v;
+  else if (opt == 102) e->two_tier = v != 0;
 }
 void* emu_field(void* h, int field) {
   EmuBatch* e = (EmuBatch*)h;
@@ -106,10 +109,10 @@ void emu_step(void* h, const double* action, double* obs, double* reward, unsign
   EmuBatch* e = (EmuBatch*)h;
   for (int env = 0; env < e->B.n_envs; env++)
   {
-    // same two-tier scheme as the device: narrow (32 rows) first, wide (64) for the envs that report overflow
-    bool ok = true;
-    run_wave([&](int lane) { bool r = env_step<double, 32>(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); if (lane == 0) ok = r; });
-    if (!ok) run_wave([&](int lane) { env_step<double, MAXEFC>(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); });
+    // same scheme as the device: register tier (32 columns of A here, so that the overflow strip is exercised by every
+    // evaluation with more than 32 rows) or, with option 102 = 0, all 64 columns in registers
+    if (e->two_tier) run_wave([&](int lane) { env_step<double, 32>(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); });
+    else run_wave([&](int lane) { env_step<double, MAXEFC>(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); });
   }
 }
 void emu_set_state(void* h, const double* qpos, const double* qvel, const int* fidx, const unsigned char* mask) {

@@ -128,3 +128,27 @@ def compare_rollout(batch, om, idx, q, v, steps, seed=0, reward_mode=0, n_subste
         assert rel_err(wf[e], ods[e].get("qacc_warmstart")) < max(tol, 1e-8)
         assert abs(tf[e] - ods[e].get("time")[0]) < 1e-12
     return worst, ndone
+
+
+def many_row_states(lo, hi, want=4, seed=13, pool=80):
+    """Seeded states whose first forward evaluation has lo < nefc <= hi constraint rows (oracle count): exercises the
+    overflow strip of the register-tier kernel (columns of A past its register capacity)."""
+    from oracle import oracle as O
+    om = oracle_model()
+    idx, q, v, _ws, _c = varied_states(pool, seed=seed)
+    rng = np.random.RandomState(seed)
+    for e in range(pool):                       # crouched / lying / half-sunk poses collect many contacts
+        if e % 2:
+            q[e, 2] = 0.05 + 0.25 * rng.rand(); v[e] *= 0.2
+    od = O.Data(om)
+    keep = []
+    for e in range(pool):
+        od.reset(); od.set_state(q[e], v[e])
+        ne = int(od.get("nefc")[0])
+        if lo < ne <= hi:
+            keep.append(e)
+        if len(keep) == want:
+            break
+    assert len(keep) >= min(want, 2), "no states with %d < nefc <= %d in the pool" % (lo, hi)
+    k = np.asarray(keep)
+    return idx[k], q[k], v[k]

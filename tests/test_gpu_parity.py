@@ -227,3 +227,24 @@ def test_dpenv_gym_surface_on_gpu():
     assert np.all(np.abs(ob3) <= 0.01 + 1e-12)
     assert abs(env.get_time() - 0.0166) < 1e-12        # reset() zeroed time, one step since; reset_model_init keeps it
     env.close()
+
+
+def test_overflow_strip_rows_match_oracle_and_the_all_register_tier():
+    """More constraint rows than k_step_narrow keeps in registers: the remaining columns of A live in the per-env memory
+    strip.  Must match the oracle, and the all-register kernel (option 102 = 0) to rounding."""
+    idx, q, v = H.many_row_states(40, 64, want=6)
+    n = len(q)
+    b = make_batch(n)
+    worst, _ = H.compare_rollout(b, H.oracle_model(), idx, q, v, steps=6, seed=4, action_scale=0.3)
+    print("overflow-strip rollout worst rel err %.2e" % worst)
+    b.close()
+    outs = []
+    for tier in (1, 0):
+        bb = make_batch(n)
+        bb.set_option(102, tier)
+        bb.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); bb.set_state(q, v, frame_idx=idx)
+        rng = np.random.RandomState(0)
+        o = [bb.step(rng.randn(n, 28) * 0.3)[0].copy() for _ in range(3)]
+        assert bb.get(A.F_NEFC).max() > 40
+        outs.append(np.stack(o)); bb.close()
+    assert H.rel_err(outs[0], outs[1]) < 1e-11

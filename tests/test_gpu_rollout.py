@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _run(pol, stochastic, n, steps, seed=0):
+def _run(pol, stochastic, n, steps, seed=0, first_reset="rsi"):
     env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=seed)
     pol.seed(seed)
-    gen = traj_segment_generator(pol, env, steps, stochastic=stochastic)
+    gen = traj_segment_generator(pol, env, steps, stochastic=stochastic, first_reset=first_reset)
     seg = next(gen)
     env.close()
     return seg
@@ -48,16 +48,16 @@ def test_rollout_segment_is_consistent_and_gae_matches_reference_loop():
 def test_shipped_policy_episode_lengths_on_gpu_match_training_log():
     log = np.load(os.path.join(GOLD, "trpo_walk0_log.npz"))["EpLenMean"]
     n = 2048
-    seg = _run(MlpPolicy(device=DEV, seed=0), True, n, 160, seed=1)
+    seg = _run(MlpPolicy(device=DEV, seed=0), True, n, 160, seed=1, first_reset="init")
     first = _first_lengths(seg, 160)
     print("untrained policy: first-episode length mean %.1f (reference log, first 5 iterations: %.1f)" % (first.mean(), log[:5].mean()))
     assert abs(first.mean() - log[:5].mean()) < 4
-    seg = _run(MlpPolicy.from_tf_checkpoint(CKPT, device=DEV), True, n, 2000, seed=1)
+    seg = _run(MlpPolicy.from_tf_checkpoint(CKPT, device=DEV), True, n, 2000, seed=1, first_reset="init")
     first = _first_lengths(seg, 2000)
     print("shipped policy: first-episode length mean %.1f median %.0f (reference log, last 100 iterations: %.1f, range %.0f-%.0f)"
           % (first.mean(), np.median(first), log[-100:].mean(), log[-100:].min(), log[-100:].max()))
     assert 0.8 * log[-100:].mean() < first.mean() < 1.35 * log[-100:].mean()
-    seg = _run(MlpPolicy.from_tf_checkpoint(CKPT, device=DEV), False, 512, 1000, seed=1)
+    seg = _run(MlpPolicy.from_tf_checkpoint(CKPT, device=DEV), False, 512, 1000, seed=1, first_reset="init")
     alive = float((_first_lengths(seg, 1000) == 1000).mean())
     print("deterministic shipped policy: %.1f%% of envs still up after 1000 steps" % (100 * alive))
     assert alive > 0.9

@@ -132,3 +132,23 @@ def test_box_box_contacts_on_testbench():
     H.compare_forward(b, H.oracle_model(), np.zeros(n, dtype=np.int32), qs, np.zeros((n, 34)), np.zeros((n, 34)), np.zeros((n, 28)))
     cg = b.get(A.F_CONTACT_GEOMS)
     assert all(any(tuple(c) == (12, 15) for c in cg[e]) for e in range(n))
+
+
+def test_overflow_strip_rows_match_oracle_and_the_all_register_tier():
+    """Evaluations with more rows than the register tier holds (32 on the testbench) keep the remaining columns of A in the
+    per-env memory strip: results must match the oracle and be bit-identical to the all-register (64-column) tier."""
+    idx, q, v = H.many_row_states(32, 64, want=4)
+    n = len(q)
+    b = make(n)
+    worst, _ = H.compare_rollout(b, H.oracle_model(), idx, q, v, steps=4, seed=4, action_scale=0.3)
+    assert worst < 1e-10
+    outs = []
+    for tier in (1, 0):
+        bb = make(n)
+        bb.set_option(102, tier)
+        bb.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); bb.set_state(q, v, frame_idx=idx)
+        rng = np.random.RandomState(0)
+        o = [bb.step(rng.randn(n, 28) * 0.3)[0].copy() for _ in range(3)]
+        assert bb.get(A.F_NEFC).max() > 32
+        outs.append(np.stack(o))
+    assert np.array_equal(outs[0], outs[1])

@@ -13,7 +13,7 @@ def main():
     tot = sum(r[5] for r in rows) or 1
     lines += ["## Kernel trace (`rocprofv3 --kernel-trace --stats`)", "",
               "| kernel | calls | avg us | min us | max us | total ms | % | VGPR | AGPR | SGPR | LDS B | scratch B/lane |", "|---|---|---|---|---|---|---|---|---|---|---|---|"]
-    for r in rows[:8]:
+    for r in rows[:int(__import__("os").environ.get("ROWS", "8"))]:
         lines.append("| %s | %d | %.1f | %.1f | %.1f | %.2f | %.1f | %s | %s | %s | %s | %s |" % (
             r[0].split("(")[0][:48], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e6, 100 * r[5] / tot, r[6], r[7], r[8], r[9], r[10]))
     lines += ["", "## PMC (one counter group per pass; averages per launch)", "", "| kernel | counter | avg per launch | launches |", "|---|---|---|---|"]
