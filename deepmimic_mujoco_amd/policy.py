@@ -144,24 +144,31 @@ class MlpPolicy:
         self._noise_gen = torch.Generator(device=self.device)
         self._noise_gen.manual_seed(int(seed))
 
-    def act(self, stochastic, ob, out=None):
+    def act(self, stochastic, ob, out=None, vpred_out=None):
         """mlp_policy_trpo.py:63-65 for a batch: returns (ac [N, ac_dim] float64, vpred [N] float32).
-        `out` (float64 [N, ac_dim]) receives the action in place when given (the buffer handed to dm_batch_step)."""
+        `out` (float64 [N, ac_dim]) receives the action in place when given (the buffer handed to dm_batch_step);
+        `vpred_out` (float32 [N]) likewise receives the value prediction."""
         single = ob.dim() == 1
         if single:
             ob = ob[None]
         mean, vpred = self.forward(ob)
         if stochastic:
             noise = torch.randn(mean.shape, dtype=torch.float32, device=mean.device, generator=self._noise_gen)
-            ac = mean + torch.exp(self.params["logstd"]) * noise
+            ac = torch.addcmul(mean, self._std(), noise)
         else:
             ac = mean
+        if vpred_out is not None:
+            vpred_out.copy_(vpred)
+            vpred = vpred_out
         if out is not None:
             out.copy_(ac)
             ac = out
         else:
             ac = ac.to(torch.float64)
         return (ac[0], vpred[0]) if single else (ac, vpred)
+
+    def _std(self):
+        return torch.exp(self.params["logstd"])
 
     # ---- distribution (src/distributions.py:220-243 DiagGaussianPd) ---------------------------------------------------
     def neglogp(self, ob, ac):

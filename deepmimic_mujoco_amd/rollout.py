@@ -82,56 +82,71 @@ def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first
     the reference does on the host (`env.reset(); ob = env.env.reset_model_init()`, :77-79) and returns the fresh
     episode's observation.  Yields, every `horizon` steps, the reference's segment dict with a leading [T, N] shape:
     ob [T,N,56] f32, ac / prevac [T,N,28] f32, rew / vpred [T,N] f32, new [T,N] int32 (new[t] = ob[t] starts an episode),
-    nextvpred [N], ep_rets / ep_lens (lists of finished episodes, host ints — the only host transfer, once per segment).
-    Observations, actions, rewards and dones never leave the device; policy and env share the current torch stream."""
+    nextvpred [N], ep_rets / ep_lens (lists of finished episodes, host numbers — the only host transfer, once per segment).
+
+    Per step the loop issues only the policy forward and ONE env launch: the policy writes its action and value straight
+    into row t of the segment buffers, and `dm_batch_step` reads that action row and writes the next observation, the
+    reward and the done flag straight into rows t+1 / t / t of theirs (float64, as the C ABI produces them).  The float32
+    segment views, `new`, `prevac` and the episode statistics are derived once per segment with [T, N]-wide ops.
+    Nothing leaves the device or the stream."""
     import torch
-    n = env.num_envs
+    n, T = env.num_envs, int(horizon)
     if device is None:
         device = pi.device
+    device = torch.device(device)
     f32, f64 = torch.float32, torch.float64
-    obs = torch.zeros((horizon, n, 56), dtype=f32, device=device)
-    acs = torch.zeros((horizon, n, 28), dtype=f32, device=device)
-    prevacs = torch.zeros_like(acs)
-    rews = torch.zeros((horizon, n), dtype=f32, device=device)
-    vpreds = torch.zeros((horizon, n), dtype=f32, device=device)
-    news = torch.zeros((horizon, n), dtype=torch.int32, device=device)
-    ep_ret_log = torch.zeros((horizon, n), dtype=f64, device=device)      # return / length of the episode that ended at (t, e)
-    ep_len_log = torch.zeros((horizon, n), dtype=torch.int32, device=device)
-
-    ob = torch.empty((n, 56), dtype=f64, device=device)
-    rew = torch.empty(n, dtype=f64, device=device)
-    done = torch.empty(n, dtype=torch.uint8, device=device)
-    ac = torch.zeros((n, 28), dtype=f64, device=device)
-    prevac = torch.zeros((n, 28), dtype=f64, device=device)
-    new = torch.ones(n, dtype=torch.int32, device=device)
-    cur_ret = torch.zeros(n, dtype=f64, device=device)
-    cur_len = torch.zeros(n, dtype=torch.int32, device=device)
-    as_buf = (lambda x: x) if torch.device(device).type == "cuda" else (lambda x: x.numpy())   # host tensors: shared-memory views
-    step_out = (as_buf(ob), as_buf(rew), as_buf(done))
-    env.reset(first_reset, out=as_buf(ob))                                # trpo.py:32 `ob = env.reset()` (RSI); later episodes: noisy init
-    t = 0
+    ob64 = torch.zeros((T + 1, n, 56), dtype=f64, device=device)         # row t: observation the policy sees at step t
+    ac64 = torch.zeros((T, n, 28), dtype=f64, device=device)
+    rew64 = torch.zeros((T, n), dtype=f64, device=device)
+    done8 = torch.zeros((T, n), dtype=torch.uint8, device=device)
+    vpreds = torch.zeros((T + 1, n), dtype=f32, device=device)
+    first = torch.ones(n, dtype=torch.int32, device=device)               # `new` of row 0: carried over from the last segment
+    last_ac = torch.zeros((n, 28), dtype=f32, device=device)              # prevac of row 0 (trpo.py:29 samples a random one)
+    cur_ret = torch.zeros(n, dtype=f64, device=device)                    # running return / length of the open episodes
+    cur_len = torch.zeros(n, dtype=torch.int64, device=device)
+    as_buf = (lambda x: x) if device.type == "cuda" else (lambda x: x.numpy())   # host tensors: shared-memory views
+    env.reset(first_reset, out=as_buf(ob64[0]))                           # trpo.py:32 `ob = env.reset()` (RSI); later episodes: noisy init
+    step_idx = torch.arange(1, T + 1, device=device, dtype=torch.int64)[:, None]
     while True:
-        prevac.copy_(ac)
-        _, vpred = pi.act(stochastic, ob, out=ac)
-        if t > 0 and t % horizon == 0:
-            ended = ep_len_log > 0
-            # time-major order = the order in which a single-env loop would have appended them
-            ep_rets = ep_ret_log[ended].tolist()
-            ep_lens = ep_len_log[ended].tolist()
-            yield {"ob": obs, "rew": rews, "vpred": vpreds, "new": news, "ac": acs, "prevac": prevacs,
-                   "nextvpred": vpred * (1 - new).to(f32), "ep_rets": ep_rets, "ep_lens": ep_lens}
-            ep_ret_log.zero_(); ep_len_log.zero_()
-        i = t % horizon
-        obs[i] = ob; vpreds[i] = vpred; news[i] = new; acs[i] = ac; prevacs[i] = prevac
-        env.batch.step(as_buf(ac), 1, step_out)                          # :66 `env.step(ac)` for every env, one launch
-        rews[i] = rew
-        cur_ret += rew; cur_len += 1
-        new = done.to(torch.int32)
-        fin = done.bool()
-        ep_ret_log[i] = torch.where(fin, cur_ret, torch.zeros_like(cur_ret))
-        ep_len_log[i] = torch.where(fin, cur_len, torch.zeros_like(cur_len))
-        cur_ret.masked_fill_(fin, 0.0); cur_len.masked_fill_(fin, 0)
-        t += 1
+        for t in range(T):
+            pi.act(stochastic, ob64[t], out=ac64[t], vpred_out=vpreds[t])                       # :49
+            env.batch.step(as_buf(ac64[t]), 1, (as_buf(ob64[t + 1]), as_buf(rew64[t]), as_buf(done8[t])))   # :66, one launch
+        vpreds[T] = pi.forward(ob64[T])[1]                                 # value of the observation after the segment (:49-52);
+        # the action for it is sampled at the top of the next segment, i.e. from the policy as updated in between
+        done = done8.to(torch.bool)
+        new = torch.cat([first[None], done8[:-1].to(torch.int32)], 0)
+        acs = ac64.to(f32)
+        prevacs = torch.cat([last_ac[None], acs[:-1]], 0)
+        # episode statistics: return / length of every episode that ended inside the segment, in time-major order
+        # (= the order in which a single-env loop would have appended them, :72-76)
+        csum = torch.cumsum(rew64, 0)
+        ends = done.nonzero()                                              # [K, 2] (t, env), sorted by t then env
+        ep_rets, ep_lens = [], []
+        if ends.numel():
+            te, ee = ends[:, 0], ends[:, 1]
+            # previous end of the same env inside the segment (or -1): sort by (env, t) and shift
+            order = torch.argsort(ee * T + te)
+            te_s, ee_s = te[order], ee[order]
+            prev_t = torch.full_like(te_s, -1)
+            same = ee_s[1:] == ee_s[:-1]
+            prev_t[1:] = torch.where(same, te_s[:-1], torch.full_like(te_s[:-1], -1))
+            seg_ret = csum[te_s, ee_s] - torch.where(prev_t >= 0, csum[prev_t.clamp(min=0), ee_s], torch.zeros_like(csum[te_s, ee_s]))
+            seg_len = te_s - prev_t
+            opening = prev_t < 0                                           # first end of that env: add what it carried in
+            seg_ret = seg_ret + torch.where(opening, cur_ret[ee_s], torch.zeros_like(seg_ret))
+            seg_len = seg_len + torch.where(opening, cur_len[ee_s], torch.zeros_like(seg_len))
+            inv = torch.empty_like(order); inv[order] = torch.arange(order.numel(), device=device)
+            ep_rets = seg_ret[inv].tolist(); ep_lens = seg_len[inv].tolist()
+        # carry the open episodes into the next segment
+        last_end = torch.where(done, step_idx.expand(T, n), torch.zeros((T, n), dtype=torch.int64, device=device)).amax(0)   # 1-based
+        tail_ret = csum[-1] - torch.where(last_end > 0, csum[(last_end - 1).clamp(min=0), torch.arange(n, device=device)], torch.zeros_like(csum[-1]))
+        cur_ret = torch.where(last_end > 0, tail_ret, cur_ret + tail_ret)
+        cur_len = torch.where(last_end > 0, T - last_end, cur_len + T)
+        yield {"ob": ob64[:T].to(f32), "rew": rew64.to(f32), "vpred": vpreds[:T].clone(), "new": new, "ac": acs, "prevac": prevacs,
+               "nextvpred": vpreds[T] * (1 - done8[-1].to(f32)), "ep_rets": ep_rets, "ep_lens": ep_lens}
+        first = done8[-1].to(torch.int32)
+        last_ac = acs[-1].clone()
+        ob64[0].copy_(ob64[T])
 
 
 def flatten_segment(seg):

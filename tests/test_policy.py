@@ -202,3 +202,49 @@ def test_shipped_policy_reproduces_training_log_episode_lengths():
     assert abs(untrained.mean() - log[:5].mean()) < 6, untrained.mean()
     trained = _first_episode_lengths(MlpPolicy.from_tf_checkpoint(CKPT), True, 48, 1500, 0)
     assert 0.7 * log[-100:].mean() < trained.mean() < 1.5 * log[-100:].mean(), trained.mean()
+
+
+class _ScriptedEnv:
+    """Host stand-in for DPVecEnv with scripted rewards / dones: checks the generator's bookkeeping only."""
+
+    def __init__(self, n, steps, seed):
+        rng = np.random.RandomState(seed)
+        self.num_envs = n
+        self.rew = rng.rand(steps, n)
+        self.done = (rng.rand(steps, n) < 0.15).astype(np.uint8)
+        self.t = 0
+        self.batch = self
+
+    def reset(self, mode, out=None):
+        out[...] = 0.0
+        return out
+
+    def step(self, ac, nsub, out):
+        ob, rew, done = out
+        ob[...] = self.t + 1
+        rew[...] = self.rew[self.t]; done[...] = self.done[self.t]
+        self.t += 1
+        return out
+
+
+def test_segment_episode_statistics_across_segment_boundaries():
+    n, T, segs = 7, 16, 4
+    env = _ScriptedEnv(n, T * segs, 3)
+    gen = traj_segment_generator(MlpPolicy(), env, T, stochastic=False)
+    got_rets, got_lens, news = [], [], []
+    for _ in range(segs):
+        seg = next(gen)
+        got_rets += seg["ep_rets"]; got_lens += seg["ep_lens"]; news.append(seg["new"].numpy().copy())
+        assert float(seg["ob"][3, 0, 0]) == float(len(news) - 1) * T + 3          # row t holds the observation seen at step t
+    # the reference's single-env bookkeeping (src/trpo.py:70-76), replayed env by env in time-major order
+    want = []
+    cur_ret = np.zeros(n); cur_len = np.zeros(n, int)
+    for t in range(T * segs):
+        cur_ret += env.rew[t]; cur_len += 1
+        for e in range(n):
+            if env.done[t, e]:
+                want.append((cur_ret[e], cur_len[e])); cur_ret[e] = 0; cur_len[e] = 0
+    assert got_lens == [w[1] for w in want]
+    assert np.allclose(got_rets, [w[0] for w in want], rtol=1e-12, atol=1e-12)
+    new = np.concatenate(news)
+    assert np.array_equal(new[0], np.ones(n, int)) and np.array_equal(new[1:], env.done[:T * segs - 1])
