@@ -2,6 +2,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I../../include dmenv.hip -o libdmenv.so
 // There is no CPU execution path in this library: every entry point that computes runs a HIP kernel.
+#include <cstddef>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -27,7 +28,7 @@ typedef double Real;
 // the single-tier fallback (DM option 102 = 0) and the profiling / debug instantiation.  Both perform identical
 // arithmetic on the rows that exist.
 constexpr int NARROW_ROWS = 32;
-static_assert(NARROW_ROWS + AOVF_COLS >= MAXEFC, "overflow strip too small");
+static_assert(AOVF_COLS >= MAXEFC, "memory strip too small");
 __global__ __launch_bounds__(64, 2) void k_step_narrow(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ action,
                                                     Real* __restrict__ obs, Real* __restrict__ reward, unsigned char* __restrict__ done,
                                                     int n_substeps) {
@@ -230,6 +231,12 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
     case DM_OPT_SEED: b->B.seed = (unsigned long long)v; break;
     case 100: b->B.env_offset = (int)v; break;  /* global id of env 0 (multi-GPU sharding) */
     case 102: b->two_tier = v != 0; break;       /* 1 (default): register tier of NARROW_ROWS columns + overflow strip; 0: all 64 columns in registers */
+    case 103: {                                 /* test hook: 1 = every PGS sweep takes the guarded-replay path (results must not change) */
+      const Real lvl = v ? Real(-1e300) : Real(1e-10);
+      HIPCHK(hipMemcpyAsync((char*)b->d_model + offsetof(DevModel<Real>, pgs_detect), &lvl, sizeof lvl, hipMemcpyHostToDevice, b->stream));
+      HIPCHK(hipStreamSynchronize(b->stream));
+      break;
+    }
     case 101:                                   /* per-stage cycle profile on/off (diagnostic) */
       b->prof = v != 0;
       if (b->prof && !b->d_prof) { if (hipMalloc((void**)&b->d_prof, (size_t)b->n * 16 * sizeof(long long)) != hipSuccess) return fail(DM_ENOMEM, "prof alloc"); }

@@ -54,6 +54,7 @@ struct DevModel {
   R qpos0[NQ];
   R timestep, gravity[3], tolerance, solref[2], solimp[5], meaninertia, total_mass;
   R K, B, pgs_scale;  // constraint stiffness / damping (refsafe applied), 1/(meaninertia*nv)
+  R pgs_detect;       // cost-increase level that sends a PGS sweep to the guarded replay (1e-10 = [MJ costChange]; tests lower it)
   int iterations, enable_contact, enable_limit;
 };
 
@@ -86,7 +87,7 @@ struct Shared {
   int rowi[MAXEFC];    // type | b1<<8 | b2<<16   (limit: type | dof<<8)
   int cong[MAXEFC][2]; // contact geom ids
   int nefc, ncon, status, solver_iter;
-  R* aovf;   // this env's overflow columns of A (rows >= the register tier's capacity), [MAXEFC - ROWS][64] in global memory
+  R* aovf;   // this env's memory strip for columns of A, [MAXEFC][64]: columns past the register tier; all of them during a PGS replay
   // static index tables staged from the compile-time topology once per kernel (LDS lookups instead of global loads)
   unsigned short tab_dst[NV][14];   // tab_dst[k][a] = madr[anc_a(k)]: first stored entry of the row of k's a-th ancestor
   unsigned short tab_ent[312];      // entry e of the sparse M -> (i << 8) | j
@@ -961,6 +962,9 @@ struct RowStep {
 };
 template <class R> struct RowStep<NV, R> { static DM_DEV void run(R*, RowAcc<R>&, const Shared<R>&, const R*) {} };
 
+// PGS candidate force of one row: f' = max(f - r / A_ii, 0)   [MJ mj_solPGS, scalar row]
+template <class R> DM_DEV R pgs_candidate(R f, R res, R dinvr) { return fmax(f - res * dinvr, R(0)); }
+
 // constraint solve.  Lane r < nefc owns constraint row r (limits first, then contacts in list order).
 //   [MJ mj_fwdAcceleration, mj_projectConstraint, mj_fwdConstraint (warmstart, mj_solPGS)]
 template <class R, int ROWS, bool PROF = false>
@@ -1043,7 +1047,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     for (int d = 0; d < NV; d++) y[d] *= s.dsq[d];
     DM_STAMP(10)
     // overflow tier first (while AR is not live yet): columns ROWS.. of A do not fit the register budget of this
-    // instantiation; they go to a per-env global-memory strip [col - ROWS][lane] that only this lane ever reads back
+    // instantiation; they go to a per-env global-memory strip [col][lane] that only this lane ever reads back
     // (rare: < 1% of evaluations).
     if (ROWS < MAXEFC && nefc > ROWS) {
       R* const aov = (&s.aovf)[dmw::pin_zero()];      // (re-read where needed: a live pointer would cost registers on the hot path)
@@ -1061,7 +1065,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
 #pragma unroll
           for (int d = 0; d < NV; d++) acc += y[d] * s.u.ybuf[ii][d];
           if (lane == i) { acc += Rr; diag = acc; }
-          aov[(i - ROWS) * 64 + lane] = acc;
+          aov[i * 64 + lane] = acc;
         }
       }
     }
@@ -1130,7 +1134,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   }
   if (ROWS < MAXEFC && nefc > ROWS) {
     const R* const aov = (&s.aovf)[dmw::pin_zero()];
-    for (int i = ROWS; i < nefc; i++) res += aov[(i - ROWS) * 64 + lane] * dmw::bcast(f, i);
+    for (int i = ROWS; i < nefc; i++) res += aov[i * 64 + lane] * dmw::bcast(f, i);
   }
   {
     const R cost = dmw::wave_sum(active ? f * (R(0.5) * (res - bb) + bb) : R(0));
@@ -1142,12 +1146,24 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   // loop constants pinned in VGPRs: left to itself the compiler re-loads them from memory (s_load + wait) every sweep
   R pgs_scale = M.pgs_scale, pgs_tol = M.tolerance;
   dmw::pin_value(pgs_scale); dmw::pin_value(pgs_tol);
+  R pgs_detect = M.pgs_detect;
+  dmw::pin_value(pgs_detect);
   while (iter < maxiter) {
     R myimp = 0;
     // fresh opaque copies per sweep: otherwise the 64 row-exists tests and 64 lane==row masks are hoisted out of the
     // sweep loop as 128 SGPR pairs, spilled to VGPR lanes and read back with v_readlane on every row
     const int ne = dmw::launder_uniform(nefc);
     const int ln = dmw::launder(lane);
+    // [MJ costChange] rejects an update that would raise the dual cost by more than 1e-10.  In exact arithmetic the
+    // one-dimensional step never raises it, so the sweep runs speculatively with the test OFF the serial dependency
+    // chain (res -> f' -> delta -> broadcast -> res); if any row did trip it, the sweep is replayed from its starting
+    // state with the guarded update below — results are identical to testing every row in place.
+    // Row i only ever needs lane i's force, and lane i's force only changes at row i, so the sweep leaves f alone: each
+    // row costs the serial chain (candidate -> delta -> broadcast -> residual update) plus one select that records the
+    // residual lane i saw at its own row; forces, cost changes and the costChange test follow once per sweep, lane-wise,
+    // from exactly the operands the row-by-row form would have used.
+    const R f0 = f, res0 = res;
+    R rsave = res;
 #pragma unroll
     for (int blk = 0; blk < ROWS / 8; blk++) {
       if (blk * 8 < ne) {          // scalar branch per block of 8 rows; rows past nefc cost one scalar compare each
@@ -1155,29 +1171,46 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
         for (int ii = 0; ii < 8; ii++) {
           const int i = blk * 8 + ii;
           if (i < ne) {
-            // every lane evaluates its own candidate update; only lane i's is taken (v_readlane broadcast of delta)
-            const R fn = fmax(f - res * dinvr, R(0));
-            R delta = fn - f;
-            const R change = delta * (R(0.5) * delta * diag + res);
-            const bool rej = change > R(1e-10);          // [MJ costChange]: never accept an increase
-            if (rej) delta = 0;
+            const R delta = pgs_candidate(f0, res, dinvr) - f0;      // every lane evaluates its own; only lane i's is used
             const R di = dmw::bcast(delta, i);
-            if (ln == i && !rej) { f = fn; myimp -= change; }
+            if (ln == i) rsave = res;
             res += AR[i] * di;
           }
         }
       }
     }
     if (ROWS < MAXEFC && ne > ROWS) for (int i = ROWS; i < ne; i++) {      // overflow rows: same update, column of A from memory
-      const R a = ((const R*)(&s.aovf)[dmw::pin_zero()])[(i - ROWS) * 64 + ln];
-      const R fn = fmax(f - res * dinvr, R(0));
-      R delta = fn - f;
-      const R change = delta * (R(0.5) * delta * diag + res);
-      const bool rej = change > R(1e-10);
-      if (rej) delta = 0;
+      const R a = ((const R*)(&s.aovf)[dmw::pin_zero()])[i * 64 + ln];
+      const R delta = pgs_candidate(f0, res, dinvr) - f0;
       const R di = dmw::bcast(delta, i);
-      if (ln == i && !rej) { f = fn; myimp -= change; }
+      if (ln == i) rsave = res;
       res += a * di;
+    }
+    bool bad = false;
+    if (ln < ne) {
+      const R fn = pgs_candidate(f0, rsave, dinvr);
+      const R delta = fn - f0;
+      const R change = delta * (R(0.5) * delta * diag + rsave);
+      f = fn; myimp = -change; bad = change > pgs_detect;
+    }
+    if (dmw::ballot(bad) != 0) {
+      // guarded replay (cold): the register columns are parked in the env's memory strip so that one compact loop can
+      // walk all rows with a run-time index
+      R* const strip = (&s.aovf)[dmw::pin_zero()];
+#pragma unroll
+      for (int i = 0; i < ROWS; i++) strip[i * 64 + ln] = AR[i];
+      f = f0; res = res0; myimp = 0;
+      for (int i = 0; i < ne; i++) {
+        const R a = strip[i * 64 + ln];
+        const R fn = fmax(f - res * dinvr, R(0));
+        R delta = fn - f;
+        const R change = delta * (R(0.5) * delta * diag + res);
+        const bool rej = change > R(1e-10);          // never accept an increase
+        if (rej) delta = 0;
+        const R di = dmw::bcast(delta, i);
+        if (ln == i && !rej) { f = fn; myimp -= change; }
+        res += a * di;
+      }
     }
     const R improvement = dmw::wave_sum(active ? myimp : R(0)) * pgs_scale;
     iter++;

@@ -89,6 +89,7 @@ inline int build_dev_model(const dm_model_desc* d, DevModel<double>* hp, std::st
   h.K = 1 / std::fmax(DM_MINVAL, dmax * dmax * tc * tc * dr * dr);
   h.B = 2 / std::fmax(DM_MINVAL, dmax * tc);
   h.pgs_scale = 1 / (d->meaninertia * (NV > 1 ? NV : 1));
+  h.pgs_detect = 1e-10;
   h.enable_contact = 1; h.enable_limit = 1;
   return DM_OK;
 }

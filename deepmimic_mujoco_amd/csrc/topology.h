@@ -11,7 +11,7 @@ namespace dmt {
 
 constexpr int NB = 14, NV = 34, NQ = 35, NJ = 29, NG = 16, NU = 28, NOBS = 56;
 constexpr int MAXPAIR = 128, MAXEFC = 64;   // one constraint row per lane
-constexpr int AOVF_COLS = 32;            // columns of A a register-tier kernel may keep in its global-memory strip (tier capacity >= MAXEFC - AOVF_COLS)
+constexpr int AOVF_COLS = MAXEFC;     // per-env memory strip for columns of A: [AOVF_COLS][64] (overflow columns; all columns during a PGS replay)
 constexpr int MAXDEPTH_BODY = 4;
 
 struct Topo {

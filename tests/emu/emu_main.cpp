@@ -93,6 +93,7 @@ void emu_set_option(void* h, int opt, long long v) {
   else if (opt == DM_OPT_SEED) e->B.seed = (unsigned long long)v;
   else if (opt == 100) e->B.env_offset = (int)v;
   else if (opt == 102) e->two_tier = v != 0;
+  else if (opt == 103) e->M.pgs_detect = v ? -1e300 : 1e-10;
 }
 void* emu_field(void* h, int field) {
   EmuBatch* e = (EmuBatch*)h;

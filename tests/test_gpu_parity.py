@@ -248,3 +248,21 @@ def test_overflow_strip_rows_match_oracle_and_the_all_register_tier():
         assert bb.get(A.F_NEFC).max() > 40
         outs.append(np.stack(o)); bb.close()
     assert H.rel_err(outs[0], outs[1]) < 1e-11
+
+
+def test_pgs_guarded_replay_path_gives_identical_results():
+    """Option 103: every PGS sweep takes the guarded-replay path; must equal the speculative sweep bit for bit."""
+    idx, q, v, _w, _c = H.varied_states(24, seed=17)
+    i2, q2, v2 = H.many_row_states(32, 64, want=4)
+    idx = np.concatenate([idx, i2]); q = np.concatenate([q, q2]); v = np.concatenate([v, v2])
+    n = len(q)
+    outs = []
+    for force in (0, 1):
+        b = make_batch(n)
+        b.set_option(103, force)
+        b.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); b.set_state(q, v, frame_idx=idx)
+        rng = np.random.RandomState(1)
+        o = [b.step(rng.randn(n, 28) * 0.5)[0].copy() for _ in range(4)]
+        outs.append((np.stack(o), b.get(A.F_SOLVER_ITER).copy(), b.get(A.F_QACC_WARMSTART).copy()))
+        b.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
