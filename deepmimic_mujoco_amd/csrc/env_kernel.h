@@ -80,8 +80,7 @@ struct Shared {
     R fdof[NV][6];
     struct { R cvel[NB][6], cacc[NB][6], cfrc[NB][6], csub[NB][6]; } v;
     R rowd[MAXEFC][10];  // w[6], dist, margin, dA, rscale
-    R ybuf[16][NV];
-    struct { R rowf[MAXEFC][6], G[NB][6], Gsub[NB][6]; } c;   // constraint forces as body wrenches (end of the solve)
+    R ybuf[17][NV];      // 16 broadcast slots + slot 16: z = D^-1/2 L^-T tau (lives from the half solve to the final assembly)
   } u;
   R boxc[6][4][4];     // contacts (dist, pos) of the pair types with > 2 contacts: plane-box (slots 0..3), box-box (4..5)
   int rowi[MAXEFC];    // type | b1<<8 | b2<<16   (limit: type | dof<<8)
@@ -870,7 +869,7 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
           const int rk = r0 + k * rows_per;
           if (c0 + k < MAXEFC) { s.cong[c0 + k][0] = g1; s.cong[c0 + k][1] = g2; }
           // rows past the on-chip capacity are dropped contact-wise, in list order (status bit 0)
-          if (rk + rows_per > MAXEFC) { if (rk < firstdrop) firstdrop = rk; continue; }
+          if (rk + rows_per > MAXROWS) { if (rk < firstdrop) firstdrop = rk; continue; }
           for (int q = 0; q < rows_per; q++) {
             R dir[3];
             if (dim == 1) { dir[0] = fr[0]; dir[1] = fr[1]; dir[2] = fr[2]; }
@@ -931,14 +930,15 @@ struct RowAcc {
   R w[6];
   unsigned plus_lo, plus_hi, minus_lo, minus_hi;   // ancestor-chain masks of body2 (+) and body1 (-)
   int ldof;
-  R lsgn, vel, jsm, jws;
+  R lsgn, vel, jws;
+  bool is_tau;     // TAU_LANE: this lane's "row" is the smooth force itself
 };
 template <int D, class R>
 DM_DEV void load_dof_operands(R* dst, const Shared<R>& s, int z) {
   if constexpr (D < NV) {
 #pragma unroll
     for (int r = 0; r < 6; r++) dst[r] = s.cdof[D + z][r];
-    dst[6] = s.qvel[D + z]; dst[7] = s.ua.f.qaccs[D + z]; dst[8] = s.qws[D + z];
+    dst[6] = s.qvel[D + z]; dst[7] = s.ua.f.tau[D + z]; dst[8] = s.qws[D + z];
   }
 }
 template <int D, class R>
@@ -952,15 +952,45 @@ struct RowStep {
     R j = ra.w[0] * cur[0] + ra.w[1] * cur[1] + ra.w[2] * cur[2] + ra.w[3] * cur[3] + ra.w[4] * cur[4] + ra.w[5] * cur[5];
     j = (pb == mb) ? R(0) : (pb ? j : -j);   // a dof that moves both bodies (common ancestor) cancels exactly
     if (D == ra.ldof) j = ra.lsgn;
-    ra.vel += j * cur[6]; ra.jsm += j * cur[7]; ra.jws += j * cur[8];
+    if (ra.is_tau) j = cur[7];
+    ra.vel += j * cur[6]; ra.jws += j * cur[8];
     y[D] = j;
-    // pin all three running sums: an unpinned one is sunk to the end of the loop by the optimiser, which keeps its 34
+    // pin both running sums: an unpinned one is sunk to the end of the loop by the optimiser, which keeps its 34
     // operands (loaded here) alive — and spilled — until then
-    dmw::pin_value(ra.vel); dmw::pin_value(ra.jsm); dmw::pin_value(ra.jws);
+    dmw::pin_value(ra.vel); dmw::pin_value(ra.jws);
     RowStep<D + 1, R>::run(y, ra, s, nxt);
   }
 };
 template <class R> struct RowStep<NV, R> { static DM_DEV void run(R*, RowAcc<R>&, const Shared<R>&, const R*) {} };
+
+// dot(Y_lane, q) for a 34-vector q read at wave-uniform LDS addresses (broadcast), in chunks of 6 entries, double-buffered:
+// the next chunk is loaded while the current one is multiplied (order pins: see solve_LT above).
+template <class R>
+DM_DEV R row_dot(const R* y, const R* q) {
+  R acc = 0;
+  R qa[6], qb[6];
+  { const int zc = dmw::pin_zero();
+#pragma unroll
+    for (int d = 0; d < 6; d++) qa[d] = q[d + zc]; }
+#pragma unroll
+  for (int c0 = 0; c0 < NV; c0 += 12) {
+    { const int zc = dmw::pin_zero();
+#pragma unroll
+      for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) qb[d] = q[c0 + 6 + d + zc]; }
+    dmw::sched_fence();
+#pragma unroll
+    for (int d = 0; d < 6; d++) if (c0 + d < NV) acc += y[c0 + d] * qa[d];
+    dmw::pin_value(acc);
+    { const int zc = dmw::pin_zero();
+#pragma unroll
+      for (int d = 0; d < 6; d++) if (c0 + 12 + d < NV) qa[d] = q[c0 + 12 + d + zc]; }
+    dmw::sched_fence();
+#pragma unroll
+    for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) acc += y[c0 + 6 + d] * qb[d];
+    dmw::pin_value(acc);
+  }
+  return acc;
+}
 
 // PGS candidate force of one row: f' = max(f - r / A_ii, 0)   [MJ mj_solPGS, scalar row]
 template <class R> DM_DEV R pgs_candidate(R f, R res, R dinvr) { return fmax(f - res * dinvr, R(0)); }
@@ -975,8 +1005,15 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
 #define DM_STAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
   const int nefc = dmw::uniform(s.nefc);   // in an SGPR so that the row loops branch scalar
   const bool active = lane < nefc;
-  // ---- qacc_smooth = M^-1 tau --------------------------------------------------------------------------------
-  {
+  const bool taul = lane == TAU_LANE;
+  // With M = L^T D L and Y_r = D^-1/2 L^-T J_r^T (one row per lane), every product the solver needs is a dot product of
+  // half-solved vectors:  A = Y Y^T + diag(R),  J qacc_smooth = Y z  with  z = D^-1/2 L^-T tau,  and
+  //     qacc = M^-1 (tau + J^T f) = L^-1 D^-1/2 (z + sum_r f_r Y_r).
+  // The smooth force tau rides through the rows' half solve in the spare lane TAU_LANE (no cost: the solve is SIMD over
+  // lanes), so one evaluation costs one L^-T pass for all rows + tau and one L^-1 pass on the final vector; qacc_smooth
+  // itself is only formed when there are no rows at all (or for the debug dump).
+  if (lane == 0) s.solver_iter = 0;
+  if (nefc == 0 || dbg) {
     R x[NV];
 #pragma unroll
     for (int d = 0; d < NV; d++) x[d] = s.ua.f.tau[d];
@@ -985,28 +1022,27 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     if (lane == 0) {
 #pragma unroll
       for (int d = 0; d < NV; d++) { s.ua.f.qaccs[d] = x[d]; s.ua.f.qacc[d] = x[d]; }
-      s.solver_iter = 0;
     }
     if (dbg && lane == 0) {
 #pragma unroll
       for (int d = 0; d < NV; d++) dbg->out[34 * 34 + 34 + d] = (double)x[d];
     }
+    dmw::sync();
   }
-  dmw::sync();
   DM_STAMP(8)
   if (nefc == 0) return;
 
   // ---- this lane's row: Jacobian from the contact wrench, reference acceleration, warm-start force -----------------
   const int info = active ? s.rowi[lane] : 0;
   const int type = info & 0xff;
-  R w[6] = {0, 0, 0, 0, 0, 0};
   int ldof = -1;
   R lsgn = 0;
   R Rr = 1, aref = 0, bb = 0, f = 0, pos = 0, margin = 0;
   R AR[ROWS];
   R diag = 1;
+  R y[NV];     // stays live through the PGS sweeps: the final assembly needs f_r Y_r
   {
-    R y[NV];
+    R w[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long mplus = 0, mminus = 0;
     R dA = 0, rscale = 1;
     if (active) {
@@ -1021,13 +1057,13 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     RowAcc<R> ra;
     for (int r = 0; r < 6; r++) ra.w[r] = w[r];
     ra.plus_lo = (unsigned)mplus; ra.plus_hi = (unsigned)(mplus >> 32); ra.minus_lo = (unsigned)mminus; ra.minus_hi = (unsigned)(mminus >> 32);
-    ra.ldof = ldof; ra.lsgn = lsgn; ra.vel = 0; ra.jsm = 0; ra.jws = 0;
+    ra.ldof = ldof; ra.lsgn = lsgn; ra.vel = 0; ra.jws = 0; ra.is_tau = taul;
     {
       R cur[9];
       load_dof_operands<0>(cur, s, dmw::pin_zero());
       RowStep<0, R>::run(y, ra, s, cur);
     }
-    const R vel = ra.vel, jsm = ra.jsm, jws = ra.jws;
+    const R vel = ra.vel, jws = ra.jws;
     if (dbg && active) {
       double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + lane * (34 + 6);
 #pragma unroll
@@ -1038,14 +1074,21 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     Rr = fmax(R(DM_MINVAL), (1 - imp) * dA / imp);
     if (rscale != R(1)) Rr = fmax(R(DM_MINVAL), rscale * Rr);
     aref = -M.B * vel - M.K * imp * (pos - margin);
-    bb = active ? jsm - aref : R(0);
     const R jar = jws - aref;
     f = (active && jar < 0) ? -jar / Rr : R(0);
-    // half solve: y <- D^-1/2 L^-T J^T, so that A = Y Y^T
+    // half solve: y <- D^-1/2 L^-T y  (rows: J^T -> Y;  TAU_LANE: tau -> z)
     solve_LT(y, s.qLD);
 #pragma unroll
     for (int d = 0; d < NV; d++) y[d] *= s.dsq[d];
     DM_STAMP(10)
+    // z goes to the extra slot of the broadcast buffer (it aliases the row descriptors, which every lane has read by now)
+    dmw::sync();
+    if (taul) {
+#pragma unroll
+      for (int d = 0; d < NV; d++) s.u.ybuf[16][d] = y[d];
+    }
+    dmw::sync();
+    bb = active ? row_dot(y, s.u.ybuf[16]) - aref : R(0);     // b = J qacc_smooth - aref
     // overflow tier first (while AR is not live yet): columns ROWS.. of A do not fit the register budget of this
     // instantiation; they go to a per-env global-memory strip [col][lane] that only this lane ever reads back
     // (rare: < 1% of evaluations).
@@ -1088,31 +1131,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
         const int i = c * 16 + ii;
         if (i >= ROWS) continue;
         R acc = 0;
-        if (i < nefc) {
-          // dot(Y_lane, Y_i) in chunks of 6 entries read at a wave-uniform LDS address, double-buffered: the next chunk
-          // is loaded while the current one is multiplied
-          R qa[6], qb[6];
-          { const int zc = dmw::pin_zero();
-#pragma unroll
-            for (int d = 0; d < 6; d++) qa[d] = s.u.ybuf[ii][d + zc]; }
-#pragma unroll
-          for (int c0 = 0; c0 < NV; c0 += 12) {
-            { const int zc = dmw::pin_zero();
-#pragma unroll
-              for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) qb[d] = s.u.ybuf[ii][c0 + 6 + d + zc]; }
-            dmw::sched_fence();
-#pragma unroll
-            for (int d = 0; d < 6; d++) if (c0 + d < NV) acc += y[c0 + d] * qa[d];
-            dmw::pin_value(acc);
-            { const int zc = dmw::pin_zero();
-#pragma unroll
-              for (int d = 0; d < 6; d++) if (c0 + 12 + d < NV) qa[d] = s.u.ybuf[ii][c0 + 12 + d + zc]; }
-            dmw::sched_fence();
-#pragma unroll
-            for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) acc += y[c0 + 6 + d] * qb[d];
-            dmw::pin_value(acc);
-          }
-        }
+        if (i < nefc) acc = row_dot(y, s.u.ybuf[ii]);
         if (lane == i) { acc += Rr; diag = acc; }
         AR[i] = acc;
       }
@@ -1164,6 +1183,8 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     // from exactly the operands the row-by-row form would have used.
     const R f0 = f, res0 = res;
     R rsave = res;
+    long long ps0 = 0, ps1 = 0;
+    if (PROF) ps0 = dmw::clk();
 #pragma unroll
     for (int blk = 0; blk < ROWS / 8; blk++) {
       if (blk * 8 < ne) {          // scalar branch per block of 8 rows; rows past nefc cost one scalar compare each
@@ -1186,6 +1207,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       if (ln == i) rsave = res;
       res += a * di;
     }
+    if (PROF) { ps1 = dmw::clk(); prof[14] += ps1 - ps0; }
     bool bad = false;
     if (ln < ne) {
       const R fn = pgs_candidate(f0, rsave, dinvr);
@@ -1214,57 +1236,42 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     }
     const R improvement = dmw::wave_sum(active ? myimp : R(0)) * pgs_scale;
     iter++;
-    if (dmw::uniform(improvement < pgs_tol)) break;
+    const bool converged = dmw::uniform(improvement < pgs_tol);
+    if (PROF) prof[15] += dmw::clk() - ps1;
+    if (converged) break;
   }
   DM_STAMP(12)
   if (dbg && active) {
     double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + lane * (34 + 6) + 34;
     o[0] = (double)pos; o[1] = (double)margin; o[2] = (double)Rr; o[3] = (double)aref; o[4] = (double)bb; o[5] = (double)f;
   }
-  // ---- qfrc_constraint = J^T f, assembled as body wrenches like the RNE backward pass; qacc = qacc_smooth + M^-1 (.) --
-  dmw::sync();
-  if (lane < NV) s.ua.f.tau[lane] = 0;          // tau is dead: reuse it for qfrc_constraint
-  dmw::sync();
-  {
+  // ---- qacc = L^-1 D^-1/2 (z + sum_r f_r Y_r): the scaled rows are summed through the broadcast buffer, 16 at a time
+  // (lane d < NV owns component d; idle lanes carry f = 0 and add nothing), z is still in its slot ------------------
+  R wsum = 0;
+  for (int c = 0; c * 16 < nefc; c++) {
+    dmw::sync();
+    if ((lane >> 4) == c) {
 #pragma unroll
-    for (int r = 0; r < 6; r++) s.u.c.rowf[lane][r] = f * w[r];      // zero for limit rows and idle lanes
-    if (active && type == ROW_LIMIT) s.ua.f.tau[ldof] = lsgn * f;    // at most one limit row per hinge: no conflict
-  }
-  dmw::sync();
-  if (lane < NB - 1) {
-    const int b = lane + 1;
-    R g[6] = {0, 0, 0, 0, 0, 0};
-    for (int r = 0; r < nefc; r++) {
-      const int inf = s.rowi[r];
-      if ((inf & 0xff) == ROW_CONTACT) {
-        const int b1 = (inf >> 8) & 0xff, b2 = (inf >> 16) & 0xff;
-        const R sg = (b2 == b ? R(1) : R(0)) - (b1 == b ? R(1) : R(0));
-        if (sg != R(0)) for (int k = 0; k < 6; k++) g[k] += sg * s.u.c.rowf[r][k];
-      }
+      for (int d = 0; d < NV; d++) s.u.ybuf[lane & 15][d] = f * y[d];
     }
-    for (int k = 0; k < 6; k++) s.u.c.G[b][k] = g[k];
+    dmw::sync();
+    if (lane < NV) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) wsum += s.u.ybuf[k][lane];
+    }
   }
-  dmw::sync();
-  if (lane < NB - 1) {
-    const int b = lane + 1;
-    R acc[6] = {0, 0, 0, 0, 0, 0};
-    const unsigned msk = TOPO.subtree[b];
-    for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int k = 0; k < 6; k++) acc[k] += s.u.c.G[c][k];
-    for (int k = 0; k < 6; k++) s.u.c.Gsub[b][k] = acc[k];
-  }
-  dmw::sync();
-  if (lane < NV) s.ua.f.tau[lane] += dot6(s.cdof[lane], s.u.c.Gsub[TOPO.dof_body[lane]]);
+  if (lane < NV) s.ua.f.tau[lane] = (wsum + s.u.ybuf[16][lane]) * s.dsq[lane];     // tau is dead: reuse it as the solve's right-hand side
   dmw::sync();
   {
     R x[NV];
 #pragma unroll
     for (int d = 0; d < NV; d++) x[d] = s.ua.f.tau[d];
-    uniform_solve(s, x);
+    solve_L(x, s.qLD);
     dmw::sync();
     if (lane == 0) {
       s.solver_iter = iter;
 #pragma unroll
-      for (int d = 0; d < NV; d++) s.ua.f.qacc[d] = s.ua.f.qaccs[d] + x[d];
+      for (int d = 0; d < NV; d++) s.ua.f.qacc[d] = x[d];
     }
   }
   dmw::sync();

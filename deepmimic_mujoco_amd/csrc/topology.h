@@ -10,7 +10,8 @@
 namespace dmt {
 
 constexpr int NB = 14, NV = 34, NQ = 35, NJ = 29, NG = 16, NU = 28, NOBS = 56;
-constexpr int MAXPAIR = 128, MAXEFC = 64;   // one constraint row per lane
+constexpr int MAXPAIR = 128, MAXEFC = 64;   // one lane per constraint row ...
+constexpr int MAXROWS = 63, TAU_LANE = 63;  // ... except the last, which carries the smooth force through the rows' half solve
 constexpr int AOVF_COLS = MAXEFC;     // per-env memory strip for columns of A: [AOVF_COLS][64] (overflow columns; all columns during a PGS replay)
 constexpr int MAXDEPTH_BODY = 4;
 

@@ -33,7 +33,9 @@ extern "C" {
 #define DM_NGEOM 16
 #define DM_NOBS 56
 #define DM_MAXPAIR 128
-#define DM_MAXEFC 64   /* constraint rows per environment held on chip; overflow is reported, not silent */
+#define DM_MAXEFC 64   /* lanes of the per-env wavefront = stride of the per-row arrays */
+#define DM_MAXROWS 63  /* constraint rows per environment held on chip (one lane each; the 64th lane carries the smooth force);
+                          overflow is reported (DM_F_STATUS bit 0), not silent */
 
 enum { DM_OK = 0, DM_EINVAL = -1, DM_EHIP = -2, DM_ENOMEM = -3, DM_EUNSUPPORTED = -4, DM_ENODEVICE = -5 };
 enum { DM_PTR_HOST = 0, DM_PTR_DEVICE = 1 };
@@ -143,7 +145,7 @@ enum {
   DM_F_NCON = 9,        /* int32 [N] contacts of the last forward evaluation */
   DM_F_NEFC = 10,       /* int32 [N] constraint rows */
   DM_F_CONTACT_GEOMS = 11, /* int32 [N,DM_MAXEFC,2] (geom1, geom2) per contact, -1 padded */
-  DM_F_STATUS = 12,     /* int32 [N] bit0: constraint rows overflowed DM_MAXEFC, bit1: non-finite state */
+  DM_F_STATUS = 12,     /* int32 [N] bit0: constraint rows overflowed DM_MAXROWS, bit1: non-finite state */
   DM_F_SOLVER_ITER = 13,/* int32 [N] PGS sweeps of the last forward evaluation */
   DM_F_CTRL = 14,       /* double [N,28] last (unclamped) ctrl */
   DM_F_EPISODE = 15     /* int32 [N] episode counter used by the reset RNG */

@@ -53,7 +53,7 @@ def varied_states(n, seed=0, clip="walk"):
     return idx, q, v, ws, ctrl
 
 
-def oracle_model(max_efc=64, **opts):
+def oracle_model(max_efc=63, **opts):
     from oracle import oracle as O
     om = O.Model()
     om.set("max_efc", max_efc)
