@@ -24,6 +24,13 @@
 #include "topology.h"
 #include "wave.h"
 
+// assembly-listing marker (a comment in the .s output, no instruction): tools/isa_stage_count.py splits the listing on these
+#if defined(DM_WAVE_TESTBENCH)
+#define DM_MARK(name) ((void)0)
+#else
+#define DM_MARK(name) asm volatile("; DM_MARK " name)
+#endif
+
 namespace dm {
 
 using namespace dmt;
@@ -54,6 +61,7 @@ struct DevModel {
   R qpos0[NQ];
   R timestep, gravity[3], tolerance, solref[2], solimp[5], meaninertia, total_mass;
   R K, B, pgs_scale;  // constraint stiffness / damping (refsafe applied), 1/(meaninertia*nv)
+  R imp_rlo, imp_rhi; // 1 / midpoint^(power-1), 1 / (1-midpoint)^(power-1) of solimp (impedance, power == 2 fast path)
   R pgs_detect;       // cost-increase level that sends a PGS sweep to the guarded replay (1e-10 = [MJ costChange]; tests lower it)
   int iterations, enable_contact, enable_limit;
 };
@@ -902,14 +910,18 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
 }
 
 // [MJ getimpedance]
+// The model's solimp power is a per-model constant: for the default (2) the two pow() calls (a few hundred instructions
+// each, evaluated by every lane) reduce to a square, and the constant denominators are reciprocals prepared on the host.
 template <class R>
-DM_DEV R impedance(const R* si, R x) {
+DM_DEV R impedance(const DevModel<R>& M, R x) {
+  const R* si = M.solimp;
   if (si[0] == si[1] || si[2] <= R(DM_MINVAL)) return R(0.5) * (si[0] + si[1]);
   x = fabs(x / si[2]);
   if (x >= 1) return si[1];
   if (x <= 0) return si[0];
   R y;
   if (si[4] == R(1)) y = x;
+  else if (si[4] == R(2)) y = (x <= si[3]) ? (x * x) * M.imp_rlo : 1 - ((1 - x) * (1 - x)) * M.imp_rhi;
   else if (x <= si[3]) y = pow(x, si[4]) / pow(si[3], si[4] - 1);
   else y = 1 - pow(1 - x, si[4]) / pow(1 - si[3], si[4] - 1);
   return si[0] + y * (si[1] - si[0]);
@@ -1002,7 +1014,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   const int lane = dmw::launder(lane_in);
   long long pt0 = 0, pt1 = 0;
   if (PROF) pt0 = dmw::clk();
-#define DM_STAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
+#define DM_STAMP(k) DM_MARK("constraint_" #k); if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
   const int nefc = dmw::uniform(s.nefc);   // in an SGPR so that the row loops branch scalar
   const bool active = lane < nefc;
   const bool taul = lane == TAU_LANE;
@@ -1070,7 +1082,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       for (int d = 0; d < NV; d++) o[d] = (double)y[d];
     }
     DM_STAMP(9)
-    const R imp = impedance(M.solimp, pos - margin);
+    const R imp = impedance(M, pos - margin);
     Rr = fmax(R(DM_MINVAL), (1 - imp) * dA / imp);
     if (rscale != R(1)) Rr = fmax(R(DM_MINVAL), rscale * Rr);
     aref = -M.B * vel - M.K * imp * (pos - margin);
@@ -1141,13 +1153,15 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   DM_STAMP(11)
   // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ------------------------------------
   R res = bb;  // residual r_j = b_j + sum_i A_ji f_i, maintained incrementally
+  // (rows are taken in unguarded groups: a scalar branch costs as much as ~4 rows of work, and a row slot past nefc is
+  //  harmless — its lane is idle with f = 0, and its column of A is zero)
 #pragma unroll
-  for (int blk = 0; blk < ROWS / 8; blk++) {
+  for (int blk = 0; blk < (ROWS + 7) / 8; blk++) {
     if (blk * 8 < nefc) {
 #pragma unroll
       for (int ii = 0; ii < 8; ii++) {
         const int i = blk * 8 + ii;
-        if (i < nefc) res += AR[i] * dmw::bcast(f, i);
+        if (i < ROWS && i < MAXROWS) res += AR[i] * dmw::bcast(f, i);
       }
     }
   }
@@ -1186,12 +1200,12 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     long long ps0 = 0, ps1 = 0;
     if (PROF) ps0 = dmw::clk();
 #pragma unroll
-    for (int blk = 0; blk < ROWS / 8; blk++) {
-      if (blk * 8 < ne) {          // scalar branch per block of 8 rows; rows past nefc cost one scalar compare each
+    for (int grp = 0; grp < (ROWS + 3) / 4; grp++) {
+      if (grp * 4 < ne) {          // one scalar branch per group of 4 rows; a slot past nefc computes delta = 0 (idle lane)
 #pragma unroll
-        for (int ii = 0; ii < 8; ii++) {
-          const int i = blk * 8 + ii;
-          if (i < ne) {
+        for (int ii = 0; ii < 4; ii++) {
+          const int i = grp * 4 + ii;
+          if (i < ROWS && i < MAXROWS) {
             const R delta = pgs_candidate(f0, res, dinvr) - f0;      // every lane evaluates its own; only lane i's is used
             const R di = dmw::bcast(delta, i);
             if (ln == i) rsave = res;
@@ -1285,20 +1299,26 @@ template <class R, int ROWS = MAXEFC, bool PROF = false>
 DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt, const DebugOut* dbg, long long* prof = 0) {
   long long t0 = 0, t1 = 0;
   if (PROF) t0 = dmw::clk();
+  DM_MARK("kinematics");
   stage_kinematics(M, s, lane, lt);
   if (PROF) { t1 = dmw::clk(); prof[0] += t1 - t0; t0 = t1; }
   if (dbg) { for (int e = lane; e < NV * NV; e += 64) dbg->out[e] = 0; dmw::sync(); }
+  DM_MARK("mass_factor");
   stage_mass_matrix(M, s, lane, dbg);
   if (PROF) { t1 = dmw::clk(); prof[1] += t1 - t0; t0 = t1; }
+  DM_MARK("bias");
   stage_bias(M, s, lane, lt);
   if (PROF) { t1 = dmw::clk(); prof[2] += t1 - t0; t0 = t1; }
   if (dbg && lane < NV) {
     const double bias = (double)(-M.dof_damping[lane] * s.qvel[lane] + s.act[lane] - s.ua.f.tau[lane]);
     dbg->out[34 * 34 + lane] = bias;
   }
+  DM_MARK("rows");
   stage_rows<R, ROWS>(M, s, lane);
   if (PROF) { t1 = dmw::clk(); prof[3] += t1 - t0; t0 = t1; }
+  DM_MARK("constraint");
   stage_constraint<R, ROWS, PROF>(M, s, lane, dbg, prof);
+  DM_MARK("forward_end");
   if (PROF) { t1 = dmw::clk(); prof[4] += t1 - t0; t0 = t1; }
   if (dbg) {
     if (lane < NV) dbg->out[34 * 34 + 68 + lane] = (double)s.ua.f.qacc[lane];

@@ -90,6 +90,7 @@ inline int build_dev_model(const dm_model_desc* d, DevModel<double>* hp, std::st
   h.B = 2 / std::fmax(DM_MINVAL, dmax * tc);
   h.pgs_scale = 1 / (d->meaninertia * (NV > 1 ? NV : 1));
   h.pgs_detect = 1e-10;
+  h.imp_rlo = 1.0 / std::pow(d->solimp[3], d->solimp[4] - 1); h.imp_rhi = 1.0 / std::pow(1 - d->solimp[3], d->solimp[4] - 1);
   h.enable_contact = 1; h.enable_limit = 1;
   return DM_OK;
 }

@@ -8,7 +8,8 @@ __device__ inline double bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 template <int MODE>
-__global__ __launch_bounds__(64) void k(double* out, long long* cyc, double dinvr, double a, int reps) {
+__global__ __launch_bounds__(64) void k(double* out, long long* cyc, double dinvr, double a, int reps, int ne_in = 32) {
+  const int ne = __builtin_amdgcn_readfirstlane(ne_in);
   double res = threadIdx.x * 1e-3, f0 = 0.5, acc = 0;
   long long t0 = __builtin_readcyclecounter();
   for (int r = 0; r < reps; r++) {
@@ -19,6 +20,7 @@ __global__ __launch_bounds__(64) void k(double* out, long long* cyc, double dinv
       if (MODE == 2) { double d = fmax(fma(-dinvr, res, f0), 0.0) - f0; res = fma(a, d, res); }   // fma max add fma
       if (MODE == 3) { double d = fmax(fma(-dinvr, res, f0), 0.0) - f0; double di = bcast(d, i); res = fma(a, di, res); }  // + readlane
       if (MODE == 4) { double d = fmax(fma(-dinvr, res, f0), 0.0) - f0; double di = bcast(d, i); if (threadIdx.x == i) acc = res; res = fma(a, di, res); }
+      if (MODE == 8) { if (i < ne) { double d = fmax(fma(-dinvr, res, f0), 0.0) - f0; double di = bcast(d, i); if (threadIdx.x == i) acc = res; res = fma(a, di, res); } }
       if (MODE == 5) { float x = (float)res; x = fmaf(x, 0.5f, 1.0f); res = x; }      // cvt chain (reference point)
       if (MODE == 6) { res = res * dinvr; }                                            // mul
       if (MODE == 7) { res = res + dinvr; }                                            // add
@@ -47,6 +49,11 @@ int main() {
       double s = 0; for (auto v : h) s += v;
       printf("blocks %5d  %-28s %8.1f cycles per row-iteration\n", blocks, names[m], s / blocks / (reps * 32.0));
     }
+  }
+  for (int ne : {32, 6}) {
+    for (int rep = 0; rep < 2; rep++) { k<8><<<1, 64>>>(out, cyc, 0.3, 0.1, reps, ne); hipDeviceSynchronize(); }
+    long long t; hipMemcpy(&t, cyc, 8, hipMemcpyDeviceToHost);
+    printf("per-row scalar guard, ne=%d: %.1f cycles per executed row (%.1f per sweep of 32 slots)\n", ne, (double)t / (reps * (double)ne), (double)t / reps);
   }
   {  // calibrate the s_memtime tick against wall time
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
