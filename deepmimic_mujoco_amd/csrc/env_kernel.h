@@ -1007,6 +1007,58 @@ DM_DEV R row_dot(const R* y, const R* q) {
 // PGS candidate force of one row: f' = max(f - r / A_ii, 0)   [MJ mj_solPGS, scalar row]
 template <class R> DM_DEV R pgs_candidate(R f, R res, R dinvr) { return fmax(f - res * dinvr, R(0)); }
 
+// ---- nested unrolling over constraint rows --------------------------------------------------------------------------
+// nefc is small and wave-uniform, ROWS is the compile-time capacity.  A flat unrolled loop with one scalar test per row
+// slot pays ~35 cycles for EVERY slot, taken or not; nesting the tests (slot I+1 is only reached through slot I) makes
+// the cost proportional to nefc: one untaken branch per live slot and a single exit.
+template <int I, int ROWS, class R>
+struct ACol {        // column I of A = Y Y^T + diag(R); precondition: I < nefc
+  static DM_DEV void run(R* AR, const R* y, Shared<R>& s, int lane, int nefc, R Rr, R& diag) {
+    if constexpr (I < ROWS) {
+      if constexpr (I % 16 == 0) {          // stage rows I .. I+15 of Y in the broadcast buffer
+        dmw::sync();
+        if ((lane >> 4) == I / 16) {
+#pragma unroll
+          for (int d = 0; d < NV; d++) s.u.ybuf[lane & 15][d] = y[d];
+        }
+        dmw::sync();
+      }
+      R acc = row_dot(y, s.u.ybuf[I % 16]);
+      if (lane == I) { acc += Rr; diag = acc; }
+      AR[I] = acc;
+      if (I + 1 < nefc) ACol<I + 1, ROWS, R>::run(AR, y, s, lane, nefc, Rr, diag);
+    }
+  }
+};
+template <int B, int ROWS, class R>
+struct WarmBlock {   // res += A[:, 8B .. 8B+7] f   (slots past nefc: f = 0 and a zero column)
+  static DM_DEV void run(const R* AR, R& res, R f, int nefc) {
+    if constexpr (B * 8 < ROWS) {
+#pragma unroll
+      for (int ii = 0; ii < 8; ii++) { const int i = B * 8 + ii; if (i < ROWS && i < MAXROWS) res += AR[i] * dmw::bcast(f, i); }
+      if ((B + 1) * 8 < nefc) WarmBlock<B + 1, ROWS, R>::run(AR, res, f, nefc);
+    }
+  }
+};
+template <int G, int ROWS, class R>
+struct SweepGroup {  // PGS rows 4G .. 4G+3 (a slot past nefc computes delta = 0: idle lane, zero column)
+  static DM_DEV void run(const R* AR, R& res, R& rsave, R f0, R dinvr, int ln, int ne) {
+    if constexpr (G * 4 < ROWS) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ii++) {
+        const int i = G * 4 + ii;
+        if (i < ROWS && i < MAXROWS) {
+          const R delta = pgs_candidate(f0, res, dinvr) - f0;      // every lane evaluates its own; only lane i's is used
+          const R di = dmw::bcast(delta, i);
+          if (ln == i) rsave = res;
+          res += AR[i] * di;
+        }
+      }
+      if ((G + 1) * 4 < ne) SweepGroup<G + 1, ROWS, R>::run(AR, res, rsave, f0, dinvr, ln, ne);
+    }
+  }
+};
+
 // constraint solve.  Lane r < nefc owns constraint row r (limits first, then contacts in list order).
 //   [MJ mj_fwdAcceleration, mj_projectConstraint, mj_fwdConstraint (warmstart, mj_solPGS)]
 template <class R, int ROWS, bool PROF = false>
@@ -1125,29 +1177,11 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       }
     }
     // ---- A = Y Y^T + diag(R): rows of Y broadcast through LDS, 16 at a time ---------------------------------
-    // (every AR[i] is defined exactly here — no early zero-initialisation that would keep the array live during the
-    //  row build and the half solve)
+    // columns past nefc are exact zeros (the row groups of the sweeps may touch them); zeroed here, not earlier, so that
+    // the array is not live during the row build and the half solve
 #pragma unroll
-    for (int c = 0; c < (ROWS + 15) / 16; c++) {
-      const bool chunk_live = c * 16 < nefc;
-      if (chunk_live) {
-        dmw::sync();
-        if ((lane >> 4) == c) {
-#pragma unroll
-          for (int d = 0; d < NV; d++) s.u.ybuf[lane & 15][d] = y[d];
-        }
-        dmw::sync();
-      }
-#pragma unroll
-      for (int ii = 0; ii < 16; ii++) {
-        const int i = c * 16 + ii;
-        if (i >= ROWS) continue;
-        R acc = 0;
-        if (i < nefc) acc = row_dot(y, s.u.ybuf[ii]);
-        if (lane == i) { acc += Rr; diag = acc; }
-        AR[i] = acc;
-      }
-    }
+    for (int i = 0; i < ROWS; i++) AR[i] = 0;
+    ACol<0, ROWS, R>::run(AR, y, s, lane, nefc, Rr, diag);              // nefc > 0 here
   }
   const R dinvr = R(1) / diag;
   DM_STAMP(11)
@@ -1155,16 +1189,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   R res = bb;  // residual r_j = b_j + sum_i A_ji f_i, maintained incrementally
   // (rows are taken in unguarded groups: a scalar branch costs as much as ~4 rows of work, and a row slot past nefc is
   //  harmless — its lane is idle with f = 0, and its column of A is zero)
-#pragma unroll
-  for (int blk = 0; blk < (ROWS + 7) / 8; blk++) {
-    if (blk * 8 < nefc) {
-#pragma unroll
-      for (int ii = 0; ii < 8; ii++) {
-        const int i = blk * 8 + ii;
-        if (i < ROWS && i < MAXROWS) res += AR[i] * dmw::bcast(f, i);
-      }
-    }
-  }
+  WarmBlock<0, ROWS, R>::run(AR, res, f, nefc);
   if (ROWS < MAXEFC && nefc > ROWS) {
     const R* const aov = (&s.aovf)[dmw::pin_zero()];
     for (int i = ROWS; i < nefc; i++) res += aov[i * 64 + lane] * dmw::bcast(f, i);
@@ -1199,21 +1224,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     R rsave = res;
     long long ps0 = 0, ps1 = 0;
     if (PROF) ps0 = dmw::clk();
-#pragma unroll
-    for (int grp = 0; grp < (ROWS + 3) / 4; grp++) {
-      if (grp * 4 < ne) {          // one scalar branch per group of 4 rows; a slot past nefc computes delta = 0 (idle lane)
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) {
-          const int i = grp * 4 + ii;
-          if (i < ROWS && i < MAXROWS) {
-            const R delta = pgs_candidate(f0, res, dinvr) - f0;      // every lane evaluates its own; only lane i's is used
-            const R di = dmw::bcast(delta, i);
-            if (ln == i) rsave = res;
-            res += AR[i] * di;
-          }
-        }
-      }
-    }
+    SweepGroup<0, ROWS, R>::run(AR, res, rsave, f0, dinvr, ln, ne);
     if (ROWS < MAXEFC && ne > ROWS) for (int i = ROWS; i < ne; i++) {      // overflow rows: same update, column of A from memory
       const R a = ((const R*)(&s.aovf)[dmw::pin_zero()])[i * 64 + ln];
       const R delta = pgs_candidate(f0, res, dinvr) - f0;
