@@ -193,11 +193,19 @@ def main():
                        "mean_nefc": round(float(nefc.mean()), 2), "overflow_envs": int((status & 1).sum())},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "k_step", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
+                         "kernel": "k_step_narrow", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                          "note": "latency/ALU-bound path: see fp64 fraction",
                          "fp64_est_tflops": round(ALGO_FLOP_PER_STEP * n / (kernel_ms * 1e-3) / 1e12, 3),
                          "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS},
         }
+        tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if full and os.path.exists(tp):   # PMC HBM bytes per launch of this kernel/workload, measured by tools/collect_profile.sh (separate rocprofv3 passes)
+            try:
+                tj = json.load(open(tp))
+                out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not re-measured in this run)"
+            except Exception:
+                pass
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.clip)
