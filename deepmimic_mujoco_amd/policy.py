@@ -89,7 +89,7 @@ class MlpPolicy:
 
     # ---- weights ----------------------------------------------------------------------------------------------------
     def state_dict(self):
-        d = {k: v.detach().cpu().numpy() for k, v in self.params.items()}
+        d = {k: v.detach().cpu().numpy().copy() for k, v in self.params.items()}
         d["obfilter/runningsum"] = self.ob_rms.sum.cpu().numpy()
         d["obfilter/runningsumsq"] = self.ob_rms.sumsq.cpu().numpy()
         d["obfilter/count"] = self.ob_rms.count.cpu().numpy()
@@ -100,7 +100,8 @@ class MlpPolicy:
             v = np.asarray(d[k])
             if tuple(v.shape) != tuple(self.params[k].shape):
                 raise ValueError("%s: shape %s != %s" % (k, v.shape, tuple(self.params[k].shape)))
-            self.params[k] = torch.as_tensor(v, dtype=torch.float32).to(self.device).contiguous()
+            rg = self.params[k].requires_grad
+            self.params[k] = torch.as_tensor(v, dtype=torch.float32).to(self.device).contiguous().clone().requires_grad_(rg)
         self.ob_rms.sum = torch.as_tensor(np.asarray(d["obfilter/runningsum"]), dtype=torch.float64).to(self.device)
         self.ob_rms.sumsq = torch.as_tensor(np.asarray(d["obfilter/runningsumsq"]), dtype=torch.float64).to(self.device)
         self.ob_rms.count = torch.as_tensor(np.asarray(d["obfilter/count"]), dtype=torch.float64).to(self.device)
@@ -178,4 +179,4 @@ class MlpPolicy:
         return 0.5 * (z * z).sum(-1) + 0.5 * math.log(2.0 * math.pi) * self.ac_dim + logstd.sum(-1)
 
     def entropy(self):
-        return float((self.params["logstd"] + 0.5 * math.log(2.0 * math.pi * math.e)).sum())
+        return float((self.params["logstd"].detach() + 0.5 * math.log(2.0 * math.pi * math.e)).sum())

@@ -108,10 +108,11 @@ def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first
     env.reset(first_reset, out=as_buf(ob64[0]))                           # trpo.py:32 `ob = env.reset()` (RSI); later episodes: noisy init
     step_idx = torch.arange(1, T + 1, device=device, dtype=torch.int64)[:, None]
     while True:
-        for t in range(T):
-            pi.act(stochastic, ob64[t], out=ac64[t], vpred_out=vpreds[t])                       # :49
-            env.batch.step(as_buf(ac64[t]), 1, (as_buf(ob64[t + 1]), as_buf(rew64[t]), as_buf(done8[t])))   # :66, one launch
-        vpreds[T] = pi.forward(ob64[T])[1]                                 # value of the observation after the segment (:49-52);
+        with torch.no_grad():                                              # (the learner may hold the parameters with requires_grad)
+            for t in range(T):
+                pi.act(stochastic, ob64[t], out=ac64[t], vpred_out=vpreds[t])                       # :49
+                env.batch.step(as_buf(ac64[t]), 1, (as_buf(ob64[t + 1]), as_buf(rew64[t]), as_buf(done8[t])))   # :66, one launch
+            vpreds[T] = pi.forward(ob64[T])[1]                             # value of the observation after the segment (:49-52);
         # the action for it is sampled at the top of the next segment, i.e. from the policy as updated in between
         done = done8.to(torch.bool)
         new = torch.cat([first[None], done8[:-1].to(torch.int32)], 0)

@@ -1,0 +1,326 @@
+"""TRPO learner of the reference (`src/trpo.py:97-319`, hyper-parameters of `train()` `:338-353`) on PyTorch-ROCm, fed by the
+device-resident rollouts of `rollout.traj_segment_generator`.
+
+Same algorithm, line for line in meaning, at batched scale:
+
+    seg      = next(seg_gen);  add_vtarg_and_adv(seg, gamma, lam)                         (:235-236)
+    atarg    = (adv - mean) / std                 [per rank, like the reference]           (:240)
+    ob_rms.update(ob)                             [all-reduced moments]                    (:242)
+    old      = pi                                                                          (:247 assign_old_eq_new)
+    losses, g = surrogate + ent bonus, flat gradient w.r.t. pol* + logstd; all-mean        (:249-251)
+    stepdir  = CG(F + damping I, g, 10 iterations), F v = Hessian-vector product of mean KL(old || pi) on every 5th sample,
+               all-mean per product                                                        (:229, :245, :256; src/cg.py:2-34)
+    fullstep = stepdir / sqrt(0.5 stepdir . F stepdir / max_kl);  backtracking line search: <= 10 halvings until
+               KL <= 1.5 max_kl and the surrogate improved                                 (:258-283)
+    value fn : vf_iters epochs of Adam over shuffled minibatches on (vpred - tdlamret)^2, gradients all-mean'd,
+               the MpiAdam update rule of src/mpi_adam.py:21-35; ob_rms updated per minibatch (:288-296)
+
+What replaces what: TF1 graph functions -> torch autograd (flat gradient, double back-prop for F v); `MPI.Allreduce` /
+`MpiAdam` -> `torch.distributed.all_reduce` (RCCL over xGMI with the "nccl" backend, gloo in the CPU tests); the host
+numpy batch of 256 samples -> the [T, N] device segment (T x N samples per rank; nothing leaves the GPU except the scalars
+that are logged).  The value-function minibatch size is a parameter: the reference's 128 is kept as default, batched runs
+use a few thousand (a 1M-sample segment at 128 would be 8 000 sequential Adam steps per epoch).
+"""
+import math
+import time
+from collections import deque
+
+import torch
+
+from .rollout import add_vtarg_and_adv, flatten_segment, traj_segment_generator
+
+POL_KEYS = ("polfc1/w", "polfc1/b", "polfc2/w", "polfc2/b", "polfinal/w", "polfinal/b", "logstd")   # var_list   (:139)
+VF_KEYS = ("vffc1/w", "vffc1/b", "vffc2/w", "vffc2/b", "vffinal/w", "vffinal/b")                     # vf_var_list (:140)
+
+
+def _world(group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
+def allmean(x, group=None):
+    """`allmean` of src/trpo.py:175-180: element-wise mean over ranks (in place; identity for a single process)."""
+    import torch.distributed as dist
+    n = _world(group)
+    if n > 1:
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+        x /= n
+    return x
+
+
+def cg(f_Ax, b, cg_iters=10, residual_tol=1e-10):
+    """Conjugate gradient of src/cg.py:2-34 (Demmel p. 312) on a flat device vector."""
+    p = b.clone()
+    r = b.clone()
+    x = torch.zeros_like(b)
+    rdotr = r.dot(r)
+    for _ in range(cg_iters):
+        z = f_Ax(p)
+        v = rdotr / p.dot(z)
+        x += v * p
+        r -= v * z
+        newrdotr = r.dot(r)
+        mu = newrdotr / rdotr
+        p = r + mu * p
+        rdotr = newrdotr
+        if float(rdotr) < residual_tol:
+            break
+    return x
+
+
+def flat(tensors):
+    return torch.cat([t.reshape(-1) for t in tensors])
+
+
+def explained_variance(ypred, y):
+    """src/utils/math_util.py:25-38."""
+    vary = torch.var(y, unbiased=False)
+    return float("nan") if float(vary) == 0 else float(1 - torch.var(y - ypred, unbiased=False) / vary)
+
+
+class MpiAdam:
+    """src/mpi_adam.py:7-50 on device tensors: gradients are all-mean'd, then the bias-corrected Adam step."""
+
+    def __init__(self, params, beta1=0.9, beta2=0.999, epsilon=1e-8, group=None):
+        self.params = list(params)
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.beta1, self.beta2, self.epsilon, self.group = beta1, beta2, epsilon, group
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.t = 0
+
+    def getflat(self):
+        return flat([p.detach() for p in self.params])
+
+    def setfromflat(self, theta):
+        o = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                p.copy_(theta[o:o + n].reshape(p.shape))
+                o += n
+
+    def update(self, localg, stepsize):
+        if self.t % 100 == 0:
+            self.check_synced()
+        g = allmean(localg.to(torch.float32).clone(), self.group)
+        self.t += 1
+        a = stepsize * math.sqrt(1 - self.beta2 ** self.t) / (1 - self.beta1 ** self.t)
+        self.m.mul_(self.beta1).add_(g, alpha=1 - self.beta1)
+        self.v.mul_(self.beta2).addcmul_(g, g, value=1 - self.beta2)
+        step = (-a) * self.m / (torch.sqrt(self.v) + self.epsilon)
+        self.setfromflat(self.getflat() + step)
+
+    def sync(self):
+        import torch.distributed as dist
+        if _world(self.group) > 1:
+            theta = self.getflat().clone()
+            dist.broadcast(theta, src=0, group=self.group)
+            self.setfromflat(theta)
+
+    def check_synced(self):
+        import torch.distributed as dist
+        if _world(self.group) > 1:
+            theta = self.getflat().clone()
+            root = theta.clone()
+            dist.broadcast(root, src=0, group=self.group)
+            if not bool((root == theta).all()):
+                raise AssertionError("value-function parameters diverged across ranks")
+
+
+class TrpoLearner:
+    """One policy/value update per segment; the reference's `learn()` body between `seg_gen.__next__()` and the logging."""
+
+    def __init__(self, pi, *, max_kl=0.01, cg_iters=10, cg_damping=0.1, gamma=0.995, lam=0.97, entcoeff=0.0,
+                 vf_iters=3, vf_stepsize=1e-3, vf_batch_size=128, fvp_subsample=5, group=None, seed=0):
+        self.pi = pi
+        self.max_kl, self.cg_iters, self.cg_damping = max_kl, cg_iters, cg_damping
+        self.gamma, self.lam, self.entcoeff = gamma, lam, entcoeff
+        self.vf_iters, self.vf_stepsize, self.vf_batch_size = vf_iters, vf_stepsize, vf_batch_size
+        self.fvp_subsample = fvp_subsample
+        self.group = group
+        for k in POL_KEYS + VF_KEYS:
+            pi.params[k].requires_grad_(True)
+        self.pol = [pi.params[k] for k in POL_KEYS]
+        self.vf = [pi.params[k] for k in VF_KEYS]
+        self.vfadam = MpiAdam(self.vf, group=group)
+        self._perm_gen = torch.Generator(device=pi.device)
+        self._perm_gen.manual_seed(int(seed))
+        self.sync_from_root()
+
+    # ---- flat parameter access (U.GetFlat / U.SetFromFlat, :144-145) ----------------------------------------------------
+    def get_flat(self):
+        return flat([p.detach() for p in self.pol]).clone()
+
+    def set_from_flat(self, theta):
+        o = 0
+        with torch.no_grad():
+            for p in self.pol:
+                n = p.numel()
+                p.copy_(theta[o:o + n].reshape(p.shape))
+                o += n
+
+    def sync_from_root(self):
+        """:182-186 — rank 0's initial parameters everywhere."""
+        import torch.distributed as dist
+        if _world(self.group) > 1:
+            th = self.get_flat()
+            dist.broadcast(th, src=0, group=self.group)
+            self.set_from_flat(th)
+            self.vfadam.sync()
+
+    # ---- losses (:118-134) -------------------------------------------------------------------------------------------------
+    def _pd(self, ob):
+        mean, _ = self.pi.forward(ob)
+        return mean, self.pi.params["logstd"]
+
+    @staticmethod
+    def _kl(mean0, logstd0, mean1, logstd1):
+        """DiagGaussianPd.kl(self = 0, other = 1), src/distributions.py:235-237."""
+        return (logstd1 - logstd0 + (torch.exp(2 * logstd0) + (mean0 - mean1) ** 2) / (2.0 * torch.exp(2 * logstd1)) - 0.5).sum(-1)
+
+    @staticmethod
+    def _neglogp(x, mean, logstd):
+        return 0.5 * (((x - mean) / torch.exp(logstd)) ** 2).sum(-1) + 0.5 * math.log(2.0 * math.pi) * x.shape[-1] + logstd.sum(-1)
+
+    def _losses(self, ob, ac, atarg, old_mean, old_logstd):
+        mean, logstd = self._pd(ob)
+        meankl = self._kl(old_mean, old_logstd, mean, logstd).mean()
+        meanent = (logstd + 0.5 * math.log(2.0 * math.pi * math.e)).sum(-1).mean()
+        entbonus = self.entcoeff * meanent
+        ratio = torch.exp(self._neglogp(ac, old_mean, old_logstd) - self._neglogp(ac, mean, logstd))     # pnew / pold
+        surrgain = (ratio * atarg).mean()
+        optimgain = surrgain + entbonus
+        return optimgain, meankl, entbonus, surrgain, meanent
+
+    loss_names = ("optimgain", "meankl", "entloss", "surrgain", "entropy")
+
+    # ---- one update ----------------------------------------------------------------------------------------------------------
+    def update(self, seg):
+        pi = self.pi
+        add_vtarg_and_adv(seg, self.gamma, self.lam)
+        fl = flatten_segment(seg)
+        ob, ac, atarg, tdlamret, vpredbefore = fl["ob"], fl["ac"], fl["adv"], fl["tdlamret"], fl["vpred"]
+        atarg = (atarg - atarg.mean()) / atarg.std(unbiased=False)          # :240
+        pi.ob_rms.update(ob, group=self.group)                              # :242
+        with torch.no_grad():                                               # :247 oldpi <- pi
+            old_mean, _ = pi.forward(ob)
+            old_logstd = pi.params["logstd"].detach().clone()
+        sub = slice(None, None, self.fvp_subsample)                         # :245 fvpargs = [arr[::5] ...]
+        ob_f, om_f = ob[sub], old_mean[sub]
+
+        losses = self._losses(ob, ac, atarg, old_mean, old_logstd)
+        g = flat(torch.autograd.grad(losses[0], self.pol))
+        lossbefore = allmean(torch.stack([l.detach() for l in losses]), self.group)
+        g = allmean(g, self.group)
+        stats = {}
+        if bool(torch.allclose(g, torch.zeros_like(g))):
+            stats["note"] = "zero gradient, not updating"
+            meanlosses = lossbefore
+        else:
+            # Fisher-vector products: gradient of (grad KL . v), the KL graph is built once and re-used by every product
+            mean_f, logstd_f = self._pd(ob_f)
+            kl_f = self._kl(om_f, old_logstd, mean_f, logstd_f).mean()
+            klgrads = flat(torch.autograd.grad(kl_f, self.pol, create_graph=True))
+
+            def fisher_vector_product(p):
+                hv = flat(torch.autograd.grad(klgrads.dot(p), self.pol, retain_graph=True))
+                return allmean(hv, self.group) + self.cg_damping * p        # :229
+
+            stepdir = cg(fisher_vector_product, g, cg_iters=self.cg_iters)
+            assert bool(torch.isfinite(stepdir).all())
+            shs = 0.5 * stepdir.dot(fisher_vector_product(stepdir))
+            lm = torch.sqrt(shs / self.max_kl)
+            fullstep = stepdir / lm
+            expectedimprove = float(g.dot(fullstep))
+            del klgrads
+            surrbefore = float(lossbefore[0])
+            stepsize = 1.0
+            thbefore = self.get_flat()
+            ok = False
+            for _ in range(10):                                             # :266-283
+                self.set_from_flat(thbefore + fullstep * stepsize)
+                with torch.no_grad():
+                    meanlosses = allmean(torch.stack(self._losses(ob, ac, atarg, old_mean, old_logstd)), self.group)
+                surr, kl = float(meanlosses[0]), float(meanlosses[1])
+                improve = surr - surrbefore
+                if not bool(torch.isfinite(meanlosses).all()):
+                    pass                                                    # "Got non-finite value of losses -- bad!"
+                elif kl > self.max_kl * 1.5:
+                    pass                                                    # "violated KL constraint. shrinking step."
+                elif improve < 0:
+                    pass                                                    # "surrogate didn't improve. shrinking step."
+                else:
+                    ok = True                                               # "Stepsize OK!"
+                    break
+                stepsize *= 0.5
+            if not ok:
+                self.set_from_flat(thbefore)                                # "couldn't compute a good step"
+            stats.update(expectedimprove=expectedimprove, improve=improve, stepsize=stepsize if ok else 0.0)
+
+        # ---- value function (:288-296) ------------------------------------------------------------------------------------
+        n = ob.shape[0]
+        bs = min(self.vf_batch_size, n)
+        for _ in range(self.vf_iters):
+            inds = torch.randperm(n, device=ob.device, generator=self._perm_gen)
+            for o in range(0, n - bs + 1, bs):                              # include_final_partial_batch=False
+                mb = inds[o:o + bs]
+                mbob, mbret = ob[mb], tdlamret[mb]
+                pi.ob_rms.update(mbob, group=self.group)                    # :293
+                _, vpred = pi.forward(mbob)
+                vferr = ((vpred - mbret) ** 2).mean()
+                gv = flat(torch.autograd.grad(vferr, self.vf))
+                self.vfadam.update(gv, self.vf_stepsize)
+
+        for name, val in zip(self.loss_names, meanlosses.tolist()):
+            stats[name] = val
+        stats["ev_tdlam_before"] = explained_variance(vpredbefore, tdlamret)
+        return stats
+
+
+def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max_seconds=0, callback=None, log=print,
+          group=None, **learner_kwargs):
+    """`learn()` of src/trpo.py:97-319 over a DPVecEnv (autoreset="init") and an MlpPolicy.  Stops after `max_iters`
+    iterations, `max_timesteps` env steps (global) or `max_seconds`.  Returns the list of per-iteration stat dicts, with
+    the reference's log keys (EpLenMean / EpRewMean over the last 40 episodes, EpThisIter, EpisodesSoFar, TimestepsSoFar,
+    TimeElapsed, entropy, meankl, optimgain, surrgain, ev_tdlam_before)."""
+    import torch.distributed as dist
+    assert sum([max_iters > 0, max_timesteps > 0, max_seconds > 0]) >= 1
+    learner = TrpoLearner(pi, group=group, **learner_kwargs)
+    seg_gen = traj_segment_generator(pi, env, timesteps_per_batch, stochastic=True)
+    world = _world(group)
+    rank = dist.get_rank(group) if world > 1 else 0
+    episodes_so_far = timesteps_so_far = iters_so_far = 0
+    tstart = time.time()
+    lenbuffer, rewbuffer = deque(maxlen=40), deque(maxlen=40)
+    history = []
+    while True:
+        if callback:
+            callback(locals(), globals())
+        if max_timesteps and timesteps_so_far >= max_timesteps:
+            break
+        if max_iters and iters_so_far >= max_iters:
+            break
+        if max_seconds and time.time() - tstart >= max_seconds:
+            break
+        seg = next(seg_gen)
+        stats = learner.update(seg)
+        lens, rets = seg["ep_lens"], seg["ep_rets"]
+        n_eps = torch.tensor([len(lens), sum(lens), sum(rets)], dtype=torch.float64, device=pi.device)
+        if world > 1:                                            # :300-302 allgather of (ep_lens, ep_rets): the sums suffice here
+            dist.all_reduce(n_eps, group=group)
+        lenbuffer.extend(lens[-40:]); rewbuffer.extend(rets[-40:])
+        episodes_so_far += int(n_eps[0]); timesteps_so_far += timesteps_per_batch * env.num_envs * world
+        iters_so_far += 1
+        stats.update(EpLenMean=float(sum(lenbuffer) / max(1, len(lenbuffer))), EpRewMean=float(sum(rewbuffer) / max(1, len(rewbuffer))),
+                     EpLenMeanIter=float(n_eps[1] / max(1.0, float(n_eps[0]))), EpThisIter=int(n_eps[0]), EpisodesSoFar=episodes_so_far,
+                     TimestepsSoFar=timesteps_so_far, TimeElapsed=time.time() - tstart, iteration=iters_so_far)
+        history.append(stats)
+        if log and rank == 0:
+            log("iter %4d  steps %10d  eps %7d  EpLenMean %7.1f  (this iter %7.1f)  entropy %6.2f  meankl %.4f  surrgain %+.4f  ev %.3f  %.1fs"
+                % (iters_so_far, timesteps_so_far, stats["EpThisIter"], stats["EpLenMean"], stats["EpLenMeanIter"], stats.get("entropy", float("nan")),
+                   stats.get("meankl", float("nan")), stats.get("surrgain", float("nan")), stats["ev_tdlam_before"], stats["TimeElapsed"]))
+    return history

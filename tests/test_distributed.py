@@ -62,3 +62,35 @@ def test_single_process_gather_is_identity():
     blk.append(torch.ones(3, 56), torch.zeros(3, 28), torch.ones(3), torch.zeros(3))
     out = blk.gather()
     assert out.shape == (1, 2, 3, ROW) and torch.equal(out[0, 0, :, :56], torch.ones(3, 56))
+
+
+def _trpo_worker(rank, world, port, out_dir):
+    """Two learner replicas on different data (the reference's `mpirun -np 2 python3 trpo.py`): all-mean'd gradients, Fisher
+    products, value gradients and obs-filter moments must leave both replicas with identical parameters."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deepmimic_mujoco_amd.policy import MlpPolicy
+        from deepmimic_mujoco_amd.trpo import TrpoLearner
+        from tests.test_trpo import _segment
+        pi = MlpPolicy(seed=10 + rank)                      # different initial weights: rank 0's must win (trpo.py:182-186)
+        L = TrpoLearner(pi, vf_batch_size=256)
+        seg = _segment(pi, n=32, T=16, seed=100 + rank)     # different rollouts per rank
+        seg["rew"] = -((seg["ac"] - 0.2) ** 2).mean(-1)
+        st = L.update(seg)
+        th = torch.cat([L.get_flat(), L.vfadam.getflat(), pi.ob_rms.sum.to(torch.float32), pi.ob_rms.count.reshape(1).to(torch.float32)])
+        both = [torch.empty_like(th) for _ in range(world)]
+        dist.all_gather(both, th)
+        assert torch.equal(both[0], both[1]), float((both[0] - both[1]).abs().max())
+        assert st["meankl"] <= 0.0151 and st["stepsize"] > 0
+        if rank == 0:
+            torch.save(th, os.path.join(out_dir, "theta.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trpo_replicas_stay_in_sync_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_trpo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(str(tmp_path / "theta.pt"))

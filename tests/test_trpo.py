@@ -1,0 +1,148 @@
+"""TRPO learner: numerics of its pieces against plain restatements of src/trpo.py, src/cg.py,
+src/mpi_adam.py, src/distributions.py, and an end-to-end improvement test on a scripted environment."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from deepmimic_mujoco_amd.policy import MlpPolicy
+from deepmimic_mujoco_amd.trpo import TrpoLearner, MpiAdam, cg, flat, learn, explained_variance, POL_KEYS
+
+
+def test_cg_matches_reference_iteration_and_solves_spd():
+    rng = np.random.RandomState(0)
+    B = rng.randn(12, 12); A = B @ B.T + 12 * np.eye(12); b = rng.randn(12)
+
+    def cg_np(f_Ax, b, cg_iters=10, residual_tol=1e-10):       # src/cg.py:2-34 restated
+        p = b.copy(); r = b.copy(); x = np.zeros_like(b); rdotr = r.dot(r)
+        for _ in range(cg_iters):
+            z = f_Ax(p); v = rdotr / p.dot(z); x += v * p; r -= v * z
+            newrdotr = r.dot(r); mu = newrdotr / rdotr; p = r + mu * p; rdotr = newrdotr
+            if rdotr < residual_tol:
+                break
+        return x
+    At = torch.from_numpy(A)
+    for iters in (3, 10, 40):
+        x = cg(lambda p: At @ p, torch.from_numpy(b), cg_iters=iters)
+        assert np.allclose(x.numpy(), cg_np(lambda p: A @ p, b, iters), rtol=1e-9, atol=1e-12)
+    assert np.allclose(cg(lambda p: At @ p, torch.from_numpy(b), cg_iters=40).numpy(), np.linalg.solve(A, b), atol=1e-5)   # stops at r.r < 1e-10, as the reference
+
+
+def test_distribution_formulas_match_reference_definitions():
+    rng = np.random.RandomState(1)
+    m0, m1 = rng.randn(5, 28), rng.randn(5, 28)
+    l0, l1 = rng.randn(1, 28) * 0.3, rng.randn(1, 28) * 0.3
+    x = rng.randn(5, 28)
+    kl = TrpoLearner._kl(*(torch.from_numpy(a) for a in (m0, l0, m1, l1))).numpy()
+    ref = (l1 - l0 + (np.exp(l0) ** 2 + (m0 - m1) ** 2) / (2 * np.exp(l1) ** 2) - 0.5).sum(-1)     # distributions.py:235-237
+    assert np.allclose(kl, ref, rtol=1e-12)
+    nl = TrpoLearner._neglogp(torch.from_numpy(x), torch.from_numpy(m0), torch.from_numpy(l0)).numpy()
+    ref = 0.5 * (((x - m0) / np.exp(l0)) ** 2).sum(-1) + 0.5 * np.log(2 * np.pi) * 28 + l0.sum(-1)  # :231-234
+    assert np.allclose(nl, ref, rtol=1e-12)
+    assert np.all(TrpoLearner._kl(*(torch.from_numpy(a) for a in (m0, l0, m0, l0))).numpy() == 0)
+
+
+def _segment(pi, n=48, T=16, seed=0):
+    g = torch.Generator(); g.manual_seed(seed)
+    ob = torch.randn((T, n, 56), generator=g)
+    pi.seed(seed)
+    with torch.no_grad():
+        ac, vpred = pi.act(True, ob.reshape(-1, 56))
+    return {"ob": ob, "ac": ac.to(torch.float32).reshape(T, n, 28), "vpred": vpred.reshape(T, n),
+            "rew": torch.rand((T, n), generator=g), "new": (torch.rand((T, n), generator=g) < 0.1).to(torch.int32),
+            "nextvpred": torch.zeros(n)}
+
+
+def test_fisher_vector_product_is_the_kl_hessian():
+    pi = MlpPolicy(seed=3)
+    L = TrpoLearner(pi, cg_damping=0.0)
+    ob = torch.randn(64, 56)
+    with torch.no_grad():
+        old_mean, _ = pi.forward(ob); old_logstd = pi.params["logstd"].clone()
+    mean, logstd = L._pd(ob)
+    kl = L._kl(old_mean, old_logstd, mean, logstd).mean()
+    klgrads = flat(torch.autograd.grad(kl, L.pol, create_graph=True))
+    v = torch.randn_like(klgrads); v = v / v.norm()
+    hv = flat(torch.autograd.grad(klgrads.dot(v), L.pol, retain_graph=True))
+    # finite-difference Hessian-vector product of the same KL
+    th = L.get_flat()
+
+    def grad_at(theta):
+        L.set_from_flat(theta)
+        m, ls = L._pd(ob)
+        return flat(torch.autograd.grad(L._kl(old_mean, old_logstd, m, ls).mean(), L.pol)).to(torch.float64)
+    eps = 5e-2
+    fd = (grad_at(th + eps * v) - grad_at(th - eps * v)) / (2 * eps)
+    L.set_from_flat(th)
+    assert float((fd - hv.to(torch.float64)).norm() / hv.norm()) < 2e-2
+    assert float(v.dot(hv)) > 0                                  # Fisher matrix: positive (semi-)definite
+
+
+def test_mpi_adam_update_rule():
+    p = torch.tensor([1.0, -2.0, 0.5], requires_grad=True)
+    opt = MpiAdam([p])
+    th = p.detach().numpy().astype(np.float32).copy(); m = np.zeros(3, np.float32); v = np.zeros(3, np.float32)
+    rng = np.random.RandomState(0)
+    for t in range(1, 6):
+        g = rng.randn(3).astype(np.float32)
+        opt.update(torch.from_numpy(g), 1e-3)
+        a = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)      # src/mpi_adam.py:30-34
+        m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g * g
+        th = th + (-a) * m / (np.sqrt(v) + 1e-8)
+        assert np.allclose(p.detach().numpy(), th, rtol=1e-5, atol=1e-7)
+
+
+def test_update_respects_the_trust_region_and_improves_the_surrogate():
+    pi = MlpPolicy(seed=5)
+    L = TrpoLearner(pi, vf_batch_size=128)
+    seg = _segment(pi)
+    seg["rew"] = -((seg["ac"] - 0.3) ** 2).mean(-1)             # reward prefers actions near 0.3
+    before = L.get_flat()
+    st = L.update(seg)
+    assert st["stepsize"] > 0 and 0 < st["meankl"] <= 1.5 * 0.01 + 1e-6 and st["improve"] >= 0
+    assert not torch.equal(before, L.get_flat())
+    assert abs(st["entropy"] - pi.entropy()) < 0.5 and math.isfinite(st["ev_tdlam_before"])
+    assert float(pi.ob_rms.count) > 48 * 16                       # obs filter saw the batch (+ the vf minibatches)
+
+
+class _ToyVecEnv:
+    """obs ~ N(0,1) i.i.d.; reward = -|a - 0.5 obs[:28]|^2 / 28; never done.  A policy can only score by reading the obs."""
+
+    def __init__(self, n, seed=0):
+        self.num_envs = n
+        self.g = torch.Generator(); self.g.manual_seed(seed)
+        self.batch = self
+        self.ob = None
+
+    def reset(self, mode, out=None):
+        self.ob = torch.randn((self.num_envs, 56), generator=self.g, dtype=torch.float64).numpy()
+        out[...] = self.ob
+        return out
+
+    def step(self, ac, nsub, out):
+        ob, rew, done = out
+        rew[...] = -((np.asarray(ac) - 0.5 * self.ob[:, :28]) ** 2).mean(-1)
+        self.ob = torch.randn((self.num_envs, 56), generator=self.g, dtype=torch.float64).numpy()
+        ob[...] = self.ob; done[...] = 0
+        return out
+
+
+def test_learn_improves_return_on_a_scripted_env():
+    torch.manual_seed(0)
+    pi = MlpPolicy(seed=7); pi.seed(7)
+    hist = learn(_ToyVecEnv(256, 1), pi, timesteps_per_batch=16, max_iters=12, log=None, gamma=0.0, lam=0.0, vf_batch_size=1024)
+    assert len(hist) == 12 and hist[-1]["TimestepsSoFar"] == 12 * 16 * 256
+    # with gamma = 0 the advantage is the immediate reward: the surrogate keeps finding improvement and the policy mean moves
+    ob = torch.randn(4096, 56)
+    with torch.no_grad():
+        ac, _ = pi.act(False, ob)
+    err_after = float(((ac - 0.5 * ob[:, :28].to(torch.float64)) ** 2).mean())
+    err_init = float((0.5 * ob[:, :28] ** 2).mean()) * 0.5          # policy mean ~ 0 at init: E|0.5 ob|^2 = 0.25
+    assert err_after < 0.8 * 0.25, (err_after, err_init)
+    assert all(h["meankl"] <= 0.0151 for h in hist)
+
+
+def test_explained_variance():
+    y = torch.tensor([1.0, 2.0, 3.0, 4.0])
+    assert explained_variance(y, y) == 1.0 and abs(explained_variance(torch.zeros(4), y)) < 1e-12

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Train the humanoid with the TRPO learner on device-resident rollouts (the reference's `python3 trpo.py`, src/trpo.py:438-491).
+
+    python tools/train_trpo.py --envs 1024 --horizon 64 --seconds 120 [--out gpurun_out/trpo_curve.json]
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_trpo.py ...      (one rank per GPU, all-mean'd updates)
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from deepmimic_mujoco_amd import DPVecEnv, MlpPolicy  # noqa: E402
+from deepmimic_mujoco_amd.trpo import learn  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=1024)
+    ap.add_argument("--horizon", type=int, default=64)
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--iters", type=int, default=0)
+    ap.add_argument("--vf-batch", type=int, default=4096)
+    ap.add_argument("--vf-stepsize", type=float, default=1e-3)
+    ap.add_argument("--max-kl", type=float, default=0.01)
+    ap.add_argument("--motion", default="walk")
+    ap.add_argument("--reward", default="alive")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--save", default=None, help="write the trained policy as .npz (reference variable names)")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); lr = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(lr)
+    dev = torch.device("cuda", lr)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    env = DPVecEnv(args.envs, motion=args.motion, device=lr, reward=args.reward, autoreset="init", seed=args.seed + 10000 * rank,
+                   env_offset=rank * args.envs)
+    pi = MlpPolicy(device=dev, seed=args.seed); pi.seed(args.seed + 10000 * rank)
+    hist = learn(env, pi, timesteps_per_batch=args.horizon, max_seconds=args.seconds if not args.iters else 0, max_iters=args.iters,
+                 vf_batch_size=args.vf_batch, vf_stepsize=args.vf_stepsize, max_kl=args.max_kl, seed=args.seed)
+    if rank == 0:
+        if args.out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+            json.dump({"args": vars(args), "world": world, "history": hist}, open(args.out, "w"))
+        if args.save:
+            pi.save_npz(args.save)
+        best = max(h["EpLenMeanIter"] for h in hist)
+        print("done: %d iterations, %d env steps in %.1f s (%.0f steps/s incl. learner), EpLenMean(last iter) %.1f, best %.1f"
+              % (len(hist), hist[-1]["TimestepsSoFar"], hist[-1]["TimeElapsed"], hist[-1]["TimestepsSoFar"] / hist[-1]["TimeElapsed"],
+                 hist[-1]["EpLenMeanIter"], best))
+
+
+if __name__ == "__main__":
+    main()
