@@ -248,3 +248,29 @@ def test_segment_episode_statistics_across_segment_boundaries():
     assert np.allclose(got_rets, [w[0] for w in want], rtol=1e-12, atol=1e-12)
     new = np.concatenate(news)
     assert np.array_equal(new[0], np.ones(n, int)) and np.array_equal(new[1:], env.done[:T * segs - 1])
+
+
+def test_reference_log_formats_round_trip(tmp_path):
+    """progress.csv / monitor.csv: parse the head of the reference's own files (fixtures are verbatim
+    excerpts of src/log_tmp/DeepMimic/trpo-walk-0/*), write the same content with our writers, get identical bytes back."""
+    from deepmimic_mujoco_amd.logio import ProgressCsv, MonitorWriter, read_progress_csv, read_monitor_csv
+    ref = os.path.join(GOLD, "ref_progress_head.csv")
+    kv = read_progress_csv(ref)
+    assert list(kv)[0] == "EpRewMean" and kv["EpLenMean"][0] == 36.8 and len(kv["meankl"]) == 40
+    raw = open(ref).read().splitlines()
+    w = ProgressCsv(str(tmp_path / "progress.csv"))
+    keys = raw[0].split(",")
+    for line in raw[1:]:
+        w.writekvs(dict(zip(keys, line.split(","))))          # cells as the reference printed them
+    w.close()
+    assert open(str(tmp_path / "progress.csv")).read().splitlines() == raw
+    w = ProgressCsv(str(tmp_path / "p2.csv")); w.writekvs({"a": 1}); w.writekvs({"a": 2, "b": 3}); w.close()
+    assert open(str(tmp_path / "p2.csv")).read() == "a,b\n1,\n2,3\n"       # late keys pad earlier rows (logger.py:110-124)
+    hdr, r, l, t = read_monitor_csv(os.path.join(GOLD, "ref_monitor_head.csv"))
+    assert hdr["env_id"] is None and r[:3] == [18.0, 31.0, 25.0] and l[:3] == [18, 31, 25] and len(l) == 200
+    m = MonitorWriter(str(tmp_path / "run"), t_start=hdr["t_start"])
+    for ri, li, ti in zip(r, l, t):
+        m.write_episodes([ri], [li], t=hdr["t_start"] + ti)
+    m.close()
+    h2, r2, l2, t2 = read_monitor_csv(str(tmp_path / "run.monitor.csv"))
+    assert h2 == hdr and r2 == r and l2 == l and np.allclose(t2, t, atol=1e-6)
