@@ -1067,6 +1067,114 @@ void dmo_env_step(const dmo_model* m, dmo_data* d, const double* action, int n_s
   *done = dmo_is_done(m, d);
 }
 
+
+/* ============================ 5-term imitation reward (code.md:1017-1143) ============================
+ * cSceneImitate::CalcRewardImitate as quoted in the reference's porting notes; the reference itself never implemented it
+ * (src/dp_env_v3.py:117-128 returns 1.0).  A feature row (112 doubles, layout in deepmimic_mujoco_amd/imitation.py) of the
+ * simulated state is compared with the row of the mocap frame.  params[32]: joint weights [12] (model body order 2..13),
+ * root weight, cycle shift x y, loop flag, end-effector body ids [4], offsets [4][3].  Items marked [upstream] come from
+ * upstream DeepMimic (KinTree / MathUtil), not from the reference's files. */
+#define DMO_FEAT 112
+static double quat_diff_theta(const double* q0, const double* q1) {    /* [upstream] cMathUtil::QuatDiffTheta */
+  const double c[4] = {q0[0], -q0[1], -q0[2], -q0[3]};
+  double dq[4];
+  quat_mul(dq, q1, c);
+  double w = dq[0] > 1 ? 1 : (dq[0] < -1 ? -1 : dq[0]);
+  if (sqrt(fmax(0.0, 1 - w * w)) <= 1e-6) return 0;
+  double th = 2 * acos(w);
+  return th > M_PI ? th - 2 * M_PI : th;
+}
+void dmo_imitation_features(const dmo_model* m, const double* qpos, const double* qvel, const double* params, double* f) {
+  const dmo_spec* sp = &m->s;
+  dmo_data* d = dmo_data_create(m);          /* scratch: kinematics of THIS state, the caller's derived quantities stay untouched */
+  for (int i = 0; i < m->nq; i++) d->qpos[i] = qpos[i];
+  for (int i = 0; i < m->nv; i++) d->qvel[i] = qvel[i];
+  kinematics(m, d);
+  for (int i = 0; i < DMO_FEAT; i++) f[i] = 0;
+  double rq[4] = {qpos[3], qpos[4], qpos[5], qpos[6]};
+  normalize4(rq);
+  for (int k = 0; k < 3; k++) { f[k] = qpos[k]; f[7 + k] = qvel[k]; }
+  for (int k = 0; k < 4; k++) f[3 + k] = rq[k];
+  quat_rot(f + 10, rq, qvel + 3);                                      /* free-joint angular velocity is body-local */
+  for (int g = 0; g < 12; g++) {
+    int b = g + 2, j0 = m->body_jntadr[b], nj = m->body_jntnum[b];
+    if (nj == 1) { f[13 + 4 * g] = qpos[m->jnt_qposadr[j0]]; f[61 + 3 * g] = qvel[m->jnt_dofadr[j0]]; continue; }
+    double ql[4] = {1, 0, 0, 0}, wl[3] = {0, 0, 0};
+    for (int j = j0; j < j0 + nj; j++) {                               /* child = R1 R2 R3;  w = sum_k R1..R(k-1) a_k rate_k */
+      double a[3], qa[4], t[4];
+      quat_rot(a, ql, sp->jnt_axis[j]);
+      for (int k = 0; k < 3; k++) wl[k] += a[k] * qvel[m->jnt_dofadr[j]];
+      axisangle2quat(qa, sp->jnt_axis[j], qpos[m->jnt_qposadr[j]]);
+      quat_mul(t, ql, qa);
+      for (int k = 0; k < 4; k++) ql[k] = t[k];
+    }
+    for (int k = 0; k < 4; k++) f[13 + 4 * g + k] = ql[k];
+    for (int k = 0; k < 3; k++) f[61 + 3 * g + k] = wl[k];
+  }
+  const double ex[3] = {1, 0, 0};
+  double fwd[3];
+  quat_rot(fwd, rq, ex);
+  const double hd = atan2(fwd[1], fwd[0]), c = cos(hd), sn = sin(hd);  /* heading about the vertical */
+  for (int e = 0; e < 4; e++) {
+    int b = (int)params[16 + e];
+    double p[3], rel[3];
+    mat_vec(p, d->xmat[b], params + 20 + 3 * e);
+    for (int k = 0; k < 3; k++) { p[k] += d->xpos[b][k]; rel[k] = p[k] - qpos[k]; }
+    rel[2] = p[2];                                                     /* height above the ground plane */
+    f[97 + 3 * e] = c * rel[0] + sn * rel[1]; f[98 + 3 * e] = -sn * rel[0] + c * rel[1]; f[99 + 3 * e] = rel[2];
+  }
+  double mom[3] = {0, 0, 0};                                           /* linear momentum: sum_b m_b (v_origin + w x xipos) */
+  for (int b = 1; b < sp->nbody; b++) {
+    double cv[6] = {0, 0, 0, 0, 0, 0};
+    for (int bb = b; bb > 0; bb = sp->body_parent[bb])
+      for (int dd = m->body_dofadr[bb]; dd < m->body_dofadr[bb] + m->body_dofnum[bb]; dd++)
+        for (int k = 0; k < 6; k++) cv[k] += d->cdof[dd][k] * qvel[dd];
+    double wxr[3];
+    cross3(wxr, cv, d->xipos[b]);
+    for (int k = 0; k < 3; k++) mom[k] += m->body_mass[b] * (cv[3 + k] + wxr[k]);
+  }
+  for (int k = 0; k < 3; k++) f[109 + k] = mom[k] / m->total_mass;
+  dmo_data_destroy(d);
+}
+double dmo_imitation_reward(const dmo_model* m, const double* f0, const double* f1, const double* params, double shift_x,
+                            double shift_y, double* terms) {
+  const double th = quat_diff_theta(f0 + 3, f1 + 3);
+  double dw2 = 0, dv2 = 0, dp2 = 0, dc2 = 0, de2 = 0;
+  for (int k = 0; k < 3; k++) { double a = f1[10 + k] - f0[10 + k]; dw2 += a * a; }
+  double pose = params[12] * th * th, vel = params[12] * dw2;
+  for (int g = 0; g < 12; g++) {
+    double pe;
+    if (m->body_jntnum[g + 2] == 1) { double a = f1[13 + 4 * g] - f0[13 + 4 * g]; pe = a * a; }
+    else { double t = quat_diff_theta(f0 + 13 + 4 * g, f1 + 13 + 4 * g); pe = t * t; }
+    double ve = 0;
+    for (int k = 0; k < 3; k++) { double a = f1[61 + 3 * g + k] - f0[61 + 3 * g + k]; ve += a * a; }
+    pose += params[g] * pe; vel += params[g] * ve;
+  }
+  for (int k = 0; k < 12; k++) { double a = f1[97 + k] - f0[97 + k]; de2 += a * a; }
+  const double p1[3] = {f1[0] + shift_x, f1[1] + shift_y, f1[2]};
+  for (int k = 0; k < 3; k++) { double a = f0[k] - p1[k]; dp2 += a * a; a = f1[7 + k] - f0[7 + k]; dv2 += a * a; a = f1[109 + k] - f0[109 + k]; dc2 += a * a; }
+  const double e[5] = {pose, vel, de2 / 4, dp2 + 0.1 * th * th + 0.01 * dv2 + 0.001 * dw2, 0.1 * dc2};
+  static const double w[5] = {0.5, 0.05, 0.15, 0.2, 0.1}, sc[5] = {2, 0.1, 40, 5, 10};   /* code.md:1019-1037 (weights sum to 1) */
+  double r = 0;
+  for (int k = 0; k < 5; k++) { if (terms) terms[k] = e[k]; r += w[k] * exp(-sc[k] * e[k]); }
+  return r;
+}
+/* one env step in imitation mode: the state after the step is compared with frame idx_curr + 1 (wrapping clips add the
+ * cycle shift per completed cycle; "Loop: none" clips hold the last frame and end the episode there). */
+void dmo_env_step_imitation(const dmo_model* m, dmo_data* d, const double* action, int n_substeps, const double* table, int F,
+                            const double* params, int* idx_curr, int* cycle, double* obs, double* reward, int* done) {
+  for (int u = 0; u < m->s.nu; u++) d->ctrl[u] = action[u];
+  for (int k = 0; k < n_substeps; k++) dmo_step(m, d);
+  dmo_get_obs(m, d, obs);
+  int k = *idx_curr + 1, ended = 0;
+  if (k >= F) { if (params[15] != 0) { k = 0; *cycle += 1; } else { k = F - 1; ended = 1; } }
+  *idx_curr = k;
+  double f0[DMO_FEAT];
+  dmo_imitation_features(m, d->qpos, d->qvel, params, f0);
+  *reward = dmo_imitation_reward(m, f0, table + (size_t)k * DMO_FEAT, params, *cycle * params[13], *cycle * params[14], 0);
+  *done = dmo_is_done(m, d) || ended;
+}
+
 void dmo_batch_step(const dmo_model* m, dmo_data** ds, int n, const double* actions, int n_substeps,
                     double* obs, double* reward, unsigned char* done, int nthreads) {
   int nu = m->s.nu;

@@ -75,6 +75,11 @@ def lib():
         L.dmo_config_reward.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_int, C.POINTER(C.c_int)]
         L.dmo_env_step.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_int, C.c_int, dp, C.c_int,
                                    C.POINTER(C.c_int), C.c_int, dp, dp, C.POINTER(C.c_int)]
+        L.dmo_imitation_features.argtypes = [C.c_void_p, dp, dp, dp, dp]
+        L.dmo_imitation_reward.restype = C.c_double
+        L.dmo_imitation_reward.argtypes = [C.c_void_p, dp, dp, dp, C.c_double, C.c_double, dp]
+        L.dmo_env_step_imitation.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_int, dp, C.c_int, dp, C.POINTER(C.c_int),
+                                             C.POINTER(C.c_int), dp, dp, C.POINTER(C.c_int)]
         L.dmo_batch_step.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, dp, C.c_int, dp, dp,
                                      C.POINTER(C.c_ubyte), C.c_int]
         _LIB = L
@@ -175,6 +180,31 @@ class Data(object):
         lib().dmo_env_step(self.m.h, self.h, _dp(a), n_substeps, reward_mode, _dp(cfg), cfg.shape[0],
                            C.byref(ic), int(idx_init), _dp(o), _dp(rr), C.byref(dn))
         return o, float(rr[0]), bool(dn.value), ic.value
+
+
+def imitation_features(model, qpos, qvel, params):
+    """Feature row (112) of a state: code.md:1017-1143 reward inputs; layout in deepmimic_mujoco_amd/imitation.py."""
+    q = np.ascontiguousarray(qpos, dtype=np.float64); v = np.ascontiguousarray(qvel, dtype=np.float64)
+    p = np.ascontiguousarray(params, dtype=np.float64); f = np.zeros(112)
+    lib().dmo_imitation_features(model.h, _dp(q), _dp(v), _dp(p), _dp(f))
+    return f
+
+
+def imitation_reward(model, f0, f1, params, shift=(0.0, 0.0)):
+    a = np.ascontiguousarray(f0, dtype=np.float64); b = np.ascontiguousarray(f1, dtype=np.float64)
+    p = np.ascontiguousarray(params, dtype=np.float64); t = np.zeros(5)
+    r = lib().dmo_imitation_reward(model.h, _dp(a), _dp(b), _dp(p), float(shift[0]), float(shift[1]), _dp(t))
+    return float(r), t
+
+
+def env_step_imitation(model, data, action, n_substeps, table, params, idx_curr, cycle):
+    """-> (obs, reward, done, idx_curr, cycle)"""
+    a = np.ascontiguousarray(action, dtype=np.float64); tb = np.ascontiguousarray(table, dtype=np.float64)
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    o = np.zeros(56); rr = np.zeros(1); dn = C.c_int(0); ic = C.c_int(int(idx_curr)); cy = C.c_int(int(cycle))
+    lib().dmo_env_step_imitation(model.h, data.h, _dp(a), int(n_substeps), _dp(tb), tb.shape[0], _dp(p), C.byref(ic), C.byref(cy),
+                                 _dp(o), _dp(rr), C.byref(dn))
+    return o, float(rr[0]), bool(dn.value), ic.value, cy.value
 
 
 def batch_step(model, datas, actions, n_substeps=1, nthreads=1):
