@@ -15,7 +15,7 @@ PTR_HOST, PTR_DEVICE = 0, 1
 FLAG_NO_CONTACT, FLAG_NO_LIMIT = 1, 2
 OPT_REWARD_MODE, OPT_AUTORESET, OPT_ACTION_MODE, OPT_SEED, OPT_ENV_OFFSET = 1, 2, 3, 4, 100
 (F_QPOS, F_QVEL, F_QACC_WARMSTART, F_TIME, F_FRAME_IDX, F_FRAME_INIT, F_XIPOS, F_COM_Z, F_NCON, F_NEFC,
- F_CONTACT_GEOMS, F_STATUS, F_SOLVER_ITER, F_CTRL, F_EPISODE) = range(1, 16)
+ F_CONTACT_GEOMS, F_STATUS, F_SOLVER_ITER, F_CTRL, F_EPISODE, F_CYCLE) = range(1, 17)
 
 # field -> (numpy dtype, per-env shape)
 FIELD_SPEC = {
@@ -23,7 +23,7 @@ FIELD_SPEC = {
     F_TIME: (np.float64, ()), F_FRAME_IDX: (np.int32, ()), F_FRAME_INIT: (np.int32, ()),
     F_XIPOS: (np.float64, (NBODY, 3)), F_COM_Z: (np.float64, ()), F_NCON: (np.int32, ()), F_NEFC: (np.int32, ()),
     F_CONTACT_GEOMS: (np.int32, (MAXEFC, 2)), F_STATUS: (np.int32, ()), F_SOLVER_ITER: (np.int32, ()),
-    F_CTRL: (np.float64, (NU,)), F_EPISODE: (np.int32, ()),
+    F_CTRL: (np.float64, (NU,)), F_EPISODE: (np.int32, ()), F_CYCLE: (np.int32, ()),
 }
 
 _dp = C.POINTER(C.c_double)
@@ -86,7 +86,7 @@ def make_model_desc(cm):
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DMENV_LIB") or os.path.join(_HERE, "csrc", "libdmenv.so")   # DMENV_LIB: developer override (A/B builds)
-EXPORTS = ["dm_model_create", "dm_model_destroy", "dm_mocap_create", "dm_mocap_destroy", "dm_batch_create",
+EXPORTS = ["dm_model_create", "dm_model_destroy", "dm_mocap_create", "dm_mocap_set_imitation", "dm_mocap_destroy", "dm_batch_create",
            "dm_batch_destroy", "dm_batch_set_stream", "dm_batch_set_option", "dm_batch_set_state", "dm_batch_reset",
            "dm_batch_step", "dm_batch_get_obs", "dm_batch_get", "dm_batch_set", "dm_batch_debug_forward",
            "dm_batch_last_step_ms", "dm_batch_enable_timing", "dm_batch_read_profile", "dm_batch_sync", "dm_last_error", "dm_abi_version",
@@ -112,6 +112,7 @@ def load():
     L.dm_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
     L.dm_model_destroy.argtypes = [vp]; L.dm_model_destroy.restype = None
     L.dm_mocap_create.argtypes = [_dp, _dp, i32, C.c_double, C.POINTER(vp)]
+    L.dm_mocap_set_imitation.argtypes = [vp, _dp, i32, _dp]
     L.dm_mocap_destroy.argtypes = [vp]; L.dm_mocap_destroy.restype = None
     L.dm_batch_create.argtypes = [vp, vp, i32, i32, C.c_uint32, C.POINTER(vp)]
     L.dm_batch_destroy.argtypes = [vp]; L.dm_batch_destroy.restype = None

@@ -15,7 +15,7 @@ def _is_torch(x):
 
 
 class Batch(object):
-    def __init__(self, compiled_model, data_config, data_vel, n_envs, device=0, flags=0, mocap_dt=0.0):
+    def __init__(self, compiled_model, data_config, data_vel, n_envs, device=0, flags=0, mocap_dt=0.0, imitation=None):
         L = A.load()
         self._L = L
         self.n = int(n_envs)
@@ -29,6 +29,11 @@ class Batch(object):
         self.n_frames = cfg.shape[0]
         A.check(L.dm_mocap_create(cfg.ctypes.data_as(A._dp), vel.ctypes.data_as(A._dp), cfg.shape[0], float(mocap_dt),
                                   C.byref(self._mocap)), L)
+        if imitation is not None:            # (table [F,112], params [32]) from imitation.ImitationSpec: enables reward mode 3
+            tab = np.ascontiguousarray(imitation[0], dtype=np.float64); par = np.ascontiguousarray(imitation[1], dtype=np.float64)
+            if tab.shape != (cfg.shape[0], 112) or par.shape != (32,):
+                raise ValueError("imitation = (table [F,112], params [32])")
+            A.check(L.dm_mocap_set_imitation(self._mocap, tab.ctypes.data_as(A._dp), 112, par.ctypes.data_as(A._dp)), L)
         A.check(L.dm_batch_create(self._model, self._mocap, self.n, self.device, int(flags), C.byref(self._h)), L)
 
     def close(self):

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void k_set_state(const DevModel<Real>* __restri
   load_env(*Mp, B, s, env, lane, (const Real*)0);
   if (lane < NQ) s.qpos[lane] = qpos[(size_t)env * NQ + lane];
   if (lane < NV) s.qvel[lane] = qvel[(size_t)env * NV + lane];
-  if (frame_idx && lane == 0) { B.frame_idx[env] = frame_idx[env]; B.frame_init[env] = frame_idx[env]; }
+  if (frame_idx && lane == 0) { B.frame_idx[env] = frame_idx[env]; B.frame_init[env] = frame_idx[env]; B.cycle[env] = 0; }
   dmw::sync();
   store_state(B, s, env, lane);
   { const LaneTopo lt = lane_topo(lane); stage_tables(s, lane); dmw::sync(); forward(*Mp, s, lane, lt, (const DebugOut*)0); }   // sim.forward()
@@ -114,13 +114,13 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(DM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct dm_model { DevModel<Real> h; };
-struct dm_mocap { std::vector<double> cfg, vel; int n_frames; double dt; };
+struct dm_mocap { std::vector<double> cfg, vel, imit_table, imit_params; int n_frames; double dt; };
 struct dm_batch {
   int n = 0, device = 0;
   hipStream_t stream = nullptr; bool own_stream = false;
   DevModel<Real>* d_model = nullptr;
   Batch<Real> B{};
-  Real *d_cfg = nullptr, *d_vel = nullptr;
+  Real *d_cfg = nullptr, *d_vel = nullptr, *d_imit = nullptr;
   // staging for DM_PTR_HOST callers
   Real *d_action = nullptr, *d_obs = nullptr, *d_reward = nullptr; unsigned char *d_done = nullptr, *d_mask = nullptr;
   Real *d_qpos_in = nullptr, *d_qvel_in = nullptr; int* d_fidx_in = nullptr;
@@ -154,6 +154,14 @@ extern "C" int dm_mocap_create(const double* cfg, const double* vel, int32_t F, 
   *out = mc;
   return DM_OK;
 }
+extern "C" int dm_mocap_set_imitation(dm_mocap* mc, const double* table, int32_t n_cols, const double* params) {
+  if (!mc || !table || !params) return fail(DM_EINVAL, "dm_mocap_set_imitation: null argument");
+  if (n_cols != IMIT_FEAT) return fail(DM_EINVAL, "dm_mocap_set_imitation: a feature row has 112 columns");
+  for (int e = 0; e < 4; e++) { const int b = (int)params[16 + e]; if (b < 1 || b >= NB) return fail(DM_EINVAL, "dm_mocap_set_imitation: end-effector body id out of range"); }
+  mc->imit_table.assign(table, table + (size_t)mc->n_frames * IMIT_FEAT);
+  mc->imit_params.assign(params, params + 32);
+  return DM_OK;
+}
 extern "C" void dm_mocap_destroy(dm_mocap* mc) { delete mc; }
 
 template <class T> static hipError_t dalloc(T** p, size_t n) { hipError_t e = hipMalloc((void**)p, n * sizeof(T)); if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T)); return e; }
@@ -164,7 +172,7 @@ extern "C" void dm_batch_destroy(dm_batch* b) {
   if (b->stream) hipStreamSynchronize(b->stream);
   void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
                   b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
-                  b->d_reward, b->d_done, b->d_mask, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf};
+                  b->d_reward, b->d_done, b->d_mask, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit};
   for (void* p : ptrs) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
@@ -192,8 +200,9 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   A(b->d_model, 1);
   A(b->B.qpos, (size_t)n * NQ); A(b->B.qvel, (size_t)n * NV); A(b->B.qws, (size_t)n * NV); A(b->B.time, n); A(b->B.ctrl, (size_t)n * NU);
   A(b->B.xipos, (size_t)n * NB * 3); A(b->B.comz, n); A(b->B.frame_idx, n); A(b->B.frame_init, n); A(b->B.ncon, n); A(b->B.nefc, n);
-  A(b->B.cong, (size_t)n * MAXEFC * 2); A(b->B.status, n); A(b->B.solver_iter, n); A(b->B.episode, n);
+  A(b->B.cong, (size_t)n * MAXEFC * 2); A(b->B.status, n); A(b->B.solver_iter, n); A(b->B.episode, n); A(b->B.cycle, n);
   A(b->d_cfg, (size_t)mc->n_frames * NQ); A(b->d_vel, (size_t)mc->n_frames * NV);
+  if (!mc->imit_table.empty()) A(b->d_imit, mc->imit_table.size());
   A(b->d_action, (size_t)n * NU); A(b->d_obs, (size_t)n * NOBS); A(b->d_reward, n); A(b->d_done, n); A(b->d_mask, n);
   A(b->B.aovf, (size_t)n * AOVF_COLS * 64);
   A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
@@ -202,6 +211,11 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   ok = hipMemcpy(b->d_model, &hm, sizeof hm, hipMemcpyHostToDevice) == hipSuccess;
   ok = ok && hipMemcpy(b->d_cfg, mc->cfg.data(), mc->cfg.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
   ok = ok && hipMemcpy(b->d_vel, mc->vel.data(), mc->vel.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  if (b->d_imit) {
+    ok = ok && hipMemcpy(b->d_imit, mc->imit_table.data(), mc->imit_table.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    for (int k = 0; k < 32; k++) b->B.imit_params[k] = mc->imit_params[k];
+  }
+  b->B.imit_table = b->d_imit;
   // initial state = MjSim(model): qpos0, zero velocity
   std::vector<double> q0((size_t)n * NQ);
   for (int e2 = 0; e2 < n; e2++) for (int k = 0; k < NQ; k++) q0[(size_t)e2 * NQ + k] = hm.qpos0[k];
@@ -225,7 +239,10 @@ extern "C" int dm_batch_set_stream(dm_batch* b, void* s) {
 extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
   if (!b) return fail(DM_EINVAL, "null batch");
   switch (opt) {
-    case DM_OPT_REWARD_MODE: if (v < 0 || v > 2) return fail(DM_EINVAL, "reward mode must be 0..2"); b->B.reward_mode = (int)v; break;
+    case DM_OPT_REWARD_MODE:
+      if (v < 0 || v > 3) return fail(DM_EINVAL, "reward mode must be 0..3");
+      if (v == 3 && !b->d_imit) return fail(DM_EINVAL, "reward mode 3 needs dm_mocap_set_imitation() before dm_batch_create()");
+      b->B.reward_mode = (int)v; break;
     case DM_OPT_AUTORESET: if (v < 0 || v > 2) return fail(DM_EINVAL, "autoreset must be 0..2"); b->B.autoreset = (int)v; break;
     case DM_OPT_ACTION_MODE: if (v < 0 || v > 2) return fail(DM_EINVAL, "action mode must be 0..2"); b->B.action_mode = (int)v; break;
     case DM_OPT_SEED: b->B.seed = (unsigned long long)v; break;
@@ -332,6 +349,7 @@ static int field_ptr(dm_batch* b, int field, void** p, size_t* bytes) {
     case DM_F_SOLVER_ITER: *p = b->B.solver_iter; *bytes = n * 4; break;
     case DM_F_CTRL: *p = b->B.ctrl; *bytes = n * NU * 8; break;
     case DM_F_EPISODE: *p = b->B.episode; *bytes = n * 4; break;
+    case DM_F_CYCLE: *p = b->B.cycle; *bytes = n * 4; break;
     default: return fail(DM_EINVAL, "unknown field");
   }
   return DM_OK;

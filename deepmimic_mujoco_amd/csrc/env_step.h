@@ -26,8 +26,11 @@ struct Batch {
   int* status;      // [N]
   int* solver_iter; // [N]
   int* episode;     // [N]
+  int* cycle;       // [N] completed motion cycles since the episode started (imitation reward: root advance of the reference)
   const R* mocap_cfg;  // [F,35]
   const R* mocap_vel;  // [F,34]
+  const R* imit_table; // [F,112] reference feature rows of the 5-term imitation reward (nullptr: not provided)
+  R imit_params[32];   // joint weights [12], root weight, cycle shift x y, loop flag, end-effector bodies [4], offsets [4][3]
   int n_frames;
   int n_envs;
   int env_offset;      // global id of env 0 of this shard (multi-GPU: RNG streams do not depend on the sharding)
@@ -176,7 +179,93 @@ DM_DEV void reset_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int
     if (lane == 0) B.time[env] = 0;
   }
   dmw::sync();
-  if (lane == 0) B.episode[env] = ep + 1;
+  if (lane == 0) { B.episode[env] = ep + 1; B.cycle[env] = 0; }
+}
+
+// ---- 5-term imitation reward (code.md:1017-1143; feature layout: deepmimic_mujoco_amd/imitation.py) -----------------------
+// [upstream] cMathUtil::QuatDiffTheta: rotation angle of q1 * conj(q0), normalised to [-pi, pi]
+template <class R>
+DM_DEV R quat_diff_theta(const R* q0, const R* q1) {
+  const R c[4] = {q0[0], -q0[1], -q0[2], -q0[3]};
+  R dq[4];
+  quat_mul(dq, q1, c);
+  const R w = dq[0] > R(1) ? R(1) : (dq[0] < R(-1) ? R(-1) : dq[0]);
+  if (sqrt(fmax(R(0), 1 - w * w)) <= R(1e-6)) return 0;
+  const R th = 2 * acos(w);
+  return th > R(M_PI) ? th - R(2 * M_PI) : th;
+}
+// The simulated state's features are formed from the FK of the INTEGRATED state (one extra kinematics pass; the 4th-stage
+// quantities `is_done` reads have been stored by then) and compared with row `ref` of the reference table.
+// Lanes 0..11: joint groups (pose / velocity terms); lane 12: root; lanes 13..16: end effectors; lanes 0..12 again: body momenta.
+template <class R>
+DM_DEV R imitation_reward(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int lane, const LaneTopo& lt, const R* ref, R shx, R shy) {
+  stage_kinematics(M, s, lane, lt);
+  dmw::sync();
+  const R* P = B.imit_params;
+  R rq[4] = {s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
+  normalize4(rq);
+  R pose = 0, vel = 0, eff = 0, root = 0, mx = 0, my = 0, mz = 0;
+  if (lane < 12) {
+    const int g = lane, b = g + 2, da = TOPO.body_dofadr[b], nd = TOPO.body_dofnum[b];
+    R pe, ve = 0;
+    if (nd == 1) {
+      const R a = ref[13 + 4 * g] - s.qpos[da + 1], w = ref[61 + 3 * g] - s.qvel[da];
+      pe = a * a; ve = w * w;
+    } else {
+      R ql[4] = {1, 0, 0, 0}, wl[3] = {0, 0, 0};
+      for (int k = 0; k < 3; k++) {                       // child = R1 R2 R3;  w = sum_k R1..R(k-1) a_k rate_k
+        const R* ax = M.jnt_axis[da + k - 5];
+        R a[3], qa[4], t[4];
+        quat_rot(a, ql, ax);
+        const R rate = s.qvel[da + k];
+        wl[0] += a[0] * rate; wl[1] += a[1] * rate; wl[2] += a[2] * rate;
+        axisangle2quat(qa, ax, s.qpos[da + k + 1]);
+        quat_mul(t, ql, qa);
+        ql[0] = t[0]; ql[1] = t[1]; ql[2] = t[2]; ql[3] = t[3];
+      }
+      const R th = quat_diff_theta(ql, ref + 13 + 4 * g);
+      pe = th * th;
+      for (int k = 0; k < 3; k++) { const R w = ref[61 + 3 * g + k] - wl[k]; ve += w * w; }
+    }
+    pose = P[g] * pe; vel = P[g] * ve;
+  } else if (lane == 12) {
+    const R th = quat_diff_theta(rq, ref + 3);
+    R wv[3];
+    const R wloc[3] = {s.qvel[3], s.qvel[4], s.qvel[5]};
+    quat_rot(wv, rq, wloc);                               // free-joint angular velocity is body-local
+    R dw2 = 0, dv2 = 0, dp2 = 0;
+    for (int k = 0; k < 3; k++) { const R a = ref[10 + k] - wv[k]; dw2 += a * a; const R c = ref[7 + k] - s.qvel[k]; dv2 += c * c; }
+    const R p1[3] = {ref[0] + shx, ref[1] + shy, ref[2]};
+    for (int k = 0; k < 3; k++) { const R a = s.qpos[k] - p1[k]; dp2 += a * a; }
+    pose = P[12] * th * th; vel = P[12] * dw2;
+    root = dp2 + R(0.1) * th * th + R(0.01) * dv2 + R(0.001) * dw2;
+  } else if (lane < 17) {
+    const int e = lane - 13, b = (int)P[16 + e];
+    const R ex[3] = {1, 0, 0};
+    R fwd[3], p[3], rel[3];
+    quat_rot(fwd, rq, ex);
+    const R hd = atan2(fwd[1], fwd[0]), c = cos(hd), sn = sin(hd);
+    mat_vec(p, s.xmat[b], P + 20 + 3 * e);
+    for (int k = 0; k < 3; k++) { p[k] += s.xpos[b][k]; rel[k] = p[k] - s.qpos[k]; }
+    rel[2] = p[2];                                        // height above the ground plane
+    const R f0[3] = {c * rel[0] + sn * rel[1], -sn * rel[0] + c * rel[1], rel[2]};
+    for (int k = 0; k < 3; k++) { const R a = ref[97 + 3 * e + k] - f0[k]; eff += a * a; }
+  }
+  if (lane < NB - 1) {                                    // linear momentum of body lane + 1: m (v_origin + w x xipos)
+    const int b = lane + 1;
+    const unsigned long long chain = TOPO.chain[b];
+    R cv[6] = {0, 0, 0, 0, 0, 0};
+    for (int d = 0; d < NV; d++) if ((chain >> d) & 1ull) { const R qd = s.qvel[d]; for (int k = 0; k < 6; k++) cv[k] += s.cdof[d][k] * qd; }
+    R wxr[3];
+    cross3(wxr, cv, s.xipos[b]);
+    const R m = M.body_mass[b];
+    mx = m * (cv[3] + wxr[0]); my = m * (cv[4] + wxr[1]); mz = m * (cv[5] + wxr[2]);
+  }
+  pose = dmw::wave_sum(pose); vel = dmw::wave_sum(vel); eff = dmw::wave_sum(eff) / 4; root = dmw::wave_sum(root);
+  mx = dmw::wave_sum(mx) / M.total_mass; my = dmw::wave_sum(my) / M.total_mass; mz = dmw::wave_sum(mz) / M.total_mass;
+  const R dc[3] = {ref[109] - mx, ref[110] - my, ref[111] - mz};
+  const R com = R(0.1) * dot3(dc, dc);
+  return R(0.5) * exp(R(-2) * pose) + R(0.05) * exp(R(-0.1) * vel) + R(0.15) * exp(R(-40) * eff) + R(0.2) * exp(R(-5) * root) + R(0.1) * exp(R(-10) * com);
 }
 
 // DPEnv.step for one environment
@@ -194,7 +283,8 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
   for (int k = 0; k < n_substeps; k++)   // do_simulation(action, n)
     if (!rk4_step<R, ROWS, PROF>(M, s, x, lane, lt, prof)) return false;
   const R z = com_z(M, s);
-  const bool dn = (z < R(0.7)) || (z > R(2.0));
+  bool dn = (z < R(0.7)) || (z > R(2.0));
+  store_derived(B, M, s, env, lane);          // sim.data.* as they stand after sim.step(): 4th-stage quantities
   // reward
   R rew = 1;
   if (B.reward_mode == REW_V3_CONFIG) {          // src/dp_env_v3.py:89-104
@@ -213,8 +303,15 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     rew = exp(R(-2) * err) - R(0.1) * acs;
     dmw::sync();
     if (lane == 0) B.frame_idx[env] = idx;
+  } else if (B.reward_mode == REW_IMITATION) {   // code.md:1017-1143: the state after the step against frame idx + 1
+    int k = dmw::uniform(B.frame_idx[env]) + 1, cyc = dmw::uniform(B.cycle[env]);
+    bool ended = false;
+    if (k >= B.n_frames) { if (B.imit_params[15] != R(0)) { k = 0; cyc += 1; } else { k = B.n_frames - 1; ended = true; } }
+    rew = imitation_reward(M, B, s, lane, lt, B.imit_table + (size_t)k * IMIT_FEAT, cyc * B.imit_params[13], cyc * B.imit_params[14]);
+    dn = dn || ended;                            // a "Loop: none" clip holds its last frame and ends the episode there
+    dmw::sync();
+    if (lane == 0) { B.frame_idx[env] = k; B.cycle[env] = cyc; }
   }
-  store_derived(B, M, s, env, lane);
   if (lane == 0) { B.time[env] += M.timestep * n_substeps; reward[env] = rew; done[env] = dn ? 1 : 0; }
   if (dn && B.autoreset) {                        // DummyVecEnv convention: obs of the fresh episode is returned
     dmw::sync();

@@ -32,7 +32,7 @@ from .mocap import MocapDM
 from .model import CompiledModel
 from .spaces import Box
 
-REWARD_MODES = {"alive": 0, "v3-config": 1, "v2-pose": 2}
+REWARD_MODES = {"alive": 0, "v3-config": 1, "v2-pose": 2, "imitation": 3}
 
 
 def _load_model(xml_path=None):
@@ -244,7 +244,10 @@ class DPVecEnv(object):
     """N DeepMimic humanoids in lock step on one GPU (one wavefront per environment)."""
 
     def __init__(self, num_envs, motion="walk", xml_path=None, device=0, reward="alive", autoreset="rsi", seed=0,
-                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None):
+                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=1):
+        """reward="imitation": the 5-term reward of code.md:1017-1143 (imitation.py) against the frame after the current one.
+        frame_skip: sim steps per env step (src/dp_env_v3.py:108-112 hard-codes 1); "mocap" = floor(mocap_dt / timestep), the
+        commented intent of :107-110, so that one env step spans one mocap frame."""
         self.num_envs = int(num_envs)
         self.mocap = MocapDM()
         self.mocap.load_mocap(motion)
@@ -253,9 +256,18 @@ class DPVecEnv(object):
         self._cm = _load_model(xml_path)
         self.model = _ModelView(self._cm)
         flags = (0 if contacts else A.FLAG_NO_CONTACT) | (0 if limits else A.FLAG_NO_LIMIT)
+        self.frame_skip = max(1, int(float(self.mocap_dt) / float(self._cm.timestep))) if frame_skip == "mocap" else int(frame_skip)
+        imit = None
+        if reward == "imitation":
+            from .imitation import ImitationSpec
+            self.imitation = ImitationSpec(self._cm)
+            imit = (self.imitation.build_table(self.mocap.data_config, self.mocap.data_vel),
+                    self.imitation.params(self.mocap.data_config, self.mocap.loop))
         if batch_factory is None:
             self._batch = Batch(self._cm, self.mocap.data_config, self.mocap.data_vel, self.num_envs, device=device,
-                                flags=flags, mocap_dt=float(self.mocap_dt))
+                                flags=flags, mocap_dt=float(self.mocap_dt), imitation=imit)
+        elif imit is not None:
+            self._batch = batch_factory(self._cm, self.mocap.data_config, self.mocap.data_vel, self.num_envs, flags, imitation=imit)
         else:
             self._batch = batch_factory(self._cm, self.mocap.data_config, self.mocap.data_vel, self.num_envs, flags)
         b = self._batch
@@ -284,7 +296,7 @@ class DPVecEnv(object):
         self._pending = actions
 
     def step_wait(self, out=None):
-        obs, rew, done = self._batch.step(self._pending, 1, out)
+        obs, rew, done = self._batch.step(self._pending, self.frame_skip, out)
         self._pending = None
         return obs, rew, done, [{} for _ in range(self.num_envs)]
 

@@ -111,7 +111,7 @@ def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first
         with torch.no_grad():                                              # (the learner may hold the parameters with requires_grad)
             for t in range(T):
                 pi.act(stochastic, ob64[t], out=ac64[t], vpred_out=vpreds[t])                       # :49
-                env.batch.step(as_buf(ac64[t]), 1, (as_buf(ob64[t + 1]), as_buf(rew64[t]), as_buf(done8[t])))   # :66, one launch
+                env.batch.step(as_buf(ac64[t]), getattr(env, "frame_skip", 1), (as_buf(ob64[t + 1]), as_buf(rew64[t]), as_buf(done8[t])))   # :66, one launch
             vpreds[T] = pi.forward(ob64[T])[1]                             # value of the observation after the segment (:49-52);
         # the action for it is sampled at the top of the next segment, i.e. from the policy as updated in between
         done = done8.to(torch.bool)

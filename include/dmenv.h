@@ -88,6 +88,10 @@ void dm_model_destroy(dm_model* m);
  * src/dp_env_v3.py:93,150-151 — the tables become device-resident. */
 int dm_mocap_create(const double* data_config, const double* data_vel, int32_t n_frames, double dt,
                     dm_mocap** out);
+/* Reference feature rows of the full 5-term imitation reward (code.md:1017-1143 — the reward the reference's notes
+ * specify but dp_env_v3.py:117-128 never computes): table [n_frames, 112] and params [32], both built on the host by
+ * deepmimic_mujoco_amd/imitation.py (row layout documented there).  Call before dm_batch_create; enables reward mode 3. */
+int dm_mocap_set_imitation(dm_mocap* mc, const double* table, int32_t n_cols, const double* params);
 void dm_mocap_destroy(dm_mocap* mc);
 
 /* flags for dm_batch_create */
@@ -103,7 +107,8 @@ int dm_batch_set_stream(dm_batch* b, void* hip_stream); /* default: a stream own
 
 /* options */
 enum {
-  DM_OPT_REWARD_MODE = 1, /* 0 alive=1.0 (dp_env_v3.py:117-128, default), 1 v3-config (:89-104), 2 v2-pose (dp_env_v2.py:116-183) */
+  DM_OPT_REWARD_MODE = 1, /* 0 alive=1.0 (dp_env_v3.py:117-128, default), 1 v3-config (:89-104), 2 v2-pose (dp_env_v2.py:116-183),
+                             3 imitation: pose/velocity/end-effector/root/COM terms of code.md:1017-1143 against frame idx+1 */
   DM_OPT_AUTORESET = 2,   /* 0 off (default), 1 RSI on done, 2 noisy-init on done (DummyVecEnv convention) */
   DM_OPT_ACTION_MODE = 3, /* 0 raw ctrl (dp_env_v3.py:112, default), 1 P-control 0.8*(mocap_cfg - q) + action (env_torque_test.py:20),
                              2 PD kp*(mocap_cfg - q) + kd*(mocap_vel - v) + action (setting_states.py:207-226, gains mocap_util.py:22-24) */
@@ -148,7 +153,8 @@ enum {
   DM_F_STATUS = 12,     /* int32 [N] bit0: constraint rows overflowed DM_MAXROWS, bit1: non-finite state */
   DM_F_SOLVER_ITER = 13,/* int32 [N] PGS sweeps of the last forward evaluation */
   DM_F_CTRL = 14,       /* double [N,28] last (unclamped) ctrl */
-  DM_F_EPISODE = 15     /* int32 [N] episode counter used by the reset RNG */
+  DM_F_EPISODE = 15,    /* int32 [N] episode counter used by the reset RNG */
+  DM_F_CYCLE = 16       /* int32 [N] completed motion cycles since the episode started (reward mode 3) */
 };
 int dm_batch_get(dm_batch* b, int32_t field, void* out, size_t bytes, int32_t ptr_kind);
 int dm_batch_set(dm_batch* b, int32_t field, const void* in, size_t bytes, int32_t ptr_kind);

@@ -21,6 +21,7 @@ def lib():
         L.emu_create.argtypes = [C.POINTER(A.ModelDesc), A._dp, A._dp, C.c_int, C.c_int, C.c_uint]
         L.emu_destroy.argtypes = [C.c_void_p]
         L.emu_set_option.argtypes = [C.c_void_p, C.c_int, C.c_longlong]
+        L.emu_set_imitation.argtypes = [C.c_void_p, A._dp, A._dp]
         L.emu_field.restype = C.c_void_p
         L.emu_field.argtypes = [C.c_void_p, C.c_int]
         L.emu_step.argtypes = [C.c_void_p, A._dp, A._dp, A._dp, C.POINTER(C.c_uint8), C.c_int]
@@ -32,13 +33,16 @@ def lib():
 
 
 class EmuBatch(object):
-    def __init__(self, cm, data_config, data_vel, n_envs, flags=0):
+    def __init__(self, cm, data_config, data_vel, n_envs, flags=0, imitation=None):
         self.n = n_envs
         md, self._keep = A.make_model_desc(cm)
         cfg = np.ascontiguousarray(data_config, dtype=np.float64); vel = np.ascontiguousarray(data_vel, dtype=np.float64)
         self.h = lib().emu_create(C.byref(md), cfg.ctypes.data_as(A._dp), vel.ctypes.data_as(A._dp), cfg.shape[0], n_envs, flags)
         if not self.h:
             raise RuntimeError("emu_create failed")
+        if imitation is not None:
+            tab = np.ascontiguousarray(imitation[0], dtype=np.float64); par = np.ascontiguousarray(imitation[1], dtype=np.float64)
+            lib().emu_set_imitation(self.h, tab.ctypes.data_as(A._dp), par.ctypes.data_as(A._dp))
 
     def __del__(self):
         if getattr(self, "h", None):

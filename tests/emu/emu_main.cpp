@@ -54,9 +54,9 @@ using namespace dm;
 struct EmuBatch {
   DevModel<double> M;
   Batch<double> B;
-  std::vector<double> qpos, qvel, qws, time, ctrl, xipos, comz, cfg, vel, aovf;
+  std::vector<double> qpos, qvel, qws, time, ctrl, xipos, comz, cfg, vel, aovf, imit;
   bool two_tier = true;
-  std::vector<int> fidx, finit, ncon, nefc, cong, status, siter, episode;
+  std::vector<int> fidx, finit, ncon, nefc, cong, status, siter, episode, cycle;
   Shared<double> sh;
   StepScratch<double> xs;
 };
@@ -73,16 +73,22 @@ void* emu_create(const dm_model_desc* d, const double* cfg, const double* vel, i
   e->time.assign(n, 0); e->ctrl.assign((size_t)n * NU, 0); e->xipos.assign((size_t)n * NB * 3, 0); e->comz.assign(n, 0);
   e->cfg.assign(cfg, cfg + (size_t)F * NQ); e->vel.assign(vel, vel + (size_t)F * NV);
   e->fidx.assign(n, 0); e->finit.assign(n, 0); e->ncon.assign(n, 0); e->nefc.assign(n, 0); e->cong.assign((size_t)n * MAXEFC * 2, -1);
-  e->status.assign(n, 0); e->siter.assign(n, 0); e->episode.assign(n, 0); e->aovf.assign((size_t)n * AOVF_COLS * 64, 0);
+  e->status.assign(n, 0); e->siter.assign(n, 0); e->episode.assign(n, 0); e->cycle.assign(n, 0); e->aovf.assign((size_t)n * AOVF_COLS * 64, 0);
   for (int i = 0; i < n; i++) for (int k = 0; k < NQ; k++) e->qpos[(size_t)i * NQ + k] = e->M.qpos0[k];
   Batch<double>& B = e->B;
   B.qpos = e->qpos.data(); B.qvel = e->qvel.data(); B.qws = e->qws.data(); B.time = e->time.data(); B.ctrl = e->ctrl.data();
   B.xipos = e->xipos.data(); B.comz = e->comz.data(); B.frame_idx = e->fidx.data(); B.frame_init = e->finit.data();
   B.ncon = e->ncon.data(); B.nefc = e->nefc.data(); B.cong = e->cong.data(); B.status = e->status.data();
-  B.aovf = e->aovf.data();
+  B.aovf = e->aovf.data(); B.cycle = e->cycle.data(); B.imit_table = nullptr;
   B.solver_iter = e->siter.data(); B.episode = e->episode.data(); B.mocap_cfg = e->cfg.data(); B.mocap_vel = e->vel.data();
   B.n_frames = F; B.n_envs = n; B.env_offset = 0; B.reward_mode = 0; B.autoreset = 0; B.action_mode = 0; B.seed = 0;
   return e;
+}
+void emu_set_imitation(void* h, const double* table, const double* params) {
+  EmuBatch* e = (EmuBatch*)h;
+  e->imit.assign(table, table + (size_t)e->B.n_frames * IMIT_FEAT);
+  e->B.imit_table = e->imit.data();
+  for (int k = 0; k < 32; k++) e->B.imit_params[k] = params[k];
 }
 void emu_destroy(void* h) { delete (EmuBatch*)h; }
 void emu_set_option(void* h, int opt, long long v) {
@@ -103,6 +109,7 @@ void* emu_field(void* h, int field) {
     case DM_F_XIPOS: return e->xipos.data(); case DM_F_COM_Z: return e->comz.data(); case DM_F_NCON: return e->ncon.data();
     case DM_F_NEFC: return e->nefc.data(); case DM_F_CONTACT_GEOMS: return e->cong.data(); case DM_F_STATUS: return e->status.data();
     case DM_F_SOLVER_ITER: return e->siter.data(); case DM_F_CTRL: return e->ctrl.data(); case DM_F_EPISODE: return e->episode.data();
+    case DM_F_CYCLE: return e->cycle.data();
   }
   return nullptr;
 }
@@ -124,7 +131,7 @@ void emu_set_state(void* h, const double* qpos, const double* qvel, const int* f
       load_env(e->M, e->B, e->sh, env, lane, (const double*)0);
       if (lane < NQ) e->sh.qpos[lane] = qpos[(size_t)env * NQ + lane];
       if (lane < NV) e->sh.qvel[lane] = qvel[(size_t)env * NV + lane];
-      if (fidx && lane == 0) { e->B.frame_idx[env] = fidx[env]; e->B.frame_init[env] = fidx[env]; }
+      if (fidx && lane == 0) { e->B.frame_idx[env] = fidx[env]; e->B.frame_init[env] = fidx[env]; e->B.cycle[env] = 0; }
       dmw::sync();
       store_state(e->B, e->sh, env, lane);
       { const LaneTopo lt = lane_topo(lane); stage_tables(e->sh, lane); dmw::sync(); forward(e->M, e->sh, lane, lt, (const DebugOut*)0); }
