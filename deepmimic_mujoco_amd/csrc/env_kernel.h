@@ -45,6 +45,18 @@ constexpr int IMIT_FEAT = 112;   // doubles per reference feature row (deepmimic
 enum { ROW_NONE = 0, ROW_LIMIT = 1, ROW_CONTACT = 2 };
 
 // ---------------------------------------------------------------------------------------------------------
+// everything the collision stage needs to know about one candidate geom pair, in one 96-byte record: lane L always handles
+// pairs L and 64 + L, so its record is fetched with one burst of loads at the top of the stage instead of a chain of
+// dependent per-geom table look-ups (pair -> geom -> type / size / margin / body -> inverse weight: 4 global-load latencies).
+template <class R>
+struct alignas(16) PairRec {
+  int g1, g2;          // geom ids (geom1 = lower geom type)
+  int t1t2;            // type1 | type2 << 8 | condim << 16
+  int meta;            // body1 | body2 << 8 | (staging slot + 1) << 16
+  R margin, mu, bound, tran;   // max margin, max friction, broad-phase bound (incl. margin), invweight(body1) + invweight(body2)
+  R s1[3], s2[3];      // geom sizes
+};
+
 // device-resident constant model (one copy in HBM, L2-resident; uniform reads become scalar loads)
 template <class R>
 struct DevModel {
@@ -59,6 +71,7 @@ struct DevModel {
   int npair;
   short pair_g1[MAXPAIR], pair_g2[MAXPAIR];
   short pair_stage[MAXPAIR];   // LDS staging slot of a pair that can yield > 2 contacts (plane-box 0..3, box-box 4..5), else -1
+  PairRec<R> pair_rec[MAXPAIR];
   R qpos0[NQ];
   R timestep, gravity[3], tolerance, solref[2], solimp[5], meaninertia, total_mass;
   R K, B, pgs_scale;  // constraint stiffness / damping (refsafe applied), 1/(meaninertia*nv)
@@ -365,80 +378,23 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   dmw::sync();
 }
 
-// mass matrix (tree-sparse, MuJoCo qM order) and its L^T D L factor   [MJ mj_crb, mj_factorM]
-template <int K, class R>
-DM_DEV void eliminate_dof(Shared<R>& s, int lane_in) {
-  const int lane = dmw::launder(lane_in);
-  // column K of the elimination: for every ancestor pair (a, c), row i = anc_a(K):
-  //   M(i, anc_c(i)) -= M(K, anc_{a+c}(K)) * M(K, i) / M(K, K)
-  // Row K itself is left unscaled (nothing reads it again during the factorisation); all rows are scaled at the end.
-  constexpr int nk = TOPO.dof_depth[K] - 1;   // proper ancestors
-  constexpr int base = TOPO.madr[K];
-  if (nk > 0) {
-    const R inv = R(1) / s.qLD[base];
-#pragma unroll
-    for (int t0 = 0; t0 < nk * nk; t0 += 64) {
-      const int t = t0 + lane;
-      const int a = t / nk + 1, c = t % nk;
-      if (t < nk * nk && c <= nk - a) {
-        const int dst = s.tab_dst[K][a] + c;
-        s.qLD[dst] -= s.qLD[base + a + c] * (s.qLD[base + a] * inv);
-      }
-    }
-    dmw::sync();
-  }
-}
-template <int K, class R>
-struct EliminateFrom {
-  static DM_DEV void run(Shared<R>& s, int lane) { eliminate_dof<K>(s, lane); EliminateFrom<K - 1, R>::run(s, lane); }
-};
-template <class R>
-struct EliminateFrom<0, R> {
-  static DM_DEV void run(Shared<R>&, int) {}
-};
-
-template <class R>
-DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane_in, const DebugOut* dbg) {
-  const int lane = dmw::launder(lane_in);
-  if (lane < NV) {
-    R f[6];
-    sinert_mul(f, s.ub.i.crb[TOPO.dof_body[lane]], s.cdof[lane]);
-    for (int r = 0; r < 6; r++) s.u.fdof[lane][r] = f[r];
-  }
-  dmw::sync();
-  for (int e = lane; e < TOPO.nM; e += 64) {
-    const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
-    R v = dot6(s.cdof[j], s.u.fdof[i]);
-    if (i == j) v += M.dof_armature[i];
-    s.qLD[e] = v;
-    if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
-  }
-  dmw::sync();
-  EliminateFrom<NV - 1, R>::run(s, lane);      // dofs 33 .. 1, one barrier each (fully unrolled, compile-time shapes)
-  // D^-1, D^-1/2 and the unit-triangular scaling L(k, j) = M(k, j) / D_k, all entries at once
-  if (lane < NV) { const R inv = R(1) / s.qLD[TOPO.madr[lane]]; s.dinv[lane] = inv; s.dsq[lane] = sqrt(inv); }
-  dmw::sync();
-  for (int e = lane; e < TOPO.nM; e += 64) {
-    const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
-    if (i != j) s.qLD[e] *= s.dinv[i];
-  }
-  dmw::sync();
-}
-
 // velocity stage: bias forces C(q, v) incl. gravity; smooth generalized force   [MJ mj_comVel, mj_rne, mj_passive]
-template <class R>
-DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt) {
-  const int lane = dmw::launder(lane_in);
+// Seven phases, each of which only needs an LDS hand-off (a sync) from the one before:
+//   0: world body;  1..4: bodies of tree depth 1..4 (cvel, cacc, cfrc);  5: subtree sums of cfrc;  6: tau per dof.
+// (Measured dead end, kept as structure only: issuing phase P inside elimination step NV-1-P of the L^T D L factorisation,
+//  to overlap the two independent serial chains in one instruction stream, gained nothing — each phase's own dependent LDS
+//  reads are longer than an elimination step and simply lengthened it.)
+template <int P, class R>
+DM_DEV void bias_phase(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) {
   const int b = lane + 1;
   const bool isbody = lane < NB - 1;
-  const int depth = lt.depth;
-  if (lane == 0) {
-    for (int r = 0; r < 6; r++) { s.u.v.cvel[0][r] = 0; s.u.v.cacc[0][r] = 0; }
-    s.u.v.cacc[0][3] = -M.gravity[0]; s.u.v.cacc[0][4] = -M.gravity[1]; s.u.v.cacc[0][5] = -M.gravity[2];
-  }
-  dmw::sync();
-  for (int L = 1; L <= MAXDEPTH_BODY; L++) {
-    if (isbody && depth == L) {
+  if constexpr (P == 0) {
+    if (lane == 0) {
+      for (int r = 0; r < 6; r++) { s.u.v.cvel[0][r] = 0; s.u.v.cacc[0][r] = 0; }
+      s.u.v.cacc[0][3] = -M.gravity[0]; s.u.v.cacc[0][4] = -M.gravity[1]; s.u.v.cacc[0][5] = -M.gravity[2];
+    }
+  } else if constexpr (P <= MAXDEPTH_BODY) {
+    if (isbody && lt.depth == P) {
       const int p = lt.parent, da = lt.dofadr, nd = lt.dofnum;
       R v[6], a[6];
       for (int r = 0; r < 6; r++) { v[r] = s.u.v.cvel[p][r]; a[r] = s.u.v.cacc[p][r]; }
@@ -463,18 +419,88 @@ DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane_in, const La
       sinert_mul(Ia, s.ub.i.sin[b], a); sinert_mul(Iv, s.ub.i.sin[b], v); cross_force(x, v, Iv);
       for (int r = 0; r < 6; r++) s.u.v.cfrc[b][r] = Ia[r] + x[r];
     }
+  } else if constexpr (P == MAXDEPTH_BODY + 1) {
+    if (isbody) {
+      R acc[6] = {0, 0, 0, 0, 0, 0};
+      const unsigned msk = lt.subtree;
+      for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int r = 0; r < 6; r++) acc[r] += s.u.v.cfrc[c][r];
+      for (int r = 0; r < 6; r++) s.u.v.csub[b][r] = acc[r];
+    }
+  } else if constexpr (P == MAXDEPTH_BODY + 2) {
+    if (lane < NV) {
+      const R bias = dot6(s.cdof[lane], s.u.v.csub[TOPO.dof_body[lane]]);
+      s.ua.f.tau[lane] = -M.dof_damping[lane] * s.qvel[lane] - bias + s.act[lane];
+    }
+  }
+}
+constexpr int BIAS_PHASES = MAXDEPTH_BODY + 3;
+template <int P, class R>
+struct BiasFrom {
+  static DM_DEV void run(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) {
+    if constexpr (P < BIAS_PHASES) { bias_phase<P>(M, s, lane, lt); dmw::sync(); BiasFrom<P + 1, R>::run(M, s, lane, lt); }
+  }
+};
+template <class R>
+DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt) {
+  BiasFrom<0, R>::run(M, s, dmw::launder(lane_in), lt);
+}
+
+// mass matrix (tree-sparse, MuJoCo qM order) and its L^T D L factor   [MJ mj_crb, mj_factorM]
+template <int K, class R>
+DM_DEV void eliminate_dof(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt) {
+  const int lane = dmw::launder(lane_in);
+  // column K of the elimination: for every ancestor pair (a, c), row i = anc_a(K):
+  //   M(i, anc_c(i)) -= M(K, anc_{a+c}(K)) * M(K, i) / M(K, K)
+  // Row K itself is left unscaled (nothing reads it again during the factorisation); all rows are scaled at the end.
+  constexpr int nk = TOPO.dof_depth[K] - 1;   // proper ancestors
+  constexpr int base = TOPO.madr[K];
+  if (nk > 0) {
+    const R inv = R(1) / s.qLD[base];
+#pragma unroll
+    for (int t0 = 0; t0 < nk * nk; t0 += 64) {
+      const int t = t0 + lane;
+      const int a = t / nk + 1, c = t % nk;
+      if (t < nk * nk && c <= nk - a) {
+        const int dst = s.tab_dst[K][a] + c;
+        s.qLD[dst] -= s.qLD[base + a + c] * (s.qLD[base + a] * inv);
+      }
+    }
     dmw::sync();
   }
-  if (isbody) {
-    R acc[6] = {0, 0, 0, 0, 0, 0};
-    const unsigned msk = lt.subtree;
-    for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int r = 0; r < 6; r++) acc[r] += s.u.v.cfrc[c][r];
-    for (int r = 0; r < 6; r++) s.u.v.csub[b][r] = acc[r];
+}
+template <int K, class R>
+struct EliminateFrom {
+  static DM_DEV void run(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) { eliminate_dof<K>(M, s, lane, lt); EliminateFrom<K - 1, R>::run(M, s, lane, lt); }
+};
+template <class R>
+struct EliminateFrom<0, R> {
+  static DM_DEV void run(const DevModel<R>&, Shared<R>&, int, const LaneTopo&) {}
+};
+
+template <class R>
+DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt, const DebugOut* dbg) {
+  const int lane = dmw::launder(lane_in);
+  if (lane < NV) {
+    R f[6];
+    sinert_mul(f, s.ub.i.crb[TOPO.dof_body[lane]], s.cdof[lane]);
+    for (int r = 0; r < 6; r++) s.u.fdof[lane][r] = f[r];
   }
   dmw::sync();
-  if (lane < NV) {
-    const R bias = dot6(s.cdof[lane], s.u.v.csub[TOPO.dof_body[lane]]);
-    s.ua.f.tau[lane] = -M.dof_damping[lane] * s.qvel[lane] - bias + s.act[lane];
+  for (int e = lane; e < TOPO.nM; e += 64) {
+    const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
+    R v = dot6(s.cdof[j], s.u.fdof[i]);
+    if (i == j) v += M.dof_armature[i];
+    s.qLD[e] = v;
+    if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
+  }
+  dmw::sync();
+  EliminateFrom<NV - 1, R>::run(M, s, lane, lt);      // dofs 33 .. 1, one barrier each (fully unrolled, compile-time shapes)
+  // D^-1, D^-1/2 and the unit-triangular scaling L(k, j) = M(k, j) / D_k, all entries at once
+  if (lane < NV) { const R inv = R(1) / s.qLD[TOPO.madr[lane]]; s.dinv[lane] = inv; s.dsq[lane] = sqrt(inv); }
+  dmw::sync();
+  for (int e = lane; e < TOPO.nM; e += 64) {
+    const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
+    if (i != j) s.qLD[e] *= s.dinv[i];
   }
   dmw::sync();
 }
@@ -628,15 +654,13 @@ DM_DEV void box_box(Shared<R>& s, const R* p1, const R* m1, const R* s1, const R
 }
 
 template <class R>
-DM_DEV void narrowphase(const DevModel<R>& M, Shared<R>& s, int g1, int g2, int stage_slot, R margin, PairContacts<R>& pc) {
+DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s1, const R* s2, int stage_slot, R margin, PairContacts<R>& pc) {
   pc.n = 0; pc.boxslot = -1;
   pc.hint[0] = pc.hint[1] = pc.hint[2] = 0;
   pc.nrm[0] = pc.nrm[1] = 0; pc.nrm[2] = 1;
   pc.d0 = pc.d1 = 0; pc.p0[0] = pc.p0[1] = pc.p0[2] = 0; pc.p1[0] = pc.p1[1] = pc.p1[2] = 0;
-  const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
   const R* p1 = s.ub.g.gpos[g1]; const R* p2 = s.ub.g.gpos[g2];
   const R* m1 = s.ub.g.gmat[g1]; const R* m2 = s.ub.g.gmat[g2];
-  const R* s1 = M.geom_size[g1]; const R* s2 = M.geom_size[g2];
   if (t1 == GEOM_PLANE) {
     const R n[3] = {m1[2], m1[5], m1[8]};
     pc.nrm[0] = n[0]; pc.nrm[1] = n[1]; pc.nrm[2] = n[2];
@@ -727,29 +751,28 @@ DM_DEV void narrowphase(const DevModel<R>& M, Shared<R>& s, int g1, int g2, int 
     return;
   }
   if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) {
-    // closest point of the capsule segment to the box by a fixed 48-step golden-section search on the convex point-box
-    // distance, then one sphere-box contact there (own algorithm, identical to the oracle's; MuJoCo's mjc_CapsuleBox is a
-    // case analysis that is not restated)
+    // closest point of the capsule segment to the box, then one sphere-box contact there (own algorithm, identical to the
+    // oracle's; MuJoCo's mjc_CapsuleBox is a case analysis that is not restated).  In the box frame the squared distance of
+    // c0 + t u to the box is convex and piecewise quadratic in t: its half-derivative g(t) = sum_k u_k (p_k - clamp(p_k)) is
+    // piecewise linear, non-decreasing, with breakpoints where a coordinate crosses a face plane.  The zero of g is bracketed
+    // between consecutive breakpoints inside [-L, L] and interpolated: exact up to rounding, no iteration (an earlier
+    // 48-step golden-section search cost ~7 k cycles whenever a leg came near the other foot).
     const R ax[3] = {m1[2], m1[5], m1[8]};
     R t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, c0[3], u[3];
     matT_vec(c0, m2, t); matT_vec(u, m2, ax);
-    R lo = -s1[1], hi = s1[1];
-    const R gr = R(0.6180339887498949);
-    auto d2 = [&](R tt) { R acc = 0; for (int k = 0; k < 3; k++) { const R pk = c0[k] + tt * u[k]; const R ck = clampr(pk, -s2[k], s2[k]); acc += (pk - ck) * (pk - ck); } return acc; };
-    R x1 = hi - gr * (hi - lo), x2 = lo + gr * (hi - lo), f1 = d2(x1), f2 = d2(x2);
-    for (int it = 0; it < 48; it++) {
-      if (f1 <= f2) { hi = x2; x2 = x1; f2 = f1; x1 = hi - gr * (hi - lo); f1 = d2(x1); }
-      else { lo = x1; x1 = x2; f1 = f2; x2 = lo + gr * (hi - lo); f2 = d2(x2); }
-    }
-    R ts = R(0.5) * (lo + hi);
-    {  // closed-form refinement with the clamping pattern the search found (the search alone is only sqrt(eps)-accurate)
-      R num = 0, den = 0;
-      for (int k = 0; k < 3; k++) {
-        const R pk = c0[k] + ts * u[k];
-        if (pk > s2[k]) { num += u[k] * (c0[k] - s2[k]); den += u[k] * u[k]; }
-        else if (pk < -s2[k]) { num += u[k] * (c0[k] + s2[k]); den += u[k] * u[k]; }
+    auto gfun = [&](R tt) { R acc = 0; for (int k = 0; k < 3; k++) { const R pk = c0[k] + tt * u[k]; acc += u[k] * (pk - clampr(pk, -s2[k], s2[k])); } return acc; };
+    R ta = -s1[1], tb = s1[1], ga = gfun(ta), gb = gfun(tb), ts;
+    if (ga >= 0) ts = ta;
+    else if (gb <= 0) ts = tb;
+    else {
+      for (int k = 0; k < 3; k++) for (int sg = 0; sg < 2; sg++) {
+        if (fabs(u[k]) <= R(1e-12)) continue;
+        const R tc = ((sg ? s2[k] : -s2[k]) - c0[k]) / u[k];
+        if (!(tc > ta && tc < tb)) continue;
+        const R gc = gfun(tc);
+        if (gc <= 0) { ta = tc; ga = gc; } else { tb = tc; gb = gc; }
       }
-      if (den > R(1e-12)) ts = clampr(-num / den, -s1[1], s1[1]);
+      ts = (gb - ga > R(1e-300)) ? ta - ga * (tb - ta) / (gb - ga) : R(0.5) * (ta + tb);
     }
     R center[3], clamped[3], nrm[3], pl[3];
     for (int k = 0; k < 3; k++) { center[k] = c0[k] + ts * u[k]; clamped[k] = clampr(center[k], -s2[k], s2[k]); t[k] = center[k] - clamped[k]; }
@@ -799,6 +822,12 @@ template <class R, int ROWS>
 DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
   const int lane = dmw::launder(lane_in);
   int nrow = 0;
+  // this lane's two candidate pairs: issued here, consumed after the geom poses and the limit rows are done
+  const int npair = dmw::uniform(M.npair);
+  // (scalars, not a struct copy: the narrow phase indexes the sizes dynamically, which would pin a local struct in scratch)
+  int pr = lane < npair ? lane : 0;
+  int r_g1 = M.pair_rec[pr].g1, r_g2 = M.pair_rec[pr].g2, r_tt = M.pair_rec[pr].t1t2, r_meta = M.pair_rec[pr].meta;
+  R r_margin = M.pair_rec[pr].margin, r_mu = M.pair_rec[pr].mu, r_bound = M.pair_rec[pr].bound, r_tran = M.pair_rec[pr].tran;
   if (M.enable_contact) {   // (the inertia region these poses overwrite is dead by now)
     // geom world poses
     if (lane < NG) {
@@ -833,34 +862,31 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
   // ---- contacts: lanes over candidate pairs, two passes of 64
   int ncon = 0, firstdrop = 1 << 20;
   if (M.enable_contact) {
-    const int npair = dmw::uniform(M.npair);
     for (int pass = 0; pass * 64 < npair; pass++) {
+      if (pass > 0) {
+        pr = pass * 64 + lane < npair ? pass * 64 + lane : 0;
+        r_g1 = M.pair_rec[pr].g1; r_g2 = M.pair_rec[pr].g2; r_tt = M.pair_rec[pr].t1t2; r_meta = M.pair_rec[pr].meta;
+        r_margin = M.pair_rec[pr].margin; r_mu = M.pair_rec[pr].mu; r_bound = M.pair_rec[pr].bound; r_tran = M.pair_rec[pr].tran;
+      }
       const int pidx = pass * 64 + lane;
       PairContacts<R> pc;
       pc.n = 0; pc.boxslot = -1;
       bool cand = false;
-      int g1 = 0, g2 = 0, dim = 1;
-      R margin = 0, mu = 0;
+      const int g1 = r_g1, g2 = r_g2, t1 = r_tt & 0xff, t2 = (r_tt >> 8) & 0xff, dim = (r_tt >> 16) & 0xff;
+      const R margin = r_margin, mu = r_mu;
       if (pidx < npair) {
-        g1 = M.pair_g1[pidx]; g2 = M.pair_g2[pidx];
-        margin = fmax(M.geom_margin[g1], M.geom_margin[g2]);
         // bounding-sphere rejection (conservative; [MJ mj_collideGeoms] does the same before the narrow phase)
-        bool maybe = true;
-        if (M.geom_type[g1] == GEOM_PLANE) {
+        if (t1 == GEOM_PLANE) {
           const R* m1 = s.ub.g.gmat[g1];
           const R dz = (s.ub.g.gpos[g2][0] - s.ub.g.gpos[g1][0]) * m1[2] + (s.ub.g.gpos[g2][1] - s.ub.g.gpos[g1][1]) * m1[5] + (s.ub.g.gpos[g2][2] - s.ub.g.gpos[g1][2]) * m1[8];
-          maybe = dz <= M.geom_rbound[g2] + margin;
+          cand = dz <= r_bound;
         } else {
           const R d[3] = {s.ub.g.gpos[g2][0] - s.ub.g.gpos[g1][0], s.ub.g.gpos[g2][1] - s.ub.g.gpos[g1][1], s.ub.g.gpos[g2][2] - s.ub.g.gpos[g1][2]};
-          const R bound = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
-          maybe = dot3(d, d) <= bound * bound;
+          cand = dot3(d, d) <= r_bound * r_bound;
         }
-        cand = maybe;
-        dim = M.geom_condim[g1] > M.geom_condim[g2] ? M.geom_condim[g1] : M.geom_condim[g2];
-        mu = fmax(M.geom_mu[g1], M.geom_mu[g2]);
       }
       if (dmw::ballot(cand) == 0ull) continue;        // nothing near anything in this pass (the common case for body-body pairs)
-      if (cand) narrowphase(M, s, g1, g2, M.pair_stage[pidx], margin, pc);
+      if (cand) narrowphase(s, g1, g2, t1, t2, M.pair_rec[pr].s1, M.pair_rec[pr].s2, ((r_meta >> 16) & 0xff) - 1, margin, pc);
       if (dmw::ballot(pc.n > 0) == 0ull) continue;
       const int rows_per = dim == 1 ? 1 : 2 * (dim - 1);
       int tot_rows, tot_con;
@@ -869,8 +895,8 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
       if (pc.n > 0) {
         R fr[9];
         make_frame(fr, pc.nrm, pc.hint);
-        const int b1 = M.geom_body[g1], b2 = M.geom_body[g2];
-        const R tran = M.body_invw[b1] + M.body_invw[b2];
+        const int b1 = r_meta & 0xff, b2 = (r_meta >> 8) & 0xff;
+        const R tran = r_tran;
         for (int k = 0; k < pc.n; k++) {
           R cdist, cpos[3];
           if (pc.boxslot >= 0) { const R* o = s.boxc[pc.boxslot][k]; cdist = o[0]; cpos[0] = o[1]; cpos[1] = o[2]; cpos[2] = o[3]; }
@@ -902,9 +928,11 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
     }
   }
   // first dropped row index over the wave (min), if any
-  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 32)); firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 16));
-  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 8));  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 4));
-  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 2));  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 1));
+  if (dmw::ballot(firstdrop < (1 << 20)) != 0ull) {      // only when some contact did not fit (six cross-lane round trips otherwise wasted)
+    firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 32)); firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 16));
+    firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 8));  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 4));
+    firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 2));  firstdrop = imin(firstdrop, dmw::shfl_xor_i(firstdrop, 1));
+  }
   int status = 0;
   if (firstdrop < nrow) { status = 1; nrow = firstdrop; }
   if (lane == 0) { s.nefc = nrow; s.ncon = ncon; s.status |= status; }
@@ -1317,7 +1345,7 @@ DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo
   if (PROF) { t1 = dmw::clk(); prof[0] += t1 - t0; t0 = t1; }
   if (dbg) { for (int e = lane; e < NV * NV; e += 64) dbg->out[e] = 0; dmw::sync(); }
   DM_MARK("mass_factor");
-  stage_mass_matrix(M, s, lane, dbg);
+  stage_mass_matrix(M, s, lane, lt, dbg);
   if (PROF) { t1 = dmw::clk(); prof[1] += t1 - t0; t0 = t1; }
   DM_MARK("bias");
   stage_bias(M, s, lane, lt);

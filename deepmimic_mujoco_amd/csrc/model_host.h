@@ -77,6 +77,19 @@ inline int build_dev_model(const dm_model_desc* d, DevModel<double>* hp, std::st
       }
     }
   }
+  for (int p = 0; p < d->npair; p++) {
+    const int a = h.pair_g1[p], b = h.pair_g2[p];
+    auto& r = h.pair_rec[p];
+    r.g1 = a; r.g2 = b;
+    const int dim = h.geom_condim[a] > h.geom_condim[b] ? h.geom_condim[a] : h.geom_condim[b];
+    r.t1t2 = h.geom_type[a] | (h.geom_type[b] << 8) | (dim << 16);
+    r.meta = h.geom_body[a] | (h.geom_body[b] << 8) | ((h.pair_stage[p] + 1) << 16);
+    r.margin = std::fmax(h.geom_margin[a], h.geom_margin[b]);
+    r.mu = std::fmax(h.geom_mu[a], h.geom_mu[b]);
+    r.bound = (h.geom_type[a] == GEOM_PLANE ? 0.0 : h.geom_rbound[a]) + h.geom_rbound[b] + r.margin;
+    r.tran = h.body_invw[h.geom_body[a]] + h.body_invw[h.geom_body[b]];
+    for (int k = 0; k < 3; k++) { r.s1[k] = h.geom_size[a][k]; r.s2[k] = h.geom_size[b][k]; }
+  }
   h.qpos0[0] = d->body_pos[3]; h.qpos0[1] = d->body_pos[4]; h.qpos0[2] = d->body_pos[5]; h.qpos0[3] = 1;
   h.timestep = d->timestep; h.tolerance = d->tolerance; h.meaninertia = d->meaninertia; h.iterations = d->iterations;
   for (int k = 0; k < 3; k++) h.gravity[k] = d->gravity[k];

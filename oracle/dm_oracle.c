@@ -697,32 +697,31 @@ static int narrowphase(const dmo_model* m, const dmo_data* d, int g1, int g2, do
   }
   if (t1 == DMO_GEOM_CAPSULE && t2 == DMO_GEOM_BOX) {
     /* OWN ALGORITHM (MuJoCo's mjc_CapsuleBox is a long case analysis that is not restated): the point of the capsule
-     * segment closest to the box is found by a fixed 48-step golden-section search on the (convex) point-box distance,
-     * and one sphere-box contact [MJ mjc_SphereBox] is generated there.  The HIP kernel runs the identical search. */
+     * segment closest to the box, then one sphere-box contact [MJ mjc_SphereBox] there.  In the box frame the squared
+     * distance of c0 + t u to the box is convex and piecewise quadratic in t; its half-derivative
+     *     g(t) = sum_k u_k (p_k - clamp(p_k, -s_k, s_k))
+     * is piecewise linear and non-decreasing, with breakpoints where a coordinate crosses a face plane (at most 6).  The
+     * zero of g is bracketed between consecutive breakpoints inside [-L, L] and found by linear interpolation — exact up to
+     * rounding, no iteration.  The HIP kernel runs the identical sequence of operations. */
     double ax[3] = {m1[2], m1[5], m1[8]}, t[3], c0[3], u[3];
     sub3(t, p1, p2); matT_vec(c0, m2, t); matT_vec(u, m2, ax);
-    double lo = -s1[1], hi = s1[1];
-    const double gr = 0.6180339887498949;
-    double x1 = hi - gr * (hi - lo), x2 = lo + gr * (hi - lo), f1, f2;
-#define SEGBOX_D2(tt, out) do { double d2_ = 0; for (int k_ = 0; k_ < 3; k_++) { double pk_ = c0[k_] + (tt) * u[k_]; \
-      double ck_ = clampd(pk_, -s2[k_], s2[k_]); d2_ += (pk_ - ck_) * (pk_ - ck_); } (out) = d2_; } while (0)
-    SEGBOX_D2(x1, f1); SEGBOX_D2(x2, f2);
-    for (int it = 0; it < 48; it++) {
-      if (f1 <= f2) { hi = x2; x2 = x1; f2 = f1; x1 = hi - gr * (hi - lo); SEGBOX_D2(x1, f1); }
-      else { lo = x1; x1 = x2; f1 = f2; x2 = lo + gr * (hi - lo); SEGBOX_D2(x2, f2); }
-    }
-#undef SEGBOX_D2
-    double ts = 0.5 * (lo + hi), center[3], clamped[3], nrm[3], pl[3];
-    { /* the search locates the minimiser only to ~sqrt(eps); with the clamping pattern it found, the distance is an exact
-       * quadratic in t: one closed-form refinement makes the result reproducible to rounding */
-      double num = 0, den = 0;
-      for (int k = 0; k < 3; k++) {
-        double pk = c0[k] + ts * u[k];
-        if (pk > s2[k]) { num += u[k] * (c0[k] - s2[k]); den += u[k] * u[k]; }
-        else if (pk < -s2[k]) { num += u[k] * (c0[k] + s2[k]); den += u[k] * u[k]; }
+#define SEGBOX_G(tt, out) do { double g_ = 0; for (int k_ = 0; k_ < 3; k_++) { double pk_ = c0[k_] + (tt) * u[k_]; \
+      g_ += u[k_] * (pk_ - clampd(pk_, -s2[k_], s2[k_])); } (out) = g_; } while (0)
+    double ta = -s1[1], tb = s1[1], ga, gb, ts, center[3], clamped[3], nrm[3], pl[3];
+    SEGBOX_G(ta, ga); SEGBOX_G(tb, gb);
+    if (ga >= 0) ts = ta;
+    else if (gb <= 0) ts = tb;
+    else {
+      for (int k = 0; k < 3; k++) for (int sg = 0; sg < 2; sg++) {
+        if (fabs(u[k]) <= 1e-12) continue;
+        double tc = ((sg ? s2[k] : -s2[k]) - c0[k]) / u[k], gc;
+        if (!(tc > ta && tc < tb)) continue;
+        SEGBOX_G(tc, gc);
+        if (gc <= 0) { ta = tc; ga = gc; } else { tb = tc; gb = gc; }
       }
-      if (den > 1e-12) ts = clampd(-num / den, -s1[1], s1[1]);
+      ts = (gb - ga > 1e-300) ? ta - ga * (tb - ta) / (gb - ga) : 0.5 * (ta + tb);
     }
+#undef SEGBOX_G
     for (int k = 0; k < 3; k++) { center[k] = c0[k] + ts * u[k]; clamped[k] = clampd(center[k], -s2[k], s2[k]); t[k] = center[k] - clamped[k]; }
     double dist = norm3(t);
     if (dist - s1[0] > margin) return 0;

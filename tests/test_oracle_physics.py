@@ -218,3 +218,33 @@ def test_box_box_stack_rests_and_overhang_is_clipped():
     assert len(pos) == 4 and np.all(np.abs(pos[:, 0]) <= 0.3 + 1e-6) and np.all(np.abs(pos[:, 1]) <= 0.2 + 1e-6)
     fr = d.get("contact_frame").reshape(-1, 9)[4:]
     assert np.allclose(fr[:, :3], [0, 0, 1], atol=1e-4)             # normal from geom1 (lower box) to geom2 (upper box)
+
+
+def test_capsule_box_closest_point_is_exact_against_dense_sampling():
+    from tests import helpers as H
+    """The capsule-box narrow phase brackets the zero of the piecewise-linear distance derivative between face-crossing
+    breakpoints (own algorithm, shared with the kernel): its contact distance must equal the brute-force minimum of the
+    segment-to-box distance minus the capsule radius."""
+    from oracle import oracle as O
+    cm = H.compiled_model()
+    om = H.oracle_model(); d = O.Data(om)
+    qs = np.load(H.GOLDEN + "/capsule_box_poses.npy")
+    checked = 0
+    for q in qs:
+        d.reset(); d.set_state(q, np.zeros(34))
+        geoms = d.get("contact_geom").reshape(-1, 2).astype(int); dist = d.get("contact_dist")
+        xpos, xmat, _xi, _a, _b, _c = cm.kinematics(q)
+        for (g1, g2), dd in zip(geoms, dist):
+            if cm.geom_type[g1] != 3 or cm.geom_type[g2] != 6:          # capsule (3) vs box (6)
+                continue
+            b1, b2 = cm.geom_bodyid[g1], cm.geom_bodyid[g2]
+            p1 = xpos[b1] + xmat[b1] @ cm.geom_pos[g1]; m1 = xmat[b1] @ cm.geom_mat[g1]
+            p2 = xpos[b2] + xmat[b2] @ cm.geom_pos[g2]; m2 = xmat[b2] @ cm.geom_mat[g2]
+            ts = np.linspace(-cm.geom_size[g1][1], cm.geom_size[g1][1], 200001)
+            pts = (p1[None, :] + ts[:, None] * m1[:, 2][None, :] - p2[None, :]) @ m2          # box frame
+            ex = np.abs(pts) - cm.geom_size[g2][None, :]
+            dmin = np.sqrt((np.maximum(ex, 0) ** 2).sum(1)).min()
+            if dmin > 1e-9:                                              # (axis through the box: penetration branch, not a distance)
+                assert abs((dmin - cm.geom_size[g1][0]) - dd) < 1e-9, (g1, g2, dmin - cm.geom_size[g1][0], dd)
+                checked += 1
+    assert checked >= 3
