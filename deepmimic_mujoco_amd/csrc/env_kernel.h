@@ -1229,6 +1229,17 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     if (cost > 0) { f = 0; res = bb; }
   }
   // ---- projected Gauss-Seidel, rows in order; one broadcast + one FMA per row, no memory ------------------------
+  // Row i only ever needs lane i's force, and lane i's force only changes at row i, so a sweep leaves f alone: each row costs
+  // the serial chain (candidate -> delta -> broadcast -> residual update) plus one select that records the residual lane i
+  // saw at its own row; forces and cost changes follow once per sweep, lane-wise, from exactly the operands the row-by-row
+  // form would have used.
+  // [MJ costChange] rejects an update that would raise the dual cost by more than 1e-10.  In exact arithmetic the
+  // one-dimensional step never raises it, so the sweeps run without the test; if any row of any sweep did trip it
+  // (`anybad`), the whole solve is redone from the warm-start state with the in-place guarded update (cold path below) —
+  // results are identical to testing every row in place.
+  // The termination test of sweep k (a 6-stage cross-lane reduction + compare) is independent of the rows of sweep k + 1,
+  // so sweep k + 1 is issued speculatively right behind the reduction and dropped if sweep k turns out to have converged:
+  // one discarded sweep per solve buys the reduction latency off the serial chain of every sweep.
   int iter = 0;
   const int maxiter = dmw::uniform(M.iterations);
   // loop constants pinned in VGPRs: left to itself the compiler re-loads them from memory (s_load + wait) every sweep
@@ -1236,24 +1247,15 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   dmw::pin_value(pgs_scale); dmw::pin_value(pgs_tol);
   R pgs_detect = M.pgs_detect;
   dmw::pin_value(pgs_detect);
-  while (iter < maxiter) {
-    R myimp = 0;
+  const R f_ws = f, res_ws = res;
+  bool anybad = false;
+  auto sweep = [&](R& myimp) {
     // fresh opaque copies per sweep: otherwise the 64 row-exists tests and 64 lane==row masks are hoisted out of the
     // sweep loop as 128 SGPR pairs, spilled to VGPR lanes and read back with v_readlane on every row
     const int ne = dmw::launder_uniform(nefc);
     const int ln = dmw::launder(lane);
-    // [MJ costChange] rejects an update that would raise the dual cost by more than 1e-10.  In exact arithmetic the
-    // one-dimensional step never raises it, so the sweep runs speculatively with the test OFF the serial dependency
-    // chain (res -> f' -> delta -> broadcast -> res); if any row did trip it, the sweep is replayed from its starting
-    // state with the guarded update below — results are identical to testing every row in place.
-    // Row i only ever needs lane i's force, and lane i's force only changes at row i, so the sweep leaves f alone: each
-    // row costs the serial chain (candidate -> delta -> broadcast -> residual update) plus one select that records the
-    // residual lane i saw at its own row; forces, cost changes and the costChange test follow once per sweep, lane-wise,
-    // from exactly the operands the row-by-row form would have used.
-    const R f0 = f, res0 = res;
+    const R f0 = f;
     R rsave = res;
-    long long ps0 = 0, ps1 = 0;
-    if (PROF) ps0 = dmw::clk();
     SweepGroup<0, ROWS, R>::run(AR, res, rsave, f0, dinvr, ln, ne);
     if (ROWS < MAXEFC && ne > ROWS) for (int i = ROWS; i < ne; i++) {      // overflow rows: same update, column of A from memory
       const R a = ((const R*)(&s.aovf)[dmw::pin_zero()])[i * 64 + ln];
@@ -1262,38 +1264,52 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       if (ln == i) rsave = res;
       res += a * di;
     }
-    if (PROF) { ps1 = dmw::clk(); prof[14] += ps1 - ps0; }
-    bool bad = false;
+    myimp = 0;
     if (ln < ne) {
       const R fn = pgs_candidate(f0, rsave, dinvr);
       const R delta = fn - f0;
       const R change = delta * (R(0.5) * delta * diag + rsave);
-      f = fn; myimp = -change; bad = change > pgs_detect;
+      f = fn; myimp = -change; anybad = anybad || (change > pgs_detect);
     }
-    if (dmw::ballot(bad) != 0) {
-      // guarded replay (cold): the register columns are parked in the env's memory strip so that one compact loop can
-      // walk all rows with a run-time index
-      R* const strip = (&s.aovf)[dmw::pin_zero()];
+  };
+  if (maxiter > 0) {
+    R myimp;
+    sweep(myimp);
+    iter = 1;
+    while (iter < maxiter) {
+      const R fprev = f, rprev = res;
+      const R improvement = dmw::wave_sum(active ? myimp : R(0)) * pgs_scale;     // of sweep `iter`
+      R myimp_next;
+      sweep(myimp_next);                                                          // sweep iter + 1, speculative
+      if (dmw::uniform(improvement < pgs_tol)) { f = fprev; res = rprev; break; }
+      myimp = myimp_next;
+      iter++;
+    }
+  }
+  if (dmw::ballot(anybad) != 0) {
+    // guarded re-solve (cold): the register columns are parked in the env's memory strip so that one compact loop can walk
+    // all rows with a run-time index
+    R* const strip = (&s.aovf)[dmw::pin_zero()];
 #pragma unroll
-      for (int i = 0; i < ROWS; i++) strip[i * 64 + ln] = AR[i];
-      f = f0; res = res0; myimp = 0;
-      for (int i = 0; i < ne; i++) {
-        const R a = strip[i * 64 + ln];
+    for (int i = 0; i < ROWS; i++) strip[i * 64 + lane] = AR[i];
+    f = f_ws; res = res_ws; iter = 0;
+    while (iter < maxiter) {
+      R myimp = 0;
+      for (int i = 0; i < nefc; i++) {
+        const R a = strip[i * 64 + lane];
         const R fn = fmax(f - res * dinvr, R(0));
         R delta = fn - f;
         const R change = delta * (R(0.5) * delta * diag + res);
         const bool rej = change > R(1e-10);          // never accept an increase
         if (rej) delta = 0;
         const R di = dmw::bcast(delta, i);
-        if (ln == i && !rej) { f = fn; myimp -= change; }
+        if (lane == i && !rej) { f = fn; myimp -= change; }
         res += a * di;
       }
+      const R improvement = dmw::wave_sum(active ? myimp : R(0)) * pgs_scale;
+      iter++;
+      if (dmw::uniform(improvement < pgs_tol)) break;
     }
-    const R improvement = dmw::wave_sum(active ? myimp : R(0)) * pgs_scale;
-    iter++;
-    const bool converged = dmw::uniform(improvement < pgs_tol);
-    if (PROF) prof[15] += dmw::clk() - ps1;
-    if (converged) break;
   }
   DM_STAMP(12)
   if (dbg && active) {

@@ -28,7 +28,7 @@ for wl in ("cfg3", "cfg2"):
         print("   %-16s %10.0f  (%.1f%%)" % (nme, v, 100 * v / acc[5]))
     print("   mean nefc(last eval) %.2f  mean PGS sweeps %.2f" % (np.mean(nefc), np.mean(its)))
     p = env.batch.read_profile()
-    sub = ["smooth solve", "J rows", "imp + half-solve", "A build", "warm start + PGS", "force assembly + back-solve", "  PGS rows", "  PGS sweep epilogue"]
+    sub = ["smooth solve", "J rows", "imp + half-solve", "A build", "warm start + PGS", "force assembly + back-solve"]
     for k, nme in enumerate(sub):  # slots 8..15
         print("      constraint/%-28s %9.0f" % (nme, p[:, 8 + k].mean()))
     for lo, hi in [(0, 1), (1, 8), (8, 16), (16, 32), (32, 64)]:
