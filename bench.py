@@ -55,7 +55,13 @@ def cpu_baseline(clip, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s and steps >= 4:
             break
-    return {"value": round(n * steps / el, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+    # the same C loop on ONE core (a scalar port's honest per-core figure), ~2 s
+    n1 = 4
+    t1 = time.perf_counter(); s1 = 0
+    while time.perf_counter() - t1 < 2.0:
+        O.batch_step(om, ds[:n1], rng.randn(n1, 28) * 0.9, 1, 1); s1 += 1
+    one_core = n1 * s1 / (time.perf_counter() - t1)
+    return {"value": round(n * steps / el, 1), "unit": "env-steps/s", "cores": cores, "kind": "port", "single_core_value": round(one_core, 1),
             "sample": "%d envs x %d steps of the same workload (walk, contacts+limits, N(0,0.9^2) actions, RSI reset on done), "
                       "oracle/dm_oracle.c fp64 with OpenMP over envs, %.1f s" % (n, steps, el)}
 
@@ -196,7 +202,8 @@ def main():
                          "kernel": "k_step_narrow", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                          "note": "latency/ALU-bound path: see fp64 fraction",
                          "fp64_est_tflops": round(ALGO_FLOP_PER_STEP * n / (kernel_ms * 1e-3) / 1e12, 3),
-                         "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS},
+                         "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                         "fp64_frac": round(ALGO_FLOP_PER_STEP * n / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, 4)},
         }
         tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if full and os.path.exists(tp):   # PMC HBM bytes per launch of this kernel/workload, measured by tools/collect_profile.sh (separate rocprofv3 passes)

@@ -248,3 +248,109 @@ def test_capsule_box_closest_point_is_exact_against_dense_sampling():
                 assert abs((dmin - cm.geom_size[g1][0]) - dd) < 1e-9, (g1, g2, dmin - cm.geom_size[g1][0], dd)
                 checked += 1
     assert checked >= 3
+
+
+def _free_flight_humanoid(seed=0, damping=False):
+    s = O.humanoid_spec()
+    if not damping:
+        for j in range(s.njnt):
+            s.jnt_damping[j] = 0.0
+    m = O.Model(s); m.set("enable_contact", 0); m.set("enable_limit", 0)
+    d = O.Data(m)
+    rng = np.random.RandomState(seed)
+    q = m.get("qpos0"); q[7:] = rng.uniform(-0.5, 0.5, 28); q[3:7] = rng.randn(4); q[3:7] /= np.linalg.norm(q[3:7])
+    d.set("qpos", q); d.set("qvel", rng.randn(34)); d.forward()
+    return m, d
+
+
+def _momenta(cm, m, d):
+    """Linear momentum and angular momentum about the world origin, from the host model's Jacobians (independent code path)."""
+    q, v = d.get("qpos"), d.get("qvel")
+    xpos, xmat, xipos, axes, anchors, is_rot = cm.kinematics(q)
+    p = np.zeros(3); L = np.zeros(3)
+    for b in range(1, cm.nbody):
+        jp, jr = cm.body_jacobian(b, xipos[b], axes, anchors, is_rot)
+        vc, w = jp @ v, jr @ v
+        Iw = xmat[b] @ cm.body_inertia[b] @ xmat[b].T
+        p += cm.body_mass[b] * vc
+        L += np.cross(xipos[b], cm.body_mass[b] * vc) + Iw @ w
+    return p, L
+
+
+def test_momentum_conservation_in_free_flight():
+    """No contacts, no limits, no gravity, no actuation: linear and angular momentum are invariants of the continuous
+    system (joint damping is internal).  The integrator keeps them up to its truncation error: small at the model's step and
+    shrinking with the step."""
+    from tests import helpers as H
+    cm = H.compiled_model()
+    errs = []
+    for h, n in ((0.0166, 30), (0.0083, 60)):
+        m, d = _free_flight_humanoid(seed=4, damping=True)
+        m.set("gravity_z", 0.0); m.set("timestep", h)
+        d.forward()
+        p0, L0 = _momenta(cm, m, d)
+        for _ in range(n):
+            d.step()
+        p1, L1 = _momenta(cm, m, d)
+        errs.append((np.abs(p1 - p0).max() / np.abs(p0).max(), np.abs(L1 - L0).max() / np.abs(L0).max()))
+    assert errs[0][0] < 5e-5 and errs[0][1] < 5e-5
+    # (the free joint's orientation update holds the angular velocity fixed within a stage, as MuJoCo's mj_integratePos does:
+    #  second order in the rotation, so halving h cuts the drift by ~4)
+    assert errs[1][0] < errs[0][0] / 3 and errs[1][1] < errs[0][1] / 3
+
+
+def test_mass_matrix_is_spd_and_agrees_with_jacobian_sum():
+    from tests import helpers as H
+    cm = H.compiled_model()
+    m, d = _free_flight_humanoid(seed=5)
+    M = d.get("M").reshape(34, 34)
+    assert np.abs(M - M.T).max() < 1e-13 and np.linalg.eigvalsh(M).min() > 1e-3
+    Mh = cm.mass_matrix(d.get("qpos"))                                    # sum_b m Jp^T Jp + Jr^T I Jr (+ armature): other formulation
+    assert np.abs(M - Mh).max() < 1e-11 * np.abs(M).max()
+    # the factorisation the oracle solves with reproduces M^-1: M qacc_smooth == applied smooth force
+    f = d.get("qfrc_passive") + d.get("qfrc_actuator") - d.get("qfrc_bias")
+    assert np.abs(M @ d.get("qacc_smooth") - f).max() < 1e-10 * max(1.0, np.abs(f).max())
+
+
+def test_bias_force_matches_finite_difference_lagrangian():
+    """RNE(q, v, 0) = C(q, v) v + g(q).  Energy bookkeeping gives an independent check: d/dt (1/2 v^T M v) = v^T (tau - g) for
+    any applied tau when C is right (v^T (Mdot - 2C) v = 0), i.e. power balance over one tiny step."""
+    m, d = _free_flight_humanoid(seed=6)
+    m.set("timestep", 1e-5)
+    d.forward()
+    e0 = energy(m, d)
+    for _ in range(10):
+        d.step()
+    d.forward()
+    assert abs(energy(m, d) - e0) < 1e-9 * abs(e0)                        # conservative system: any error in C or g shows up at O(h)
+    # gravity part alone: at rest the bias equals the gradient of the potential energy (central differences over the hinges)
+    m2, d2 = _free_flight_humanoid(seed=7)
+    q = d2.get("qpos"); d2.set("qvel", np.zeros(34)); d2.forward()
+    g = d2.get("qfrc_bias")
+    mass = m2.get("body_mass")
+    eps = 1e-6
+    for k in (7, 12, 20, 27, 34):
+        def pot(qq):
+            d2.set("qpos", qq); d2.forward()
+            return 9.81 * (mass * d2.get("xipos").reshape(-1, 3)[:, 2]).sum()
+        qp, qm = q.copy(), q.copy(); qp[k] += eps; qm[k] -= eps
+        assert abs((pot(qp) - pot(qm)) / (2 * eps) - g[k - 1]) < 1e-6 * max(1.0, abs(g[k - 1]))
+
+
+def test_forward_inverse_dynamics_round_trip():
+    """qacc from the forward pass, pushed back through M qacc + bias - passive - actuator - constraint, must vanish —
+    with active limits and contacts included (qfrc_constraint = J^T f)."""
+    from tests import helpers as H
+    om = H.oracle_model(); d = O.Data(om)
+    idx, q, v, ws, ctrl = H.varied_states(8, seed=9)
+    for e in range(8):
+        d.set("qacc_warmstart", ws[e]); d.set("ctrl", ctrl[e]); d.set_state(q[e], v[e])
+        M = d.get("M").reshape(34, 34)
+        resid = M @ d.get("qacc") + d.get("qfrc_bias") - d.get("qfrc_passive") - d.get("qfrc_actuator") - d.get("qfrc_constraint")
+        scale = max(1.0, np.abs(d.get("qfrc_bias")).max(), np.abs(d.get("qfrc_constraint")).max())
+        assert np.abs(resid).max() < 1e-9 * scale
+        n = int(d.get("nefc")[0])
+        if n:
+            J = d.get("efc_J").reshape(n, 34)
+            assert np.abs(J.T @ d.get("efc_force") - d.get("qfrc_constraint")).max() < 1e-10 * scale
+            assert d.get("efc_force").min() >= 0.0                        # unilateral rows (limits, pyramid edges)
