@@ -26,6 +26,7 @@ struct Batch {
   int* status;      // [N]
   int* solver_iter; // [N]
   int* episode;     // [N]
+  int* order;       // [N] dispatch order: workgroup w steps env order[w] (nullptr: identity) — costly envs first shortens the tail
   int* cycle;       // [N] completed motion cycles since the episode started (imitation reward: root advance of the reference)
   const R* mocap_cfg;  // [F,35]
   const R* mocap_vel;  // [F,34]

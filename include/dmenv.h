@@ -114,6 +114,12 @@ enum {
                              2 PD kp*(mocap_cfg - q) + kd*(mocap_vel - v) + action (setting_states.py:207-226, gains mocap_util.py:22-24) */
   DM_OPT_SEED = 4
 };
+/* further option ids (diagnostics / tests; defaults are what the timed path uses):
+ *   100 global id of env 0 of this batch (multi-GPU sharding: RNG streams are keyed by the global env id)
+ *   101 per-stage shader-clock profile (k_step_prof + dm_batch_read_profile)
+ *   102 1: register tier of 32 columns of A + memory strip (default); 0: all 64 columns in registers (k_step)
+ *   103 1: force the guarded PGS re-solve path (results must not change)
+ *   104 1: longest-first dispatch order, recomputed every step from the previous step's row counts (default); 0: identity */
 int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t value);
 
 /* Replaces: MujocoEnv.set_state(qpos, qvel) = sim.set_state(...) + sim.forward() (src/dp_env_v3.py:153,160):

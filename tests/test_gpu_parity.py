@@ -266,3 +266,22 @@ def test_pgs_guarded_replay_path_gives_identical_results():
         outs.append((np.stack(o), b.get(A.F_SOLVER_ITER).copy(), b.get(A.F_QACC_WARMSTART).copy()))
         b.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_dispatch_order_does_not_change_results():
+    """Longest-first dispatch (k_order, option 104) only changes which workgroup steps which env: outputs must be bit-identical."""
+    n = 4096 + 37                                                      # > resident waves, so the reordering is active
+    outs = []
+    for on in (1, 0):
+        b = make_batch(n)
+        b.set_option(104, on); b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, 3)
+        b.reset(0, 1)
+        rng = np.random.RandomState(0)
+        o = None
+        for t in range(6):
+            o, r, d = b.step(rng.randn(n, 28) * 0.9)
+        outs.append((o.copy(), r.copy(), d.copy(), b.get(A.F_QPOS), b.get(A.F_NEFC)))
+        b.close()
+    for x, y in zip(outs[0], outs[1]):
+        assert np.array_equal(x, y)
+    assert outs[0][4].max() > 8                                        # contacts are present, so the order is not the identity
