@@ -1009,7 +1009,7 @@ template <class R> struct RowStep<NV, R> { static DM_DEV void run(R*, RowAcc<R>&
 // the next chunk is loaded while the current one is multiplied (order pins: see solve_LT above).
 template <class R>
 DM_DEV R row_dot(const R* y, const R* q) {
-  R acc = 0;
+  R acc0 = 0, acc1 = 0;      // two partial sums (even / odd chunks): halves the dependent-FMA chain of the 34-term dot product
   R qa[6], qb[6];
   { const int zc = dmw::pin_zero();
 #pragma unroll
@@ -1021,17 +1021,17 @@ DM_DEV R row_dot(const R* y, const R* q) {
       for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) qb[d] = q[c0 + 6 + d + zc]; }
     dmw::sched_fence();
 #pragma unroll
-    for (int d = 0; d < 6; d++) if (c0 + d < NV) acc += y[c0 + d] * qa[d];
-    dmw::pin_value(acc);
+    for (int d = 0; d < 6; d++) if (c0 + d < NV) acc0 += y[c0 + d] * qa[d];
+    dmw::pin_value(acc0);
     { const int zc = dmw::pin_zero();
 #pragma unroll
       for (int d = 0; d < 6; d++) if (c0 + 12 + d < NV) qa[d] = q[c0 + 12 + d + zc]; }
     dmw::sched_fence();
 #pragma unroll
-    for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) acc += y[c0 + 6 + d] * qb[d];
-    dmw::pin_value(acc);
+    for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) acc1 += y[c0 + 6 + d] * qb[d];
+    dmw::pin_value(acc1);
   }
-  return acc;
+  return acc0 + acc1;
 }
 
 // PGS candidate force of one row: f' = max(f - r / A_ii, 0)   [MJ mj_solPGS, scalar row]
@@ -1198,9 +1198,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
         for (int ii = 0; ii < 16; ii++) {
           const int i = c * 16 + ii;
           if (i < ROWS || i >= nefc) continue;
-          R acc = 0;
-#pragma unroll
-          for (int d = 0; d < NV; d++) acc += y[d] * s.u.ybuf[ii][d];
+          R acc = row_dot(y, s.u.ybuf[ii]);        // same arithmetic as the register columns
           if (lane == i) { acc += Rr; diag = acc; }
           aov[i * 64 + lane] = acc;
         }
