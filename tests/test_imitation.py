@@ -195,3 +195,22 @@ def test_imitation_vec_env_and_frame_skip_on_gpu():
     with pytest.raises(Exception):
         DPVecEnv(4, motion="walk", device=0, reward="alive").batch.set_option(A.OPT_REWARD_MODE, 3)   # no table provided
     env.close()
+
+
+def test_reference_tables_for_every_clip():
+    """All 15 clips of the reference (src/mujoco/motions/*.txt): finite feature tables, reward exactly 1 on each frame of the
+    clip itself, loop mode and cycle advance taken from the clip, frame_skip = floor(mocap_dt / timestep) >= 1."""
+    from deepmimic_mujoco_amd.mocap import ALL_CLIPS, MocapDM
+    sp = _spec()
+    loops = set()
+    for clip in ALL_CLIPS:
+        mc = MocapDM(); mc.load_mocap(clip)
+        T = sp.build_table(mc.data_config, mc.data_vel)
+        P = sp.params(mc.data_config, mc.loop)
+        assert T.shape == (len(mc.data_config), FEAT) and np.isfinite(T).all() and np.isfinite(P).all()
+        for k in (0, len(T) // 2, len(T) - 1):
+            assert abs(sp.reward(sp.features(mc.data_config[k], mc.data_vel[k]), T[k]) - 1) < 1e-12
+        assert P[15] == (1.0 if mc.loop == "wrap" else 0.0)
+        assert max(1, int(float(mc.dt) / 0.0166)) >= 1
+        loops.add(mc.loop)
+    assert loops == {"wrap", "none"}
