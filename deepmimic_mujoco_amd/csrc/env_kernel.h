@@ -118,12 +118,19 @@ struct Shared {
 struct LaneTopo {
   int parent, dofadr, dofnum, depth;
   unsigned subtree;
+  int tri0, tri1;    // (e << 8) | a of the lower-triangular pair number t = lane, lane + 64:  t = e (e - 1) / 2 + (a - 1),  1 <= a <= e
 };
+DM_DEV int tri_pair(int t) {   // once per kernel per lane (the elimination steps index their rank-1 updates with it)
+  int e = 1;
+  while (e * (e + 1) / 2 <= t) e++;
+  return (e << 8) | (t - e * (e - 1) / 2 + 1);
+}
 DM_DEV LaneTopo lane_topo(int lane) {
   LaneTopo t;
   const int b = lane < NB - 1 ? lane + 1 : 0;
   t.parent = TOPO.body_parent[b]; t.dofadr = TOPO.body_dofadr[b]; t.dofnum = TOPO.body_dofnum[b];
   t.depth = lane < NB - 1 ? TOPO.body_depth[b] : 0; t.subtree = TOPO.subtree[b];
+  t.tri0 = tri_pair(lane); t.tri1 = tri_pair(lane + 64);
   return t;
 }
 template <class R>
@@ -456,13 +463,18 @@ DM_DEV void eliminate_dof(const DevModel<R>& M, Shared<R>& s, int lane_in, const
   constexpr int base = TOPO.madr[K];
   if (nk > 0) {
     const R inv = R(1) / s.qLD[base];
+    // the update pairs (a, e = a + c), 1 <= a <= e <= nk, are the lower triangle of an nk x nk matrix; enumerated by
+    // t = e (e - 1) / 2 + a - 1 the first nk (nk + 1) / 2 numbers are exactly this step's pairs, whatever nk is, so each lane
+    // keeps its two (e, a) codes for the whole kernel (LaneTopo) and a step needs no index arithmetic beyond an unpack
+    constexpr int npairs = nk * (nk + 1) / 2;
+    static_assert(npairs <= 128, "two passes of 64 lanes cover every step of this tree");
 #pragma unroll
-    for (int t0 = 0; t0 < nk * nk; t0 += 64) {
-      const int t = t0 + lane;
-      const int a = t / nk + 1, c = t % nk;
-      if (t < nk * nk && c <= nk - a) {
-        const int dst = s.tab_dst[K][a] + c;
-        s.qLD[dst] -= s.qLD[base + a + c] * (s.qLD[base + a] * inv);
+    for (int p = 0; p * 64 < npairs; p++) {
+      const int code = p == 0 ? lt.tri0 : lt.tri1;
+      const int e = code >> 8, a = code & 0xff;
+      if (p * 64 + lane < npairs) {
+        const int dst = s.tab_dst[K][a] + (e - a);
+        s.qLD[dst] -= s.qLD[base + e] * (s.qLD[base + a] * inv);
       }
     }
     dmw::sync();
