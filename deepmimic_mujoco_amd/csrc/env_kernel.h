@@ -276,6 +276,38 @@ template <class R> DM_DEV void solve_L(R* x, const R* qLD) {
   SolveLStep<1, R>::run(x, qLD, cur);
 }
 
+// ---- subtree sums, lane-parallel over (body, component) ------------------------------------------------------------------
+// out[b][k] = sum over the bodies c of b's subtree of in[c][k].  One lane per body would make the root's lane walk all 13
+// bodies x NC components while the others idle; instead a lane owns one (body, component) pair — W lanes per body, 64 / W
+// bodies per pass — and a pass only visits the bodies that occur in the subtrees of ITS bodies (compile-time union).
+template <int NC, int W, int PASS>
+constexpr unsigned subtree_union() {
+  unsigned u = 0;
+  for (int g = 0; g < 64 / W; g++) { const int b = 1 + PASS * (64 / W) + g; if (b < NB) u |= TOPO.subtree[b]; }
+  return u;
+}
+template <int NC, int W, int PASS, int C, class R>
+struct SubtreeAcc {
+  static DM_DEV void run(R& acc, unsigned msk, const R (*in)[NC], int k) {
+    if constexpr (C < NB) {
+      if constexpr ((subtree_union<NC, W, PASS>() >> C) & 1u) acc += ((msk >> C) & 1u) ? in[C][k] : R(0);
+      SubtreeAcc<NC, W, PASS, C + 1, R>::run(acc, msk, in, k);
+    }
+  }
+};
+template <int NC, int W, int PASS, class R>
+DM_DEV void subtree_sums_pass(const R (*in)[NC], R (*out)[NC], int lane) {
+  if constexpr (1 + PASS * (64 / W) < NB) {
+    const int b = 1 + PASS * (64 / W) + lane / W, k = lane % W;       // W is a power of two
+    if (b < NB && k < NC) {
+      R acc = 0;
+      SubtreeAcc<NC, W, PASS, 1, R>::run(acc, TOPO.subtree[b], in, k);
+      out[b][k] = acc;
+    }
+    subtree_sums_pass<NC, W, PASS + 1, R>(in, out, lane);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // position stage: kinematics, motion axes, spatial inertias   [MJ mj_kinematics, mj_comPos]
 // Only the composition of a body's frame with its parent's is serial in the tree depth, so the work is split:
@@ -375,13 +407,7 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   }
   dmw::sync();
   // 4. composite inertias: sum over the (static) subtree   [MJ mj_crb backward pass]
-  if (isbody) {
-    R acc[10];
-    for (int k = 0; k < 10; k++) acc[k] = 0;
-    const unsigned msk = lt.subtree;
-    for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int k = 0; k < 10; k++) acc[k] += s.ub.i.sin[c][k];
-    for (int k = 0; k < 10; k++) s.ub.i.crb[b][k] = acc[k];
-  }
+  subtree_sums_pass<10, 16, 0, R>(s.ub.i.sin, s.ub.i.crb, lane);
   dmw::sync();
 }
 
@@ -427,12 +453,7 @@ DM_DEV void bias_phase(const DevModel<R>& M, Shared<R>& s, int lane, const LaneT
       for (int r = 0; r < 6; r++) s.u.v.cfrc[b][r] = Ia[r] + x[r];
     }
   } else if constexpr (P == MAXDEPTH_BODY + 1) {
-    if (isbody) {
-      R acc[6] = {0, 0, 0, 0, 0, 0};
-      const unsigned msk = lt.subtree;
-      for (int c = 1; c < NB; c++) if ((msk >> c) & 1u) for (int r = 0; r < 6; r++) acc[r] += s.u.v.cfrc[c][r];
-      for (int r = 0; r < 6; r++) s.u.v.csub[b][r] = acc[r];
-    }
+    subtree_sums_pass<6, 8, 0, R>(s.u.v.cfrc, s.u.v.csub, lane);
   } else if constexpr (P == MAXDEPTH_BODY + 2) {
     if (lane < NV) {
       const R bias = dot6(s.cdof[lane], s.u.v.csub[TOPO.dof_body[lane]]);
@@ -496,12 +517,13 @@ DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane_in, c
     R f[6];
     sinert_mul(f, s.ub.i.crb[TOPO.dof_body[lane]], s.cdof[lane]);
     for (int r = 0; r < 6; r++) s.u.fdof[lane][r] = f[r];
-  }
+    s.dinv[lane] = M.dof_armature[lane];     // staged once (coalesced) — s.dinv is dead until the end of the factorisation;
+  }                                          // a per-entry `M.dof_armature[i]` would be a divergent global load in every pass
   dmw::sync();
   for (int e = lane; e < TOPO.nM; e += 64) {
     const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
     R v = dot6(s.cdof[j], s.u.fdof[i]);
-    if (i == j) v += M.dof_armature[i];
+    if (i == j) v += s.dinv[i];
     s.qLD[e] = v;
     if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
   }
