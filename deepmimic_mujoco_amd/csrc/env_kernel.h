@@ -785,8 +785,8 @@ DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s
     return;
   }
   if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) {
-    // closest point of the capsule segment to the box, then one sphere-box contact there (own algorithm, identical to the
-    // oracle's; MuJoCo's mjc_CapsuleBox is a case analysis that is not restated).  In the box frame the squared distance of
+    // closest point of the capsule segment to the box, then one sphere-box contact there (own algorithm, shared with the CPU oracle;
+    // MuJoCo's mjc_CapsuleBox is a case analysis that is not restated).  In the box frame the squared distance of
     // c0 + t u to the box is convex and piecewise quadratic in t: its half-derivative g(t) = sum_k u_k (p_k - clamp(p_k)) is
     // piecewise linear, non-decreasing, with breakpoints where a coordinate crosses a face plane.  The zero of g is bracketed
     // between consecutive breakpoints inside [-L, L] and interpolated: exact up to rounding, no iteration (an earlier
