@@ -7,7 +7,8 @@ Workload (config.workload): BASELINE.json configs[2] — 'walk' clip, 4096 envs 
 solve (PGS 50), imitation reward `v3-config`, RSI auto-reset on done, actions ~ N(0, 0.9^2) i.i.d. (pre-generated on
 the device).  One "step" = one `dm_batch_step` launch = one DPEnv.step (one RK4 mj_step, h = 0.0166 s) of every env
 of the rank.  With N > 1 the env index range is sharded over ranks (weak scaling, no per-step collective) and every
-256 steps the [256, 4096, 87] f32 rollout block is all-gathered over RCCL, as the learner would consume it.
+256 steps the [256, 4096, 87] f32 rollout block is all-gathered over RCCL, as the learner would consume it — asynchronously,
+double-buffered, so the envs keep stepping while the block travels; every gather completes inside the timed region.
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -151,20 +152,32 @@ def main():
         obs = torch.empty((n, A.NOBS), dtype=torch.float64, device=dev)
         rew = torch.empty(n, dtype=torch.float64, device=dev)
         done = torch.empty(n, dtype=torch.uint8, device=dev)
-        block = torch.zeros((HORIZON, n, 87), dtype=torch.float32, device=dev)   # obs 56 + act 28 + rew + done + vpred
-        gathered = torch.empty((world * HORIZON, n, 87), dtype=torch.float32, device=dev) if world > 1 else None
+        # rollout blocks (obs 56 + act 28 + rew + done + vpred), double-buffered: while one 256-step block is all-gathered over
+        # RCCL (async, on the collective's own stream) the envs keep stepping into the other one
+        blocks = [torch.zeros((HORIZON, n, 87), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+        gathered = [torch.empty((world * HORIZON, n, 87), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+        pending = [None, None]
         env.reset("rsi")
 
         def one_step(t):
             a = actions[t % pool]
             env.batch.step(a, 1, (obs, rew, done))
-            row = block[t % HORIZON]
+            k = (t // HORIZON) % len(blocks)
+            if world > 1 and t % HORIZON == 0 and pending[k] is not None:
+                pending[k].wait(); pending[k] = None                       # this buffer's previous gather must be done before it is overwritten
+            row = blocks[k][t % HORIZON]
             row[:, :56] = obs; row[:, 56:84] = a; row[:, 84] = rew; row[:, 85] = done
             if world > 1 and (t + 1) % HORIZON == 0:
-                dist.all_gather_into_tensor(gathered, block)
+                pending[k] = dist.all_gather_into_tensor(gathered[k], blocks[k], async_op=True)
+
+        def drain():
+            for k in range(2):
+                if pending[k] is not None:
+                    pending[k].wait(); pending[k] = None
 
         for t in range(args.warmup):
             one_step(t)
+        drain()
         stream.synchronize()
         if world > 1:
             dist.barrier()
@@ -175,6 +188,7 @@ def main():
         ev0.record(stream)
         for t in range(args.steps):
             one_step(t)
+        drain()                                                            # outstanding gathers finish inside the timed region
         ev1.record(stream)
         stream.synchronize()
         torch.cuda.synchronize()
