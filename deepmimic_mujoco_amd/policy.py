@@ -36,9 +36,13 @@ class RunningMeanStd:
         self._refresh()
 
     def _refresh(self):
-        self.mean = (self.sum / self.count).to(torch.float32)
-        var = (self.sumsq / self.count).to(torch.float32) - self.mean * self.mean
-        self.std = torch.sqrt(torch.clamp(var, min=1e-2))
+        mean = (self.sum / self.count).to(torch.float32)
+        var = (self.sumsq / self.count).to(torch.float32) - mean * mean
+        std = torch.sqrt(torch.clamp(var, min=1e-2))
+        if getattr(self, "mean", None) is not None and self.mean.shape == mean.shape and self.mean.device == mean.device:
+            self.mean.copy_(mean); self.std.copy_(std)       # in place: a captured graph of the policy keeps reading these buffers
+        else:
+            self.mean, self.std = mean, std
 
     def update(self, x, group=None):
         x = x.reshape(-1, *self.shape).to(torch.float64)
