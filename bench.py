@@ -154,26 +154,18 @@ def main():
         done = torch.empty(n, dtype=torch.uint8, device=dev)
         # rollout blocks (obs 56 + act 28 + rew + done + vpred), double-buffered: while one 256-step block is all-gathered over
         # RCCL (async, on the collective's own stream) the envs keep stepping into the other one
-        blocks = [torch.zeros((HORIZON, n, 87), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
-        gathered = [torch.empty((world * HORIZON, n, 87), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
-        pending = [None, None]
+        from deepmimic_mujoco_amd.rollout import DoubleBufferedGather
+        dbg = DoubleBufferedGather(HORIZON, n, device=dev, world=world)
         env.reset("rsi")
 
         def one_step(t):
             a = actions[t % pool]
             env.batch.step(a, 1, (obs, rew, done))
-            k = (t // HORIZON) % len(blocks)
-            if world > 1 and t % HORIZON == 0 and pending[k] is not None:
-                pending[k].wait(); pending[k] = None                       # this buffer's previous gather must be done before it is overwritten
-            row = blocks[k][t % HORIZON]
+            row = dbg.row(t)
             row[:, :56] = obs; row[:, 56:84] = a; row[:, 84] = rew; row[:, 85] = done
-            if world > 1 and (t + 1) % HORIZON == 0:
-                pending[k] = dist.all_gather_into_tensor(gathered[k], blocks[k], async_op=True)
+            dbg.commit(t)
 
-        def drain():
-            for k in range(2):
-                if pending[k] is not None:
-                    pending[k].wait(); pending[k] = None
+        drain = dbg.drain
 
         for t in range(args.warmup):
             one_step(t)

@@ -159,3 +159,46 @@ def flatten_segment(seg):
             v = seg[k]
             out[k] = v.transpose(0, 1).reshape((-1,) + tuple(v.shape[2:]))
     return out
+
+
+class DoubleBufferedGather:
+    """Per-horizon all-gather of the rollout block, overlapped with stepping: two [T, n, 87] blocks per rank; while block k
+    travels (async all-gather on the collective's own stream) the envs fill block 1 - k.  `row(t)` returns the row to fill at
+    step t (first making sure that this block's previous gather has finished), `commit(t)` launches the gather when step t
+    completes a horizon, `drain()` waits for everything outstanding.  Single-process runs degenerate to one local block."""
+
+    def __init__(self, horizon, n_local, device="cpu", world=None):
+        import torch
+        import torch.distributed as dist
+        if world is None:
+            world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.T, self.n, self.world = int(horizon), int(n_local), int(world)
+        nb = 2 if self.world > 1 else 1
+        self.blocks = [torch.zeros((self.T, self.n, ROW), dtype=torch.float32, device=device) for _ in range(nb)]
+        self.gathered = [torch.empty((self.world * self.T, self.n, ROW), dtype=torch.float32, device=device) for _ in range(nb)] if self.world > 1 else None
+        self.pending = [None] * nb
+        self.completed = 0                      # gathers launched so far
+
+    def _k(self, t):
+        return (t // self.T) % len(self.blocks)
+
+    def row(self, t):
+        k = self._k(t)
+        if t % self.T == 0 and self.pending[k] is not None:
+            self.pending[k].wait(); self.pending[k] = None
+        return self.blocks[k][t % self.T]
+
+    def commit(self, t):
+        """Call after step t's row has been written.  Returns the index of the gathered buffer when a gather was launched."""
+        if self.world > 1 and (t + 1) % self.T == 0:
+            import torch.distributed as dist
+            k = self._k(t)
+            self.pending[k] = dist.all_gather_into_tensor(self.gathered[k], self.blocks[k], async_op=True)
+            self.completed += 1
+            return k
+        return None
+
+    def drain(self):
+        for k in range(len(self.pending)):
+            if self.pending[k] is not None:
+                self.pending[k].wait(); self.pending[k] = None

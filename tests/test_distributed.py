@@ -94,3 +94,46 @@ def test_trpo_replicas_stay_in_sync_world2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_trpo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(str(tmp_path / "theta.pt"))
+
+
+def _dbg_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deepmimic_mujoco_amd.rollout import DoubleBufferedGather
+        T, n = 4, 3
+        g = DoubleBufferedGather(T, n)
+        assert len(g.blocks) == 2 and g.gathered[0].shape == (world * T, n, ROW)
+        seen = []
+        for t in range(5 * T):                                   # five horizons: every buffer is reused at least twice
+            row = g.row(t)
+            row[:] = float(1000 * rank + t)                      # rank- and step-dependent content
+            k = g.commit(t)
+            if k is not None:
+                seen.append((t, k))
+        g.drain()
+        assert [k for _t, k in seen] == [0, 1, 0, 1, 0] and g.completed == 5
+        # the last two horizons are still intact in the two gathered buffers: every rank's rows, in rank order
+        for h, k in ((4, 0), (3, 1)):
+            out = g.gathered[k].view(world, T, n, ROW)
+            for r in range(world):
+                for i in range(T):
+                    assert torch.all(out[r, i] == float(1000 * r + h * T + i)), (h, k, r, i)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_double_buffered_gather_world2_gloo():
+    port = _free_port()
+    mp.spawn(_dbg_worker, args=(2, port), nprocs=2, join=True)
+
+
+def test_double_buffered_gather_single_process():
+    from deepmimic_mujoco_amd.rollout import DoubleBufferedGather
+    g = DoubleBufferedGather(4, 2, world=1)
+    for t in range(9):
+        g.row(t)[:] = t
+        assert g.commit(t) is None
+    g.drain()
+    assert len(g.blocks) == 1 and float(g.blocks[0][0, 0, 0]) == 8.0
