@@ -193,7 +193,8 @@ template <class R> DM_DEV void matT_vec(R* r, const R* m, const R* v) {
 }
 template <class R> DM_DEV void quat_rot(R* r, const R* q, const R* v) { R m[9]; quat2mat(m, q); mat_vec(r, m, v); }
 template <class R> DM_DEV void axisangle2quat(R* q, const R* axis, R angle) {
-  R s = sin(angle * R(0.5)), c = cos(angle * R(0.5));
+  R s, c;
+  sincos(angle * R(0.5), &s, &c);      // one range reduction for both
   q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
 DM_DEV int imin(int a, int b) { return a < b ? a : b; }
@@ -330,7 +331,9 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   // 1a. half-angle sine / cosine of every hinge, one lane per hinge (one sincos evaluation deep instead of three)
   if (lane < NU) {
     const R half = (s.qpos[lane + 7] - M.qpos0[lane + 7]) * R(0.5);
-    s.u.fdof[lane][0] = cos(half); s.u.fdof[lane][1] = sin(half);     // (u.fdof is free until the mass-matrix stage)
+    R sh, ch;
+    sincos(half, &sh, &ch);                                           // one range reduction for both
+    s.u.fdof[lane][0] = ch; s.u.fdof[lane][1] = sh;                   // (u.fdof is free until the mass-matrix stage)
   }
   dmw::sync();
   // 1b. local hinge chain (bodies 2..13)
