@@ -282,11 +282,13 @@ class TrpoLearner:
 
 
 def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max_seconds=0, callback=None, log=print,
-          group=None, **learner_kwargs):
+          group=None, log_dir=None, **learner_kwargs):
     """`learn()` of src/trpo.py:97-319 over a DPVecEnv (autoreset="init") and an MlpPolicy.  Stops after `max_iters`
     iterations, `max_timesteps` env steps (global) or `max_seconds`.  Returns the list of per-iteration stat dicts, with
     the reference's log keys (EpLenMean / EpRewMean over the last 40 episodes, EpThisIter, EpisodesSoFar, TimestepsSoFar,
-    TimeElapsed, entropy, meankl, optimgain, surrgain, ev_tdlam_before)."""
+    TimeElapsed, entropy, meankl, optimgain, surrgain, ev_tdlam_before).  With `log_dir`, rank 0 also writes the reference's
+    files there: `progress.csv` (logger CSV, src/logger.py:101-135) and `monitor.json.monitor.csv` (bench.Monitor, one row per
+    finished episode of rank 0's envs) — readable by the reference's plot_curve.py / load_results."""
     import torch.distributed as dist
     assert sum([max_iters > 0, max_timesteps > 0, max_seconds > 0]) >= 1
     learner = TrpoLearner(pi, group=group, **learner_kwargs)
@@ -297,6 +299,13 @@ def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max
     tstart = time.time()
     lenbuffer, rewbuffer = deque(maxlen=40), deque(maxlen=40)
     history = []
+    progress = monitor = None
+    if log_dir and rank == 0:
+        import os
+        from .logio import ProgressCsv, MonitorWriter
+        os.makedirs(log_dir, exist_ok=True)
+        progress = ProgressCsv(os.path.join(log_dir, "progress.csv"))
+        monitor = MonitorWriter(os.path.join(log_dir, "monitor.json"), t_start=tstart)
     while True:
         if callback:
             callback(locals(), globals())
@@ -319,8 +328,14 @@ def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max
                      EpLenMeanIter=float(n_eps[1] / max(1.0, float(n_eps[0]))), EpThisIter=int(n_eps[0]), EpisodesSoFar=episodes_so_far,
                      TimestepsSoFar=timesteps_so_far, TimeElapsed=time.time() - tstart, iteration=iters_so_far)
         history.append(stats)
+        if progress is not None:
+            progress.writekvs({k: stats.get(k) for k in ("EpRewMean", "EpThisIter", "TimestepsSoFar", "EpisodesSoFar", "surrgain", "optimgain",
+                                                        "TimeElapsed", "meankl", "entloss", "ev_tdlam_before", "entropy", "EpLenMean")})
+            monitor.write_episodes(rets, lens)
         if log and rank == 0:
             log("iter %4d  steps %10d  eps %7d  EpLenMean %7.1f  (this iter %7.1f)  entropy %6.2f  meankl %.4f  surrgain %+.4f  ev %.3f  %.1fs"
                 % (iters_so_far, timesteps_so_far, stats["EpThisIter"], stats["EpLenMean"], stats["EpLenMeanIter"], stats.get("entropy", float("nan")),
                    stats.get("meankl", float("nan")), stats.get("surrgain", float("nan")), stats["ev_tdlam_before"], stats["TimeElapsed"]))
+    if progress is not None:
+        progress.close(); monitor.close()
     return history

@@ -128,10 +128,16 @@ class _ToyVecEnv:
         return out
 
 
-def test_learn_improves_return_on_a_scripted_env():
+def test_learn_improves_return_on_a_scripted_env(tmp_path):
     torch.manual_seed(0)
     pi = MlpPolicy(seed=7); pi.seed(7)
-    hist = learn(_ToyVecEnv(256, 1), pi, timesteps_per_batch=16, max_iters=12, log=None, gamma=0.0, lam=0.0, vf_batch_size=1024)
+    hist = learn(_ToyVecEnv(256, 1), pi, timesteps_per_batch=16, max_iters=12, log=None, gamma=0.0, lam=0.0, vf_batch_size=1024,
+                 log_dir=str(tmp_path))
+    from deepmimic_mujoco_amd.logio import read_progress_csv, read_monitor_csv
+    kv = read_progress_csv(str(tmp_path / "progress.csv"))
+    assert list(kv)[:3] == ["EpRewMean", "EpThisIter", "TimestepsSoFar"] and len(kv["meankl"]) == 12 and kv["TimestepsSoFar"][-1] == 12 * 16 * 256
+    hdr, r, l, t = read_monitor_csv(str(tmp_path / "monitor.json.monitor.csv"))
+    assert "t_start" in hdr and len(r) == 0            # the toy env never ends an episode
     assert len(hist) == 12 and hist[-1]["TimestepsSoFar"] == 12 * 16 * 256
     # with gamma = 0 the advantage is the immediate reward: the surrogate keeps finding improvement and the policy mean moves
     ob = torch.randn(4096, 56)

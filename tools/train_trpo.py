@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--frame-skip", default="1", help="sim steps per env step, or 'mocap'")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--log-dir", default=None, help="write progress.csv and monitor.csv in the reference's formats")
     ap.add_argument("--save", default=None, help="write the trained policy as .npz (reference variable names)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); lr = int(os.environ.get("LOCAL_RANK", "0"))
@@ -44,7 +45,7 @@ def main():
                    env_offset=rank * args.envs, frame_skip=args.frame_skip if args.frame_skip == "mocap" else int(args.frame_skip))
     pi = MlpPolicy(device=dev, seed=args.seed); pi.seed(args.seed + 10000 * rank)
     hist = learn(env, pi, timesteps_per_batch=args.horizon, max_seconds=args.seconds if not args.iters else 0, max_iters=args.iters,
-                 vf_batch_size=args.vf_batch, vf_stepsize=args.vf_stepsize, max_kl=args.max_kl, seed=args.seed)
+                 vf_batch_size=args.vf_batch, vf_stepsize=args.vf_stepsize, max_kl=args.max_kl, seed=args.seed, log_dir=args.log_dir)
     if rank == 0:
         if args.out:
             os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
