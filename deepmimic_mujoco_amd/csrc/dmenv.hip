@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "dmenv.h"
+#include "policy_kernel.h"
 #include "env_step.h"
 #include "model_host.h"
 
@@ -424,6 +425,15 @@ extern "C" int dm_batch_last_step_ms(dm_batch* b, float* ms) {
   HIPCHK(hipEventSynchronize(b->ev1));
   HIPCHK(hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));
   *ms = b->last_ms;
+  return DM_OK;
+}
+extern "C" int dm_policy_weight_count(void) { return dmp::N_WEIGHTS; }
+extern "C" int dm_policy_act(const float* weights, const double* obs, double* action, float* vpred, int32_t n, int32_t stochastic,
+                             uint64_t seed, uint64_t counter, void* hip_stream) {
+  if (!weights || !obs || !action || !vpred || n <= 0) return fail(DM_EINVAL, "dm_policy_act: bad argument");
+  hipLaunchKernelGGL(dmp::k_policy_act, dim3((n + dmp::EB - 1) / dmp::EB), dim3(256), 0, (hipStream_t)hip_stream, weights, obs, action, vpred,
+                     (int)n, (int)stochastic, (unsigned long long)seed, (unsigned long long)counter);
+  HIPCHK(hipGetLastError());
   return DM_OK;
 }
 extern "C" int dm_batch_sync(dm_batch* b) { if (!b) return fail(DM_EINVAL, "null batch"); HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return DM_OK; }

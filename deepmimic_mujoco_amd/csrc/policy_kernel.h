@@ -1,0 +1,102 @@
+// policy_kernel.h — the learner's policy step for a batch of environments as ONE kernel:
+//   obz = clip((ob - mean) / std, -5, 5);  two 2x100 tanh MLPs (policy mean [28], value [1]);  ac = mean + exp(logstd) * N(0,1)
+// (src/mlp_policy_trpo.py:35-58, src/distributions.py:220-245).  It replaces ~15 launch-bound library calls per rollout step.
+// The matrices are tiny (56x100, 100x100, 100x28): a workgroup takes 32 environments, keeps their activations in LDS and
+// streams the weights once per workgroup from L2 (coalesced across the 200 hidden-unit threads); every LDS read feeds four
+// FMAs.  fp32 like the reference's TF graph.  No MFMA: 37 k MACs per env would not amortise a fragment layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dmp {
+
+constexpr int OB = 56, HID = 100, AC = 28, EB = 32, HS = 204;   // HS: padded row stride of the hidden activations (bank spread)
+// packed weight layout (floats)
+constexpr int O_MEAN = 0, O_STD = O_MEAN + OB;
+constexpr int O_PW1 = O_STD + OB, O_PB1 = O_PW1 + OB * HID, O_PW2 = O_PB1 + HID, O_PB2 = O_PW2 + HID * HID;
+constexpr int O_PW3 = O_PB2 + HID, O_PB3 = O_PW3 + HID * AC, O_LOGSTD = O_PB3 + AC;
+constexpr int O_VW1 = O_LOGSTD + AC, O_VB1 = O_VW1 + OB * HID, O_VW2 = O_VB1 + HID, O_VB2 = O_VW2 + HID * HID;
+constexpr int O_VW3 = O_VB2 + HID, O_VB3 = O_VW3 + HID, N_WEIGHTS = O_VB3 + 1;
+
+__device__ inline unsigned long long mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// standard normal from a counter: two 24-bit uniforms, Box-Muller
+__device__ inline float normal_from(unsigned long long seed, unsigned long long counter, unsigned idx) {
+  const unsigned long long h = mix64(mix64(seed ^ (counter * 0xD1342543DE82EF95ull)) + idx);
+  const float u1 = ((float)((h >> 40) & 0xFFFFFF) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
+  const float u2 = (float)((h >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+// one dense layer for 32 environments: thread u (< 2 * HID) owns hidden unit (net = u / HID, j = u % HID)
+template <int K>
+__device__ inline void dense32(const float* __restrict__ W, const float* __restrict__ bias, int j, const float* in, int in_stride,
+                               int in_off, float* acc) {
+  const float b = bias[j];
+#pragma unroll
+  for (int e = 0; e < EB; e++) acc[e] = b;
+  for (int k = 0; k < K; k += 4) {
+    const float w0 = W[(k + 0) * HID + j], w1 = W[(k + 1) * HID + j], w2 = W[(k + 2) * HID + j], w3 = W[(k + 3) * HID + j];
+#pragma unroll
+    for (int e = 0; e < EB; e++) {
+      const float4 x = *reinterpret_cast<const float4*>(in + e * in_stride + in_off + k);   // same address in every lane: broadcast
+      acc[e] += x.x * w0 + x.y * w1 + x.z * w2 + x.w * w3;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_policy_act(const float* __restrict__ P, const double* __restrict__ obs, double* __restrict__ action,
+                                                    float* __restrict__ vpred, int n, int stochastic, unsigned long long seed,
+                                                    unsigned long long counter) {
+  __shared__ __attribute__((aligned(16))) float z[EB * OB];
+  __shared__ __attribute__((aligned(16))) float h1[EB * HS];
+  __shared__ __attribute__((aligned(16))) float h2[EB * HS];
+  const int tid = threadIdx.x, e0 = blockIdx.x * EB;
+  for (int i = tid; i < EB * OB; i += 256) {
+    const int e = i / OB, k = i % OB, env = e0 + e;
+    float v = 0.0f;
+    if (env < n) { v = ((float)obs[(size_t)env * OB + k] - P[O_MEAN + k]) / P[O_STD + k]; v = fminf(fmaxf(v, -5.0f), 5.0f); }
+    z[i] = v;
+  }
+  __syncthreads();
+  float acc[EB];
+  const int net = tid / HID, j = tid % HID;                    // net 0: policy, 1: value (threads >= 200 idle in the hidden layers)
+  if (tid < 2 * HID) {
+    dense32<OB>(P + (net ? O_VW1 : O_PW1), P + (net ? O_VB1 : O_PB1), j, z, OB, 0, acc);
+#pragma unroll
+    for (int e = 0; e < EB; e++) h1[e * HS + tid] = tanhf(acc[e]);
+  }
+  __syncthreads();
+  if (tid < 2 * HID) {
+    dense32<HID>(P + (net ? O_VW2 : O_PW2), P + (net ? O_VB2 : O_PB2), j, h1, HS, net * HID, acc);
+#pragma unroll
+    for (int e = 0; e < EB; e++) h2[e * HS + tid] = tanhf(acc[e]);
+  }
+  __syncthreads();
+  // output layer: (env, output) pairs over all 256 threads; outputs 0..27 = action means, 28 = value
+  const int e = tid % EB, env = e0 + e;
+  for (int o = tid / EB; o < AC + 1; o += 256 / EB) {
+    const bool isv = o == AC;
+    const float* W = P + (isv ? O_VW3 : O_PW3);
+    const int ws = isv ? 1 : AC, wo = isv ? 0 : o;
+    const float* h = h2 + e * HS + (isv ? HID : 0);
+    float s = isv ? P[O_VB3] : P[O_PB3 + o];
+    for (int k = 0; k < HID; k += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(h + k);
+      s += x.x * W[(k + 0) * ws + wo] + x.y * W[(k + 1) * ws + wo] + x.z * W[(k + 2) * ws + wo] + x.w * W[(k + 3) * ws + wo];
+    }
+    if (env < n) {
+      if (isv) vpred[env] = s;
+      else {
+        if (stochastic) s += expf(P[O_LOGSTD + o]) * normal_from(seed, counter, (unsigned)(env * AC + o));
+        action[(size_t)env * AC + o] = (double)s;
+      }
+    }
+  }
+}
+
+}  // namespace dmp

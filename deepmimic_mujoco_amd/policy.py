@@ -9,8 +9,10 @@ Mirror of `src/mlp_policy_trpo.py:13-79` (class MlpPolicy) and `src/utils/misc_u
 
 `act(stochastic, ob)` takes the whole [N, 56] observation batch that `dm_batch_step` wrote on the device and returns
 ([N, 28] float64 actions ready for the next `dm_batch_step`, [N] vpred) without leaving the device or the stream.
-The network arithmetic is float32 like the reference's TF graph; the two 100-wide GEMMs are library GEMMs (rocBLAS
-through torch) — they are ~1% of a rollout step next to the physics kernel, so no hand-written kernel is warranted.
+On a GPU the whole step is ONE launch of the hand-written `k_policy_act` kernel of libdmenv.so (`dm_policy_act`,
+csrc/policy_kernel.h: normalisation, both MLPs, Gaussian sample; float32 like the reference's TF graph) instead of ~15
+launch-bound library calls; `forward()` — what the learner differentiates — and the CPU path are plain torch ops, and the
+two agree to float32 rounding (tests/test_gpu_rollout.py).
 
 Weights are interchangeable with the reference's checkpoints: `MlpPolicy.from_tf_checkpoint(prefix)` reads a
 `tf.train.Saver` bundle (scope 'pi'), `state_dict()/load_state_dict()` use the reference's variable names.
@@ -90,6 +92,10 @@ class MlpPolicy:
         p["logstd"] = torch.zeros((1, ac_dim), dtype=torch.float32, device=self.device)
         self.params = p
         self._noise_gen = None
+        self._packed = None        # float32 device block for dm_policy_act; rebuilt when `_dirty`
+        self._dirty = True
+        self._seed, self._counter = 0, 0
+        self.native = True         # use the HIP kernel for act() on CUDA tensors (False: torch ops everywhere)
 
     # ---- weights ----------------------------------------------------------------------------------------------------
     def state_dict(self):
@@ -110,6 +116,7 @@ class MlpPolicy:
         self.ob_rms.sumsq = torch.as_tensor(np.asarray(d["obfilter/runningsumsq"]), dtype=torch.float64).to(self.device)
         self.ob_rms.count = torch.as_tensor(np.asarray(d["obfilter/count"]), dtype=torch.float64).to(self.device)
         self.ob_rms._refresh()
+        self._dirty = True
         return self
 
     @classmethod
@@ -148,6 +155,47 @@ class MlpPolicy:
     def seed(self, seed):
         self._noise_gen = torch.Generator(device=self.device)
         self._noise_gen.manual_seed(int(seed))
+        self._seed, self._counter = int(seed), 0
+
+    # ---- native path -------------------------------------------------------------------------------------------------------
+    def mark_dirty(self):
+        """Parameters or obs-filter moments changed in place (the learner calls this): repack before the next native act()."""
+        self._dirty = True
+
+    def pack(self):
+        """Flat float32 block in the layout of csrc/policy_kernel.h (dm_policy_weight_count() floats)."""
+        p = self.params
+        parts = [self.ob_rms.mean, self.ob_rms.std,
+                 p["polfc1/w"], p["polfc1/b"], p["polfc2/w"], p["polfc2/b"], p["polfinal/w"], p["polfinal/b"], p["logstd"],
+                 p["vffc1/w"], p["vffc1/b"], p["vffc2/w"], p["vffc2/b"], p["vffinal/w"], p["vffinal/b"]]
+        with torch.no_grad():
+            flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in parts])
+        if self._packed is None or self._packed.shape != flat.shape:
+            self._packed = flat.contiguous()
+        else:
+            self._packed.copy_(flat)
+        self._dirty = False
+        return self._packed
+
+    def _act_native(self, stochastic, ob, out, vpred_out):
+        import ctypes as C
+        from . import _abi as A
+        L = A.load()
+        n = ob.shape[0]
+        if self._dirty or self._packed is None:
+            self.pack()
+            if self._packed.numel() != L.dm_policy_weight_count():
+                raise RuntimeError("packed policy has %d floats, the kernel expects %d" % (self._packed.numel(), L.dm_policy_weight_count()))
+        if out is None:
+            out = torch.empty((n, self.ac_dim), dtype=torch.float64, device=ob.device)
+        if vpred_out is None:
+            vpred_out = torch.empty(n, dtype=torch.float32, device=ob.device)
+        self._counter += 1
+        stream = torch.cuda.current_stream(ob.device).cuda_stream
+        A.check(L.dm_policy_act(C.c_void_p(self._packed.data_ptr()), C.c_void_p(ob.data_ptr()), C.c_void_p(out.data_ptr()),
+                                C.c_void_p(vpred_out.data_ptr()), n, 1 if stochastic else 0, self._seed & (2 ** 64 - 1), self._counter,
+                                C.c_void_p(stream)), L)
+        return out, vpred_out
 
     def act(self, stochastic, ob, out=None, vpred_out=None):
         """mlp_policy_trpo.py:63-65 for a batch: returns (ac [N, ac_dim] float64, vpred [N] float32).
@@ -156,6 +204,11 @@ class MlpPolicy:
         single = ob.dim() == 1
         if single:
             ob = ob[None]
+        if (self.native and ob.is_cuda and ob.dtype == torch.float64 and ob.is_contiguous() and self.ob_dim == 56 and self.ac_dim == 28
+                and self.hid_size == 100 and (out is None or (out.is_contiguous() and out.dtype == torch.float64))
+                and (vpred_out is None or (vpred_out.is_contiguous() and vpred_out.dtype == torch.float32))):
+            ac, vpred = self._act_native(stochastic, ob, out, vpred_out)
+            return (ac[0], vpred[0]) if single else (ac, vpred)
         mean, vpred = self.forward(ob)
         if stochastic:
             noise = torch.randn(mean.shape, dtype=torch.float32, device=mean.device, generator=self._noise_gen)

@@ -275,6 +275,7 @@ class TrpoLearner:
                 gv = flat(torch.autograd.grad(vferr, self.vf))
                 self.vfadam.update(gv, self.vf_stepsize)
 
+        pi.mark_dirty()                                                     # parameters / obs filter changed in place: the native act() repacks
         for name, val in zip(self.loss_names, meanlosses.tolist()):
             stats[name] = val
         stats["ev_tdlam_before"] = explained_variance(vpredbefore, tdlamret)

@@ -180,6 +180,15 @@ int dm_batch_enable_timing(dm_batch* b, int32_t on);
  * out [N,8] int64 = kinematics, mass matrix+factor, bias, rows(collision), constraint, whole step, nefc, PGS sweeps */
 int dm_batch_read_profile(dm_batch* b, long long* out_host);
 
+/* Replaces: MlpPolicy.act(stochastic, ob) (src/mlp_policy_trpo.py:63-65; network :35-58, DiagGaussianPd src/distributions.py:220-245)
+ * for a whole batch in one launch: obz = clip((ob - mean) / std, +-5), policy and value 2x100 tanh MLPs, Gaussian sample.
+ * All pointers are DEVICE pointers on the current HIP device; `weights` is the packed float32 parameter block
+ * (dm_policy_weight_count() floats; layout in csrc/policy_kernel.h, filled by deepmimic_mujoco_amd/policy.py MlpPolicy.pack).
+ * Noise is a counter-based stream keyed by (seed, counter, env, action): pass a fresh `counter` per call. */
+int dm_policy_weight_count(void);
+int dm_policy_act(const float* weights, const double* obs, double* action, float* vpred, int32_t n, int32_t stochastic,
+                  uint64_t seed, uint64_t counter, void* hip_stream);
+
 int dm_batch_sync(dm_batch* b);
 const char* dm_last_error(void);
 int dm_abi_version(void);

@@ -82,3 +82,33 @@ def test_trpo_learns_to_stay_up_on_gpu():
     print("TRPO: EpLenMean %.1f -> %.1f in %d iterations, %.1f s, %d env steps" % (first, last, len(hist), hist[-1]["TimeElapsed"], hist[-1]["TimestepsSoFar"]))
     assert first < 45 and last > 1.8 * first
     assert all(h["meankl"] <= 0.0151 for h in hist) and all(np.isfinite(h["surrgain"]) for h in hist)
+
+
+def test_native_policy_kernel_matches_torch_forward():
+    """dm_policy_act (one HIP launch) against the torch graph the learner differentiates: means and values to float32 rounding,
+    sampled actions = mean + exp(logstd) * standard normal noise, a fresh stream per call and per (env, action)."""
+    pol = MlpPolicy.from_tf_checkpoint(CKPT, device=DEV)
+    pol.seed(5)
+    n = 4096 + 17                                                     # not a multiple of the kernel's 32-env tile
+    g = torch.Generator(device=DEV); g.manual_seed(0)
+    ob = (pol.ob_rms.mean + pol.ob_rms.std * torch.randn((n, 56), generator=g, device=DEV) * 2.5).to(torch.float64).contiguous()
+    mean, vpred = pol.forward(ob)
+    ac, vp = pol.act(False, ob)                                       # native path
+    assert ac.dtype == torch.float64 and float((ac - mean.to(torch.float64)).abs().max()) < 2e-4 * max(1.0, float(mean.abs().max()))
+    assert float((vp - vpred).abs().max()) < 2e-4 * max(1.0, float(vpred.abs().max()))
+    pol.native = False
+    ac_t, vp_t = pol.act(False, ob)                                   # torch path, same API
+    pol.native = True
+    assert float((ac - ac_t).abs().max()) < 2e-4 * max(1.0, float(mean.abs().max()))
+    a1, _ = pol.act(True, ob); a2, _ = pol.act(True, ob)
+    resid = ((a1 - mean.to(torch.float64)) / torch.exp(pol.params["logstd"]).to(torch.float64)).to(torch.float32)
+    assert abs(float(resid.mean())) < 0.01 and abs(float(resid.std()) - 1.0) < 0.01 and float(resid.abs().max()) < 6.5
+    assert not torch.equal(a1, a2)                                    # the counter advances
+    c = torch.corrcoef(torch.stack([resid[:, 0], resid[:, 1]]))[0, 1]
+    assert abs(float(c)) < 0.05                                       # independent across actions
+    # parameters changed in place are picked up after mark_dirty()
+    with torch.no_grad():
+        pol.params["polfinal/b"] += 0.5
+    pol.mark_dirty()
+    ac2, _ = pol.act(False, ob)
+    assert float((ac2 - ac - 0.5).abs().max()) < 1e-4
