@@ -436,4 +436,12 @@ extern "C" int dm_policy_act(const float* weights, const double* obs, double* ac
   HIPCHK(hipGetLastError());
   return DM_OK;
 }
+extern "C" int dm_gae(const float* rew, const float* vpred, const int32_t* isnew, const float* nextvpred, float* adv, float* tdlamret,
+                      int32_t T, int32_t n, double gamma, double lam, void* hip_stream) {
+  if (!rew || !vpred || !isnew || !nextvpred || !adv || !tdlamret || T <= 0 || n <= 0) return fail(DM_EINVAL, "dm_gae: bad argument");
+  hipLaunchKernelGGL(dmp::k_gae, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, rew, vpred, (const int*)isnew, nextvpred, adv,
+                     tdlamret, (int)T, (int)n, (float)gamma, (float)lam);
+  HIPCHK(hipGetLastError());
+  return DM_OK;
+}
 extern "C" int dm_batch_sync(dm_batch* b) { if (!b) return fail(DM_EINVAL, "null batch"); HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return DM_OK; }

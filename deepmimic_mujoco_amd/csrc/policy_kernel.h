@@ -99,4 +99,23 @@ __global__ __launch_bounds__(256) void k_policy_act(const float* __restrict__ P,
   }
 }
 
+// GAE(lambda) of src/trpo.py:83-94 for N environments: thread = env, a backward loop over the T rows of the [T, N] segment
+// (coalesced across envs), instead of T small launches.
+__global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, const float* __restrict__ vpred, const int* __restrict__ isnew,
+                                             const float* __restrict__ nextvpred, float* __restrict__ adv, float* __restrict__ tdlamret,
+                                             int T, int n, float gamma, float lam) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float last = 0.0f, vnext = nextvpred[e];
+  float nonterminal = 1.0f;                                   // new[T] := 0
+  for (int t = T - 1; t >= 0; t--) {
+    const size_t i = (size_t)t * n + e;
+    const float v = vpred[i];
+    const float delta = rew[i] + gamma * vnext * nonterminal - v;
+    last = delta + gamma * lam * nonterminal * last;
+    adv[i] = last; tdlamret[i] = last + v;
+    vnext = v; nonterminal = 1.0f - (float)isnew[i];         // for row t - 1: new[t]
+  }
+}
+
 }  // namespace dmp

@@ -60,6 +60,19 @@ def add_vtarg_and_adv(seg, gamma, lam):
     import torch
     rew, vpred, new = seg["rew"], seg["vpred"], seg["new"]
     T = rew.shape[0]
+    if (rew.is_cuda and rew.dim() == 2 and rew.dtype == torch.float32 and vpred.dtype == torch.float32 and new.dtype == torch.int32
+            and rew.is_contiguous() and vpred.is_contiguous() and new.is_contiguous()):
+        # one launch of the k_gae kernel (csrc/policy_kernel.h) instead of T small ones
+        import ctypes as C
+        from . import _abi as A
+        L = A.load()
+        nxt = seg["nextvpred"].to(torch.float32).contiguous()
+        adv = torch.empty_like(rew); ret = torch.empty_like(rew)
+        p = lambda x: C.c_void_p(x.data_ptr())
+        A.check(L.dm_gae(p(rew), p(vpred), p(new), p(nxt), p(adv), p(ret), T, rew.shape[1], float(gamma), float(lam),
+                         C.c_void_p(torch.cuda.current_stream(rew.device).cuda_stream)), L)
+        seg["adv"], seg["tdlamret"] = adv, ret
+        return seg
     new1 = torch.cat([new.to(torch.float32), torch.zeros_like(new[:1], dtype=torch.float32)], 0)     # np.append(new, 0)
     vp1 = torch.cat([vpred.to(torch.float32), seg["nextvpred"].to(torch.float32)[None]], 0)          # np.append(vpred, nextvpred)
     nonterminal = 1.0 - new1[1:]

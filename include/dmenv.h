@@ -189,6 +189,11 @@ int dm_policy_weight_count(void);
 int dm_policy_act(const float* weights, const double* obs, double* action, float* vpred, int32_t n, int32_t stochastic,
                   uint64_t seed, uint64_t counter, void* hip_stream);
 
+/* Replaces: add_vtarg_and_adv (src/trpo.py:83-94) for N environments at once: rew, vpred, adv, tdlamret [T, N] float32,
+ * isnew [T, N] int32 (isnew[t] = the observation of step t starts an episode), nextvpred [N]; device pointers. */
+int dm_gae(const float* rew, const float* vpred, const int32_t* isnew, const float* nextvpred, float* adv, float* tdlamret,
+           int32_t T, int32_t n, double gamma, double lam, void* hip_stream);
+
 int dm_batch_sync(dm_batch* b);
 const char* dm_last_error(void);
 int dm_abi_version(void);
