@@ -1048,21 +1048,21 @@ template <class R>
 DM_DEV R row_dot(const R* y, const R* q) {
   R acc0 = 0, acc1 = 0;      // two partial sums (even / odd chunks): halves the dependent-FMA chain of the 34-term dot product
   R qa[6], qb[6];
-  { const int zc = dmw::pin_zero();
+  dmw::reload_fence();
 #pragma unroll
-    for (int d = 0; d < 6; d++) qa[d] = q[d + zc]; }
+  for (int d = 0; d < 6; d++) qa[d] = q[d];
 #pragma unroll
   for (int c0 = 0; c0 < NV; c0 += 12) {
-    { const int zc = dmw::pin_zero();
+    dmw::reload_fence();
 #pragma unroll
-      for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) qb[d] = q[c0 + 6 + d + zc]; }
+    for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) qb[d] = q[c0 + 6 + d];
     dmw::sched_fence();
 #pragma unroll
     for (int d = 0; d < 6; d++) if (c0 + d < NV) acc0 += y[c0 + d] * qa[d];
     dmw::pin_value(acc0);
-    { const int zc = dmw::pin_zero();
+    dmw::reload_fence();
 #pragma unroll
-      for (int d = 0; d < 6; d++) if (c0 + 12 + d < NV) qa[d] = q[c0 + 12 + d + zc]; }
+    for (int d = 0; d < 6; d++) if (c0 + 12 + d < NV) qa[d] = q[c0 + 12 + d];
     dmw::sched_fence();
 #pragma unroll
     for (int d = 0; d < 6; d++) if (c0 + 6 + d < NV) acc1 += y[c0 + 6 + d] * qb[d];
