@@ -239,7 +239,8 @@ template <int I, class R>
 struct SolveLTStep {   // x <- L^-T x, rows NV-1 .. 1:  x[anc] -= L(I, anc) * x[I]
   static DM_DEV void run(R* x, const R* qLD, const R* cur) {
     R nxt[14];
-    load_factor_row<I - 1>(nxt, qLD + dmw::pin_zero());
+    dmw::reload_fence();
+    load_factor_row<I - 1>(nxt, qLD);
     dmw::sched_fence();
 #pragma unroll
     for (int a = 1; a < 14; a++) { const int j = TOPO.dof_anc[I][a]; if (j >= 0) x[j] -= cur[a] * x[I]; }
@@ -250,14 +251,16 @@ struct SolveLTStep {   // x <- L^-T x, rows NV-1 .. 1:  x[anc] -= L(I, anc) * x[
 template <class R> struct SolveLTStep<0, R> { static DM_DEV void run(R*, const R*, const R*) {} };
 template <class R> DM_DEV void solve_LT(R* x, const R* qLD) {
   R cur[14];
-  load_factor_row<NV - 1>(cur, qLD + dmw::pin_zero());
+  dmw::reload_fence();
+  load_factor_row<NV - 1>(cur, qLD);
   SolveLTStep<NV - 1, R>::run(x, qLD, cur);
 }
 template <int I, class R>
 struct SolveLStep {    // x <- L^-1 x, rows 1 .. NV-1:  x[I] -= L(I, anc) * x[anc]
   static DM_DEV void run(R* x, const R* qLD, const R* cur) {
     R nxt[14];
-    load_factor_row<I + 1>(nxt, qLD + dmw::pin_zero());
+    dmw::reload_fence();
+    load_factor_row<I + 1>(nxt, qLD);
     dmw::sched_fence();
     R acc0 = 0, acc1 = 0;   // two partial sums: halves the dependent FMA chain of a 13-entry row
 #pragma unroll
@@ -273,7 +276,8 @@ struct SolveLStep {    // x <- L^-1 x, rows 1 .. NV-1:  x[I] -= L(I, anc) * x[an
 template <class R> struct SolveLStep<NV, R> { static DM_DEV void run(R*, const R*, const R*) {} };
 template <class R> DM_DEV void solve_L(R* x, const R* qLD) {
   R cur[14];
-  load_factor_row<1>(cur, qLD + dmw::pin_zero());
+  dmw::reload_fence();
+  load_factor_row<1>(cur, qLD);
   SolveLStep<1, R>::run(x, qLD, cur);
 }
 
@@ -1024,7 +1028,8 @@ template <int D, class R>
 struct RowStep {
   static DM_DEV void run(R* y, RowAcc<R>& ra, const Shared<R>& s, const R* cur) {
     R nxt[9];
-    load_dof_operands<D + 1>(nxt, s, dmw::pin_zero());
+    dmw::reload_fence();
+    load_dof_operands<D + 1>(nxt, s, 0);
     dmw::sched_fence();
     const unsigned pb = D < 32 ? (ra.plus_lo >> D) & 1u : (ra.plus_hi >> (D - 32)) & 1u;
     const unsigned mb = D < 32 ? (ra.minus_lo >> D) & 1u : (ra.minus_hi >> (D - 32)) & 1u;
@@ -1191,7 +1196,8 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     ra.ldof = ldof; ra.lsgn = lsgn; ra.vel = 0; ra.jws = 0; ra.is_tau = taul;
     {
       R cur[9];
-      load_dof_operands<0>(cur, s, dmw::pin_zero());
+      dmw::reload_fence();
+      load_dof_operands<0>(cur, s, 0);
       RowStep<0, R>::run(y, ra, s, cur);
     }
     const R vel = ra.vel, jws = ra.jws;
