@@ -1251,8 +1251,8 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     // columns past nefc are exact zeros (the row groups of the sweeps may touch them); zeroed here, not earlier, so that
     // the array is not live during the row build and the half solve
 #pragma unroll
-    for (int i = 0; i < ROWS; i++) AR[i] = 0;
-    ACol<0, ROWS, R>::run(AR, y, s, lane, nefc, Rr, diag);              // nefc > 0 here
+    for (int i = 0; i < ROWS; i++) { AR[i] = 0; dmw::pin_value(AR[i]); }   // (opaque zeros stay in their registers: as known constants
+    ACol<0, ROWS, R>::run(AR, y, s, lane, nefc, Rr, diag);              //  they would be re-materialised before every early-exit test)
   }
   const R dinvr = R(1) / diag;
   DM_STAMP(11)
