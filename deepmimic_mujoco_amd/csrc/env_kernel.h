@@ -191,10 +191,20 @@ template <class R> DM_DEV void matT_vec(R* r, const R* m, const R* v) {
   R x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2], z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
+// sin and cos of one angle with a single range reduction.  Not inlined: inlined into the RK loop, the compiler hoists the
+// polynomial's dozen literal coefficients to kernel entry as loop invariants and, for want of registers, SPILLS them there and
+// re-reads them from scratch in every evaluation (measured: 45 MB of scratch writes per launch).
+// (Results come back by value: out-pointers of a non-inlined function would live in scratch memory.)
+template <class R> struct SinCos { R s, c; };
+#if defined(DM_WAVE_TESTBENCH)
+template <class R> DM_DEV SinCos<R> sincos_once(R x) { return SinCos<R>{sin(x), cos(x)}; }
+#else
+template <class R> __device__ __attribute__((noinline)) SinCos<R> sincos_once(R x) { SinCos<R> r; sincos(x, &r.s, &r.c); return r; }
+#endif
 template <class R> DM_DEV void quat_rot(R* r, const R* q, const R* v) { R m[9]; quat2mat(m, q); mat_vec(r, m, v); }
 template <class R> DM_DEV void axisangle2quat(R* q, const R* axis, R angle) {
-  R s, c;
-  sincos(angle * R(0.5), &s, &c);      // one range reduction for both
+  const SinCos<R> sc = sincos_once(angle * R(0.5));
+  const R s = sc.s, c = sc.c;
   q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
 DM_DEV int imin(int a, int b) { return a < b ? a : b; }
@@ -325,7 +335,9 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   const int lane = dmw::launder(lane_in);
   const int b = lane + 1;
   const bool isbody = lane < NB - 1;
-  const int depth = lt.depth, da = lt.dofadr, nd = lt.dofnum, p = lt.parent;
+  // laundered: otherwise every model constant indexed by these per-lane values (joint axes, body offsets, inertias) is
+  // hoisted out of the RK loop as loop-invariant, spilled at kernel entry and re-read from scratch in every evaluation
+  const int depth = dmw::launder(lt.depth), da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum), p = dmw::launder(lt.parent);
   R qloc[4] = {1, 0, 0, 0}, aloc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   if (lane == 0) {
     s.xpos[0][0] = s.xpos[0][1] = s.xpos[0][2] = 0; s.xipos[0][0] = s.xipos[0][1] = s.xipos[0][2] = 0;
@@ -335,9 +347,8 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   // 1a. half-angle sine / cosine of every hinge, one lane per hinge (one sincos evaluation deep instead of three)
   if (lane < NU) {
     const R half = (s.qpos[lane + 7] - M.qpos0[lane + 7]) * R(0.5);
-    R sh, ch;
-    sincos(half, &sh, &ch);                                           // one range reduction for both
-    s.u.fdof[lane][0] = ch; s.u.fdof[lane][1] = sh;                   // (u.fdof is free until the mass-matrix stage)
+    const SinCos<R> sc = sincos_once(half);
+    s.u.fdof[lane][0] = sc.c; s.u.fdof[lane][1] = sc.s;                   // (u.fdof is free until the mass-matrix stage)
   }
   dmw::sync();
   // 1b. local hinge chain (bodies 2..13)
@@ -435,7 +446,7 @@ DM_DEV void bias_phase(const DevModel<R>& M, Shared<R>& s, int lane, const LaneT
     }
   } else if constexpr (P <= MAXDEPTH_BODY) {
     if (isbody && lt.depth == P) {
-      const int p = lt.parent, da = lt.dofadr, nd = lt.dofnum;
+      const int p = dmw::launder(lt.parent), da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum);
       R v[6], a[6];
       for (int r = 0; r < 6; r++) { v[r] = s.u.v.cvel[p][r]; a[r] = s.u.v.cacc[p][r]; }
       if (b == 1) {
