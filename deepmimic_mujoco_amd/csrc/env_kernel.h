@@ -194,7 +194,17 @@ template <class R> DM_DEV void matT_vec(R* r, const R* m, const R* v) {
 // sin and cos of one angle with a single range reduction.  Not inlined: inlined into the RK loop, the compiler hoists the
 // polynomial's dozen literal coefficients to kernel entry as loop invariants and, for want of registers, SPILLS them there and
 // re-reads them from scratch in every evaluation (measured: 45 MB of scratch writes per launch).
+// The same holds for the other libm routines used once per step or on cold paths (pow, exp, acos, atan2).
 // (Results come back by value: out-pointers of a non-inlined function would live in scratch memory.)
+#if defined(DM_WAVE_TESTBENCH)
+#define DM_OUTLINE DM_DEV
+#else
+#define DM_OUTLINE __device__ __attribute__((noinline))
+#endif
+template <class R> DM_OUTLINE R pow_once(R x, R y) { return pow(x, y); }
+template <class R> DM_OUTLINE R exp_once(R x) { return exp(x); }
+template <class R> DM_OUTLINE R acos_once(R x) { return acos(x); }
+template <class R> DM_OUTLINE R atan2_once(R y, R x) { return atan2(y, x); }
 template <class R> struct SinCos { R s, c; };
 #if defined(DM_WAVE_TESTBENCH)
 template <class R> DM_DEV SinCos<R> sincos_once(R x) { return SinCos<R>{sin(x), cos(x)}; }
@@ -1004,8 +1014,8 @@ DM_DEV R impedance(const DevModel<R>& M, R x) {
   R y;
   if (si[4] == R(1)) y = x;
   else if (si[4] == R(2)) y = (x <= si[3]) ? (x * x) * M.imp_rlo : 1 - ((1 - x) * (1 - x)) * M.imp_rhi;
-  else if (x <= si[3]) y = pow(x, si[4]) / pow(si[3], si[4] - 1);
-  else y = 1 - pow(1 - x, si[4]) / pow(1 - si[3], si[4] - 1);
+  else if (x <= si[3]) y = pow_once(x, si[4]) / pow_once(si[3], si[4] - 1);
+  else y = 1 - pow_once(1 - x, si[4]) / pow_once(1 - si[3], si[4] - 1);
   return si[0] + y * (si[1] - si[0]);
 }
 

@@ -192,7 +192,7 @@ DM_DEV R quat_diff_theta(const R* q0, const R* q1) {
   quat_mul(dq, q1, c);
   const R w = dq[0] > R(1) ? R(1) : (dq[0] < R(-1) ? R(-1) : dq[0]);
   if (sqrt(fmax(R(0), 1 - w * w)) <= R(1e-6)) return 0;
-  const R th = 2 * acos(w);
+  const R th = 2 * acos_once(w);
   return th > R(M_PI) ? th - R(2 * M_PI) : th;
 }
 // The simulated state's features are formed from the FK of the INTEGRATED state (one extra kinematics pass; the 4th-stage
@@ -245,7 +245,9 @@ DM_DEV R imitation_reward(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s,
     const R ex[3] = {1, 0, 0};
     R fwd[3], p[3], rel[3];
     quat_rot(fwd, rq, ex);
-    const R hd = atan2(fwd[1], fwd[0]), c = cos(hd), sn = sin(hd);
+    const R hd = atan2_once(fwd[1], fwd[0]);
+    const SinCos<R> hsc = sincos_once(hd);
+    const R c = hsc.c, sn = hsc.s;
     mat_vec(p, s.xmat[b], P + 20 + 3 * e);
     for (int k = 0; k < 3; k++) { p[k] += s.xpos[b][k]; rel[k] = p[k] - s.qpos[k]; }
     rel[2] = p[2];                                        // height above the ground plane
@@ -266,7 +268,7 @@ DM_DEV R imitation_reward(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s,
   mx = dmw::wave_sum(mx) / M.total_mass; my = dmw::wave_sum(my) / M.total_mass; mz = dmw::wave_sum(mz) / M.total_mass;
   const R dc[3] = {ref[109] - mx, ref[110] - my, ref[111] - mz};
   const R com = R(0.1) * dot3(dc, dc);
-  return R(0.5) * exp(R(-2) * pose) + R(0.05) * exp(R(-0.1) * vel) + R(0.15) * exp(R(-40) * eff) + R(0.2) * exp(R(-5) * root) + R(0.1) * exp(R(-10) * com);
+  return R(0.5) * exp_once(R(-2) * pose) + R(0.05) * exp_once(R(-0.1) * vel) + R(0.15) * exp_once(R(-40) * eff) + R(0.2) * exp_once(R(-5) * root) + R(0.1) * exp_once(R(-10) * com);
 }
 
 // DPEnv.step for one environment
@@ -292,7 +294,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     const int idx = B.frame_idx[env];
     R err = 0;
     for (int i = 7; i < NQ; i++) err += fabs(s.qpos[i] - B.mocap_cfg[(size_t)idx * NQ + i]);
-    rew = exp(-err);
+    rew = exp_once(-err);
     dmw::sync();
     if (lane == 0) B.frame_idx[env] = (idx + 1) % B.n_frames;
   } else if (B.reward_mode == REW_V2_POSE) {     // src/dp_env_v2.py:116-183
@@ -301,7 +303,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     R err = 0, acs = 0;
     for (int i = 3; i < NQ; i++) err += fabs(s.qpos[i] - B.mocap_cfg[(size_t)im * NQ + i]);
     for (int u = 0; u < NU; u++) { const R c = B.ctrl[(size_t)env * NU + u]; acs += c * c; }
-    rew = exp(R(-2) * err) - R(0.1) * acs;
+    rew = exp_once(R(-2) * err) - R(0.1) * acs;
     dmw::sync();
     if (lane == 0) B.frame_idx[env] = idx;
   } else if (B.reward_mode == REW_IMITATION) {   // code.md:1017-1143: the state after the step against frame idx + 1
