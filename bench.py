@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Workload (config.workload): BASELINE.json configs[2] — 'walk' clip, 4096 envs per GPU, full contact + joint-limit
-solve (PGS 50), imitation reward `v3-config`, RSI auto-reset on done, actions ~ N(0, 0.9^2) i.i.d. (pre-generated on
+solve (PGS 50), the 5-term DeepMimic imitation reward (pose / velocity / end-effector / root / COM against the mocap frame;
+`--reward v3-config` selects dp_env_v3's own disabled config reward instead), RSI auto-reset on done, actions ~ N(0, 0.9^2) i.i.d. (pre-generated on
 the device).  One "step" = one `dm_batch_step` launch = one DPEnv.step (one RK4 mj_step, h = 0.0166 s) of every env
 of the rank.  With N > 1 the env index range is sharded over ranks (weak scaling, no per-step collective) and every
 256 steps the [256, 4096, 87] f32 rollout block is all-gathered over RCCL, as the learner would consume it — asynchronously,
@@ -31,12 +32,13 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X fp64 vector peak (public spec)
 
 
-def cpu_baseline(clip, budget_s=12.0):
+def cpu_baseline(clip, reward="imitation", budget_s=12.0):
     """Time the CPU oracle (oracle/, float64 C, OpenMP over envs) on a bounded sample of the same workload.  The host may
     expose more logical CPUs than the container can use, so a few thread counts are tried and the best one is reported
     together with the one-core figure."""
     from oracle import oracle as O
-    from deepmimic_mujoco_amd import MocapDM
+    from deepmimic_mujoco_amd import MocapDM, CompiledModel, humanoid_spec
+    from deepmimic_mujoco_amd.imitation import ImitationSpec
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -45,21 +47,29 @@ def cpu_baseline(clip, budget_s=12.0):
     F = mc.data_config.shape[0]
     om = O.Model()
     rng = np.random.RandomState(0)
+    imit = reward == "imitation"
+    if imit:
+        spec = ImitationSpec(CompiledModel(humanoid_spec()))
+        table = spec.build_table(mc.data_config, mc.data_vel); params = spec.params(mc.data_config, mc.loop)
 
     def run(nthreads, seconds):
         n = max(8, nthreads * 8)
         ds = [O.Data(om) for _ in range(n)]
+        idx = (np.arange(n) % F).astype(np.int32); cyc = np.zeros(n, dtype=np.int32)
         for e, d in enumerate(ds):
             d.reset(); d.set_state(mc.data_config[e % F], mc.data_vel[e % F])
         steps = 0
         t0 = time.perf_counter()
         while True:
             a = rng.randn(n, 28) * 0.9
-            _o, _r, done = O.batch_step(om, ds, a, 1, nthreads)
+            if imit:
+                _o, _r, done = O.batch_step_imitation(om, ds, a, 1, table, params, idx, cyc, nthreads)
+            else:
+                _o, _r, done = O.batch_step(om, ds, a, 1, nthreads)
             steps += 1
             for e in np.nonzero(done)[0]:
                 k = rng.randint(F)
-                ds[e].reset(); ds[e].set_state(mc.data_config[k], mc.data_vel[k])
+                ds[e].reset(); ds[e].set_state(mc.data_config[k], mc.data_vel[k]); idx[e] = k; cyc[e] = 0
             el = time.perf_counter() - t0
             if el > seconds and steps >= 4:
                 return n * steps / el, n, steps, el
@@ -71,8 +81,8 @@ def cpu_baseline(clip, budget_s=12.0):
     v, n, steps, el = results[best]
     return {"value": round(v, 1), "unit": "env-steps/s", "cores": best, "kind": "port", "single_core_value": round(results[1][0], 1),
             "by_threads": {str(c): round(results[c][0], 1) for c in counts}, "logical_cpus": avail,
-            "sample": "%d envs x %d steps of the same workload (walk, contacts+limits, N(0,0.9^2) actions, RSI reset on done), "
-                      "oracle/dm_oracle.c fp64 with OpenMP over envs, %d threads (best of %s), %.1f s" % (n, steps, best, counts, el)}
+            "sample": "%d envs x %d steps of the same workload (%s, contacts+limits, %s reward, N(0,0.9^2) actions, RSI reset on done), "
+                      "oracle/dm_oracle.c fp64 with OpenMP over envs, %d threads (best of %s), %.1f s" % (n, steps, clip, reward, best, counts, el)}
 
 
 def rollout_bench(args, dev, rank, world, local_rank):
@@ -111,7 +121,10 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "rollout"],
                     help="cfg3 (default, the judged line) / cfg2: BASELINE.json configs; rollout: policy-in-the-loop segments + GAE (informational)")
     ap.add_argument("--clip", default="walk")
+    ap.add_argument("--reward", default="imitation", choices=["imitation", "v3-config", "alive"],
+                    help="cfg3 reward: the 5-term DeepMimic imitation reward (default), dp_env_v3's config reward, or the constant 1.0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm-horizons", type=int, default=6, help="untimed 256-step horizons before the warm-up steps (cold-box clock ramp, ~1 s)")
     args = ap.parse_args()
 
     import torch
@@ -136,7 +149,7 @@ def main():
     if args.workload == "rollout":
         return rollout_bench(args, dev, rank, world, local_rank)
     full = args.workload == "cfg3"
-    env = DPVecEnv(n, motion=args.clip, device=local_rank, reward="v3-config" if full else "alive",
+    env = DPVecEnv(n, motion=args.clip, device=local_rank, reward=args.reward if full else "alive",
                    autoreset="rsi", seed=0, contacts=full, limits=full,
                    action_mode="raw" if full else "p-control", env_offset=rank * n)
     stream = torch.cuda.Stream(device=dev)
@@ -149,24 +162,35 @@ def main():
             actions = torch.randn((pool, n, A.NU), generator=gen, device=dev, dtype=torch.float64) * 0.9
         else:
             actions = torch.zeros((pool, n, A.NU), device=dev, dtype=torch.float64)   # cfg2: pure P-controller
-        obs = torch.empty((n, A.NOBS), dtype=torch.float64, device=dev)
-        rew = torch.empty(n, dtype=torch.float64, device=dev)
-        done = torch.empty(n, dtype=torch.uint8, device=dev)
-        # rollout blocks (obs 56 + act 28 + rew + done + vpred), double-buffered: while one 256-step block is all-gathered over
-        # RCCL (async, on the collective's own stream) the envs keep stepping into the other one
+        # the kernel writes obs / reward / done of step t straight into row t of [T, n, .] staging buffers (no per-step copy
+        # kernels); at the end of each 256-step horizon they are packed into the f32 rollout block (obs 56 + act 28 + rew + done
+        # + vpred) in one go.  Blocks are double-buffered: while one is all-gathered over RCCL (async, on the collective's own
+        # stream) the envs keep stepping
         from deepmimic_mujoco_amd.rollout import DoubleBufferedGather
+        obs_T = torch.zeros((HORIZON, n, A.NOBS), dtype=torch.float64, device=dev)    # zeros: every page is touched before the clock starts
+        rew_T = torch.zeros((HORIZON, n), dtype=torch.float64, device=dev)
+        done_T = torch.zeros((HORIZON, n), dtype=torch.uint8, device=dev)
+        tidx = torch.arange(HORIZON, device=dev)
         dbg = DoubleBufferedGather(HORIZON, n, device=dev, world=world)
         env.reset("rsi")
 
         def one_step(t):
-            a = actions[t % pool]
-            env.batch.step(a, 1, (obs, rew, done))
-            row = dbg.row(t)
-            row[:, :56] = obs; row[:, 56:84] = a; row[:, 84] = rew; row[:, 85] = done
-            dbg.commit(t)
+            k = t % HORIZON
+            env.batch.step(actions[t % pool], 1, (obs_T[k], rew_T[k], done_T[k]))
+            if k == HORIZON - 1:
+                blk = dbg.block(t)
+                blk[:, :, :56] = obs_T; blk[:, :, 56:84] = actions[(tidx + (t - k)) % pool]
+                blk[:, :, 84] = rew_T; blk[:, :, 85] = done_T
+                dbg.commit(t)
 
         drain = dbg.drain
 
+        # untimed: bring a cold box (first process after boot: idle clocks, unmapped VRAM) to its steady state, then the W warm-up steps
+        # (a fixed number of horizons, so that every rank issues the same sequence of collectives)
+        for _ in range(args.prewarm_horizons):
+            for t in range(HORIZON):
+                one_step(t)
+            drain(); stream.synchronize()
         for t in range(args.warmup):
             one_step(t)
         drain()
@@ -199,14 +223,14 @@ def main():
     if rank == 0:
         total_steps = world * n * args.steps
         value = total_steps / elapsed
-        kernel_ms = gpu_ms / args.steps       # per-launch duration on the launch stream (incl. the 4 tiny rollout-copy ops)
+        kernel_ms = gpu_ms / args.steps       # per-launch duration on the launch stream (incl. k_order and the per-horizon block packing)
         ach_gbs = ALGO_BYTES_PER_STEP * n / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: 'walk' mocap, %d envs/GPU, full contact + joint-limit PGS solve, "
-                                    "v3-config imitation reward, RSI auto-reset" % n) if full else
+                                    "%s reward, RSI auto-reset" % (n, "5-term DeepMimic imitation" if args.reward == "imitation" else args.reward)) if full else
                                    ("BASELINE.json configs[1]: 'walk' mocap, %d envs/GPU, P-controller torque, contacts and limits off" % n),
                        "envs_per_gpu": n, "global_envs": world * n, "clip": args.clip, "parallelism": "env-shard x%d" % world,
                        "rollout_allgather_every": HORIZON if world > 1 else None,
@@ -229,7 +253,7 @@ def main():
                 pass
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.clip)
+                out["cpu_baseline"] = cpu_baseline(args.clip, args.reward if full else "alive")
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

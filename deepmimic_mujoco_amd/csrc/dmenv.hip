@@ -220,7 +220,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   A(b->B.xipos, (size_t)n * NB * 3); A(b->B.comz, n); A(b->B.frame_idx, n); A(b->B.frame_init, n); A(b->B.ncon, n); A(b->B.nefc, n);
   A(b->B.cong, (size_t)n * MAXEFC * 2); A(b->B.status, n); A(b->B.solver_iter, n); A(b->B.episode, n); A(b->B.cycle, n); A(b->d_order, n);
   A(b->d_cfg, (size_t)mc->n_frames * NQ); A(b->d_vel, (size_t)mc->n_frames * NV);
-  if (!mc->imit_table.empty()) A(b->d_imit, mc->imit_table.size());
+  if (!mc->imit_table.empty()) A(b->d_imit, mc->imit_table.size() + 32);   // [32 parameters][F x 112 feature rows]
   A(b->d_action, (size_t)n * NU); A(b->d_obs, (size_t)n * NOBS); A(b->d_reward, n); A(b->d_done, n); A(b->d_mask, n);
   A(b->B.aovf, (size_t)n * AOVF_COLS * 64);
   A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
@@ -230,10 +230,12 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   ok = ok && hipMemcpy(b->d_cfg, mc->cfg.data(), mc->cfg.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
   ok = ok && hipMemcpy(b->d_vel, mc->vel.data(), mc->vel.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
   if (b->d_imit) {
-    ok = ok && hipMemcpy(b->d_imit, mc->imit_table.data(), mc->imit_table.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(b->d_imit, mc->imit_params.data(), 32 * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(b->d_imit + 32, mc->imit_table.data(), mc->imit_table.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
     for (int k = 0; k < 32; k++) b->B.imit_params[k] = mc->imit_params[k];
   }
-  b->B.imit_table = b->d_imit;
+  b->B.imit_pdev = b->d_imit;
+  b->B.imit_table = b->d_imit ? b->d_imit + 32 : nullptr;
   // initial state = MjSim(model): qpos0, zero velocity
   std::vector<double> q0((size_t)n * NQ);
   for (int e2 = 0; e2 < n; e2++) for (int k = 0; k < NQ; k++) q0[(size_t)e2 * NQ + k] = hm.qpos0[k];

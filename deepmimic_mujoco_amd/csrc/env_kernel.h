@@ -341,7 +341,7 @@ DM_DEV void subtree_sums_pass(const R (*in)[NC], R (*out)[NC], int lane) {
 //   3. per body (parallel): world joint axes -> cdof (about the world origin), xipos, spatial inertia;
 //   4. composite inertias as static subtree sums.
 template <class R>
-DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt) {
+DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt, R* qloc_out = nullptr, R (*aloc_out)[3] = nullptr) {
   const int lane = dmw::launder(lane_in);
   const int b = lane + 1;
   const bool isbody = lane < NB - 1;
@@ -374,6 +374,10 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       const R ql[4] = {c, axl[0] * sn, axl[1] * sn, axl[2] * sn};
       quat_mul(qloc, qloc, ql);
     }
+  }
+  if (qloc_out) {   // by-products the imitation reward's joint features are made of: child-in-parent rotation, hinge axes in the parent frame
+    for (int k = 0; k < 4; k++) qloc_out[k] = qloc[k];
+    for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) aloc_out[k][r] = aloc[k][r];
   }
   // 2. compose down the tree
   for (int L = 1; L <= MAXDEPTH_BODY; L++) {

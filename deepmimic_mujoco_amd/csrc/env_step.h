@@ -31,6 +31,7 @@ struct Batch {
   const R* mocap_cfg;  // [F,35]
   const R* mocap_vel;  // [F,34]
   const R* imit_table; // [F,112] reference feature rows of the 5-term imitation reward (nullptr: not provided)
+  const R* imit_pdev;  // the same 32 parameters in device memory (the reward indexes them per lane)
   R imit_params[32];   // joint weights [12], root weight, cycle shift x y, loop flag, end-effector bodies [4], offsets [4][3]
   int n_frames;
   int n_envs;
@@ -197,78 +198,79 @@ DM_DEV R quat_diff_theta(const R* q0, const R* q1) {
 }
 // The simulated state's features are formed from the FK of the INTEGRATED state (one extra kinematics pass; the 4th-stage
 // quantities `is_done` reads have been stored by then) and compared with row `ref` of the reference table.
-// Lanes 0..11: joint groups (pose / velocity terms); lane 12: root; lanes 13..16: end effectors; lanes 0..12 again: body momenta.
+// Lane = body - 1 as in the kinematics stage, whose by-products ARE the joint features (child-in-parent quaternion, hinge
+// axes in the parent frame): lane 0 root, lanes 1..12 joint groups; lanes 13..16 end effectors; lanes 0..33 again one dof
+// each for the linear momentum  p = sum_d qvel_d (m_sub(d) lin_d + ang_d x S_sub(d))  with the subtree mass / first moment the
+// composite-inertia pass has just left in LDS.  One acos, one exp per lane; no other transcendental.
 template <class R>
 DM_DEV R imitation_reward(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int lane, const LaneTopo& lt, const R* ref, R shx, R shy) {
-  stage_kinematics(M, s, lane, lt);
-  dmw::sync();
-  const R* P = B.imit_params;
+  R qloc[4], aloc[3][3];
+  stage_kinematics(M, s, lane, lt, qloc, aloc);          // ends with a sync
+  const R* P = B.imit_pdev;                               // device copy of the parameter block (per-lane indexing)
   R rq[4] = {s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
   normalize4(rq);
   R pose = 0, vel = 0, eff = 0, root = 0, mx = 0, my = 0, mz = 0;
-  if (lane < 12) {
-    const int g = lane, b = g + 2, da = TOPO.body_dofadr[b], nd = TOPO.body_dofnum[b];
-    R pe, ve = 0;
-    if (nd == 1) {
+  if (lane < 13) {
+    const int g = lane - 1;                               // joint group (lane 0: the root, weight slot 12)
+    const int da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum);
+    const bool isroot = lane == 0, ball = !isroot && nd == 3;
+    const R* rquat = ref + (isroot ? 3 : 13 + 4 * g);
+    const R ident[4] = {1, 0, 0, 0};
+    R q0[4], q1[4];
+    for (int k = 0; k < 4; k++) { q0[k] = isroot ? rq[k] : (ball ? qloc[k] : ident[k]); q1[k] = (isroot || ball) ? rquat[k] : ident[k]; }
+    const R th = quat_diff_theta(q0, q1);
+    R pe = th * th, ve = 0;
+    if (isroot) {
+      R wv[3];
+      const R wloc[3] = {s.qvel[3], s.qvel[4], s.qvel[5]};
+      quat_rot(wv, rq, wloc);                             // free-joint angular velocity is body-local
+      R dv2 = 0, dp2 = 0;
+      for (int k = 0; k < 3; k++) { const R a = ref[10 + k] - wv[k]; ve += a * a; const R c = ref[7 + k] - s.qvel[k]; dv2 += c * c; }
+      const R p1[3] = {ref[0] + shx, ref[1] + shy, ref[2]};
+      for (int k = 0; k < 3; k++) { const R a = s.qpos[k] - p1[k]; dp2 += a * a; }
+      root = dp2 + R(0.1) * pe + R(0.01) * dv2 + R(0.001) * ve;
+    } else if (ball) {
+      R wl[3] = {0, 0, 0};                                // child = R1 R2 R3;  w = sum_k (R1..R(k-1) a_k) rate_k
+      for (int k = 0; k < 3; k++) { const R rate = s.qvel[da + k]; wl[0] += aloc[k][0] * rate; wl[1] += aloc[k][1] * rate; wl[2] += aloc[k][2] * rate; }
+      for (int k = 0; k < 3; k++) { const R w = ref[61 + 3 * g + k] - wl[k]; ve += w * w; }
+    } else {
       const R a = ref[13 + 4 * g] - s.qpos[da + 1], w = ref[61 + 3 * g] - s.qvel[da];
       pe = a * a; ve = w * w;
-    } else {
-      R ql[4] = {1, 0, 0, 0}, wl[3] = {0, 0, 0};
-      for (int k = 0; k < 3; k++) {                       // child = R1 R2 R3;  w = sum_k R1..R(k-1) a_k rate_k
-        const R* ax = M.jnt_axis[da + k - 5];
-        R a[3], qa[4], t[4];
-        quat_rot(a, ql, ax);
-        const R rate = s.qvel[da + k];
-        wl[0] += a[0] * rate; wl[1] += a[1] * rate; wl[2] += a[2] * rate;
-        axisangle2quat(qa, ax, s.qpos[da + k + 1]);
-        quat_mul(t, ql, qa);
-        ql[0] = t[0]; ql[1] = t[1]; ql[2] = t[2]; ql[3] = t[3];
-      }
-      const R th = quat_diff_theta(ql, ref + 13 + 4 * g);
-      pe = th * th;
-      for (int k = 0; k < 3; k++) { const R w = ref[61 + 3 * g + k] - wl[k]; ve += w * w; }
     }
-    pose = P[g] * pe; vel = P[g] * ve;
-  } else if (lane == 12) {
-    const R th = quat_diff_theta(rq, ref + 3);
-    R wv[3];
-    const R wloc[3] = {s.qvel[3], s.qvel[4], s.qvel[5]};
-    quat_rot(wv, rq, wloc);                               // free-joint angular velocity is body-local
-    R dw2 = 0, dv2 = 0, dp2 = 0;
-    for (int k = 0; k < 3; k++) { const R a = ref[10 + k] - wv[k]; dw2 += a * a; const R c = ref[7 + k] - s.qvel[k]; dv2 += c * c; }
-    const R p1[3] = {ref[0] + shx, ref[1] + shy, ref[2]};
-    for (int k = 0; k < 3; k++) { const R a = s.qpos[k] - p1[k]; dp2 += a * a; }
-    pose = P[12] * th * th; vel = P[12] * dw2;
-    root = dp2 + R(0.1) * th * th + R(0.01) * dv2 + R(0.001) * dw2;
+    const R wj = P[isroot ? 12 : g];
+    pose = wj * pe; vel = wj * ve;
   } else if (lane < 17) {
     const int e = lane - 13, b = (int)P[16 + e];
     const R ex[3] = {1, 0, 0};
     R fwd[3], p[3], rel[3];
     quat_rot(fwd, rq, ex);
-    const R hd = atan2_once(fwd[1], fwd[0]);
-    const SinCos<R> hsc = sincos_once(hd);
-    const R c = hsc.c, sn = hsc.s;
+    const R hn = sqrt(fwd[0] * fwd[0] + fwd[1] * fwd[1]);   // heading about the vertical: (cos, sin) of atan2(fwd_y, fwd_x)
+    const R c = hn > R(0) ? fwd[0] / hn : R(1), sn = hn > R(0) ? fwd[1] / hn : R(0);
     mat_vec(p, s.xmat[b], P + 20 + 3 * e);
     for (int k = 0; k < 3; k++) { p[k] += s.xpos[b][k]; rel[k] = p[k] - s.qpos[k]; }
     rel[2] = p[2];                                        // height above the ground plane
     const R f0[3] = {c * rel[0] + sn * rel[1], -sn * rel[0] + c * rel[1], rel[2]};
     for (int k = 0; k < 3; k++) { const R a = ref[97 + 3 * e + k] - f0[k]; eff += a * a; }
   }
-  if (lane < NB - 1) {                                    // linear momentum of body lane + 1: m (v_origin + w x xipos)
-    const int b = lane + 1;
-    const unsigned long long chain = TOPO.chain[b];
-    R cv[6] = {0, 0, 0, 0, 0, 0};
-    for (int d = 0; d < NV; d++) if ((chain >> d) & 1ull) { const R qd = s.qvel[d]; for (int k = 0; k < 6; k++) cv[k] += s.cdof[d][k] * qd; }
-    R wxr[3];
-    cross3(wxr, cv, s.xipos[b]);
-    const R m = M.body_mass[b];
-    mx = m * (cv[3] + wxr[0]); my = m * (cv[4] + wxr[1]); mz = m * (cv[5] + wxr[2]);
+  if (lane < NV) {                                        // momentum carried by dof `lane`: its whole subtree moves with it
+    const int b = TOPO.dof_body[lane];
+    const R* cb = s.ub.i.crb[b];
+    const R* cd = s.cdof[lane];
+    const R qd = s.qvel[lane], ms = cb[9];
+    R axs[3];
+    cross3(axs, cd, cb + 6);
+    mx = qd * (ms * cd[3] + axs[0]); my = qd * (ms * cd[4] + axs[1]); mz = qd * (ms * cd[5] + axs[2]);
   }
-  pose = dmw::wave_sum(pose); vel = dmw::wave_sum(vel); eff = dmw::wave_sum(eff) / 4; root = dmw::wave_sum(root);
+  pose = dmw::wave_sum(pose); vel = dmw::wave_sum(vel); eff = dmw::wave_sum(eff) / 4; root = dmw::bcast(root, 0);
   mx = dmw::wave_sum(mx) / M.total_mass; my = dmw::wave_sum(my) / M.total_mass; mz = dmw::wave_sum(mz) / M.total_mass;
   const R dc[3] = {ref[109] - mx, ref[110] - my, ref[111] - mz};
   const R com = R(0.1) * dot3(dc, dc);
-  return R(0.5) * exp_once(R(-2) * pose) + R(0.05) * exp_once(R(-0.1) * vel) + R(0.15) * exp_once(R(-40) * eff) + R(0.2) * exp_once(R(-5) * root) + R(0.1) * exp_once(R(-10) * com);
+  // the five terms, one lane each:  0.5 e^(-2 pose) + 0.05 e^(-0.1 vel) + 0.15 e^(-40 eff) + 0.2 e^(-5 root) + 0.1 e^(-10 com)
+  const R arg = lane == 0 ? R(-2) * pose : lane == 1 ? R(-0.1) * vel : lane == 2 ? R(-40) * eff : lane == 3 ? R(-5) * root : R(-10) * com;
+  const R wgt = lane == 0 ? R(0.5) : lane == 1 ? R(0.05) : lane == 2 ? R(0.15) : lane == 3 ? R(0.2) : R(0.1);
+  R term = 0;
+  if (lane < 5) term = wgt * exp_once(arg);
+  return dmw::wave_sum(term);
 }
 
 // DPEnv.step for one environment

@@ -201,6 +201,13 @@ class DoubleBufferedGather:
             self.pending[k].wait(); self.pending[k] = None
         return self.blocks[k][t % self.T]
 
+    def block(self, t):
+        """The whole [T, n, 87] block step t belongs to (for producers that fill a block in one go at the end of a horizon)."""
+        k = self._k(t)
+        if self.pending[k] is not None:
+            self.pending[k].wait(); self.pending[k] = None
+        return self.blocks[k]
+
     def commit(self, t):
         """Call after step t's row has been written.  Returns the index of the gathered buffer when a gather was launched."""
         if self.world > 1 and (t + 1) % self.T == 0:

@@ -1188,6 +1188,22 @@ void dmo_batch_step(const dmo_model* m, dmo_data** ds, int n, const double* acti
   }
 }
 
+/* the same loop with the 5-term imitation reward (bench.py's cpu_baseline for the default workload) */
+void dmo_batch_step_imitation(const dmo_model* m, dmo_data** ds, int n, const double* actions, int n_substeps, const double* table, int F,
+                              const double* params, int* idx_curr, int* cycle, double* obs, double* reward, unsigned char* done, int nthreads) {
+  int nu = m->s.nu;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int e = 0; e < n; e++) {
+    int dn;
+    dmo_env_step_imitation(m, ds[e], actions + (size_t)e * nu, n_substeps, table, F, params, idx_curr + e, cycle + e,
+                           obs + (size_t)e * 56, reward + e, &dn);
+    done[e] = (unsigned char)dn;
+  }
+}
+
 int dmo_sizeof_model(void) { return (int)sizeof(dmo_model); }
 int dmo_sizeof_data(void) { return (int)sizeof(dmo_data); }
 

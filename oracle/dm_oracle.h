@@ -150,6 +150,8 @@ void dmo_env_step_imitation(const dmo_model* m, dmo_data* d, const double* actio
                             const double* params, int* idx_curr, int* cycle, double* obs, double* reward, int* done);
 void dmo_batch_step(const dmo_model* m, dmo_data** ds, int n, const double* actions, int n_substeps,
                     double* obs, double* reward, unsigned char* done, int nthreads);
+void dmo_batch_step_imitation(const dmo_model* m, dmo_data** ds, int n, const double* actions, int n_substeps, const double* table, int F,
+                              const double* params, int* idx_curr, int* cycle, double* obs, double* reward, unsigned char* done, int nthreads);
 
 /* heap model + string-keyed accessors for the ctypes test harness (oracle/oracle.py) */
 dmo_model* dmo_model_new(const dmo_spec* s);         /* s == NULL -> the dp_env_v3 humanoid */

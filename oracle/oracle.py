@@ -82,6 +82,8 @@ def lib():
                                              C.POINTER(C.c_int), dp, dp, C.POINTER(C.c_int)]
         L.dmo_batch_step.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, dp, C.c_int, dp, dp,
                                      C.POINTER(C.c_ubyte), C.c_int]
+        L.dmo_batch_step_imitation.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, dp, C.c_int, dp, C.c_int, dp,
+                                               C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp, C.POINTER(C.c_ubyte), C.c_int]
         _LIB = L
     return _LIB
 
@@ -214,4 +216,18 @@ def batch_step(model, datas, actions, n_substeps=1, nthreads=1):
     obs = np.zeros((n, 56)); rew = np.zeros(n); done = np.zeros(n, dtype=np.uint8)
     lib().dmo_batch_step(model.h, arr, n, _dp(a), n_substeps, _dp(obs), _dp(rew),
                          done.ctypes.data_as(C.POINTER(C.c_ubyte)), nthreads)
+    return obs, rew, done
+
+
+def batch_step_imitation(model, datas, actions, n_substeps, table, params, idx_curr, cycle, nthreads=1):
+    """OpenMP loop of `env_step_imitation`; `idx_curr` / `cycle` (int32 [n]) are advanced in place."""
+    n = len(datas)
+    arr = (C.c_void_p * n)(*[d.h for d in datas])
+    a = np.ascontiguousarray(actions, dtype=np.float64); tb = np.ascontiguousarray(table, dtype=np.float64)
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    assert idx_curr.dtype == np.int32 and cycle.dtype == np.int32 and idx_curr.flags.c_contiguous and cycle.flags.c_contiguous
+    obs = np.zeros((n, 56)); rew = np.zeros(n); done = np.zeros(n, dtype=np.uint8)
+    lib().dmo_batch_step_imitation(model.h, arr, n, _dp(a), int(n_substeps), _dp(tb), tb.shape[0], _dp(p),
+                                   idx_curr.ctypes.data_as(C.POINTER(C.c_int)), cycle.ctypes.data_as(C.POINTER(C.c_int)),
+                                   _dp(obs), _dp(rew), done.ctypes.data_as(C.POINTER(C.c_ubyte)), int(nthreads))
     return obs, rew, done

@@ -79,7 +79,7 @@ void* emu_create(const dm_model_desc* d, const double* cfg, const double* vel, i
   B.qpos = e->qpos.data(); B.qvel = e->qvel.data(); B.qws = e->qws.data(); B.time = e->time.data(); B.ctrl = e->ctrl.data();
   B.xipos = e->xipos.data(); B.comz = e->comz.data(); B.frame_idx = e->fidx.data(); B.frame_init = e->finit.data();
   B.ncon = e->ncon.data(); B.nefc = e->nefc.data(); B.cong = e->cong.data(); B.status = e->status.data();
-  B.aovf = e->aovf.data(); B.cycle = e->cycle.data(); B.imit_table = nullptr; B.order = nullptr;
+  B.aovf = e->aovf.data(); B.cycle = e->cycle.data(); B.imit_table = nullptr; B.imit_pdev = nullptr; B.order = nullptr;
   B.solver_iter = e->siter.data(); B.episode = e->episode.data(); B.mocap_cfg = e->cfg.data(); B.mocap_vel = e->vel.data();
   B.n_frames = F; B.n_envs = n; B.env_offset = 0; B.reward_mode = 0; B.autoreset = 0; B.action_mode = 0; B.seed = 0;
   return e;
@@ -89,6 +89,7 @@ void emu_set_imitation(void* h, const double* table, const double* params) {
   e->imit.assign(table, table + (size_t)e->B.n_frames * IMIT_FEAT);
   e->B.imit_table = e->imit.data();
   for (int k = 0; k < 32; k++) e->B.imit_params[k] = params[k];
+  e->B.imit_pdev = e->B.imit_params;
 }
 void emu_destroy(void* h) { delete (EmuBatch*)h; }
 void emu_set_option(void* h, int opt, long long v) {

@@ -119,6 +119,16 @@ def _dbg_worker(rank, world, port):
             for r in range(world):
                 for i in range(T):
                     assert torch.all(out[r, i] == float(1000 * r + h * T + i)), (h, k, r, i)
+        # block-at-once producers (bench.py packs a whole horizon at its last step): same buffers, same gathers
+        for h in range(5, 8):
+            t = h * T + T - 1
+            g.block(t)[:] = float(1000 * rank + 7 * h)
+            assert g.commit(t) == h % 2
+        g.drain()
+        for h, k in ((7, 1), (6, 0)):
+            out = g.gathered[k].view(world, T, n, ROW)
+            for r in range(world):
+                assert torch.all(out[r] == float(1000 * r + 7 * h))
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -115,6 +115,30 @@ def test_oracle_imitation_episode_wraps_with_cycle_shift_and_ends_non_looping_cl
     assert (idx, cyc, dn) == (F - 1, 0, True)
 
 
+def test_oracle_batched_imitation_step_equals_the_single_env_loop():
+    """bench.py's cpu_baseline loop (OpenMP over envs) is the same computation as env_step_imitation, env by env."""
+    from oracle import oracle as O
+    sp = _spec(); mc = H.mocap()
+    T = sp.build_table(mc.data_config, mc.data_vel); P = sp.params(mc.data_config, mc.loop); F = len(T)
+    om = H.oracle_model(); n = 6
+    rng = np.random.RandomState(3)
+    start = np.array([F - 2, 0, 5, 11, 17, 30], dtype=np.int32)
+    da = [O.Data(om) for _ in range(n)]; db = [O.Data(om) for _ in range(n)]
+    for e in range(n):
+        for d in (da[e], db[e]):
+            d.reset(); d.set_state(mc.data_config[start[e]], mc.data_vel[start[e]])
+    idx = start.copy(); cyc = np.zeros(n, dtype=np.int32)
+    fi = start.astype(int).copy(); fc = np.zeros(n, int)
+    for t in range(5):
+        a = rng.randn(n, 28) * 0.5
+        obs, rew, done = O.batch_step_imitation(om, da, a, 1, T, P, idx, cyc, nthreads=3)
+        for e in range(n):
+            o, r, dn, fi[e], fc[e] = O.env_step_imitation(om, db[e], a[e], 1, T, P, fi[e], fc[e])
+            assert np.array_equal(o, obs[e]) and r == rew[e] and bool(done[e]) == dn
+        assert np.array_equal(idx, fi) and np.array_equal(cyc, fc)
+    assert cyc[0] == 1
+
+
 def _imit_inputs():
     sp = _spec(); mc = H.mocap()
     return sp, mc, sp.build_table(mc.data_config, mc.data_vel), sp.params(mc.data_config, mc.loop)

@@ -8,7 +8,7 @@ from deepmimic_mujoco_amd import DPVecEnv, _abi as A
 for wl in ("cfg3", "cfg2"):
     full = wl == "cfg3"
     n = 4096
-    env = DPVecEnv(n, motion="walk", device=0, reward="v3-config" if full else "alive", autoreset="rsi", seed=0,
+    env = DPVecEnv(n, motion="walk", device=0, reward=os.environ.get("DM_PROF_REWARD", "v3-config") if full else "alive", autoreset="rsi", seed=0,
                    contacts=full, limits=full, action_mode="raw" if full else "p-control")
     env.reset("rsi")
     rng = np.random.RandomState(0)
