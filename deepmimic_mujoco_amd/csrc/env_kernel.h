@@ -118,19 +118,21 @@ struct Shared {
 struct LaneTopo {
   int parent, dofadr, dofnum, depth;
   unsigned subtree;
-  int tri0, tri1;    // (e << 8) | a of the lower-triangular pair number t = lane, lane + 64:  t = e (e - 1) / 2 + (a - 1),  1 <= a <= e
+  unsigned long long tri;   // six byte codes (e << 4) | a of the lower-triangular pair numbers t = (lane & 15) + 16 j, j = 0..5:
+                            // t = e (e - 1) / 2 + (a - 1),  1 <= a <= e   (byte j of the word)
 };
-DM_DEV int tri_pair(int t) {   // once per kernel per lane (the elimination steps index their rank-1 updates with it)
+DM_DEV unsigned tri_pair(int t) {   // once per kernel per lane (the elimination steps index their rank-1 updates with it)
   int e = 1;
   while (e * (e + 1) / 2 <= t) e++;
-  return (e << 8) | (t - e * (e - 1) / 2 + 1);
+  return (unsigned)((e << 4) | (t - e * (e - 1) / 2 + 1));
 }
 DM_DEV LaneTopo lane_topo(int lane) {
   LaneTopo t;
   const int b = lane < NB - 1 ? lane + 1 : 0;
   t.parent = TOPO.body_parent[b]; t.dofadr = TOPO.body_dofadr[b]; t.dofnum = TOPO.body_dofnum[b];
   t.depth = lane < NB - 1 ? TOPO.body_depth[b] : 0; t.subtree = TOPO.subtree[b];
-  t.tri0 = tri_pair(lane); t.tri1 = tri_pair(lane + 64);
+  t.tri = 0;
+  for (int j = 0; j < 6; j++) t.tri |= (unsigned long long)(tri_pair((lane & 15) + 16 * j) & 0xff) << (8 * j);
   return t;
 }
 template <class R>
@@ -506,40 +508,91 @@ DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane_in, const La
 }
 
 // mass matrix (tree-sparse, MuJoCo qM order) and its L^T D L factor   [MJ mj_crb, mj_factorM]
-template <int K, class R>
-DM_DEV void eliminate_dof(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt) {
-  const int lane = dmw::launder(lane_in);
-  // column K of the elimination: for every ancestor pair (a, c), row i = anc_a(K):
-  //   M(i, anc_c(i)) -= M(K, anc_{a+c}(K)) * M(K, i) / M(K, K)
-  // Row K itself is left unscaled (nothing reads it again during the factorisation); all rows are scaled at the end.
-  constexpr int nk = TOPO.dof_depth[K] - 1;   // proper ancestors
-  constexpr int base = TOPO.madr[K];
-  if (nk > 0) {
-    const R inv = R(1) / s.qLD[base];
-    // the update pairs (a, e = a + c), 1 <= a <= e <= nk, are the lower triangle of an nk x nk matrix; enumerated by
-    // t = e (e - 1) / 2 + a - 1 the first nk (nk + 1) / 2 numbers are exactly this step's pairs, whatever nk is, so each lane
-    // keeps its two (e, a) codes for the whole kernel (LaneTopo) and a step needs no index arithmetic beyond an unpack
-    constexpr int npairs = nk * (nk + 1) / 2;
-    static_assert(npairs <= 128, "two passes of 64 lanes cover every step of this tree");
-#pragma unroll
-    for (int p = 0; p * 64 < npairs; p++) {
-      const int code = p == 0 ? lt.tri0 : lt.tri1;
-      const int e = code >> 8, a = code & 0xff;
-      if (p * 64 + lane < npairs) {
-        const int dst = s.tab_dst[K][a] + (e - a);
-        s.qLD[dst] -= s.qLD[base + e] * (s.qLD[base + a] * inv);
-      }
-    }
-    dmw::sync();
-  }
+// Elimination schedule.  Column K only touches entries (i, j) with i, j proper ancestors of K, and reads its own row, so
+// columns of dofs in different branches of the tree commute: the four limbs (and the neck beside the hips) are eliminated
+// side by side, each in its own group of lanes — 15 dependent steps instead of 33.  Entries of common ancestors (root and
+// chest blocks) receive one contribution per limb in the same step; the updates are LDS atomics (dmw::lds_sub), which
+// also makes every update fire-and-forget.
+struct ElimStep { int ncol; int K[4]; };
+constexpr int N_ELIM_STEPS = 15;
+constexpr ElimStep ELIM_STEPS[N_ELIM_STEPS] = {
+  {4, {33, 26, 19, 15}}, {4, {32, 25, 18, 14}}, {4, {31, 24, 17, 13}}, {4, {30, 23, 16, 12}},   // ankles | elbows, shoulders;  knees
+  {3, {29, 22, 11, 0}}, {3, {28, 21, 10, 0}}, {3, {27, 20, 9, 0}},                                // hips (16 lanes each) | neck (32 lanes)
+  {1, {8, 0, 0, 0}}, {1, {7, 0, 0, 0}}, {1, {6, 0, 0, 0}},                                        // chest
+  {1, {5, 0, 0, 0}}, {1, {4, 0, 0, 0}}, {1, {3, 0, 0, 0}}, {1, {2, 0, 0, 0}}, {1, {1, 0, 0, 0}}}; // root
+constexpr bool dof_is_ancestor(int anc, int d) {
+  for (int a = 1; a < 16; a++) if (TOPO.dof_anc[d][a] == anc) return true;
+  return false;
 }
-template <int K, class R>
+constexpr bool elim_schedule_ok() {
+  bool seen[NV] = {};
+  for (int st = 0; st < N_ELIM_STEPS; st++) {
+    const ElimStep& e = ELIM_STEPS[st];
+    for (int c = 0; c < e.ncol; c++) {
+      const int K = e.K[c];
+      if (K < 1 || K >= NV || seen[K]) return false;
+      for (int d = 0; d < NV; d++) if (dof_is_ancestor(K, d) && !seen[d]) return false;          // descendants first
+      for (int c2 = 0; c2 < e.ncol; c2++) if (c2 != c && (dof_is_ancestor(K, e.K[c2]) || dof_is_ancestor(e.K[c2], K) || e.K[c2] == K)) return false;
+    }
+    for (int c = 0; c < e.ncol; c++) seen[e.K[c]] = true;
+  }
+  for (int d = 1; d < NV; d++) if (!seen[d]) return false;
+  return true;
+}
+static_assert(elim_schedule_ok(), "elimination schedule: every dof once, descendants before ancestors, independent columns per step");
+constexpr int elim_group_size(int ncol, int c) { return ncol == 1 ? 64 : ncol == 2 ? 32 : ncol == 4 ? 16 : (c < 2 ? 16 : 32); }
+constexpr int elim_npairs(int K) { return (TOPO.dof_depth[K] - 1) * TOPO.dof_depth[K] / 2; }
+constexpr int elim_passes(int S) {
+  const ElimStep& e = ELIM_STEPS[S];
+  int m = 0;
+  for (int c = 0; c < e.ncol; c++) { const int g = elim_group_size(e.ncol, c), q = (elim_npairs(e.K[c]) + g - 1) / g; m = q > m ? q : m; }
+  return m;
+}
+constexpr bool elim_codes_ok() {   // a lane holds the codes of pair numbers (lane & 15) + 16 j, j < 6
+  for (int S = 0; S < N_ELIM_STEPS; S++) for (int c = 0; c < ELIM_STEPS[S].ncol; c++) {
+    const int g = elim_group_size(ELIM_STEPS[S].ncol, c), np = elim_npairs(ELIM_STEPS[S].K[c]);
+    if (np > 96 || (g == 64 && np > 64)) return false;
+  }
+  return true;
+}
+static_assert(elim_codes_ok(), "pair numbers of a column must stay below 96 (below 64 for a full-wave column)");
+
+template <int S, class R>
+DM_DEV void eliminate_step(Shared<R>& s, int lane_in, const LaneTopo& lt) {
+  // column K:  for every ancestor pair (a, c), row i = anc_a(K):   M(i, anc_c(i)) -= M(K, anc_{a+c}(K)) * M(K, i) / M(K, K)
+  // Row K itself is left unscaled (nothing reads it again during the factorisation); all rows are scaled at the end.
+  // The update pairs (a, e = a + c), 1 <= a <= e <= nk, are the lower triangle of an nk x nk matrix; enumerated by
+  // t = e (e - 1) / 2 + a - 1 the first nk (nk + 1) / 2 numbers are exactly a column's pairs, whatever nk is, so each lane
+  // keeps the codes of the six pair numbers it can ever be given (LaneTopo) and a step needs no index arithmetic.
+  constexpr ElimStep st = ELIM_STEPS[S];
+  constexpr int NC = st.ncol;
+  const int lane = dmw::launder(lane_in);     // (laundered: the per-lane step constants below must not be hoisted out of the RK loop)
+  int ci, lg;                                 // this lane's column of the step, its index inside the column's lane group
+  if constexpr (NC == 1) { ci = 0; lg = lane; }
+  else if constexpr (NC == 2) { ci = lane >> 5; lg = lane & 31; }
+  else if constexpr (NC == 3) { ci = lane < 32 ? (lane >> 4) : 2; lg = lane < 32 ? (lane & 15) : lane - 32; }
+  else { ci = lane >> 4; lg = lane & 15; }
+  int base = TOPO.madr[st.K[0]], np = elim_npairs(st.K[0]), k14 = st.K[0] * 14, gs = elim_group_size(NC, 0);
+#pragma unroll
+  for (int c = 1; c < NC; c++) if (ci == c) { base = TOPO.madr[st.K[c]]; np = elim_npairs(st.K[c]); k14 = st.K[c] * 14; gs = elim_group_size(NC, c); }
+  constexpr int passes = elim_passes(S);
+  const R inv = R(1) / s.qLD[base];
+  const unsigned short* tdst = &s.tab_dst[0][0];
+#pragma unroll
+  for (int p = 0; p < passes; p++) {
+    const int t = lg + gs * p;
+    const bool on = t < np;
+    const int code = on ? (int)(lt.tri >> (8 * (t >> 4))) & 0xff : 0, e = code >> 4, a = code & 15;
+    const int dst = tdst[k14 + a] + (e - a);
+    dmw::lds_sub(on, &s.qLD[dst], s.qLD[base + e] * (s.qLD[base + a] * inv));
+  }
+  dmw::sync();
+}
+template <int S, class R>
 struct EliminateFrom {
-  static DM_DEV void run(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) { eliminate_dof<K>(M, s, lane, lt); EliminateFrom<K - 1, R>::run(M, s, lane, lt); }
-};
-template <class R>
-struct EliminateFrom<0, R> {
-  static DM_DEV void run(const DevModel<R>&, Shared<R>&, int, const LaneTopo&) {}
+  static DM_DEV void run(Shared<R>& s, int lane, const LaneTopo& lt) {
+    if constexpr (S < N_ELIM_STEPS) { eliminate_step<S>(s, lane, lt); EliminateFrom<S + 1, R>::run(s, lane, lt); }
+  }
 };
 
 template <class R>
@@ -560,7 +613,7 @@ DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane_in, c
     if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
   }
   dmw::sync();
-  EliminateFrom<NV - 1, R>::run(M, s, lane, lt);      // dofs 33 .. 1, one barrier each (fully unrolled, compile-time shapes)
+  EliminateFrom<0, R>::run(s, lane, lt);       // 15 steps of mutually independent columns, one barrier each (fully unrolled)
   // D^-1, D^-1/2 and the unit-triangular scaling L(k, j) = M(k, j) / D_k, all entries at once
   if (lane < NV) { const R inv = R(1) / s.qLD[TOPO.madr[lane]]; s.dinv[lane] = inv; s.dsq[lane] = sqrt(inv); }
   dmw::sync();

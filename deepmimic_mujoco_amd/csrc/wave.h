@@ -74,6 +74,11 @@ DM_DEV void pin_value(float& v) { asm volatile("" : "+v"(v)); }
 DM_DEV int launder(int v) { asm volatile("" : "+v"(v)); return v; }
 DM_DEV int launder_uniform(int v) { asm volatile("" : "+s"(v)); return v; }   // same for a wave-uniform (SGPR) value
 DM_DEV void reload_fence() { asm volatile("" ::: "memory"); }
+// if (pred) *p -= v in LDS as one fire-and-forget ds_add_f64: lanes of one instruction may hit the same address (the
+// LDS applies them one after the other), and nothing comes back, so the issuing lane does not wait for the old value.
+// Called by all lanes (the testbench implements it as a collective).
+DM_DEV void lds_sub(bool pred, double* p, double v) { if (pred) __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DM_DEV void lds_sub(bool pred, float* p, float v) { if (pred) __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 }  // namespace dmw
 #endif
 

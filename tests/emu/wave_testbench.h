@@ -20,6 +20,7 @@ struct WaveBench {
   int arrived;
   unsigned long long gen;
   unsigned long long slot[2][64];
+  void* aptr[64]; double aval[64];   // operands of a wave-wide LDS atomic (lds_sub)
   void (*yield_fn)(void);
 };
 WaveBench& bench();
@@ -72,6 +73,15 @@ inline double perm_half_mirror(double v) { const int l = lane(); return exchange
 inline double perm_row_mirror(double v) { const int l = lane(); return exchange(v, (l & ~15) | (15 - (l & 15))); }
 inline void sched_fence() {}
 inline void reload_fence() {}
+// wave-wide LDS atomic: a collective here (all 64 fibres call it, `pred` says who takes part) so that updates of one
+// address are applied in lane order whatever order the fibres happen to run in; the device adds the ROUNDED operand
+template <class T> inline void lds_sub(bool pred, T* p, T v) {
+  WaveBench& b = bench();
+  b.aptr[b.cur_lane] = pred ? (void*)p : nullptr; b.aval[b.cur_lane] = (double)v;
+  rendezvous();
+  if (lane() == 0) for (int l = 0; l < 64; l++) if (bench().aptr[l]) *(T*)bench().aptr[l] -= (T)bench().aval[l];
+  rendezvous();
+}
 inline int pin_zero() { return 0; }
 inline int launder(int v) { return v; }
 inline int launder_uniform(int v) { return v; }
