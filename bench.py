@@ -237,7 +237,8 @@ def main():
                        "mean_nefc": round(float(nefc.mean()), 2), "overflow_envs": int((status & 1).sum())},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "k_step_narrow", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
+                         "kernel": "k_step_narrow", "kernel_ms": round(kernel_ms, 4),
+                         "kernel_ms_covers": "one dm_batch_step on the launch stream: k_step_narrow + k_order (~0.01 ms) + 1/256 of a horizon's block packing", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                          "note": "latency/ALU-bound path: see fp64 fraction",
                          "fp64_est_tflops": round(ALGO_FLOP_PER_STEP * n / (kernel_ms * 1e-3) / 1e12, 3),
                          "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,

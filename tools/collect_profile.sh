@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d /tmp/p_sq -- $B > /dev/null 2>&1
 cd $OLDPWD
-ROWS=6 python tools/rocprof_summary.py $OUT/kstep_summary.md "k_step_narrow — $TAG, MI355X (bench.py cfg3, 4096 envs)" \
+ROWS=6 python tools/rocprof_summary.py $OUT/kstep_summary.md "k_step_narrow — $TAG, MI355X (bench.py default workload: cfg3 + 5-term imitation reward, 4096 envs)" \
   $(find /tmp/p_trace -name "*.db" | head -1) $(find /tmp/p_fetch -name "*.db" | head -1) $(find /tmp/p_write -name "*.db" | head -1) $(find /tmp/p_sq -name "*.db" | head -1) > /dev/null
 cat $OUT/bench_cfg3.json | cut -c1-400
 cat $OUT/bench_cfg2.json | cut -c1-120
