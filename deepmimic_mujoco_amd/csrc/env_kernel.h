@@ -1076,6 +1076,37 @@ DM_DEV R impedance(const DevModel<R>& M, R x) {
   return si[0] + y * (si[1] - si[0]);
 }
 
+// x = L^-1 rhs for ONE vector, one dof per lane (rhs / result in lane d < NV), level by level down the tree:
+//   x_i = rhs_i - sum_{j in anc(i)} L(i, j) x_j.
+// When the dofs of depth l are final they publish x; every deeper lane then takes the term of ITS ancestor at depth l —
+// one FMA per level and lane, 12 LDS hand-offs, instead of every lane redundantly running all 310 FMAs of the sparse
+// solve on a private copy.  x is exchanged through the row-descriptor region (s.u, must be free), indexed by the
+// ancestors' diagonal addresses that s.tab_dst already holds; terms are added root-first.
+template <class R>
+DM_DEV R lane_solve_L(Shared<R>& s, int lane_in, R rhs) {
+  constexpr int MAXD = 13;
+  static_assert([] { for (int d = 0; d < NV; d++) if (TOPO.dof_depth[d] > MAXD) return false; return true; }(), "dof chains are at most 13 deep");
+  const int ll = dmw::launder(lane_in);
+  const bool isdof = ll < NV;
+  const int dd = isdof ? TOPO.dof_depth[ll] : 0;
+  const unsigned short* td = &s.tab_dst[isdof ? ll : 0][0];
+  const int own = td[0];
+  R acc = rhs;
+  R* xs = &s.u.rowd[0][0];
+  int a = dd - 1;                               // my ancestor at depth l is my (dd - l)-th ancestor
+  R La = s.qLD[own + (a > 0 ? a : 0)]; int xi = td[a > 0 ? a : 0];
+#pragma unroll
+  for (int l = 1; l < MAXD; l++) {
+    if (dd == l) xs[own] = acc;
+    const int an = a - 1;                       // next level's operands do not depend on x: fetched ahead of the hand-off
+    const R Ln = s.qLD[own + (an > 0 ? an : 0)]; const int xn = td[an > 0 ? an : 0];
+    dmw::sync();
+    if (a >= 1) acc -= La * xs[xi];
+    a = an; La = Ln; xi = xn;
+  }
+  return acc;
+}
+
 // x <- M^-1 x for a vector held identically by every lane (uniform operands: no divergence, no reduction).
 template <class R>
 DM_DEV void uniform_solve(const Shared<R>& s, R* x) {
@@ -1227,7 +1258,25 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   // lanes), so one evaluation costs one L^-T pass for all rows + tau and one L^-1 pass on the final vector; qacc_smooth
   // itself is only formed when there are no rows at all (or for the debug dump).
   if (lane == 0) s.solver_iter = 0;
-  if (nefc == 0 || dbg) {
+  if (nefc == 0) {
+    // qacc = qacc_smooth = L^-1 D^-1 L^-T tau: the upward pass on a copy every lane holds, then lane d keeps component d and
+    // the downward pass runs one dof per lane (the row-descriptor region it exchanges x through is unused without rows)
+    R x[NV];
+#pragma unroll
+    for (int d = 0; d < NV; d++) x[d] = s.ua.f.tau[d];
+    solve_LT(x, s.qLD);
+    R mine = 0;
+#pragma unroll
+    for (int d = 0; d < NV; d++) if (lane == d) mine = x[d];
+    if (lane < NV) mine *= s.dinv[lane];
+    dmw::sync();
+    const R acc = lane_solve_L(s, lane, mine);
+    if (lane < NV) {
+      s.ua.f.qaccs[lane] = acc; s.ua.f.qacc[lane] = acc;
+      if (dbg) dbg->out[34 * 34 + 34 + lane] = (double)acc;
+    }
+    dmw::sync();
+  } else if (dbg) {   // debug dump only: qacc_smooth next to a constrained solve
     R x[NV];
 #pragma unroll
     for (int d = 0; d < NV; d++) x[d] = s.ua.f.tau[d];
@@ -1235,11 +1284,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     dmw::sync();
     if (lane == 0) {
 #pragma unroll
-      for (int d = 0; d < NV; d++) { s.ua.f.qaccs[d] = x[d]; s.ua.f.qacc[d] = x[d]; }
-    }
-    if (dbg && lane == 0) {
-#pragma unroll
-      for (int d = 0; d < NV; d++) dbg->out[34 * 34 + 34 + d] = (double)x[d];
+      for (int d = 0; d < NV; d++) { s.ua.f.qaccs[d] = x[d]; dbg->out[34 * 34 + 34 + d] = (double)x[d]; }
     }
     dmw::sync();
   }
@@ -1450,19 +1495,12 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       for (int k = 0; k < 16; k++) wsum += s.u.ybuf[k][lane];
     }
   }
-  if (lane < NV) s.ua.f.tau[lane] = (wsum + s.u.ybuf[16][lane]) * s.dsq[lane];     // tau is dead: reuse it as the solve's right-hand side
-  dmw::sync();
   {
-    R x[NV];
-#pragma unroll
-    for (int d = 0; d < NV; d++) x[d] = s.ua.f.tau[d];
-    solve_L(x, s.qLD);
-    dmw::sync();
-    if (lane == 0) {
-      s.solver_iter = iter;
-#pragma unroll
-      for (int d = 0; d < NV; d++) s.ua.f.qacc[d] = x[d];
-    }
+    const R rhs = lane < NV ? (wsum + s.u.ybuf[16][lane]) * s.dsq[lane] : R(0);
+    dmw::sync();                                  // every lane has read z (ybuf slot 16): the region becomes the solve's exchange buffer
+    const R acc = lane_solve_L(s, lane, rhs);
+    if (lane < NV) s.ua.f.qacc[lane] = acc;
+    if (lane == 0) s.solver_iter = iter;
   }
   dmw::sync();
   DM_STAMP(13)

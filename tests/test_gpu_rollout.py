@@ -33,9 +33,11 @@ def test_rollout_segment_is_consistent_and_gae_matches_reference_loop():
     # vpred / ac are the policy's outputs on the stored observations (float32 storage of float64 obs costs ~1e-6)
     mean, vpred = pol.forward(seg["ob"].reshape(-1, 56))
     assert float((vpred.reshape(T, n) - seg["vpred"]).abs().max()) < 1e-3 * max(1.0, float(seg["vpred"].abs().max()))
-    # episodes: every new[t]=1 (t>0) closes an episode whose length was logged
+    # episodes: every new[t]=1 (t>0) closes an episode whose length was logged; an episode that ends on the segment's last
+    # step is logged here too, but its `new` flag opens the NEXT segment (its nextvpred is zeroed, src/trpo.py:86-88)
     starts = seg["new"].cpu().numpy()
-    assert int(starts[1:].sum()) == len(seg["ep_lens"]) and len(seg["ep_lens"]) > 0
+    ends_on_last = int((seg["nextvpred"] == 0).sum())
+    assert int(starts[1:].sum()) + ends_on_last == len(seg["ep_lens"]) and len(seg["ep_lens"]) > 0
     assert abs(sum(seg["ep_rets"]) - sum(seg["ep_lens"])) < 1e-9
     add_vtarg_and_adv(seg, 0.995, 0.97)
     rew, vp, nw, nxt = (seg[k].cpu().numpy() for k in ("rew", "vpred", "new", "nextvpred"))
