@@ -446,8 +446,8 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
 }
 
 // velocity stage: bias forces C(q, v) incl. gravity; smooth generalized force   [MJ mj_comVel, mj_rne, mj_passive]
-// Seven phases, each of which only needs an LDS hand-off (a sync) from the one before:
-//   0: world body;  1..4: bodies of tree depth 1..4 (cvel, cacc, cfrc);  5: subtree sums of cfrc;  6: tau per dof.
+// Phases, each of which only needs an LDS hand-off (a sync) from the one before:
+//   0: world body;  1..4: bodies of tree depth 1..4 (cvel, cacc);  5: cfrc of all bodies;  6: subtree sums of cfrc;  7: tau per dof.
 // (Measured dead end, kept as structure only: issuing phase P inside elimination step NV-1-P of the L^T D L factorisation,
 //  to overlap the two independent serial chains in one instruction stream, gained nothing — each phase's own dependent LDS
 //  reads are longer than an elimination step and simply lengthened it.)
@@ -482,20 +482,27 @@ DM_DEV void bias_phase(const DevModel<R>& M, Shared<R>& s, int lane, const LaneT
         }
       }
       for (int r = 0; r < 6; r++) { s.u.v.cvel[b][r] = v[r]; s.u.v.cacc[b][r] = a[r]; }
+    }
+  } else if constexpr (P == MAXDEPTH_BODY + 1) {
+    // body forces I a + v x* (I v): they need only the body's own velocity / acceleration, so all bodies form them at once
+    // here instead of each level of the recursion above carrying them on its serial chain
+    if (isbody) {
+      R v[6], a[6];
+      for (int r = 0; r < 6; r++) { v[r] = s.u.v.cvel[b][r]; a[r] = s.u.v.cacc[b][r]; }
       R Ia[6], Iv[6], x[6];
       sinert_mul(Ia, s.ub.i.sin[b], a); sinert_mul(Iv, s.ub.i.sin[b], v); cross_force(x, v, Iv);
       for (int r = 0; r < 6; r++) s.u.v.cfrc[b][r] = Ia[r] + x[r];
     }
-  } else if constexpr (P == MAXDEPTH_BODY + 1) {
-    subtree_sums_pass<6, 8, 0, R>(s.u.v.cfrc, s.u.v.csub, lane);
   } else if constexpr (P == MAXDEPTH_BODY + 2) {
+    subtree_sums_pass<6, 8, 0, R>(s.u.v.cfrc, s.u.v.csub, lane);
+  } else if constexpr (P == MAXDEPTH_BODY + 3) {
     if (lane < NV) {
       const R bias = dot6(s.cdof[lane], s.u.v.csub[TOPO.dof_body[lane]]);
       s.ua.f.tau[lane] = -M.dof_damping[lane] * s.qvel[lane] - bias + s.act[lane];
     }
   }
 }
-constexpr int BIAS_PHASES = MAXDEPTH_BODY + 3;
+constexpr int BIAS_PHASES = MAXDEPTH_BODY + 4;
 template <int P, class R>
 struct BiasFrom {
   static DM_DEV void run(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) {
