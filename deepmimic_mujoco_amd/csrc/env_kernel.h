@@ -129,7 +129,8 @@ DM_DEV unsigned tri_pair(int t) {   // once per kernel per lane (the elimination
 DM_DEV LaneTopo lane_topo(int lane) {
   LaneTopo t;
   const int b = lane < NB - 1 ? lane + 1 : 0;
-  t.parent = TOPO.body_parent[b]; t.dofadr = TOPO.body_dofadr[b]; t.dofnum = TOPO.body_dofnum[b];
+  { const int p1 = TOPO.body_parent[b], p2 = TOPO.body_parent[p1], p3 = TOPO.body_parent[p2]; t.parent = p1 | (p2 << 4) | (p3 << 8); }   // parent, grandparent, great-grandparent (0 = world)
+  t.dofadr = TOPO.body_dofadr[b]; t.dofnum = TOPO.body_dofnum[b];
   t.depth = lane < NB - 1 ? TOPO.body_depth[b] : 0; t.subtree = TOPO.subtree[b];
   t.tri = 0;
   for (int j = 0; j < 6; j++) t.tri |= (unsigned long long)(tri_pair((lane & 15) + 16 * j) & 0xff) << (8 * j);
@@ -349,7 +350,7 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   const bool isbody = lane < NB - 1;
   // laundered: otherwise every model constant indexed by these per-lane values (joint axes, body offsets, inertias) is
   // hoisted out of the RK loop as loop-invariant, spilled at kernel entry and re-read from scratch in every evaluation
-  const int depth = dmw::launder(lt.depth), da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum), p = dmw::launder(lt.parent);
+  const int depth = dmw::launder(lt.depth), da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum), panc = dmw::launder(lt.parent), p = panc & 15;
   R qloc[4] = {1, 0, 0, 0}, aloc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   if (lane == 0) {
     s.xpos[0][0] = s.xpos[0][1] = s.xpos[0][2] = 0; s.xipos[0][0] = s.xipos[0][1] = s.xipos[0][2] = 0;
@@ -381,30 +382,44 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     for (int k = 0; k < 4; k++) qloc_out[k] = qloc[k];
     for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) aloc_out[k][r] = aloc[k][r];
   }
-  // 2. compose down the tree
+  // 2. compose down the tree.  Only the quaternion PRODUCT rides the serial chain (one quat_mul per level, unnormalised:
+  // norms are multiplicative, so normalising the product is the per-level normalisation of mj_kinematics up to rounding);
+  // normalisation, rotation matrices and frame offsets are then formed by all bodies at once, and a body's position is
+  // the root-first sum of the offsets along its (at most 4 deep) chain — the same additions in the same order as
+  // xpos = xpos_parent + R_parent pos.
+  R q[4] = {1, 0, 0, 0};
   for (int L = 1; L <= MAXDEPTH_BODY; L++) {
     if (isbody && depth == L) {
-      R xp[3], q[4], mat[9];
-      if (b == 1) {
-        xp[0] = s.qpos[0]; xp[1] = s.qpos[1]; xp[2] = s.qpos[2];
-        q[0] = s.qpos[3]; q[1] = s.qpos[4]; q[2] = s.qpos[5]; q[3] = s.qpos[6];
-      } else {
-        R v[3];
-        mat_vec(v, s.xmat[p], M.body_pos[b]);
-        xp[0] = s.xpos[p][0] + v[0]; xp[1] = s.xpos[p][1] + v[1]; xp[2] = s.xpos[p][2] + v[2];
-        quat_mul(q, s.ua.xquat[p], qloc);
-      }
-      normalize4(q);
-      quat2mat(mat, q);
-      for (int k = 0; k < 3; k++) s.xpos[b][k] = xp[k];
+      if (b == 1) { q[0] = s.qpos[3]; q[1] = s.qpos[4]; q[2] = s.qpos[5]; q[3] = s.qpos[6]; }
+      else quat_mul(q, s.ua.xquat[p], qloc);
       for (int k = 0; k < 4; k++) s.ua.xquat[b][k] = q[k];
-      for (int k = 0; k < 9; k++) s.xmat[b][k] = mat[k];
     }
     dmw::sync();
   }
+  if (isbody) {
+    R mat[9];
+    normalize4(q);
+    quat2mat(mat, q);
+    for (int k = 0; k < 4; k++) s.ua.xquat[b][k] = q[k];
+    for (int k = 0; k < 9; k++) s.xmat[b][k] = mat[k];
+  }
+  dmw::sync();
+  if (isbody) {   // own frame offset in the world (s.xipos is the scratch list: it is only filled in step 3; entry 0 = world = 0)
+    R v[3];
+    if (b == 1) { v[0] = s.qpos[0]; v[1] = s.qpos[1]; v[2] = s.qpos[2]; }
+    else mat_vec(v, s.xmat[p], M.body_pos[b]);
+    for (int k = 0; k < 3; k++) s.xipos[b][k] = v[k];
+  }
+  dmw::sync();
+  R xp[3] = {0, 0, 0};
+  if (isbody) {
+    const int p2 = (panc >> 4) & 15, p3 = (panc >> 8) & 15;
+    for (int k = 0; k < 3; k++) xp[k] = ((s.xipos[p3][k] + s.xipos[p2][k]) + s.xipos[p][k]) + s.xipos[b][k];
+  }
+  dmw::sync();                                    // (everyone has read the offsets before step 3 overwrites them)
+  if (isbody) for (int k = 0; k < 3; k++) s.xpos[b][k] = xp[k];
   // 3. motion axes, inertial frame position, own spatial inertia about the origin
   if (isbody) {
-    const R xp[3] = {s.xpos[b][0], s.xpos[b][1], s.xpos[b][2]};
     const R* mat = s.xmat[b];
     if (b == 1) {
       for (int k = 0; k < 3; k++) {
@@ -462,7 +477,7 @@ DM_DEV void bias_phase(const DevModel<R>& M, Shared<R>& s, int lane, const LaneT
     }
   } else if constexpr (P <= MAXDEPTH_BODY) {
     if (isbody && lt.depth == P) {
-      const int p = dmw::launder(lt.parent), da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum);
+      const int p = dmw::launder(lt.parent) & 15, da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum);
       R v[6], a[6];
       for (int r = 0; r < 6; r++) { v[r] = s.u.v.cvel[p][r]; a[r] = s.u.v.cacc[p][r]; }
       if (b == 1) {
