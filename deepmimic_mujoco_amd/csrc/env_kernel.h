@@ -901,6 +901,12 @@ DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s
     const R ax[3] = {m1[2], m1[5], m1[8]};
     R t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, c0[3], u[3];
     matT_vec(c0, m2, t); matT_vec(u, m2, ax);
+    // slab rejection first (a leg next to the other foot is the common case: its bounding sphere reaches the box, the
+    // capsule does not): the segment's extent along a box axis lies farther from the box's than radius + margin
+    for (int k = 0; k < 3; k++) {
+      const R half = s1[1] * fabs(u[k]), reach = s2[k] + s1[0] + margin;
+      if (c0[k] - half > reach || c0[k] + half < -reach) return;
+    }
     auto gfun = [&](R tt) { R acc = 0; for (int k = 0; k < 3; k++) { const R pk = c0[k] + tt * u[k]; acc += u[k] * (pk - clampr(pk, -s2[k], s2[k])); } return acc; };
     R ta = -s1[1], tb = s1[1], ga = gfun(ta), gb = gfun(tb), ts;
     if (ga >= 0) ts = ta;
@@ -969,6 +975,9 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
   int pr = lane < npair ? lane : 0;
   int r_g1 = M.pair_rec[pr].g1, r_g2 = M.pair_rec[pr].g2, r_tt = M.pair_rec[pr].t1t2, r_meta = M.pair_rec[pr].meta;
   R r_margin = M.pair_rec[pr].margin, r_mu = M.pair_rec[pr].mu, r_bound = M.pair_rec[pr].bound, r_tran = M.pair_rec[pr].tran;
+  // (joint-limit constants too: one exposed global-load latency for the stage instead of one per block)
+  const bool lim_on = M.enable_limit && lane < NU && M.jnt_limited[lane < NU ? lane + 1 : 1];
+  const R lim_lo = M.jnt_lo[lane < NU ? lane + 1 : 1], lim_hi = M.jnt_hi[lane < NU ? lane + 1 : 1];
   if (M.enable_contact) {   // (the inertia region these poses overwrite is dead by now)
     // geom world poses
     if (lane < NG) {
@@ -985,9 +994,9 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
   {
     bool viol = false;
     R dist = 0, sgn = 0;
-    if (M.enable_limit && lane < NU && M.jnt_limited[lane + 1]) {
+    if (lim_on) {
       const R q = s.qpos[lane + 7];
-      const R dlo = q - M.jnt_lo[lane + 1], dhi = M.jnt_hi[lane + 1] - q;
+      const R dlo = q - lim_lo, dhi = lim_hi - q;
       if (dlo < 0) { viol = true; dist = dlo; sgn = 1; }
       else if (dhi < 0) { viol = true; dist = dhi; sgn = -1; }
     }
