@@ -1042,11 +1042,14 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
       int tot_rows, tot_con;
       const int r0 = nrow + dmw::wave_exclusive_scan(pc.n * rows_per, lane, &tot_rows);
       const int c0 = ncon + dmw::wave_exclusive_scan(pc.n, lane, &tot_con);
+      // Row emission, one row per lane.  The lanes that found contacts only STAGE them — position, distance, frame and pair
+      // constants go into the contact's own (still empty) descriptor rows, a marker (row within the contact, condim, bodies)
+      // into rowi — then lane L builds row nrow + L from the staged contact.  The work no longer grows with the number of
+      // rows a single lane has to write (a foot on the floor: 4 corners x 4 pyramid rows from one lane).
       if (pc.n > 0) {
         R fr[9];
         make_frame(fr, pc.nrm, pc.hint);
         const int b1 = r_meta & 0xff, b2 = (r_meta >> 8) & 0xff;
-        const R tran = r_tran;
         for (int k = 0; k < pc.n; k++) {
           R cdist, cpos[3];
           if (pc.boxslot >= 0) { const R* o = s.boxc[pc.boxslot][k]; cdist = o[0]; cpos[0] = o[1]; cpos[1] = o[2]; cpos[2] = o[3]; }
@@ -1056,22 +1059,38 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
           if (c0 + k < MAXEFC) { s.cong[c0 + k][0] = g1; s.cong[c0 + k][1] = g2; }
           // rows past the on-chip capacity are dropped contact-wise, in list order (status bit 0)
           if (rk + rows_per > MAXROWS) { if (rk < firstdrop) firstdrop = rk; continue; }
-          for (int q = 0; q < rows_per; q++) {
-            R dir[3];
-            if (dim == 1) { dir[0] = fr[0]; dir[1] = fr[1]; dir[2] = fr[2]; }
-            else {
-              const int t = 1 + q / 2;
-              const R sg = (q & 1) ? -mu : mu;
-              dir[0] = fr[0] + sg * fr[3 * t]; dir[1] = fr[1] + sg * fr[3 * t + 1]; dir[2] = fr[2] + sg * fr[3 * t + 2];
-            }
-            R* rd = s.u.rowd[rk + q];
-            cross3(rd, cpos, dir);
-            rd[3] = dir[0]; rd[4] = dir[1]; rd[5] = dir[2];
-            rd[6] = cdist; rd[7] = margin;
-            rd[8] = dim == 1 ? tran : tran + mu * mu * tran;
-            rd[9] = dim == 1 ? R(1) : 2 * mu * mu;
-            s.rowi[rk + q] = ROW_CONTACT | (b1 << 8) | (b2 << 16);
-          }
+          R* st = s.u.rowd[rk];
+          st[0] = cpos[0]; st[1] = cpos[1]; st[2] = cpos[2]; st[3] = fr[0]; st[4] = fr[1]; st[5] = fr[2];
+          st[6] = cdist; st[7] = margin; st[8] = mu; st[9] = r_tran;
+          if (dim != 1) { R* s2 = s.u.rowd[rk + 1]; for (int t = 0; t < 6; t++) s2[t] = fr[3 + t]; }
+          const int mark = (1 << 30) | (dim << 4) | (b1 << 8) | (b2 << 16);
+          for (int q = 0; q < rows_per; q++) s.rowi[rk + q] = mark | q;
+        }
+      }
+      dmw::sync();
+      {
+        const int r = nrow + lane;
+        const int code = (lane < tot_rows && r < MAXEFC) ? s.rowi[r] : 0;
+        const bool mine = ((code >> 30) & 1) != 0;
+        const int q = code & 15, cdim = (code >> 4) & 15;
+        R st[10], tg[3] = {0, 0, 0};
+        if (mine) {
+          const R* b0 = s.u.rowd[r - q];
+          for (int t = 0; t < 10; t++) st[t] = b0[t];
+          if (cdim != 1) { const R* b1p = s.u.rowd[r - q + 1] + 3 * (q >> 1); tg[0] = b1p[0]; tg[1] = b1p[1]; tg[2] = b1p[2]; }
+        }
+        dmw::sync();                                // every lane has read its staged contact before the rows are overwritten
+        if (mine) {
+          const R cmu = st[8], ctran = st[9];
+          R dir[3] = {st[3], st[4], st[5]};
+          if (cdim != 1) { const R sg = (q & 1) ? -cmu : cmu; dir[0] += sg * tg[0]; dir[1] += sg * tg[1]; dir[2] += sg * tg[2]; }
+          R* rd = s.u.rowd[r];
+          cross3(rd, st, dir);
+          rd[3] = dir[0]; rd[4] = dir[1]; rd[5] = dir[2];
+          rd[6] = st[6]; rd[7] = st[7];
+          rd[8] = cdim == 1 ? ctran : ctran + cmu * cmu * ctran;
+          rd[9] = cdim == 1 ? R(1) : 2 * cmu * cmu;
+          s.rowi[r] = ROW_CONTACT | (code & 0x00ffff00);
         }
       }
       nrow += tot_rows; ncon += tot_con;
