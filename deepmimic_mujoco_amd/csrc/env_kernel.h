@@ -1157,6 +1157,40 @@ DM_DEV R lane_solve_L(Shared<R>& s, int lane_in, R rhs) {
   return acc;
 }
 
+// y = L^-T rhs for ONE vector, one dof per lane, level by level UP the tree:  y_j = rhs_j - sum_{i in desc(j)} L(i, j) y_i.
+// Deepest dofs first: a dof whose descendants have all reported is final and pushes its term to every ancestor with
+// fire-and-forget LDS atomics (several limbs report to the same ancestors in one step).  Same exchange buffer as above.
+template <int L, class R>
+struct PushLevel {
+  static DM_DEV void run(R* xs, int own, int dd, const R* Lr, const int* xa) {
+    if constexpr (L >= 2) {
+      const bool on = dd == L;
+      const R v = xs[on ? own : 0];
+#pragma unroll
+      for (int a = 1; a < L; a++) dmw::lds_sub(on, &xs[xa[a]], Lr[a] * v);
+      dmw::sync();
+      PushLevel<L - 1, R>::run(xs, own, dd, Lr, xa);
+    }
+  }
+};
+template <class R>
+DM_DEV R lane_solve_LT(Shared<R>& s, int lane_in, R rhs) {
+  constexpr int MAXD = 13;
+  const int ll = dmw::launder(lane_in);
+  const bool isdof = ll < NV;
+  const int dd = isdof ? TOPO.dof_depth[ll] : 0;
+  const unsigned short* td = &s.tab_dst[isdof ? ll : 0][0];
+  const int own = td[0];
+  R* xs = &s.u.rowd[0][0];
+  R Lr[MAXD]; int xa[MAXD];
+#pragma unroll
+  for (int a = 1; a < MAXD; a++) { const bool on = a < dd; Lr[a] = s.qLD[own + (on ? a : 0)]; xa[a] = td[on ? a : 0]; }
+  if (isdof) xs[own] = rhs;
+  dmw::sync();
+  PushLevel<MAXD, R>::run(xs, own, dd, Lr, xa);
+  return isdof ? xs[own] : R(0);
+}
+
 // x <- M^-1 x for a vector held identically by every lane (uniform operands: no divergence, no reduction).
 template <class R>
 DM_DEV void uniform_solve(const Shared<R>& s, R* x) {
@@ -1309,15 +1343,9 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   // itself is only formed when there are no rows at all (or for the debug dump).
   if (lane == 0) s.solver_iter = 0;
   if (nefc == 0) {
-    // qacc = qacc_smooth = L^-1 D^-1 L^-T tau: the upward pass on a copy every lane holds, then lane d keeps component d and
-    // the downward pass runs one dof per lane (the row-descriptor region it exchanges x through is unused without rows)
-    R x[NV];
-#pragma unroll
-    for (int d = 0; d < NV; d++) x[d] = s.ua.f.tau[d];
-    solve_LT(x, s.qLD);
-    R mine = 0;
-#pragma unroll
-    for (int d = 0; d < NV; d++) if (lane == d) mine = x[d];
+    // qacc = qacc_smooth = L^-1 D^-1 L^-T tau, one dof per lane: up the tree, scale, down the tree (the row-descriptor
+    // region the passes exchange the vector through is unused without rows)
+    R mine = lane_solve_LT(s, lane, lane < NV ? s.ua.f.tau[lane] : R(0));
     if (lane < NV) mine *= s.dinv[lane];
     dmw::sync();
     const R acc = lane_solve_L(s, lane, mine);
