@@ -128,7 +128,7 @@ DM_DEV void load_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int 
     const int d = lane + 6;
     s.act[d] = M.gear[d] * clampr(a, M.ctrl_lo[d], M.ctrl_hi[d]);
   }
-  dmw::sync();
+  dmw::sync_mem();
 }
 
 template <class R>
@@ -180,7 +180,7 @@ DM_DEV void reset_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int
     if (lane < NV) s.qws[lane] = 0;
     if (lane == 0) B.time[env] = 0;
   }
-  dmw::sync();
+  dmw::sync_mem();
   if (lane == 0) { B.episode[env] = ep + 1; B.cycle[env] = 0; }
 }
 
@@ -297,7 +297,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     R err = 0;
     for (int i = 7; i < NQ; i++) err += fabs(s.qpos[i] - B.mocap_cfg[(size_t)idx * NQ + i]);
     rew = exp_once(-err);
-    dmw::sync();
+    dmw::sync_mem();
     if (lane == 0) B.frame_idx[env] = (idx + 1) % B.n_frames;
   } else if (B.reward_mode == REW_V2_POSE) {     // src/dp_env_v2.py:116-183
     const int idx = B.frame_idx[env] + 1;
@@ -306,7 +306,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     for (int i = 3; i < NQ; i++) err += fabs(s.qpos[i] - B.mocap_cfg[(size_t)im * NQ + i]);
     for (int u = 0; u < NU; u++) { const R c = B.ctrl[(size_t)env * NU + u]; acs += c * c; }
     rew = exp_once(R(-2) * err) - R(0.1) * acs;
-    dmw::sync();
+    dmw::sync_mem();
     if (lane == 0) B.frame_idx[env] = idx;
   } else if (B.reward_mode == REW_IMITATION) {   // code.md:1017-1143: the state after the step against frame idx + 1
     int k = dmw::uniform(B.frame_idx[env]) + 1, cyc = dmw::uniform(B.cycle[env]);
@@ -314,12 +314,12 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     if (k >= B.n_frames) { if (B.imit_params[15] != R(0)) { k = 0; cyc += 1; } else { k = B.n_frames - 1; ended = true; } }
     rew = imitation_reward(M, B, s, lane, lt, B.imit_table + (size_t)k * IMIT_FEAT, cyc * B.imit_params[13], cyc * B.imit_params[14]);
     dn = dn || ended;                            // a "Loop: none" clip holds its last frame and ends the episode there
-    dmw::sync();
+    dmw::sync_mem();
     if (lane == 0) { B.frame_idx[env] = k; B.cycle[env] = cyc; }
   }
   if (lane == 0) { B.time[env] += M.timestep * n_substeps; reward[env] = rew; done[env] = dn ? 1 : 0; }
   if (dn && B.autoreset) {                        // DummyVecEnv convention: obs of the fresh episode is returned
-    dmw::sync();
+    dmw::sync_mem();
     reset_env(M, B, s, env, lane, B.autoreset == 1 ? 0 : 1, 1);
   }
   // obs = qpos[7:] (+) qvel[6:]   (src/dp_env_v3.py:62-65), one coalesced 56-wide store

@@ -20,8 +20,15 @@
 
 namespace dmw {
 DM_DEV int lane() { return (int)(threadIdx.x & 63u); }
-// LDS hand-off between lanes of the (single-wave) workgroup
-DM_DEV void sync() { __syncthreads(); }
+// LDS hand-off between lanes of the (single-wave) workgroup: a fence at WAVEFRONT scope.  A wave's memory instructions of
+// one kind execute in issue order, so a ds_read issued after a ds_write sees its data whichever lane wrote it; the AMDGPU
+// memory model therefore implements wavefront-scope synchronisation without any s_waitcnt (the compiler still waits where a
+// loaded REGISTER is first used) — it only keeps the compiler from moving memory accesses across the fence.
+// (__syncthreads() is a workgroup-scope fence: `s_waitcnt vmcnt(0) lgkmcnt(0)` at every hand-off, i.e. each one drained
+// all outstanding LDS traffic and every global load / scratch store in flight.)
+DM_DEV void sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// the same with a full workgroup fence: for hand-offs through GLOBAL memory (prologue / epilogue of the step)
+DM_DEV void sync_mem() { __syncthreads(); }
 DM_DEV unsigned long long ballot(bool p) { return __ballot(p); }
 DM_DEV int shfl_i(int v, int src) { return __shfl(v, src, 64); }
 DM_DEV double shfl(double v, int src) { return __shfl(v, src, 64); }

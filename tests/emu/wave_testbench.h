@@ -34,6 +34,7 @@ inline void rendezvous() {
   else while (b.gen == g) b.yield_fn();
 }
 inline void sync() { rendezvous(); }
+inline void sync_mem() { rendezvous(); }
 
 template <class T> inline unsigned long long to_bits(T v) { unsigned long long u = 0; std::memcpy(&u, &v, sizeof(T)); return u; }
 template <class T> inline T from_bits(unsigned long long u) { T v; std::memcpy(&v, &u, sizeof(T)); return v; }
