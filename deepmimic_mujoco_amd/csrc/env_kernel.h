@@ -1269,8 +1269,10 @@ DM_DEV R row_dot(const R* y, const R* q) {
   return acc0 + acc1;
 }
 
-// PGS candidate force of one row: f' = max(f - r / A_ii, 0)   [MJ mj_solPGS, scalar row]
-template <class R> DM_DEV R pgs_candidate(R f, R res, R dinvr) { return fmax(f - res * dinvr, R(0)); }
+// PGS update of one row: f' = max(f - r / A_ii, 0)   [MJ mj_solPGS, scalar row], as the step
+//   delta = f' - f = max(-f, -r / A_ii)
+// (one multiply and one max on the row-to-row chain instead of fma, max, subtract; operands: nf = -f, ndinv = -1 / A_ii)
+template <class R> DM_DEV R pgs_delta(R nf, R res, R ndinv) { return fmax(nf, res * ndinv); }
 
 // ---- nested unrolling over constraint rows --------------------------------------------------------------------------
 // nefc is small and wave-uniform, ROWS is the compile-time capacity.  A flat unrolled loop with one scalar test per row
@@ -1307,19 +1309,19 @@ struct WarmBlock {   // res += A[:, 8B .. 8B+7] f   (slots past nefc: f = 0 and 
 };
 template <int G, int ROWS, class R>
 struct SweepGroup {  // PGS rows 4G .. 4G+3 (a slot past nefc computes delta = 0: idle lane, zero column)
-  static DM_DEV void run(const R* AR, R& res, R& rsave, R f0, R dinvr, int ln, int ne) {
+  static DM_DEV void run(const R* AR, R& res, R& rsave, R nf0, R ndinv, int ln, int ne) {
     if constexpr (G * 4 < ROWS) {
 #pragma unroll
       for (int ii = 0; ii < 4; ii++) {
         const int i = G * 4 + ii;
         if (i < ROWS && i < MAXROWS) {
-          const R delta = pgs_candidate(f0, res, dinvr) - f0;      // every lane evaluates its own; only lane i's is used
+          const R delta = pgs_delta(nf0, res, ndinv);              // every lane evaluates its own; only lane i's is used
           const R di = dmw::bcast(delta, i);
           if (ln == i) rsave = res;
           res += AR[i] * di;
         }
       }
-      if ((G + 1) * 4 < ne) SweepGroup<G + 1, ROWS, R>::run(AR, res, rsave, f0, dinvr, ln, ne);
+      if ((G + 1) * 4 < ne) SweepGroup<G + 1, ROWS, R>::run(AR, res, rsave, nf0, ndinv, ln, ne);
     }
   }
 };
@@ -1490,26 +1492,28 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   R pgs_detect = M.pgs_detect;
   dmw::pin_value(pgs_detect);
   const R f_ws = f, res_ws = res;
+  R ndinv = -dinvr;
+  dmw::pin_value(ndinv);
   bool anybad = false;
   auto sweep = [&](R& myimp) {
     // fresh opaque copies per sweep: otherwise the 64 row-exists tests and 64 lane==row masks are hoisted out of the
     // sweep loop as 128 SGPR pairs, spilled to VGPR lanes and read back with v_readlane on every row
     const int ne = dmw::launder_uniform(nefc);
     const int ln = dmw::launder(lane);
-    const R f0 = f;
+    const R f0 = f, nf0 = -f;
     R rsave = res;
-    SweepGroup<0, ROWS, R>::run(AR, res, rsave, f0, dinvr, ln, ne);
+    SweepGroup<0, ROWS, R>::run(AR, res, rsave, nf0, ndinv, ln, ne);
     if (ROWS < MAXEFC && ne > ROWS) for (int i = ROWS; i < ne; i++) {      // overflow rows: same update, column of A from memory
       const R a = ((const R*)(&s.aovf)[dmw::pin_zero()])[i * 64 + ln];
-      const R delta = pgs_candidate(f0, res, dinvr) - f0;
+      const R delta = pgs_delta(nf0, res, ndinv);
       const R di = dmw::bcast(delta, i);
       if (ln == i) rsave = res;
       res += a * di;
     }
     myimp = 0;
     if (ln < ne) {
-      const R fn = pgs_candidate(f0, rsave, dinvr);
-      const R delta = fn - f0;
+      const R delta = pgs_delta(nf0, rsave, ndinv);
+      const R fn = f0 + delta;
       const R change = delta * (R(0.5) * delta * diag + rsave);
       f = fn; myimp = -change; anybad = anybad || (change > pgs_detect);
     }
@@ -1539,8 +1543,8 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       R myimp = 0;
       for (int i = 0; i < nefc; i++) {
         const R a = strip[i * 64 + lane];
-        const R fn = fmax(f - res * dinvr, R(0));
-        R delta = fn - f;
+        R delta = pgs_delta(-f, res, ndinv);
+        const R fn = f + delta;
         const R change = delta * (R(0.5) * delta * diag + res);
         const bool rej = change > R(1e-10);          // never accept an increase
         if (rej) delta = 0;
