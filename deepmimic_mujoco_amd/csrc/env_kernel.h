@@ -1270,9 +1270,9 @@ DM_DEV R row_dot(const R* y, const R* q) {
 }
 
 // PGS update of one row: f' = max(f - r / A_ii, 0)   [MJ mj_solPGS, scalar row], as the step
-//   delta = f' - f = max(-f, -r / A_ii)
-// (one multiply and one max on the row-to-row chain instead of fma, max, subtract; operands: nf = -f, ndinv = -1 / A_ii)
-template <class R> DM_DEV R pgs_delta(R nf, R res, R ndinv) { return fmax(nf, res * ndinv); }
+//   delta = f' - f = max(-f, t),   t = -r / A_ii.
+// The solver carries the SCALED residual t_j = -r_j / A_jj (and the columns of A scaled the same way, row j by -1 / A_jj),
+// so the row-to-row chain is: max, broadcast, fma — nothing else.
 
 // ---- nested unrolling over constraint rows --------------------------------------------------------------------------
 // nefc is small and wave-uniform, ROWS is the compile-time capacity.  A flat unrolled loop with one scalar test per row
@@ -1298,30 +1298,30 @@ struct ACol {        // column I of A = Y Y^T + diag(R); precondition: I < nefc
   }
 };
 template <int B, int ROWS, class R>
-struct WarmBlock {   // res += A[:, 8B .. 8B+7] f   (slots past nefc: f = 0 and a zero column)
-  static DM_DEV void run(const R* AR, R& res, R f, int nefc) {
+struct WarmBlock {   // A[:, 8B .. 8B+7] scaled in place (row j by -1 / A_jj);  t += A_scaled[:, 8B .. 8B+7] f   (slots past nefc: f = 0, zero column)
+  static DM_DEV void run(R* AR, R& t, R f, R ndinv, int nefc) {
     if constexpr (B * 8 < ROWS) {
 #pragma unroll
-      for (int ii = 0; ii < 8; ii++) { const int i = B * 8 + ii; if (i < ROWS && i < MAXROWS) res += AR[i] * dmw::bcast(f, i); }
-      if ((B + 1) * 8 < nefc) WarmBlock<B + 1, ROWS, R>::run(AR, res, f, nefc);
+      for (int ii = 0; ii < 8; ii++) { const int i = B * 8 + ii; if (i < ROWS && i < MAXROWS) { AR[i] *= ndinv; t += AR[i] * dmw::bcast(f, i); } }
+      if ((B + 1) * 8 < nefc) WarmBlock<B + 1, ROWS, R>::run(AR, t, f, ndinv, nefc);
     }
   }
 };
 template <int G, int ROWS, class R>
 struct SweepGroup {  // PGS rows 4G .. 4G+3 (a slot past nefc computes delta = 0: idle lane, zero column)
-  static DM_DEV void run(const R* AR, R& res, R& rsave, R nf0, R ndinv, int ln, int ne) {
+  static DM_DEV void run(const R* AR, R& t, R& tsave, R nf0, int ln, int ne) {
     if constexpr (G * 4 < ROWS) {
 #pragma unroll
       for (int ii = 0; ii < 4; ii++) {
         const int i = G * 4 + ii;
         if (i < ROWS && i < MAXROWS) {
-          const R delta = pgs_delta(nf0, res, ndinv);              // every lane evaluates its own; only lane i's is used
+          const R delta = fmax(nf0, t);                            // every lane evaluates its own; only lane i's is used
           const R di = dmw::bcast(delta, i);
-          if (ln == i) rsave = res;
-          res += AR[i] * di;
+          if (ln == i) tsave = t;
+          t += AR[i] * di;
         }
       }
-      if ((G + 1) * 4 < ne) SweepGroup<G + 1, ROWS, R>::run(AR, res, rsave, nf0, ndinv, ln, ne);
+      if ((G + 1) * 4 < ne) SweepGroup<G + 1, ROWS, R>::run(AR, t, tsave, nf0, ln, ne);
     }
   }
 };
@@ -1460,22 +1460,26 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   const R dinvr = R(1) / diag;
   DM_STAMP(11)
   // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ------------------------------------
-  R res = bb;  // residual r_j = b_j + sum_i A_ji f_i, maintained incrementally
+  R ndinv = -dinvr;
+  dmw::pin_value(ndinv);
+  const R tb = bb * ndinv;
+  R t = tb;    // scaled residual t_j = -(b_j + sum_i A_ji f_i) / A_jj, maintained incrementally; the columns are scaled on the way
   // (rows are taken in unguarded groups: a scalar branch costs as much as ~4 rows of work, and a row slot past nefc is
   //  harmless — its lane is idle with f = 0, and its column of A is zero)
-  WarmBlock<0, ROWS, R>::run(AR, res, f, nefc);
+  WarmBlock<0, ROWS, R>::run(AR, t, f, ndinv, nefc);
   if (ROWS < MAXEFC && nefc > ROWS) {
     const R* const aov = (&s.aovf)[dmw::pin_zero()];
-    for (int i = ROWS; i < nefc; i++) res += aov[i * 64 + lane] * dmw::bcast(f, i);
+    for (int i = ROWS; i < nefc; i++) t += (aov[i * 64 + lane] * ndinv) * dmw::bcast(f, i);     // (strip columns stay unscaled)
   }
   {
+    const R res = -t * diag;                      // the residual itself, for the dual cost
     const R cost = dmw::wave_sum(active ? f * (R(0.5) * (res - bb) + bb) : R(0));
-    if (cost > 0) { f = 0; res = bb; }
+    if (cost > 0) { f = 0; t = tb; }
   }
   // ---- projected Gauss-Seidel, rows in order; one broadcast + one FMA per row, no memory ------------------------
   // Row i only ever needs lane i's force, and lane i's force only changes at row i, so a sweep leaves f alone: each row costs
-  // the serial chain (candidate -> delta -> broadcast -> residual update) plus one select that records the residual lane i
-  // saw at its own row; forces and cost changes follow once per sweep, lane-wise, from exactly the operands the row-by-row
+  // the serial chain (delta = max(-f, t) -> broadcast -> scaled-residual update) plus one select that records the residual
+  // lane i saw at its own row; forces and cost changes follow once per sweep, lane-wise, from exactly the operands the row-by-row
   // form would have used.
   // [MJ costChange] rejects an update that would raise the dual cost by more than 1e-10.  In exact arithmetic the
   // one-dimensional step never raises it, so the sweeps run without the test; if any row of any sweep did trip it
@@ -1491,9 +1495,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   dmw::pin_value(pgs_scale); dmw::pin_value(pgs_tol);
   R pgs_detect = M.pgs_detect;
   dmw::pin_value(pgs_detect);
-  const R f_ws = f, res_ws = res;
-  R ndinv = -dinvr;
-  dmw::pin_value(ndinv);
+  const R f_ws = f, t_ws = t;
   bool anybad = false;
   auto sweep = [&](R& myimp) {
     // fresh opaque copies per sweep: otherwise the 64 row-exists tests and 64 lane==row masks are hoisted out of the
@@ -1501,20 +1503,20 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     const int ne = dmw::launder_uniform(nefc);
     const int ln = dmw::launder(lane);
     const R f0 = f, nf0 = -f;
-    R rsave = res;
-    SweepGroup<0, ROWS, R>::run(AR, res, rsave, nf0, ndinv, ln, ne);
+    R tsave = t;
+    SweepGroup<0, ROWS, R>::run(AR, t, tsave, nf0, ln, ne);
     if (ROWS < MAXEFC && ne > ROWS) for (int i = ROWS; i < ne; i++) {      // overflow rows: same update, column of A from memory
-      const R a = ((const R*)(&s.aovf)[dmw::pin_zero()])[i * 64 + ln];
-      const R delta = pgs_delta(nf0, res, ndinv);
+      const R a = ((const R*)(&s.aovf)[dmw::pin_zero()])[i * 64 + ln] * ndinv;
+      const R delta = fmax(nf0, t);
       const R di = dmw::bcast(delta, i);
-      if (ln == i) rsave = res;
-      res += a * di;
+      if (ln == i) tsave = t;
+      t += a * di;
     }
     myimp = 0;
     if (ln < ne) {
-      const R delta = pgs_delta(nf0, rsave, ndinv);
+      const R delta = fmax(nf0, tsave);
       const R fn = f0 + delta;
-      const R change = delta * (R(0.5) * delta * diag + rsave);
+      const R change = (delta * diag) * (R(0.5) * delta - tsave);      // = delta (delta A_ii / 2 + r)
       f = fn; myimp = -change; anybad = anybad || (change > pgs_detect);
     }
   };
@@ -1523,34 +1525,35 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     sweep(myimp);
     iter = 1;
     while (iter < maxiter) {
-      const R fprev = f, rprev = res;
+      const R fprev = f, tprev = t;
       const R improvement = dmw::wave_sum(active ? myimp : R(0)) * pgs_scale;     // of sweep `iter`
       R myimp_next;
       sweep(myimp_next);                                                          // sweep iter + 1, speculative
-      if (dmw::uniform(improvement < pgs_tol)) { f = fprev; res = rprev; break; }
+      if (dmw::uniform(improvement < pgs_tol)) { f = fprev; t = tprev; break; }
       myimp = myimp_next;
       iter++;
     }
   }
   if (dmw::ballot(anybad) != 0) {
-    // guarded re-solve (cold): the register columns are parked in the env's memory strip so that one compact loop can walk
-    // all rows with a run-time index
+    // guarded re-solve (cold): the (scaled) register columns are parked in the env's memory strip so that one compact loop
+    // can walk all rows with a run-time index; the strip's own columns (rows past the register tier) are unscaled
     R* const strip = (&s.aovf)[dmw::pin_zero()];
 #pragma unroll
     for (int i = 0; i < ROWS; i++) strip[i * 64 + lane] = AR[i];
-    f = f_ws; res = res_ws; iter = 0;
+    f = f_ws; t = t_ws; iter = 0;
     while (iter < maxiter) {
       R myimp = 0;
       for (int i = 0; i < nefc; i++) {
-        const R a = strip[i * 64 + lane];
-        R delta = pgs_delta(-f, res, ndinv);
+        R a = strip[i * 64 + lane];
+        if (i >= ROWS) a *= ndinv;
+        R delta = fmax(-f, t);
         const R fn = f + delta;
-        const R change = delta * (R(0.5) * delta * diag + res);
+        const R change = (delta * diag) * (R(0.5) * delta - t);
         const bool rej = change > R(1e-10);          // never accept an increase
         if (rej) delta = 0;
         const R di = dmw::bcast(delta, i);
         if (lane == i && !rej) { f = fn; myimp -= change; }
-        res += a * di;
+        t += a * di;
       }
       const R improvement = dmw::wave_sum(active ? myimp : R(0)) * pgs_scale;
       iter++;
