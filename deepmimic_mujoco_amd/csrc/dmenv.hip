@@ -53,16 +53,26 @@ __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ 
 // shader ticks from 0 to 32 rows) first.  4096 envs are two rounds of resident waves, so the launch ends when the last wave
 // of round two does; longest-first list scheduling trims that tail (measured -9 % kernel time).  Counting sort by
 // min(nefc, 63), descending; the order inside a bucket is arbitrary — results never depend on the dispatch order.
-__global__ __launch_bounds__(256) void k_order(Batch<Real> B, int* __restrict__ order) {
+__global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__ order) {
   __shared__ int hist[64], start[64];
   const int tid = threadIdx.x, n = B.n_envs;
   if (tid < 64) hist[tid] = 0;
   __syncthreads();
-  for (int e = tid; e < n; e += 256) { const int k = B.nefc[e] + (B.solver_iter[e] >> 2); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
+  constexpr int PER = 8;                 // keys of up to 8192 envs stay in registers between the two passes
+  int key[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int e = tid + j * 1024;
+    key[j] = -1;
+    if (e < n) { const int k = B.nefc[e] + (B.solver_iter[e] >> 2); key[j] = k < 0 ? 0 : (k > 63 ? 63 : k); atomicAdd(&hist[key[j]], 1); }
+  }
+  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k = B.nefc[e] + (B.solver_iter[e] >> 2); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
   __syncthreads();
   if (tid == 0) { int acc = 0; for (int k = 63; k >= 0; k--) { start[k] = acc; acc += hist[k]; } }
   __syncthreads();
-  for (int e = tid; e < n; e += 256) { const int k0 = B.nefc[e] + (B.solver_iter[e] >> 2); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[atomicAdd(&start[k], 1)] = e; }
+#pragma unroll
+  for (int j = 0; j < PER; j++) if (key[j] >= 0) order[atomicAdd(&start[key[j]], 1)] = tid + j * 1024;
+  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k0 = B.nefc[e] + (B.solver_iter[e] >> 2); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[atomicAdd(&start[k], 1)] = e; }
 }
 
 // same step with per-stage shader-clock accounting (DM_OPT 101); not used on the timed path
@@ -331,7 +341,7 @@ extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, dou
   else if (b->two_tier) {
     hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub);
     if (b->reorder && b->has_rows && b->n > b->resident_waves) {   // more envs than resident waves: a second round exists, its tail matters
-      hipLaunchKernelGGL(k_order, dim3(1), dim3(256), 0, b->stream, b->B, b->d_order);
+      hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order);
       b->B.order = b->d_order;             // valid from the next launch on (same stream: ordered after k_order)
     }
   } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub);
