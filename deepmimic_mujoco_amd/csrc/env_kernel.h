@@ -121,28 +121,42 @@ struct LaneTopo {
   unsigned long long tri;   // six byte codes (e << 4) | a of the lower-triangular pair numbers t = (lane & 15) + 16 j, j = 0..5:
                             // t = e (e - 1) / 2 + (a - 1),  1 <= a <= e   (byte j of the word)
 };
-DM_DEV unsigned tri_pair(int t) {   // once per kernel per lane (the elimination steps index their rank-1 updates with it)
+// Everything a lane reads at kernel entry is a compile-time table: one independent load per field instead of chains of
+// dependent topology look-ups and a search loop per lane in every launch.
+constexpr unsigned tri_pair(int t) {
   int e = 1;
   while (e * (e + 1) / 2 <= t) e++;
   return (unsigned)((e << 4) | (t - e * (e - 1) / 2 + 1));
 }
-DM_DEV LaneTopo lane_topo(int lane) {
-  LaneTopo t;
-  const int b = lane < NB - 1 ? lane + 1 : 0;
-  { const int p1 = TOPO.body_parent[b], p2 = TOPO.body_parent[p1], p3 = TOPO.body_parent[p2]; t.parent = p1 | (p2 << 4) | (p3 << 8); }   // parent, grandparent, great-grandparent (0 = world)
-  t.dofadr = TOPO.body_dofadr[b]; t.dofnum = TOPO.body_dofnum[b];
-  t.depth = lane < NB - 1 ? TOPO.body_depth[b] : 0; t.subtree = TOPO.subtree[b];
-  t.tri = 0;
-  for (int j = 0; j < 6; j++) t.tri |= (unsigned long long)(tri_pair((lane & 15) + 16 * j) & 0xff) << (8 * j);
-  return t;
+struct LaneTables {
+  LaneTopo lane[64];
+  unsigned short tab_ent[312];       // entry e of the sparse M -> (i << 8) | j
+  unsigned short tab_dst[NV * 14];   // [k * 14 + a] = madr[anc_a(k)]
+};
+constexpr LaneTables make_lane_tables() {
+  LaneTables T{};
+  for (int lane = 0; lane < 64; lane++) {
+    LaneTopo& t = T.lane[lane];
+    const int b = lane < NB - 1 ? lane + 1 : 0;
+    const int p1 = TOPO.body_parent[b] < 0 ? 0 : TOPO.body_parent[b], p2 = TOPO.body_parent[p1] < 0 ? 0 : TOPO.body_parent[p1], p3 = TOPO.body_parent[p2] < 0 ? 0 : TOPO.body_parent[p2];
+    t.parent = p1 | (p2 << 4) | (p3 << 8);   // parent, grandparent, great-grandparent (0 = world)
+    t.dofadr = TOPO.body_dofadr[b]; t.dofnum = TOPO.body_dofnum[b];
+    t.depth = lane < NB - 1 ? TOPO.body_depth[b] : 0; t.subtree = TOPO.subtree[b];
+    t.tri = 0;
+    for (int j = 0; j < 6; j++) t.tri |= (unsigned long long)(tri_pair((lane & 15) + 16 * j) & 0xff) << (8 * j);
+  }
+  for (int e = 0; e < 312; e++) T.tab_ent[e] = e < TOPO.nM ? (unsigned short)((TOPO.ent_i[e] << 8) | TOPO.ent_j[e]) : (unsigned short)0;
+  for (int k = 0; k < NV; k++) for (int a = 0; a < 14; a++) { const int i = TOPO.dof_anc[k][a]; T.tab_dst[k * 14 + a] = (unsigned short)(i >= 0 ? TOPO.madr[i] : 0); }
+  return T;
 }
+DM_CONSTANT LaneTables LTAB = make_lane_tables();
+DM_DEV LaneTopo lane_topo(int lane) { return LTAB.lane[lane & 63]; }
 template <class R>
 DM_DEV void stage_tables(Shared<R>& s, int lane) {
-  for (int e = lane; e < TOPO.nM; e += 64) s.tab_ent[e] = (unsigned short)((TOPO.ent_i[e] << 8) | TOPO.ent_j[e]);
-  for (int t = lane; t < NV * 14; t += 64) {
-    const int k = t / 14, a = t % 14, i = TOPO.dof_anc[k][a];
-    s.tab_dst[k][a] = (unsigned short)(i >= 0 ? TOPO.madr[i] : 0);
-  }
+#pragma unroll
+  for (int c = 0; c < (312 + 63) / 64; c++) { const int e = lane + 64 * c; if (e < 312) s.tab_ent[e] = LTAB.tab_ent[e]; }
+#pragma unroll
+  for (int c = 0; c < (NV * 14 + 63) / 64; c++) { const int t = lane + 64 * c; if (t < NV * 14) (&s.tab_dst[0][0])[t] = LTAB.tab_dst[t]; }
 }
 
 // optional dump of one forward evaluation (parity tests)
