@@ -809,7 +809,9 @@ DM_DEV void box_box(Shared<R>& s, const R* p1, const R* m1, const R* s1, const R
 }
 
 template <class R>
-DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s1, const R* s2, int stage_slot, R margin, PairContacts<R>& pc) {
+DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s1, const R* s2, const R* gs1, const R* gs2, int stage_slot, R margin, PairContacts<R>& pc) {
+  // s1 / s2: the geom sizes in registers (requested with the rest of the pair record: no load inside the divergent type
+  // branches); gs1 / gs2: the same in memory, for box-box, which indexes them with run-time axis numbers
   pc.n = 0; pc.boxslot = -1;
   pc.hint[0] = pc.hint[1] = pc.hint[2] = 0;
   pc.nrm[0] = pc.nrm[1] = 0; pc.nrm[2] = 1;
@@ -888,6 +890,7 @@ DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s
     if (dist <= R(DM_MINVAL)) {
       R closest = 2 * fmax(s2[0], fmax(s2[1], s2[2]));
       int k = 0;
+#pragma unroll
       for (int i = 0; i < 6; i++) { const R fd = fabs(((i % 2) ? R(1) : R(-1)) * s2[i / 2] - center[i / 2]); if (closest > fd) { closest = fd; k = i; } }
       nrm[0] = nrm[1] = nrm[2] = 0; nrm[k / 2] = (k % 2) ? R(-1) : R(1);
       const R sc = (s1[0] - closest) / 2;
@@ -942,6 +945,7 @@ DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s
     if (dist <= R(DM_MINVAL)) {
       R closest = 2 * fmax(s2[0], fmax(s2[1], s2[2]));
       int k = 0;
+#pragma unroll
       for (int i = 0; i < 6; i++) { const R fd = fabs(((i % 2) ? R(1) : R(-1)) * s2[i / 2] - center[i / 2]); if (closest > fd) { closest = fd; k = i; } }
       nrm[0] = nrm[1] = nrm[2] = 0; nrm[k / 2] = (k % 2) ? R(-1) : R(1);
       const R sc = (s1[0] - closest) / 2;
@@ -959,7 +963,7 @@ DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s
     pc.p0[0] += p2[0]; pc.p0[1] += p2[1]; pc.p0[2] += p2[2];
     return;
   }
-  if (t1 == GEOM_BOX && t2 == GEOM_BOX) box_box(s, p1, m1, s1, p2, m2, s2, stage_slot, margin, pc);
+  if (t1 == GEOM_BOX && t2 == GEOM_BOX) box_box(s, p1, m1, gs1, p2, m2, gs2, stage_slot, margin, pc);
 }
 
 // [MJ mju_makeFrame] rows of f: normal, tangent 1, tangent 2
@@ -989,6 +993,8 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
   int pr = lane < npair ? lane : 0;
   int r_g1 = M.pair_rec[pr].g1, r_g2 = M.pair_rec[pr].g2, r_tt = M.pair_rec[pr].t1t2, r_meta = M.pair_rec[pr].meta;
   R r_margin = M.pair_rec[pr].margin, r_mu = M.pair_rec[pr].mu, r_bound = M.pair_rec[pr].bound, r_tran = M.pair_rec[pr].tran;
+  R r_s1a = M.pair_rec[pr].s1[0], r_s1b = M.pair_rec[pr].s1[1], r_s1c = M.pair_rec[pr].s1[2];
+  R r_s2a = M.pair_rec[pr].s2[0], r_s2b = M.pair_rec[pr].s2[1], r_s2c = M.pair_rec[pr].s2[2];
   // (joint-limit constants too: one exposed global-load latency for the stage instead of one per block)
   const bool lim_on = M.enable_limit && lane < NU && M.jnt_limited[lane < NU ? lane + 1 : 1];
   const R lim_lo = M.jnt_lo[lane < NU ? lane + 1 : 1], lim_hi = M.jnt_hi[lane < NU ? lane + 1 : 1];
@@ -1031,6 +1037,8 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
         pr = pass * 64 + lane < npair ? pass * 64 + lane : 0;
         r_g1 = M.pair_rec[pr].g1; r_g2 = M.pair_rec[pr].g2; r_tt = M.pair_rec[pr].t1t2; r_meta = M.pair_rec[pr].meta;
         r_margin = M.pair_rec[pr].margin; r_mu = M.pair_rec[pr].mu; r_bound = M.pair_rec[pr].bound; r_tran = M.pair_rec[pr].tran;
+        r_s1a = M.pair_rec[pr].s1[0]; r_s1b = M.pair_rec[pr].s1[1]; r_s1c = M.pair_rec[pr].s1[2];
+        r_s2a = M.pair_rec[pr].s2[0]; r_s2b = M.pair_rec[pr].s2[1]; r_s2c = M.pair_rec[pr].s2[2];
       }
       const int pidx = pass * 64 + lane;
       PairContacts<R> pc;
@@ -1050,7 +1058,10 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
         }
       }
       if (dmw::ballot(cand) == 0ull) continue;        // nothing near anything in this pass (the common case for body-body pairs)
-      if (cand) narrowphase(s, g1, g2, t1, t2, M.pair_rec[pr].s1, M.pair_rec[pr].s2, ((r_meta >> 16) & 0xff) - 1, margin, pc);
+      if (cand) {
+        const R z1[3] = {r_s1a, r_s1b, r_s1c}, z2[3] = {r_s2a, r_s2b, r_s2c};
+        narrowphase(s, g1, g2, t1, t2, z1, z2, M.pair_rec[pr].s1, M.pair_rec[pr].s2, ((r_meta >> 16) & 0xff) - 1, margin, pc);
+      }
       if (dmw::ballot(pc.n > 0) == 0ull) continue;
       const int rows_per = dim == 1 ? 1 : 2 * (dim - 1);
       int tot_rows, tot_con;
