@@ -592,9 +592,28 @@ constexpr bool elim_codes_ok() {   // a lane holds the codes of pair numbers (la
   return true;
 }
 static_assert(elim_codes_ok(), "pair numbers of a column must stay below 96 (below 64 for a full-wave column)");
+// per step and lane: the column the lane works on, packed  row base (9 bits) | number of pairs << 9 (7) | ancestor-table row << 16 (9) |
+// log2(group size / 16) << 25;  a lane's index inside its group is lane & (group size - 1)
+struct ElimLaneTable { unsigned a[64][N_ELIM_STEPS + 1]; };
+constexpr ElimLaneTable make_elim_lane_table() {
+  ElimLaneTable T{};
+  for (int S = 0; S < N_ELIM_STEPS; S++) {
+    const ElimStep& st = ELIM_STEPS[S];
+    for (int lane = 0; lane < 64; lane++) {
+      int ci = 0;
+      if (st.ncol == 2) ci = lane >> 5;
+      else if (st.ncol == 3) ci = lane < 32 ? (lane >> 4) : 2;
+      else if (st.ncol == 4) ci = lane >> 4;
+      const int K = st.K[ci], gs = elim_group_size(st.ncol, ci);
+      T.a[lane][S] = (unsigned)TOPO.madr[K] | ((unsigned)elim_npairs(K) << 9) | ((unsigned)(K * 14) << 16) | ((unsigned)(gs == 16 ? 0 : gs == 32 ? 1 : 2) << 25);
+    }
+  }
+  return T;
+}
+DM_CONSTANT ElimLaneTable ELIM_LANE = make_elim_lane_table();
 
 template <int S, class R>
-DM_DEV void eliminate_step(Shared<R>& s, int lane_in, const LaneTopo& lt) {
+DM_DEV void eliminate_step(Shared<R>& s, int lane_in, const LaneTopo& lt, const unsigned* ew) {
   // column K:  for every ancestor pair (a, c), row i = anc_a(K):   M(i, anc_c(i)) -= M(K, anc_{a+c}(K)) * M(K, i) / M(K, K)
   // Row K itself is left unscaled (nothing reads it again during the factorisation); all rows are scaled at the end.
   // The update pairs (a, e = a + c), 1 <= a <= e <= nk, are the lower triangle of an nk x nk matrix; enumerated by
@@ -603,14 +622,11 @@ DM_DEV void eliminate_step(Shared<R>& s, int lane_in, const LaneTopo& lt) {
   constexpr ElimStep st = ELIM_STEPS[S];
   constexpr int NC = st.ncol;
   const int lane = dmw::launder(lane_in);     // (laundered: the per-lane step constants below must not be hoisted out of the RK loop)
-  int ci, lg;                                 // this lane's column of the step, its index inside the column's lane group
-  if constexpr (NC == 1) { ci = 0; lg = lane; }
-  else if constexpr (NC == 2) { ci = lane >> 5; lg = lane & 31; }
-  else if constexpr (NC == 3) { ci = lane < 32 ? (lane >> 4) : 2; lg = lane < 32 ? (lane & 15) : lane - 32; }
-  else { ci = lane >> 4; lg = lane & 15; }
-  int base = TOPO.madr[st.K[0]], np = elim_npairs(st.K[0]), k14 = st.K[0] * 14, gs = elim_group_size(NC, 0);
-#pragma unroll
-  for (int c = 1; c < NC; c++) if (ci == c) { base = TOPO.madr[st.K[c]]; np = elim_npairs(st.K[c]); k14 = st.K[c] * 14; gs = elim_group_size(NC, c); }
+  // this lane's column of the step (row base, number of pairs, ancestor-table row) and its lane group: one table word per step
+  // and lane (compile-time schedule, loaded at the top of the stage), not a chain of selects
+  const unsigned w = ew[S];
+  const int base = (int)(w & 511u), np = (int)((w >> 9) & 127u), k14 = (int)((w >> 16) & 511u);
+  const int gs = 16 << (w >> 25), lg = lane & (gs - 1);
   constexpr int passes = elim_passes(S);
   const R inv = R(1) / s.qLD[base];
   const unsigned short* tdst = &s.tab_dst[0][0];
@@ -626,14 +642,18 @@ DM_DEV void eliminate_step(Shared<R>& s, int lane_in, const LaneTopo& lt) {
 }
 template <int S, class R>
 struct EliminateFrom {
-  static DM_DEV void run(Shared<R>& s, int lane, const LaneTopo& lt) {
-    if constexpr (S < N_ELIM_STEPS) { eliminate_step<S>(s, lane, lt); EliminateFrom<S + 1, R>::run(s, lane, lt); }
+  static DM_DEV void run(Shared<R>& s, int lane, const LaneTopo& lt, const unsigned* ew) {
+    if constexpr (S < N_ELIM_STEPS) { eliminate_step<S>(s, lane, lt, ew); EliminateFrom<S + 1, R>::run(s, lane, lt, ew); }
   }
 };
 
 template <class R>
 DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt, const DebugOut* dbg) {
   const int lane = dmw::launder(lane_in);
+  // the elimination schedule's per-lane words, all requested here: their latency hides behind the assembly of M
+  unsigned ew[N_ELIM_STEPS];
+#pragma unroll
+  for (int k = 0; k < N_ELIM_STEPS; k++) ew[k] = ELIM_LANE.a[lane][k];
   if (lane < NV) {
     R f[6];
     sinert_mul(f, s.ub.i.crb[TOPO.dof_body[lane]], s.cdof[lane]);
@@ -649,7 +669,7 @@ DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane_in, c
     if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
   }
   dmw::sync();
-  EliminateFrom<0, R>::run(s, lane, lt);       // 15 steps of mutually independent columns, one barrier each (fully unrolled)
+  EliminateFrom<0, R>::run(s, lane, lt, ew);   // 15 steps of mutually independent columns, one barrier each (fully unrolled)
   // D^-1, D^-1/2 and the unit-triangular scaling L(k, j) = M(k, j) / D_k, all entries at once
   if (lane < NV) { const R inv = R(1) / s.qLD[TOPO.madr[lane]]; s.dinv[lane] = inv; s.dsq[lane] = sqrt(inv); }
   dmw::sync();
