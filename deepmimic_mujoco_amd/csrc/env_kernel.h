@@ -475,23 +475,39 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
 }
 
 // velocity stage: bias forces C(q, v) incl. gravity; smooth generalized force   [MJ mj_comVel, mj_rne, mj_passive]
-// Phases, each of which only needs an LDS hand-off (a sync) from the one before:
-//   0: world body;  1..4: bodies of tree depth 1..4 (cvel, cacc);  5: cfrc of all bodies;  6: subtree sums of cfrc;  7: tau per dof.
-// (Measured dead end, kept as structure only: issuing phase P inside elimination step NV-1-P of the L^T D L factorisation,
-//  to overlap the two independent serial chains in one instruction stream, gained nothing — each phase's own dependent LDS
-//  reads are longer than an elimination step and simply lengthened it.)
-template <int P, class R>
-DM_DEV void bias_phase(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) {
+// The recursion down the tree is  v_b = v_p + sum_k T_k,  a_b = a_p + sum_k (v_p + sum_{j<k} T_j) x T_k  with T_k = cdof_k qvel_k
+// the body's own joint velocities (x = spatial motion cross product).  The cross product is bilinear, so
+//   a_b = a_p + v_p x S_b + C_b,   S_b = sum_k T_k,   C_b = sum_{j<k} T_j x T_k
+// and S_b, C_b need nothing from the parent: all bodies form them at once, and a level of the recursion is one cross product
+// and two vector adds.  (The root's free joint keeps mj_comVel's special form: its three rotations all see the velocity
+// after the translations.)  Then, each needing only an LDS hand-off from the one before: body forces I a + v x* I v for all
+// bodies, their subtree sums, tau per dof.
+// (Measured dead end: issuing the phases inside the elimination steps of the L^T D L factorisation, to overlap the two
+//  independent serial chains in one instruction stream, gained nothing.)
+template <class R>
+DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt) {
+  const int lane = dmw::launder(lane_in);
   const int b = lane + 1;
   const bool isbody = lane < NB - 1;
-  if constexpr (P == 0) {
-    if (lane == 0) {
-      for (int r = 0; r < 6; r++) { s.u.v.cvel[0][r] = 0; s.u.v.cacc[0][r] = 0; }
-      s.u.v.cacc[0][3] = -M.gravity[0]; s.u.v.cacc[0][4] = -M.gravity[1]; s.u.v.cacc[0][5] = -M.gravity[2];
+  const int depth = dmw::launder(lt.depth), p = dmw::launder(lt.parent) & 15, da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum);
+  if (lane == 0) {
+    for (int r = 0; r < 6; r++) { s.u.v.cvel[0][r] = 0; s.u.v.cacc[0][r] = 0; }
+    s.u.v.cacc[0][3] = -M.gravity[0]; s.u.v.cacc[0][4] = -M.gravity[1]; s.u.v.cacc[0][5] = -M.gravity[2];
+  }
+  R S[6] = {0, 0, 0, 0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
+  if (isbody && b > 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (k < nd) {
+      const R qd = s.qvel[da + k];
+      R T[6], cd[6];
+      for (int r = 0; r < 6; r++) T[r] = s.cdof[da + k][r] * qd;
+      if (k > 0) { cross_motion(cd, S, T); for (int r = 0; r < 6; r++) C[r] += cd[r]; }
+      for (int r = 0; r < 6; r++) S[r] += T[r];
     }
-  } else if constexpr (P <= MAXDEPTH_BODY) {
-    if (isbody && lt.depth == P) {
-      const int p = dmw::launder(lt.parent) & 15, da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum);
+  }
+  dmw::sync();
+  for (int L = 1; L <= MAXDEPTH_BODY; L++) {
+    if (isbody && depth == L) {
       R v[6], a[6];
       for (int r = 0; r < 6; r++) { v[r] = s.u.v.cvel[p][r]; a[r] = s.u.v.cacc[p][r]; }
       if (b == 1) {
@@ -504,43 +520,30 @@ DM_DEV void bias_phase(const DevModel<R>& M, Shared<R>& s, int lane, const LaneT
           for (int r = 0; r < 6; r++) { a[r] += cd[r] * qd; v[r] += s.cdof[k][r] * qd; }
         }
       } else {
-        for (int k = 0; k < nd; k++) {
-          R cd[6]; cross_motion(cd, v, s.cdof[da + k]);
-          const R qd = s.qvel[da + k];
-          for (int r = 0; r < 6; r++) { a[r] += cd[r] * qd; v[r] += s.cdof[da + k][r] * qd; }
-        }
+        R cd[6];
+        cross_motion(cd, v, S);
+        for (int r = 0; r < 6; r++) { a[r] += cd[r] + C[r]; v[r] += S[r]; }
       }
       for (int r = 0; r < 6; r++) { s.u.v.cvel[b][r] = v[r]; s.u.v.cacc[b][r] = a[r]; }
     }
-  } else if constexpr (P == MAXDEPTH_BODY + 1) {
-    // body forces I a + v x* (I v): they need only the body's own velocity / acceleration, so all bodies form them at once
-    // here instead of each level of the recursion above carrying them on its serial chain
-    if (isbody) {
-      R v[6], a[6];
-      for (int r = 0; r < 6; r++) { v[r] = s.u.v.cvel[b][r]; a[r] = s.u.v.cacc[b][r]; }
-      R Ia[6], Iv[6], x[6];
-      sinert_mul(Ia, s.ub.i.sin[b], a); sinert_mul(Iv, s.ub.i.sin[b], v); cross_force(x, v, Iv);
-      for (int r = 0; r < 6; r++) s.u.v.cfrc[b][r] = Ia[r] + x[r];
-    }
-  } else if constexpr (P == MAXDEPTH_BODY + 2) {
-    subtree_sums_pass<6, 8, 0, R>(s.u.v.cfrc, s.u.v.csub, lane);
-  } else if constexpr (P == MAXDEPTH_BODY + 3) {
-    if (lane < NV) {
-      const R bias = dot6(s.cdof[lane], s.u.v.csub[TOPO.dof_body[lane]]);
-      s.ua.f.tau[lane] = -M.dof_damping[lane] * s.qvel[lane] - bias + s.act[lane];
-    }
+    dmw::sync();
   }
-}
-constexpr int BIAS_PHASES = MAXDEPTH_BODY + 4;
-template <int P, class R>
-struct BiasFrom {
-  static DM_DEV void run(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt) {
-    if constexpr (P < BIAS_PHASES) { bias_phase<P>(M, s, lane, lt); dmw::sync(); BiasFrom<P + 1, R>::run(M, s, lane, lt); }
+  // body forces I a + v x* (I v): they need only the body's own velocity / acceleration, so all bodies form them at once
+  if (isbody) {
+    R v[6], a[6];
+    for (int r = 0; r < 6; r++) { v[r] = s.u.v.cvel[b][r]; a[r] = s.u.v.cacc[b][r]; }
+    R Ia[6], Iv[6], x[6];
+    sinert_mul(Ia, s.ub.i.sin[b], a); sinert_mul(Iv, s.ub.i.sin[b], v); cross_force(x, v, Iv);
+    for (int r = 0; r < 6; r++) s.u.v.cfrc[b][r] = Ia[r] + x[r];
   }
-};
-template <class R>
-DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane_in, const LaneTopo& lt) {
-  BiasFrom<0, R>::run(M, s, dmw::launder(lane_in), lt);
+  dmw::sync();
+  subtree_sums_pass<6, 8, 0, R>(s.u.v.cfrc, s.u.v.csub, lane);
+  dmw::sync();
+  if (lane < NV) {
+    const R bias = dot6(s.cdof[lane], s.u.v.csub[TOPO.dof_body[lane]]);
+    s.ua.f.tau[lane] = -M.dof_damping[lane] * s.qvel[lane] - bias + s.act[lane];
+  }
+  dmw::sync();
 }
 
 // mass matrix (tree-sparse, MuJoCo qM order) and its L^T D L factor   [MJ mj_crb, mj_factorM]
