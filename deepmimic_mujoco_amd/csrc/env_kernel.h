@@ -1251,11 +1251,14 @@ DM_DEV void uniform_solve(const Shared<R>& s, R* x) {
 // Jacobian row of one constraint, one dof per step, operands of the next dof prefetched (see solve_LT above).
 template <class R>
 struct RowAcc {
-  R w[6];
-  unsigned plus_lo, plus_hi, minus_lo, minus_hi;   // ancestor-chain masks of body2 (+) and body1 (-)
-  int ldof;
-  R lsgn, vel, jws;
-  bool is_tau;     // TAU_LANE: this lane's "row" is the smooth force itself
+  // J_d = (w . cdof_d + w7 + w8 tau_d) * (plus_d - minus_d):
+  //   contact row: w = the contact wrench direction, masks = ancestor chains of body2 (+) and body1 (-) — a dof that moves
+  //                both bodies (common ancestor) cancels exactly;
+  //   limit row:   w7 = +-1, plus mask = the one dof;      TAU_LANE (the smooth force rides along): w8 = 1, plus mask = all dofs.
+  // One formula for all three kinds: an add and an FMA per dof instead of compares and selects.
+  R w[6], w7, w8;
+  unsigned plus_lo, plus_hi, minus_lo, minus_hi;
+  R vel, jws;
 };
 template <int D, class R>
 DM_DEV void load_dof_operands(R* dst, const Shared<R>& s, int z) {
@@ -1272,12 +1275,10 @@ struct RowStep {
     dmw::reload_fence();
     load_dof_operands<D + 1>(nxt, s, 0);
     dmw::sched_fence();
-    const unsigned pb = D < 32 ? (ra.plus_lo >> D) & 1u : (ra.plus_hi >> (D - 32)) & 1u;
-    const unsigned mb = D < 32 ? (ra.minus_lo >> D) & 1u : (ra.minus_hi >> (D - 32)) & 1u;
+    const int pb = (int)(D < 32 ? (ra.plus_lo >> D) & 1u : (ra.plus_hi >> (D - 32)) & 1u);
+    const int mb = (int)(D < 32 ? (ra.minus_lo >> D) & 1u : (ra.minus_hi >> (D - 32)) & 1u);
     R j = ra.w[0] * cur[0] + ra.w[1] * cur[1] + ra.w[2] * cur[2] + ra.w[3] * cur[3] + ra.w[4] * cur[4] + ra.w[5] * cur[5];
-    j = (pb == mb) ? R(0) : (pb ? j : -j);   // a dof that moves both bodies (common ancestor) cancels exactly
-    if (D == ra.ldof) j = ra.lsgn;
-    if (ra.is_tau) j = cur[7];
+    j = (j + ra.w7 + ra.w8 * cur[7]) * (R)(pb - mb);
     ra.vel += j * cur[6]; ra.jws += j * cur[8];
     y[D] = j;
     // pin both running sums: an unpinned one is sunk to the end of the loop by the optimiser, which keeps its 34
@@ -1435,7 +1436,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     if (active) {
       const R* rd = s.u.rowd[lane];
       pos = rd[6]; margin = rd[7]; dA = rd[8]; rscale = rd[9];
-      if (type == ROW_LIMIT) { ldof = (info >> 8) & 0xff; lsgn = rd[0]; }
+      if (type == ROW_LIMIT) { ldof = (info >> 8) & 0xff; lsgn = rd[0]; mplus = 1ull << ldof; }
       else {
         for (int r = 0; r < 6; r++) w[r] = rd[r];
         mminus = TOPO.chain[(info >> 8) & 0xff]; mplus = TOPO.chain[(info >> 16) & 0xff];
@@ -1444,7 +1445,8 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     RowAcc<R> ra;
     for (int r = 0; r < 6; r++) ra.w[r] = w[r];
     ra.plus_lo = (unsigned)mplus; ra.plus_hi = (unsigned)(mplus >> 32); ra.minus_lo = (unsigned)mminus; ra.minus_hi = (unsigned)(mminus >> 32);
-    ra.ldof = ldof; ra.lsgn = lsgn; ra.vel = 0; ra.jws = 0; ra.is_tau = taul;
+    ra.w7 = lsgn; ra.w8 = taul ? R(1) : R(0); ra.vel = 0; ra.jws = 0;
+    if (taul) { ra.plus_lo = 0xffffffffu; ra.plus_hi = 0xffffffffu; }
     {
       R cur[9];
       dmw::reload_fence();
