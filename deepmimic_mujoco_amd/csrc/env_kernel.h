@@ -1364,7 +1364,7 @@ struct SweepGroup {  // PGS rows 4G .. 4G+3 (a slot past nefc computes delta = 0
       for (int ii = 0; ii < 4; ii++) {
         const int i = G * 4 + ii;
         if (i < ROWS && i < MAXROWS) {
-          const R delta = fmax(nf0, t);                            // every lane evaluates its own; only lane i's is used
+          const R delta = dmw::max_raw(nf0, t);                            // every lane evaluates its own; only lane i's is used
           const R di = dmw::bcast(delta, i);
           if (ln == i) tsave = t;
           t += AR[i] * di;
@@ -1557,14 +1557,14 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     SweepGroup<0, ROWS, R>::run(AR, t, tsave, nf0, ln, ne);
     if (ROWS < MAXEFC && ne > ROWS) for (int i = ROWS; i < ne; i++) {      // overflow rows: same update, column of A from memory
       const R a = ((const R*)(&s.aovf)[dmw::pin_zero()])[i * 64 + ln] * ndinv;
-      const R delta = fmax(nf0, t);
+      const R delta = dmw::max_raw(nf0, t);
       const R di = dmw::bcast(delta, i);
       if (ln == i) tsave = t;
       t += a * di;
     }
     myimp = 0;
     if (ln < ne) {
-      const R delta = fmax(nf0, tsave);
+      const R delta = dmw::max_raw(nf0, tsave);
       const R fn = f0 + delta;
       const R change = (delta * diag) * (R(0.5) * delta - tsave);      // = delta (delta A_ii / 2 + r)
       f = fn; myimp = -change; anybad = anybad || (change > pgs_detect);
@@ -1596,7 +1596,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       for (int i = 0; i < nefc; i++) {
         R a = strip[i * 64 + lane];
         if (i >= ROWS) a *= ndinv;
-        R delta = fmax(-f, t);
+        R delta = dmw::max_raw(-f, t);
         const R fn = f + delta;
         const R change = (delta * diag) * (R(0.5) * delta - t);
         const bool rej = change > R(1e-10);          // never accept an increase

@@ -62,6 +62,10 @@ DM_DEV double perm_row_mirror(double v) { return dpp_f64<0x140>(v); }  // lane i
 // (s_cmp + s_cbranch) instead of exec-masked.  Only for values that ARE identical in all lanes.
 DM_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 DM_DEV bool uniform(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+// max(a, b) as the bare instruction.  fmax() first quiets each operand (`v_max x, x`) for signalling NaNs: one more
+// instruction on the PGS row-to-row chain, where no NaN can be signalling (operands come straight from arithmetic).
+DM_DEV double max_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DM_DEV float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // shader clock (s_memtime), for the optional per-stage profile
 DM_DEV long long clk() { return (long long)__builtin_readcyclecounter(); }
 // compiler scheduling fence: nothing moves across it (no instruction is emitted)

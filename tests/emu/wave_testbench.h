@@ -66,6 +66,7 @@ inline double bcast(double v, int src) { return exchange(v, src); }
 inline float bcast(float v, int src) { return exchange(v, src); }
 inline int bcast_i(int v, int src) { return exchange(v, src); }
 inline long long clk() { return 0; }
+template <class T> inline T max_raw(T a, T b) { return std::fmax(a, b); }
 inline int uniform(int v) { return v; }
 inline bool uniform(bool v) { return v; }
 inline double perm_xor1(double v) { return exchange(v, lane() ^ 1); }
