@@ -1510,7 +1510,9 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   const R dinvr = R(1) / diag;
   DM_STAMP(11)
   // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ------------------------------------
-  R ndinv = -dinvr;
+  // (zero for a lane without a row — TAU_LANE included, whose "row of A" is a by-product of the build: its scaled residual and
+  //  columns are then exact zeros, and the sweeps need no predicate to keep it at f = 0)
+  R ndinv = active ? -dinvr : R(0);
   dmw::pin_value(ndinv);
   const R tb = bb * ndinv;
   R t = tb;    // scaled residual t_j = -(b_j + sum_i A_ji f_i) / A_jj, maintained incrementally; the columns are scaled on the way
@@ -1562,8 +1564,8 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       if (ln == i) tsave = t;
       t += a * di;
     }
-    myimp = 0;
-    if (ln < ne) {
+    {   // every lane, unpredicated: a lane without a row has f = 0 and t = 0 throughout, so its step, its new force and its
+        // cost change are exact zeros (a branch around this block costs more than the block)
       const R delta = dmw::max_raw(nf0, tsave);
       const R fn = f0 + delta;
       const R change = (delta * diag) * (R(0.5) * delta - tsave);      // = delta (delta A_ii / 2 + r)
@@ -1576,7 +1578,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     iter = 1;
     while (iter < maxiter) {
       const R fprev = f, tprev = t;
-      const R improvement = dmw::wave_sum(active ? myimp : R(0)) * pgs_scale;     // of sweep `iter`
+      const R improvement = dmw::wave_sum(myimp) * pgs_scale;                     // of sweep `iter` (idle lanes hold 0)
       R myimp_next;
       sweep(myimp_next);                                                          // sweep iter + 1, speculative
       if (dmw::uniform(improvement < pgs_tol)) { f = fprev; t = tprev; break; }
