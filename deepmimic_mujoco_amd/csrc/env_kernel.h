@@ -631,7 +631,7 @@ DM_DEV void eliminate_step(Shared<R>& s, int lane_in, const LaneTopo& lt, const 
   const int base = (int)(w & 511u), np = (int)((w >> 9) & 127u), k14 = (int)((w >> 16) & 511u);
   const int gs = 16 << (w >> 25), lg = lane & (gs - 1);
   constexpr int passes = elim_passes(S);
-  const R inv = R(1) / s.qLD[base];
+  const R inv = dmw::rcp_fast(s.qLD[base]);
   const unsigned short* tdst = &s.tab_dst[0][0];
 #pragma unroll
   for (int p = 0; p < passes; p++) {

@@ -62,6 +62,15 @@ DM_DEV double perm_row_mirror(double v) { return dpp_f64<0x140>(v); }  // lane i
 // (s_cmp + s_cbranch) instead of exec-masked.  Only for values that ARE identical in all lanes.
 DM_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 DM_DEV bool uniform(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+// 1 / x from the hardware estimate and two Newton steps: 5 dependent instructions (a correctly rounded division is 11), within
+// an ulp of the quotient.  For the reciprocal pivots of the factorisation, which sit on its serial chain.
+DM_DEV double rcp_fast(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0); r = __builtin_fma(e, r, r);
+  e = __builtin_fma(-x, r, 1.0); r = __builtin_fma(e, r, r);
+  return r;
+}
+DM_DEV float rcp_fast(float x) { return 1.0f / x; }
 // max(a, b) as the bare instruction.  fmax() first quiets each operand (`v_max x, x`) for signalling NaNs: one more
 // instruction on the PGS row-to-row chain, where no NaN can be signalling (operands come straight from arithmetic).
 DM_DEV double max_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }

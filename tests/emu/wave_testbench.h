@@ -67,6 +67,7 @@ inline float bcast(float v, int src) { return exchange(v, src); }
 inline int bcast_i(int v, int src) { return exchange(v, src); }
 inline long long clk() { return 0; }
 template <class T> inline T max_raw(T a, T b) { return std::fmax(a, b); }
+template <class T> inline T rcp_fast(T x) { return T(1) / x; }
 inline int uniform(int v) { return v; }
 inline bool uniform(bool v) { return v; }
 inline double perm_xor1(double v) { return exchange(v, lane() ^ 1); }
