@@ -1195,11 +1195,12 @@ DM_DEV R lane_solve_L(Shared<R>& s, int lane_in, R rhs) {
   R La = s.qLD[own + (a > 0 ? a : 0)]; int xi = td[a > 0 ? a : 0];
 #pragma unroll
   for (int l = 1; l < MAXD; l++) {
-    if (dd == l) xs[own] = acc;
+    xs[dd == l ? own : 576 + ll] = acc;         // branch-free (cells 576.. are per-lane scratch): a predicated region costs ~45 cycles (tools/ubench), a select ~8
     const int an = a - 1;                       // next level's operands do not depend on x: fetched ahead of the hand-off
     const R Ln = s.qLD[own + (an > 0 ? an : 0)]; const int xn = td[an > 0 ? an : 0];
     dmw::sync();
-    if (a >= 1) acc -= La * xs[xi];
+    const R term = La * xs[xi];
+    acc -= a >= 1 ? term : R(0);
     a = an; La = Ln; xi = xn;
   }
   return acc;
