@@ -664,21 +664,31 @@ DM_DEV void stage_mass_matrix(const DevModel<R>& M, Shared<R>& s, int lane_in, c
     s.dinv[lane] = M.dof_armature[lane];     // staged once (coalesced) — s.dinv is dead until the end of the factorisation;
   }                                          // a per-entry `M.dof_armature[i]` would be a divergent global load in every pass
   dmw::sync();
-  for (int e = lane; e < TOPO.nM; e += 64) {
-    const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
-    R v = dot6(s.cdof[j], s.u.fdof[i]);
-    if (i == j) v += s.dinv[i];
-    s.qLD[e] = v;
-    if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
+  // (compile-time trip count: only the last of the 5 passes is partial and needs a lane predicate — ~45 cycles each)
+#pragma unroll
+  for (int c = 0; c < (TOPO.nM + 63) / 64; c++) {
+    const int e = lane + 64 * c;
+    if ((c + 1) * 64 <= TOPO.nM || e < TOPO.nM) {
+      const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
+      R v = dot6(s.cdof[j], s.u.fdof[i]);
+      if (i == j) v += s.dinv[i];
+      s.qLD[e] = v;
+      if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
+    }
   }
   dmw::sync();
   EliminateFrom<0, R>::run(s, lane, lt, ew);   // 15 steps of mutually independent columns, one barrier each (fully unrolled)
   // D^-1, D^-1/2 and the unit-triangular scaling L(k, j) = M(k, j) / D_k, all entries at once
   if (lane < NV) { const R inv = R(1) / s.qLD[TOPO.madr[lane]]; s.dinv[lane] = inv; s.dsq[lane] = sqrt(inv); }
   dmw::sync();
-  for (int e = lane; e < TOPO.nM; e += 64) {
-    const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
-    if (i != j) s.qLD[e] *= s.dinv[i];
+#pragma unroll
+  for (int c = 0; c < (TOPO.nM + 63) / 64; c++) {
+    const int e = lane + 64 * c;
+    if ((c + 1) * 64 <= TOPO.nM || e < TOPO.nM) {
+      const int ij = s.tab_ent[e], i = ij >> 8, j = ij & 0xff;
+      const R sc = i != j ? s.dinv[i] : R(1);     // (select, not a predicated region)
+      s.qLD[e] *= sc;
+    }
   }
   dmw::sync();
 }
