@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library (build artefacts are not in the history): build it once, as __graft_entry__.build()
+    # does, when a compiler is there — the tests never substitute anything for it
+    try:
+        from deepmimic_mujoco_amd.csrc import build as _b
+        if not os.path.exists(_b.OUT):
+            _b.build()
+    except Exception as e:   # no hipcc here: the ABI tests will say so
+        sys.stderr.write("conftest: libdmenv.so not built (%r)\n" % (e,))
 
 
 def _has_gpu():
