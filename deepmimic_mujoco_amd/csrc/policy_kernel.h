@@ -1,7 +1,7 @@
 // policy_kernel.h — the learner's policy step for a batch of environments as ONE kernel:
 //   obz = clip((ob - mean) / std, -5, 5);  two 2x100 tanh MLPs (policy mean [28], value [1]);  ac = mean + exp(logstd) * N(0,1)
 // (src/mlp_policy_trpo.py:35-58, src/distributions.py:220-245).  It replaces ~15 launch-bound library calls per rollout step.
-// The matrices are tiny (56x100, 100x100, 100x28): a workgroup takes 32 environments, keeps their activations in LDS and
+// The matrices are tiny (56x100, 100x100, 100x28): a workgroup takes 16 environments (256 workgroups at 4096 envs: one per CU; 32 per workgroup left half the chip idle: 39 -> 22 us), keeps their activations in LDS and
 // streams the weights once per workgroup from L2 (coalesced across the 200 hidden-unit threads); every LDS read feeds four
 // FMAs.  fp32 like the reference's TF graph.  No MFMA: 37 k MACs per env would not amortise a fragment layout.
 #pragma once
@@ -10,7 +10,7 @@
 
 namespace dmp {
 
-constexpr int OB = 56, HID = 100, AC = 28, EB = 32, HS = 204;   // HS: padded row stride of the hidden activations (bank spread)
+constexpr int OB = 56, HID = 100, AC = 28, EB = 16, HS = 204;   // HS: padded row stride of the hidden activations (bank spread)
 // packed weight layout (floats)
 constexpr int O_MEAN = 0, O_STD = O_MEAN + OB;
 constexpr int O_PW1 = O_STD + OB, O_PB1 = O_PW1 + OB * HID, O_PW2 = O_PB1 + HID, O_PB2 = O_PW2 + HID * HID;
@@ -32,7 +32,7 @@ __device__ inline float normal_from(unsigned long long seed, unsigned long long 
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
-// one dense layer for 32 environments: thread u (< 2 * HID) owns hidden unit (net = u / HID, j = u % HID)
+// one dense layer for EB environments: thread u (< 2 * HID) owns hidden unit (net = u / HID, j = u % HID)
 template <int K>
 __device__ inline void dense32(const float* __restrict__ W, const float* __restrict__ bias, int j, const float* in, int in_stride,
                                int in_off, float* acc) {
