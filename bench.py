@@ -20,6 +20,8 @@ import time
 
 import numpy as np
 
+# the host driver only supports dmabuf IPC: without this, RCCL's cross-process buffer sharing fails (hipIpcGetMemHandle)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -7,6 +7,7 @@
 import argparse
 import json
 import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only (RCCL across processes)
 import sys
 
 import torch
