@@ -114,3 +114,27 @@ def test_native_policy_kernel_matches_torch_forward():
     pol.mark_dirty()
     ac2, _ = pol.act(False, ob)
     assert float((ac2 - ac - 0.5).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    """bench.py's output contract: ONE JSON line with the metric, the roofline object and (N = 1) the CPU baseline."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "16", "--warmup", "4", "--prewarm-horizons", "0",
+                          "--envs", "512"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 16 and j["warmup"] == 4 and j["dtype"] == "f64" and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["value"] > 1e5 and "workload" in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and r["peak"] == 8000.0
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1000 and "sample" in c
