@@ -1369,19 +1369,30 @@ struct WarmBlock {   // A[:, 8B .. 8B+7] scaled in place (row j by -1 / A_jj);  
 };
 template <int G, int ROWS, class R>
 struct SweepGroup {  // PGS rows 4G .. 4G+3 (a slot past nefc computes delta = 0: idle lane, zero column)
-  static DM_DEV void run(const R* AR, R& t, R& tsave, R nf0, int ln, int ne) {
+  // strip / ndinv: rows past the register tier take their (unscaled) column of A from the env's memory strip; they hang off the
+  // deepest level of the nest, so a sweep with fewer rows never even tests for them
+  static DM_DEV void run(const R* AR, R& t, R& tsave, R nf0, int ln, int ne, const R* strip, R ndinv, const Shared<R>* sp) {
     if constexpr (G * 4 < ROWS) {
 #pragma unroll
       for (int ii = 0; ii < 4; ii++) {
         const int i = G * 4 + ii;
         if (i < ROWS && i < MAXROWS) {
-          const R delta = dmw::max_raw(nf0, t);                            // every lane evaluates its own; only lane i's is used
+          const R delta = dmw::max_raw(nf0, t);                    // every lane evaluates its own; only lane i's is used
           const R di = dmw::bcast(delta, i);
           if (ln == i) tsave = t;
           t += AR[i] * di;
         }
       }
-      if ((G + 1) * 4 < ne) SweepGroup<G + 1, ROWS, R>::run(AR, t, tsave, nf0, ln, ne);
+      if ((G + 1) * 4 < ne) SweepGroup<G + 1, ROWS, R>::run(AR, t, tsave, nf0, ln, ne, strip, ndinv, sp);
+    } else if constexpr (ROWS < MAXEFC) {
+      strip = sp->aovf;                                              // (the pointer is only fetched when such rows exist)
+      for (int i = ROWS; i < ne; i++) {                              // overflow rows: same update, column of A from memory
+        const R a = strip[i * 64 + ln] * ndinv;
+        const R delta = dmw::max_raw(nf0, t);
+        const R di = dmw::bcast(delta, i);
+        if (ln == i) tsave = t;
+        t += a * di;
+      }
     }
   }
 };
@@ -1567,14 +1578,7 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     const int ln = dmw::launder(lane);
     const R f0 = f, nf0 = -f;
     R tsave = t;
-    SweepGroup<0, ROWS, R>::run(AR, t, tsave, nf0, ln, ne);
-    if (ROWS < MAXEFC && ne > ROWS) for (int i = ROWS; i < ne; i++) {      // overflow rows: same update, column of A from memory
-      const R a = ((const R*)(&s.aovf)[dmw::pin_zero()])[i * 64 + ln] * ndinv;
-      const R delta = dmw::max_raw(nf0, t);
-      const R di = dmw::bcast(delta, i);
-      if (ln == i) tsave = t;
-      t += a * di;
-    }
+    SweepGroup<0, ROWS, R>::run(AR, t, tsave, nf0, ln, ne, (const R*)0, ndinv, &s);
     {   // every lane, unpredicated: a lane without a row has f = 0 and t = 0 throughout, so its step, its new force and its
         // cost change are exact zeros (a branch around this block costs more than the block)
       const R delta = dmw::max_raw(nf0, tsave);
