@@ -1591,14 +1591,17 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     R myimp;
     sweep(myimp);
     iter = 1;
-    while (iter < maxiter) {
+    bool more = iter < maxiter;
+    while (more) {                                                                  // (one exit test per sweep)
       const R fprev = f, tprev = t;
       const R improvement = dmw::wave_sum(myimp) * pgs_scale;                     // of sweep `iter` (idle lanes hold 0)
       R myimp_next;
       sweep(myimp_next);                                                          // sweep iter + 1, speculative
-      if (dmw::uniform(improvement < pgs_tol)) { f = fprev; t = tprev; break; }
+      const bool conv = dmw::uniform(improvement < pgs_tol);
+      f = conv ? fprev : f; t = conv ? tprev : t;                                   // converged: the speculative sweep is dropped
       myimp = myimp_next;
-      iter++;
+      iter += conv ? 0 : 1;
+      more = !conv && iter < maxiter;
     }
   }
   if (dmw::ballot(anybad) != 0) {
