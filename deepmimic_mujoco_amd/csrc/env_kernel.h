@@ -402,6 +402,7 @@ DM_DEV void stage_kinematics(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   // the root-first sum of the offsets along its (at most 4 deep) chain — the same additions in the same order as
   // xpos = xpos_parent + R_parent pos.
   R q[4] = {1, 0, 0, 0};
+#pragma unroll
   for (int L = 1; L <= MAXDEPTH_BODY; L++) {
     if (isbody && depth == L) {
       if (b == 1) { q[0] = s.qpos[3]; q[1] = s.qpos[4]; q[2] = s.qpos[5]; q[3] = s.qpos[6]; }
@@ -506,6 +507,7 @@ DM_DEV void stage_bias(const DevModel<R>& M, Shared<R>& s, int lane_in, const La
     }
   }
   dmw::sync();
+#pragma unroll
   for (int L = 1; L <= MAXDEPTH_BODY; L++) {
     if (isbody && depth == L) {
       R v[6], a[6];
