@@ -3,97 +3,240 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (config.workload): BASELINE.json configs[2] — 'walk' clip, 4096 envs per GPU, full contact + joint-limit
-solve (PGS 50), the 5-term DeepMimic imitation reward (pose / velocity / end-effector / root / COM against the mocap frame;
-`--reward v3-config` selects dp_env_v3's own disabled config reward instead), RSI auto-reset on done, actions ~ N(0, 0.9^2) i.i.d. (pre-generated on
-the device).  One "step" = one `dm_batch_step` launch = one DPEnv.step (one RK4 mj_step, h = 0.0166 s) of every env
-of the rank.  With N > 1 the env index range is sharded over ranks (weak scaling, no per-step collective) and every
-256 steps the [256, 4096, 87] f32 rollout block is all-gathered over RCCL, as the learner would consume it — asynchronously,
-double-buffered, so the envs keep stepping while the block travels; every gather completes inside the timed region.
-Prints ONE JSON line (rank 0).
+Workloads (`--workload`, named in config.workload):
+  cfg3 (default; the configuration the metric is quoted on) — BASELINE.json configs[2]: 'walk' clip, 4096 envs per GPU, full
+        contact + joint-limit solve (PGS 50), the 5-term DeepMimic imitation reward (`--reward v3-config` selects dp_env_v3's
+        own disabled config reward instead), RSI auto-reset on done, actions ~ N(0, 0.9^2) i.i.d. (pre-generated on the device).
+  cfg2 — configs[1]: 'walk', 4096 envs, P-controller torque, contacts and limits off.
+  cfg4 — configs[3]: 'spinkick', 32768 envs sharded 8 x 4096; a single process times ONE shard (shard 3: env_offset = 3 N).
+  cfg5 — configs[4]: 'dance_b', reference-state-init + early termination, 65536 envs sharded 8 x 8192; one shard as above.
+  rollout — informational: policy in the loop + GAE.
+One "step" = one `dm_batch_step` launch = one DPEnv.step (ONE RK4 mj_step, h = 0.0166 s, as src/dp_env_v3.py:108-112
+hard-codes) of every env of the rank.  With N > 1 the env index range is sharded over ranks (weak scaling, no per-step
+collective) and every 256 steps the [256, n, 87] f32 rollout block is all-gathered (RCCL with `--dist-backend nccl`, the
+default; `gloo` stages the block through pinned host memory and exists so that the multi-rank code path can be executed where
+only one GPU is visible) — asynchronously, double-buffered, so the envs keep stepping while the block travels; every gather
+completes inside the timed region.  Prints ONE JSON line (rank 0).
+
+Besides the contract fields the line carries (N = 1): `roofline` (HBM fraction from the algorithmic bytes; fp64 fraction from
+a flop count of the kernel's algorithm evaluated on the run's own row / sweep statistics; with rocprofv3 on PATH, live PMC
+passes of this very workload: HBM traffic, VALU issue fraction, lane efficiency), `cpu_baseline` (the oracle on the host
+cores), `single_env_gym_loop` (steps/s of a Python `DPEnv.step` loop, the path src/trpo.py:47-80 drives).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
+import warnings
 
 import numpy as np
 
-# the host driver only supports dmabuf IPC: without this, RCCL's cross-process buffer sharing fails (hipIpcGetMemHandle)
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ENVS_PER_GPU = 4096
 HORIZON = 256
-ALGO_BYTES_PER_STEP = 2353      # SURVEY.md section 8(d): fp64 state/action in + state/obs/reward/done out, per env-step
-ALGO_FLOP_PER_STEP = 1.5e6      # SURVEY.md section 8(d) estimate with ~8 floor contacts + limits
+ALGO_BYTES_PER_STEP = 2353      # DESIGN.md section 2: fp64 state/action in + state/obs/reward/done out, per env-step
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X fp64 vector peak (public spec)
+FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X fp64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 x 2.4 GHz)
+N_SIMDS = 1024
+MAX_CLOCK_HZ = 2.4e9
+
+WORKLOADS = {
+    "cfg2": dict(clip="walk", envs=4096, full=False, shards=1, label="BASELINE.json configs[1]: 'walk' mocap, %d envs/GPU, P-controller torque, contacts and limits off"),
+    "cfg3": dict(clip="walk", envs=4096, full=True, shards=1, label="BASELINE.json configs[2]: 'walk' mocap, %d envs/GPU, full contact + joint-limit PGS solve, %s reward, RSI auto-reset"),
+    "cfg4": dict(clip="spinkick", envs=4096, full=True, shards=8, label="BASELINE.json configs[3]: 'spinkick' mocap, 32768 envs sharded 8 x %d, full contact + joint-limit PGS solve, %s reward, RSI auto-reset, rollout all-gather every 256 steps"),
+    "cfg5": dict(clip="dance_b", envs=8192, full=True, shards=8, label="BASELINE.json configs[4]: 'dance_b' mocap, reference-state-init + early termination, 65536 envs sharded 8 x %d, full contact + joint-limit PGS solve, %s reward"),
+}
 
 
-def cpu_baseline(clip, reward="imitation", budget_s=12.0):
-    """Time the CPU oracle (oracle/, float64 C, OpenMP over envs) on a bounded sample of the same workload.  The host may
-    expose more logical CPUs than the container can use, so a few thread counts are tried and the best one is reported
-    together with the one-core figure."""
+# ---- flop count of the kernel's algorithm (DESIGN.md section 3, "fp64 work per evaluation") ----------------------------------
+# Useful fp64 operations (mul = add = 1, FMA = 2) of ONE forward evaluation as the kernel computes it (tree-sparse factor,
+# half-solved rows), as a function of the evaluation's constraint rows `nefc` and PGS sweeps.  Fixed part per evaluation:
+#   kinematics 6 600 (28 sincos, hinge chains, 13 frames, cdof, 13 world inertias, composite sums)
+#   mass matrix 9 600 (34 I*cdof, 310 entries x 11, 1 432 elimination updates x 3, scaling)
+#   bias 4 400 (joint velocity sums, 4-level recursion, 13 body forces, subtree sums, 34 projections)
+#   collision 4 200 (16 geom poses, 104 bounding tests, ~20 narrow-phase pairs near the floor)
+# and the no-row solve 1 200.  With rows: (nefc + 1) half-solved vectors x 1 232 (Jacobian row 646 + L^-T 552 + scale 34),
+# A = Y Y^T 68 nefc^2 (+ b 68 nefc), warm start 2 nefc^2, a PGS sweep 2 nefc^2 + 10 nefc, force assembly 68 nefc, back-solve 620.
+FIXED_FLOPS_PER_EVAL = 6600 + 9600 + 4400 + 4200
+STEP_OVERHEAD_FLOPS = 2500 + 7000          # RK4 combine / integrate / obs (+ the imitation reward's extra kinematics pass and terms)
+
+
+def eval_flops(nefc, sweeps):
+    nefc = np.asarray(nefc, dtype=np.float64); sweeps = np.asarray(sweeps, dtype=np.float64)
+    rows = (nefc + 1) * 1232 + 70 * nefc ** 2 + 136 * nefc + sweeps * (2 * nefc ** 2 + 10 * nefc) + 620
+    return FIXED_FLOPS_PER_EVAL + np.where(nefc > 0, rows, 1200.0)
+
+
+def step_flops(nefc, sweeps):
+    """fp64 flops of one env-step: 4 RK evaluations with the row / sweep counts of the last one (what the device reports)."""
+    return 4.0 * eval_flops(nefc, sweeps) + STEP_OVERHEAD_FLOPS
+
+
+def physical_cores():
+    """(physical cores, logical CPUs usable by this process) of the host."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in avail:
+        try:
+            pk = open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % c).read().strip()
+            co = open("/sys/devices/system/cpu/cpu%d/topology/core_id" % c).read().strip()
+            cores.add((pk, co))
+        except OSError:
+            cores.add(("?", c))
+    return len(cores), len(avail)
+
+
+def cpu_baseline_worker(clip, reward, nthreads, seconds):
+    """Runs in a fresh process whose OpenMP runtime was configured by the parent (OMP_NUM_THREADS / OMP_PROC_BIND / OMP_PLACES):
+    time the CPU oracle (oracle/, float64 C, OpenMP over envs) on a bounded sample of the same workload."""
     from oracle import oracle as O
     from deepmimic_mujoco_amd import MocapDM, CompiledModel, humanoid_spec
     from deepmimic_mujoco_amd.imitation import ImitationSpec
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
     mc = MocapDM(); mc.load_mocap(clip)
     F = mc.data_config.shape[0]
     om = O.Model()
     rng = np.random.RandomState(0)
     imit = reward == "imitation"
     if imit:
-        spec = ImitationSpec(CompiledModel(humanoid_spec()))
-        table = spec.build_table(mc.data_config, mc.data_vel); params = spec.params(mc.data_config, mc.loop)
+        table, params = ImitationSpec(CompiledModel(humanoid_spec())).table_for(mc)
+    n = max(8, nthreads * 8)                     # >= 4 envs per thread so that the static OpenMP schedule is balanced
+    ds = [O.Data(om) for _ in range(n)]
+    idx = (np.arange(n) % F).astype(np.int32); cyc = np.zeros(n, dtype=np.int32)
+    for e, d in enumerate(ds):
+        d.reset(); d.set_state(mc.data_config[e % F], mc.data_vel[e % F])
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        a = rng.randn(n, 28) * 0.9
+        if imit:
+            _o, _r, done = O.batch_step_imitation(om, ds, a, 1, table, params, idx, cyc, nthreads)
+        else:
+            _o, _r, done = O.batch_step(om, ds, a, 1, nthreads)
+        steps += 1
+        for e in np.nonzero(done)[0]:
+            k = rng.randint(F)
+            ds[e].reset(); ds[e].set_state(mc.data_config[k], mc.data_vel[k]); idx[e] = k; cyc[e] = 0
+        el = time.perf_counter() - t0
+        if el > seconds and steps >= 4:
+            break
+    print(json.dumps({"rate": n * steps / el, "n": n, "steps": steps, "el": el}))
 
-    def run(nthreads, seconds):
-        n = max(8, nthreads * 8)
-        ds = [O.Data(om) for _ in range(n)]
-        idx = (np.arange(n) % F).astype(np.int32); cyc = np.zeros(n, dtype=np.int32)
-        for e, d in enumerate(ds):
-            d.reset(); d.set_state(mc.data_config[e % F], mc.data_vel[e % F])
-        steps = 0
-        t0 = time.perf_counter()
-        while True:
-            a = rng.randn(n, 28) * 0.9
-            if imit:
-                _o, _r, done = O.batch_step_imitation(om, ds, a, 1, table, params, idx, cyc, nthreads)
-            else:
-                _o, _r, done = O.batch_step(om, ds, a, 1, nthreads)
-            steps += 1
-            for e in np.nonzero(done)[0]:
-                k = rng.randint(F)
-                ds[e].reset(); ds[e].set_state(mc.data_config[k], mc.data_vel[k]); idx[e] = k; cyc[e] = 0
-            el = time.perf_counter() - t0
-            if el > seconds and steps >= 4:
-                return n * steps / el, n, steps, el
 
-    counts = sorted({1, min(8, avail), min(32, avail), min(64, avail), avail})
+def cpu_baseline(clip, reward="imitation", budget_s=14.0):
+    """The oracle on the box's host cores.  Every thread count runs in its own process with threads pinned
+    (OMP_PROC_BIND=close, OMP_PLACES=cores): un-pinned, the runtime piles threads of a 256-logical-CPU host onto a few cores
+    (round 1: 129 k env-steps/s at 32 threads, 14 k at 256).  Reported: the physical-core run, next to one core."""
+    ncores, nlogical = physical_cores()
+    counts = sorted({1, min(32, ncores), ncores})
     per = budget_s / len(counts)
-    results = {c: run(c, per) for c in counts}
-    best = max(results, key=lambda c: results[c][0])
-    v, n, steps, el = results[best]
-    return {"value": round(v, 1), "unit": "env-steps/s", "cores": best, "kind": "port", "single_core_value": round(results[1][0], 1),
-            "by_threads": {str(c): round(results[c][0], 1) for c in counts}, "logical_cpus": avail,
+    res = {}
+    for c in counts:
+        env = dict(os.environ, OMP_NUM_THREADS=str(c), OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_WAIT_POLICY="active", OMP_DYNAMIC="false")
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--_cpu-worker", clip, reward, str(c), str(per)], env=env,
+                                 capture_output=True, text=True, timeout=per * 6 + 120)
+            res[c] = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            res[c] = {"rate": 0.0, "n": 0, "steps": 0, "el": 0.0, "error": repr(e)}
+    best = max(res, key=lambda c: res[c]["rate"])
+    b = res[best]
+    return {"value": round(b["rate"], 1), "unit": "env-steps/s", "cores": best, "kind": "port", "single_core_value": round(res[1]["rate"], 1),
+            "by_threads": {str(c): round(res[c]["rate"], 1) for c in counts}, "physical_cores": ncores, "logical_cpus": nlogical,
             "sample": "%d envs x %d steps of the same workload (%s, contacts+limits, %s reward, N(0,0.9^2) actions, RSI reset on done), "
-                      "oracle/dm_oracle.c fp64 with OpenMP over envs, %d threads (best of %s), %.1f s" % (n, steps, clip, reward, best, counts, el)}
+                      "oracle/dm_oracle.c fp64, OpenMP over envs, %d pinned threads (OMP_PROC_BIND=close, OMP_PLACES=cores; tried %s), %.1f s"
+                      % (b["n"], b["steps"], clip, reward, best, counts, b["el"])}
 
 
-def rollout_bench(args, dev, rank, world, local_rank):
+def single_env_gym_loop(device, seconds=2.0):
+    """BASELINE.md's C0 shape: the Python loop of src/trpo.py:47-80 on ONE `DPEnv` (host pointers, one launch per step)."""
+    import random
+    from deepmimic_mujoco_amd import DPEnv
+    random.seed(0)
+    env = DPEnv(motion="walk", device=device)
+    env.seed(0)
+    env.reset(); env.reset_model_init()
+    rng = np.random.RandomState(0)
+    acs = rng.randn(256, 28) * 0.3
+    for t in range(32):
+        env.step(acs[t])
+    steps = eps = 0
+    t0 = time.perf_counter()
+    while True:
+        ob, r, d, _ = env.step(acs[steps % 256])
+        steps += 1
+        if d:
+            env.reset(); env.reset_model_init(); eps += 1
+        if steps % 64 == 0 and time.perf_counter() - t0 > seconds:
+            break
+    el = time.perf_counter() - t0
+    env.close()
+    return {"value": round(steps / el, 1), "unit": "env-steps/s", "us_per_step": round(el / steps * 1e6, 1), "steps": steps, "episodes": eps,
+            "what": "Python `DPEnv.step` loop, 1 env, numpy in / out through the C ABI's host-pointer path (action H2D, one launch, "
+                    "one packed obs+reward+done D2H), reset() + reset_model_init() on done as src/trpo.py:78-79"}
+
+
+def pmc_passes(argv_tail, kernel_prefix, timeout_s=150):
+    """Live rocprofv3 passes of THIS workload (short run, child processes): kernel trace, HBM bytes, SQ instruction mix.
+    Counters are collected in separate passes with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC section)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    groups = [("trace", ["--stats"]),
+              ("fetch", ["--pmc", "FETCH_SIZE"]), ("write", ["--pmc", "WRITE_SIZE"]),
+              ("sq", ["--pmc", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]),
+              ("grbm", ["--pmc", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES"])]
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="dmenv_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    for name, flags in groups:
+        if time.perf_counter() - t0 > timeout_s:
+            res[name + "_error"] = "time budget spent"
+            continue
+        d = os.path.join(tmp, name)
+        cmd = [exe, "--kernel-trace"] + flags + ["-d", d, "--", sys.executable, os.path.abspath(__file__)] + argv_tail
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if not dbs:
+                res[name + "_error"] = "no output database"
+                continue
+            cur = sqlite3.connect(dbs[0]).cursor()
+            if name == "trace":
+                r = cur.execute("select count(*), avg(end-start), max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) "
+                                "from kernels where name like ?", (kernel_prefix + "%",)).fetchone()
+                res["trace"] = {"launches": r[0], "avg_us": r[1] / 1e3 if r[1] else None, "vgpr": r[2], "agpr": r[3], "sgpr": r[4], "lds_bytes": r[5], "scratch_bytes_per_lane": r[6]}
+            else:
+                for cn, val, cnt in cur.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like ? group by counter_name",
+                                                (kernel_prefix + "%",)).fetchall():
+                    res[cn] = val
+                if name == "sq":    # the same pass's kernel durations: PMC and time from ONE run (a profiled run clocks differently)
+                    r = cur.execute("select avg(end-start) from kernels where name like ?", (kernel_prefix + "%",)).fetchone()
+                    res["sq_pass_avg_us"] = r[0] / 1e3 if r and r[0] else None
+        except Exception as e:
+            res[name + "_error"] = repr(e)[:200]
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res, None
+
+
+def rollout_bench(args, dev, rank, world, local_dev):
     """Informational: the learner-facing loop of src/trpo.py:27-94 kept on the device — 2x100 tanh policy + value forward,
     Gaussian sampling, env kernel, segment bookkeeping, GAE per 256-step segment.  Not the judged metric line."""
     import torch
     from deepmimic_mujoco_amd import DPVecEnv, MlpPolicy, traj_segment_generator, add_vtarg_and_adv
-    n = args.envs
-    env = DPVecEnv(n, motion=args.clip, device=local_rank, reward="alive", autoreset="init", seed=0, env_offset=rank * n)
+    n = args.envs or 4096
+    env = DPVecEnv(n, motion=args.clip or "walk", device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n)
     pol = MlpPolicy(device=dev, seed=0); pol.seed(rank)
     gen = traj_segment_generator(pol, env, HORIZON, stochastic=True)
     segs = max(1, args.steps // HORIZON)
@@ -115,18 +258,24 @@ def rollout_bench(args, dev, rank, world, local_rank):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--_cpu-worker":
+        return cpu_baseline_worker(sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "rollout"],
-                    help="cfg3 (default, the judged line) / cfg2: BASELINE.json configs; rollout: policy-in-the-loop segments + GAE (informational)")
-    ap.add_argument("--clip", default="walk")
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's: 4096; cfg5 8192)")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "rollout"])
+    ap.add_argument("--clip", default=None, help="override the workload's mocap clip")
     ap.add_argument("--reward", default="imitation", choices=["imitation", "v3-config", "alive"],
-                    help="cfg3 reward: the 5-term DeepMimic imitation reward (default), dp_env_v3's config reward, or the constant 1.0")
+                    help="reward of the full-contact workloads: the 5-term DeepMimic imitation reward (default), dp_env_v3's config reward, or the constant 1.0")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged gather, ranks may share a GPU (LOCAL_RANK modulo the visible devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (N = 1 only; they add about a minute)")
+    ap.add_argument("--no-gym-loop", action="store_true", help="skip the single-env Python DPEnv.step loop (N = 1 only; ~3 s)")
     ap.add_argument("--prewarm-horizons", type=int, default=6, help="untimed 256-step horizons before the warm-up steps (cold-box clock ramp, ~1 s)")
+    ap.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)   # profiled child of pmc_passes: GPU loop only, prints nothing
     args = ap.parse_args()
 
     import torch
@@ -137,28 +286,47 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch N > 1 as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and world > ndev:
+        raise SystemExit("RCCL needs one GPU per rank: %d ranks, %d devices visible (use --dist-backend gloo to share a GPU)" % (world, ndev))
+    local_dev = local_rank % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    n_ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            # this image's host driver only supports dmabuf IPC; RCCL's cross-process buffer registration otherwise fails with
+            # `hipIpcGetMemHandle: invalid argument` (the platform exports the same setting; profiles/r02_two_rank_*.log)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        n_ranks_seen = dist.get_world_size()
+        assert n_ranks_seen == args.gpus, "process group has %d ranks, --gpus says %d" % (n_ranks_seen, args.gpus)
 
-    n = args.envs
     if args.workload == "rollout":
-        return rollout_bench(args, dev, rank, world, local_rank)
-    full = args.workload == "cfg3"
-    env = DPVecEnv(n, motion=args.clip, device=local_rank, reward=args.reward if full else "alive",
-                   autoreset="rsi", seed=0, contacts=full, limits=full,
-                   action_mode="raw" if full else "p-control", env_offset=rank * n)
+        return rollout_bench(args, dev, rank, world, local_dev)
+    wl = WORKLOADS[args.workload]
+    n = args.envs or wl["envs"]
+    clip = args.clip or wl["clip"]
+    full = wl["full"]
+    # shard id: the rank when the job is sharded; a single process of a sharded configuration times an interior shard (3), so
+    # that the measured shard is not the one whose global env ids start at 0
+    shard = rank if world > 1 else (3 if wl["shards"] > 1 else 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)        # frame_skip = 1 with the imitation reward is this benchmark's definition of a step
+        env = DPVecEnv(n, motion=clip, device=local_dev, reward=args.reward if full else "alive",
+                       autoreset="rsi", seed=0, contacts=full, limits=full,
+                       action_mode="raw" if full else "p-control", env_offset=shard * n, frame_skip=1)
     stream = torch.cuda.Stream(device=dev)
     env.batch.set_stream(stream.cuda_stream)
 
     with torch.cuda.stream(stream):
-        gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+        gen = torch.Generator(device=dev); gen.manual_seed(1234 + shard)
         pool = 32
         if full:
             actions = torch.randn((pool, n, A.NU), generator=gen, device=dev, dtype=torch.float64) * 0.9
@@ -166,8 +334,8 @@ def main():
             actions = torch.zeros((pool, n, A.NU), device=dev, dtype=torch.float64)   # cfg2: pure P-controller
         # the kernel writes obs / reward / done of step t straight into row t of [T, n, .] staging buffers (no per-step copy
         # kernels); at the end of each 256-step horizon they are packed into the f32 rollout block (obs 56 + act 28 + rew + done
-        # + vpred) in one go.  Blocks are double-buffered: while one is all-gathered over RCCL (async, on the collective's own
-        # stream) the envs keep stepping
+        # + vpred) in one go.  Blocks are double-buffered: while one is all-gathered (async, on the collective's own stream) the
+        # envs keep stepping
         from deepmimic_mujoco_amd.rollout import DoubleBufferedGather
         obs_T = torch.zeros((HORIZON, n, A.NOBS), dtype=torch.float64, device=dev)    # zeros: every page is touched before the clock starts
         rew_T = torch.zeros((HORIZON, n), dtype=torch.float64, device=dev)
@@ -175,8 +343,9 @@ def main():
         tidx = torch.arange(HORIZON, device=dev)
         dbg = DoubleBufferedGather(HORIZON, n, device=dev, world=world)
         env.reset("rsi")
+        stat_nefc, stat_iter = [], []
 
-        def one_step(t):
+        def one_step(t, stats=False):
             k = t % HORIZON
             env.batch.step(actions[t % pool], 1, (obs_T[k], rew_T[k], done_T[k]))
             if k == HORIZON - 1:
@@ -201,7 +370,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-        done_count = torch.zeros((), dtype=torch.int64, device=dev)
         t0 = time.perf_counter()
         ev0.record(stream)
         for t in range(args.steps):
@@ -213,54 +381,102 @@ def main():
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
+        # row / sweep statistics for the flop count: untimed, a few more steps sampled after the clock stopped
+        if not args._child:
+            for t in range(args.steps, args.steps + 8):
+                one_step(t)
+                stream.synchronize()
+                stat_nefc.append(env.batch.get(A.F_NEFC)); stat_iter.append(env.batch.get(A.F_SOLVER_ITER))
+            drain()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if args._child:
+        return
     gpu_ms = ev0.elapsed_time(ev1)
     status = env.batch.get(A.F_STATUS)
-    nefc = env.batch.get(A.F_NEFC)
+    nefc = np.concatenate(stat_nefc); iters = np.concatenate(stat_iter)
 
     if rank == 0:
         total_steps = world * n * args.steps
         value = total_steps / elapsed
         kernel_ms = gpu_ms / args.steps       # per-launch duration on the launch stream (incl. k_order and the per-horizon block packing)
         ach_gbs = ALGO_BYTES_PER_STEP * n / (kernel_ms * 1e-3) / 1e9
+        rew_name = "5-term DeepMimic imitation" if args.reward == "imitation" else args.reward
+        label = wl["label"] % ((n, rew_name) if full else (n,))
+        if wl["shards"] > 1 and world == 1:
+            label += "; ONE shard timed (shard %d of %d: global env ids %d..%d, no gather)" % (shard, wl["shards"], shard * n, shard * n + n - 1)
+        flops = float(step_flops(nefc, iters).mean())
+        tflops = flops * n / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[2]: 'walk' mocap, %d envs/GPU, full contact + joint-limit PGS solve, "
-                                    "%s reward, RSI auto-reset" % (n, "5-term DeepMimic imitation" if args.reward == "imitation" else args.reward)) if full else
-                                   ("BASELINE.json configs[1]: 'walk' mocap, %d envs/GPU, P-controller torque, contacts and limits off" % n),
-                       "envs_per_gpu": n, "global_envs": world * n, "clip": args.clip, "parallelism": "env-shard x%d" % world,
-                       "rollout_allgather_every": HORIZON if world > 1 else None,
-                       "mean_nefc": round(float(nefc.mean()), 2), "overflow_envs": int((status & 1).sum())},
+            "config": {"workload": label, "envs_per_gpu": n, "global_envs": world * n if world > 1 else n * wl["shards"], "clip": clip,
+                       "parallelism": "env-shard x%d" % max(world, wl["shards"]), "n_ranks_seen": n_ranks_seen,
+                       "dist_backend": args.dist_backend if world > 1 else None,
+                       "rollout_allgather_every": HORIZON if world > 1 else None, "gathers_completed": dbg.completed,
+                       "sim_steps_per_env_step": 1,
+                       "mean_nefc": round(float(nefc.mean()), 2), "mean_pgs_sweeps": round(float(iters.mean()), 2),
+                       "overflow_envs": int((status & 1).sum())},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                          "kernel": "k_step_narrow", "kernel_ms": round(kernel_ms, 4),
-                         "kernel_ms_covers": "one dm_batch_step on the launch stream: k_step_narrow + k_order (~0.01 ms) + 1/256 of a horizon's block packing", "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
-                         "note": "latency/ALU-bound path: see fp64 fraction",
-                         "fp64_est_tflops": round(ALGO_FLOP_PER_STEP * n / (kernel_ms * 1e-3) / 1e12, 3),
-                         "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                         "fp64_frac": round(ALGO_FLOP_PER_STEP * n / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, 4)},
+                         "kernel_ms_covers": "one dm_batch_step on the launch stream: k_step_narrow + k_order (~0.01 ms) + 1/256 of a horizon's block packing",
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
+                         "note": "latency / fp64-issue bound path, not an HBM stream: see the fp64 and VALU fields",
+                         "fp64_flops_per_env_step": round(flops, 0),
+                         "fp64_flops_source": "flop count of the kernel's algorithm (bench.py eval_flops) on this run's nefc / PGS-sweep samples (%d env-steps)" % nefc.size,
+                         "fp64_tflops": round(tflops, 4), "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                         "fp64_frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5)},
         }
-        tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if full and os.path.exists(tp):   # PMC HBM bytes per launch of this kernel/workload, measured by tools/collect_profile.sh (separate rocprofv3 passes)
+        if world == 1 and not args.no_pmc:
+            tail = ["--workload", args.workload, "--reward", args.reward, "--steps", "48", "--warmup", "8", "--prewarm-horizons", "1",
+                    "--envs", str(n), "--_child", "--no-pmc", "--no-cpu-baseline", "--no-gym-loop"] + (["--clip", args.clip] if args.clip else [])
+            pmc, err = pmc_passes(tail, "k_step_narrow")
+            r = out["roofline"]
+            if pmc is None:
+                r["pmc"] = err
+            else:
+                r["pmc"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in pmc.items()}
+                if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                    # counters are KiB per launch.  The guide's x2 gfx950 correction of FETCH_SIZE was calibrated on 16 B/lane
+                    # streaming reads; this kernel reads 8 B/lane rows, an uncalibrated width: both readings are reported
+                    r["traffic"] = round((pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
+                    r["traffic_fetch_doubled"] = round((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
+                    r["traffic_over_algorithmic"] = round(r["traffic"] / (ALGO_BYTES_PER_STEP * n), 3)
+                    r["traffic_source"] = "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (48 launches each), bytes per launch"
+                if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("sq_pass_avg_us"):
+                    cyc = pmc["sq_pass_avg_us"] * 1e-6 * MAX_CLOCK_HZ
+                    if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("trace", {}).get("avg_us"):
+                        r["effective_clock_ghz"] = round(pmc["GRBM_GUI_ACTIVE"] / (pmc["trace"]["avg_us"] * 1e-6) / 1e9, 3)
+                    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs
+                    r["valu_issue_frac"] = round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * cyc), 4)
+                    r["valu_issue_frac_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel duration of the same pass x 2.4 GHz)"
+                if pmc.get("SQ_INSTS_VALU"):
+                    r["valu_wave_instr_per_env_step"] = round(pmc["SQ_INSTS_VALU"] / n, 1)
+                    # useful fp64 lane-operations (an FMA lane does 2 flops) over the lane slots of all VALU instructions issued
+                    r["lane_efficiency"] = round((flops / 2.0) / (pmc["SQ_INSTS_VALU"] / n * 64.0), 4)
+                    r["lane_efficiency_note"] = "useful fp64 FMA-lane operations / (VALU wave-instructions x 64 lanes)"
+                if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY"):
+                    r["wave_wait_frac"] = round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4)
+                    r["wave_valu_frac"] = round(pmc.get("SQ_ACTIVE_INST_VALU", 0.0) / pmc["SQ_WAVE_CYCLES"], 4)
+        if world == 1 and not args.no_gym_loop:
             try:
-                tj = json.load(open(tp))
-                out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not re-measured in this run)"
-            except Exception:
-                pass
+                env.close()
+                out["single_env_gym_loop"] = single_env_gym_loop(local_dev)
+            except Exception as e:
+                out["single_env_gym_loop"] = {"value": None, "error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.clip, args.reward if full else "alive")
+                out["cpu_baseline"] = cpu_baseline(clip, args.reward if full else "alive")
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

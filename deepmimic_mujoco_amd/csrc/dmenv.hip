@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_set_state(const DevModel<Real>* __restri
   load_env(*Mp, B, s, env, lane, (const Real*)0);
   if (lane < NQ) s.qpos[lane] = qpos[(size_t)env * NQ + lane];
   if (lane < NV) s.qvel[lane] = qvel[(size_t)env * NV + lane];
-  if (frame_idx && lane == 0) { B.frame_idx[env] = frame_idx[env]; B.frame_init[env] = frame_idx[env]; B.cycle[env] = 0; }
+  if (frame_idx && lane == 0) set_frame(B, env, frame_idx[env]);
   dmw::sync();
   store_state(B, s, env, lane);
   { const LaneTopo lt = lane_topo(lane); stage_tables(s, lane); dmw::sync(); forward(*Mp, s, lane, lt, (const DebugOut*)0); }   // sim.forward()

@@ -157,18 +157,30 @@ DM_DEV void store_state(const Batch<R>& B, Shared<R>& s, int env, int lane) {
   if (lane < NV) { B.qvel[(size_t)env * NV + lane] = s.qvel[lane]; B.qws[(size_t)env * NV + lane] = s.qws[lane]; }
 }
 
+// DPEnv.reference_state_init for one env: `idx` is the drawn mocap frame.  dp_env_v3 (src/dp_env_v3.py:67-71) starts its frame
+// cursor AT the drawn frame; dp_env_v2 (src/dp_env_v2.py:68-70) keeps the draw in idx_init and counts steps from 0 in idx_curr
+// (its target frame is (idx_curr + idx_init) % F, :128-129).
+template <class R>
+DM_DEV void set_frame(const Batch<R>& B, int env, int idx) {
+  B.frame_init[env] = idx;
+  B.frame_idx[env] = B.reward_mode == REW_V2_POSE ? 0 : idx;
+  B.cycle[env] = 0;
+}
+
 // reset variants (src/dp_env_v3.py:67-71,148-164).  mode 0: RSI, 1: noisy init pose, 2: qpos0 / zero velocity.
 // `hard` = sim.reset() semantics: time = 0, qacc_warmstart = 0.  Writes s.qpos / s.qvel (/ s.qws) and frame indices.
+// Modes 0 and 1 with `hard` are the two episode starts of the reference's trainer: env.reset() = sim.reset() + reset_model()
+// (RSI: draws the frame, copies the mocap state), optionally followed by reset_model_init() which overrides the STATE only
+// (src/trpo.py:78-79) — so mode 1 draws the frame as well; the frame-indexed rewards then start from it.
 template <class R>
 DM_DEV void reset_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int env, int lane, int mode, int hard) {
   const int ep = B.episode[env];
   const int genv = B.env_offset + env;
+  int idx = (int)(rng_uniform(B.seed, genv, ep, 0) * (double)B.n_frames);
+  if (idx >= B.n_frames) idx = B.n_frames - 1;
   if (mode == 0) {
-    int idx = (int)(rng_uniform(B.seed, genv, ep, 0) * (double)B.n_frames);
-    if (idx >= B.n_frames) idx = B.n_frames - 1;
     if (lane < NQ) s.qpos[lane] = B.mocap_cfg[(size_t)idx * NQ + lane];
     if (lane < NV) s.qvel[lane] = B.mocap_vel[(size_t)idx * NV + lane];
-    if (lane == 0) { B.frame_idx[env] = idx; B.frame_init[env] = idx; }
   } else if (mode == 1) {
     if (lane < NQ) s.qpos[lane] = M.qpos0[lane] + (R)((rng_uniform(B.seed, genv, ep, 1 + lane) * 2.0 - 1.0) * 0.01);
     if (lane < NV) s.qvel[lane] = (R)((rng_uniform(B.seed, genv, ep, 64 + lane) * 2.0 - 1.0) * 0.01);
@@ -181,7 +193,10 @@ DM_DEV void reset_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int
     if (lane == 0) B.time[env] = 0;
   }
   dmw::sync_mem();
-  if (lane == 0) { B.episode[env] = ep + 1; B.cycle[env] = 0; }
+  if (lane == 0) {
+    B.episode[env] = ep + 1;
+    if (mode == 0 || (mode == 1 && hard)) set_frame(B, env, idx); else B.cycle[env] = 0;
+  }
 }
 
 // ---- 5-term imitation reward (code.md:1017-1143; feature layout: deepmimic_mujoco_amd/imitation.py) -----------------------

@@ -35,10 +35,14 @@ from .spaces import Box
 REWARD_MODES = {"alive": 0, "v3-config": 1, "v2-pose": 2, "imitation": 3}
 
 
-def _load_model(xml_path=None):
+def _load_model(xml_path=None, explicit=True):
+    """An explicit `xml_path` must exist; `Config.xml_path` (the reference's cwd-relative default, src/config.py:16) falls back
+    to the built-in table of the same model (humanoid.py) when the reference tree is not the working directory."""
     import os
     if xml_path and os.path.isfile(xml_path):
         return CompiledModel(load_mjcf(xml_path))
+    if xml_path and explicit:
+        raise FileNotFoundError("model file %r does not exist" % (xml_path,))
     return CompiledModel(humanoid_spec())
 
 
@@ -97,7 +101,7 @@ class DPEnv(object):
 
     def __init__(self, motion=None, mocap_path=None, xml_path=None, device=0, reward="alive", batch_factory=None):
         self.mocap = MocapDM()
-        self._cm = _load_model(xml_path if xml_path is not None else Config.xml_path)
+        self._cm = _load_model(xml_path if xml_path is not None else Config.xml_path, explicit=xml_path is not None)
         self.model = _ModelView(self._cm)
         self._device = device
         self._batch_factory = batch_factory or (lambda cm, cfg, vel, n, dt: Batch(cm, cfg, vel, n, device=device, mocap_dt=dt))
@@ -169,7 +173,9 @@ class DPEnv(object):
 
     def reference_state_init(self):
         self.idx_init = random.randint(0, self.mocap_data_len - 1)
-        self.idx_curr = self.idx_init
+        # dp_env_v3 starts its frame cursor at the draw (src/dp_env_v3.py:67-71); dp_env_v2 counts steps from 0 and adds idx_init
+        # when it looks the target frame up (src/dp_env_v2.py:68-70,128-129)
+        self.idx_curr = 0 if self._reward_mode == REWARD_MODES["v2-pose"] else self.idx_init
         self.idx_tmp_count = 0
 
     def early_termination(self):
@@ -244,10 +250,12 @@ class DPVecEnv(object):
     """N DeepMimic humanoids in lock step on one GPU (one wavefront per environment)."""
 
     def __init__(self, num_envs, motion="walk", xml_path=None, device=0, reward="alive", autoreset="rsi", seed=0,
-                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=1):
+                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=None):
         """reward="imitation": the 5-term reward of code.md:1017-1143 (imitation.py) against the frame after the current one.
         frame_skip: sim steps per env step (src/dp_env_v3.py:108-112 hard-codes 1); "mocap" = floor(mocap_dt / timestep), the
-        commented intent of :107-110, so that one env step spans one mocap frame."""
+        commented intent of :107-110, so that one env step spans one mocap frame.  Default (None): 1, except "mocap" for the
+        imitation reward — its reference advances one mocap frame per env step and its velocity features are per second, so any
+        other value plays the clip at the wrong speed (a warning says so when one is given)."""
         self.num_envs = int(num_envs)
         self.mocap = MocapDM()
         self.mocap.load_mocap(motion)
@@ -256,13 +264,20 @@ class DPVecEnv(object):
         self._cm = _load_model(xml_path)
         self.model = _ModelView(self._cm)
         flags = (0 if contacts else A.FLAG_NO_CONTACT) | (0 if limits else A.FLAG_NO_LIMIT)
-        self.frame_skip = max(1, int(float(self.mocap_dt) / float(self._cm.timestep))) if frame_skip == "mocap" else int(frame_skip)
+        per_frame = max(1, int(float(self.mocap_dt) / float(self._cm.timestep)))
+        if frame_skip is None:
+            frame_skip = "mocap" if reward == "imitation" else 1
+        self.frame_skip = per_frame if frame_skip == "mocap" else int(frame_skip)
+        if reward == "imitation" and self.frame_skip != per_frame:
+            import warnings
+            warnings.warn("imitation reward with frame_skip=%d: the reference clip advances one frame (%.4f s) per env step of "
+                          "%.4f s; use frame_skip='mocap' (= %d) to play it in sim time"
+                          % (self.frame_skip, float(self.mocap_dt), self.frame_skip * float(self._cm.timestep), per_frame))
         imit = None
         if reward == "imitation":
             from .imitation import ImitationSpec
             self.imitation = ImitationSpec(self._cm)
-            imit = (self.imitation.build_table(self.mocap.data_config, self.mocap.data_vel),
-                    self.imitation.params(self.mocap.data_config, self.mocap.loop))
+            imit = self.imitation.table_for(self.mocap)
         if batch_factory is None:
             self._batch = Batch(self._cm, self.mocap.data_config, self.mocap.data_vel, self.num_envs, device=device,
                                 flags=flags, mocap_dt=float(self.mocap_dt), imitation=imit)

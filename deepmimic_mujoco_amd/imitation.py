@@ -157,9 +157,68 @@ class ImitationSpec:
         w = TERM_W / TERM_W.sum()
         return float((w * np.exp(-TERM_SCALE * self.reward_terms(f0, f1, root_shift))).sum())
 
-    def build_table(self, data_config, data_vel):
-        """[F, FEAT] reference features, one row per mocap frame."""
-        return np.stack([self.features(data_config[k], data_vel[k]) for k in range(len(data_config))])
+    def reference_qvel(self, data_config, dura, loop="none"):
+        """[F, 34] generalized velocity of the clip with the signs a tracking character must reproduce.
+
+        `MocapDM.data_vel` keeps the reference's `calc_rot_vel(current, previous)` quirk (src/mujoco/mocap_v2.py:64-76,113,135):
+        root and 3-hinge angular rates are the NEGATED backward difference, written as an axis-angle rate into Euler-hinge slots.
+        That table is what RSI must copy into qvel (parity with `reset_model`), but as a reward TARGET it would penalise correct
+        tracking.  Here frame k gets the backward difference (k-1 -> k) over `dura[k]` in the model's own coordinates:
+        root linear as in the reference; root angular = rotation vector of conj(q_{k-1}) q_k (body-local, MuJoCo's free-joint
+        convention); 1-hinge joints the angle difference; 3-hinge joints the hinge RATES that produce the child-in-parent
+        angular velocity rotvec(ql_k conj(ql_{k-1})) / dura (3x3 solve against the hinge axes in the parent frame).
+        Frame 0 takes the last frame's value on a looping clip (same pose one cycle later), frame 1's otherwise."""
+        cm = self.cm
+        cfg = np.asarray(data_config, dtype=np.float64)
+        F = cfg.shape[0]
+        v = np.zeros((F, cm.nv))
+        if F < 2:
+            return v
+
+        def rotvec(dq):
+            dq = dq / np.linalg.norm(dq)
+            if dq[0] < 0:
+                dq = -dq
+            s = np.linalg.norm(dq[1:])
+            return np.zeros(3) if s < 1e-300 else dq[1:] * (2.0 * np.arctan2(s, dq[0]) / s)
+
+        def conj(q):
+            return np.array([q[0], -q[1], -q[2], -q[3]])
+
+        def local_chain(q, js):      # child-in-parent quaternion and the hinge axes in the parent frame
+            ql = np.array([1.0, 0, 0, 0]); cols = []
+            for j in js:
+                ax = cm.jnt_axis[j]
+                cols.append(quat_rot(ql, ax))
+                ql = quat_mul(ql, axis_quat(ax, q[cm.jnt_qposadr[j]]))
+            return ql, np.stack(cols, 1)
+
+        groups = [np.nonzero(cm.jnt_bodyid == b)[0] for b in self.bodies]
+        for k in range(1, F):
+            dt = float(dura[k])
+            v[k, 0:3] = (cfg[k, 0:3] - cfg[k - 1, 0:3]) / dt
+            v[k, 3:6] = rotvec(quat_mul(conj(cfg[k - 1, 3:7]), cfg[k, 3:7])) / dt
+            for js in groups:
+                if len(js) == 1:
+                    a = cm.jnt_qposadr[js[0]]
+                    v[k, cm.jnt_dofadr[js[0]]] = (cfg[k, a] - cfg[k - 1, a]) / dt
+                else:
+                    q1, A1 = local_chain(cfg[k], js)
+                    q0, _ = local_chain(cfg[k - 1], js)
+                    w = rotvec(quat_mul(q1, conj(q0))) / dt
+                    v[k, [cm.jnt_dofadr[j] for j in js]] = np.linalg.lstsq(A1, w, rcond=1e-9)[0]
+        v[0] = v[F - 1] if str(loop) == "wrap" else v[1]
+        return v
+
+    def build_table(self, data_config, qvel):
+        """[F, FEAT] reference features, one row per mocap frame.  `qvel` = `reference_qvel(...)` (correctly signed rates);
+        passing `MocapDM.data_vel` reproduces the reference's sign quirk in the velocity features (round-1 behaviour)."""
+        return np.stack([self.features(data_config[k], qvel[k]) for k in range(len(data_config))])
+
+    def table_for(self, mocap):
+        """(table [F, FEAT], params [32]) for a loaded `MocapDM`: what `Batch(imitation=...)` takes."""
+        qv = self.reference_qvel(mocap.data_config, np.asarray(mocap.data)[:, 0], mocap.loop)
+        return self.build_table(mocap.data_config, qv), self.params(mocap.data_config, mocap.loop)
 
     def params(self, data_config, loop):
         """The 32 doubles `dm_mocap_set_imitation` takes: joint weights [12], root weight, cycle shift (x, y), loop flag,

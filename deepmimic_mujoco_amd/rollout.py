@@ -178,7 +178,11 @@ class DoubleBufferedGather:
     """Per-horizon all-gather of the rollout block, overlapped with stepping: two [T, n, 87] blocks per rank; while block k
     travels (async all-gather on the collective's own stream) the envs fill block 1 - k.  `row(t)` returns the row to fill at
     step t (first making sure that this block's previous gather has finished), `commit(t)` launches the gather when step t
-    completes a horizon, `drain()` waits for everything outstanding.  Single-process runs degenerate to one local block."""
+    completes a horizon, `drain()` waits for everything outstanding.  Single-process runs degenerate to one local block.
+
+    Backend "nccl" (RCCL) gathers device tensors in place.  Backend "gloo" has no device all-gather: a block on a GPU is first
+    copied to pinned host memory (stream-ordered), the gather runs between host buffers (async, gloo's own threads) and the
+    result stays on the host in `gathered_host[k]` — the path the world-2 tests and single-GPU multi-rank runs use."""
 
     def __init__(self, horizon, n_local, device="cpu", world=None):
         import torch
@@ -188,7 +192,14 @@ class DoubleBufferedGather:
         self.T, self.n, self.world = int(horizon), int(n_local), int(world)
         nb = 2 if self.world > 1 else 1
         self.blocks = [torch.zeros((self.T, self.n, ROW), dtype=torch.float32, device=device) for _ in range(nb)]
-        self.gathered = [torch.empty((self.world * self.T, self.n, ROW), dtype=torch.float32, device=device) for _ in range(nb)] if self.world > 1 else None
+        on_gpu = torch.device(device).type == "cuda"
+        self.host_staged = self.world > 1 and on_gpu and dist.get_backend() == "gloo"
+        self.gathered = self.gathered_host = self.host_blocks = None
+        if self.world > 1 and self.host_staged:
+            self.host_blocks = [torch.zeros((self.T, self.n, ROW), dtype=torch.float32).pin_memory() for _ in range(nb)]
+            self.gathered_host = [torch.empty((self.world * self.T, self.n, ROW), dtype=torch.float32) for _ in range(nb)]
+        elif self.world > 1:
+            self.gathered = [torch.empty((self.world * self.T, self.n, ROW), dtype=torch.float32, device=device) for _ in range(nb)]
         self.pending = [None] * nb
         self.completed = 0                      # gathers launched so far
 
@@ -211,12 +222,22 @@ class DoubleBufferedGather:
     def commit(self, t):
         """Call after step t's row has been written.  Returns the index of the gathered buffer when a gather was launched."""
         if self.world > 1 and (t + 1) % self.T == 0:
+            import torch
             import torch.distributed as dist
             k = self._k(t)
-            self.pending[k] = dist.all_gather_into_tensor(self.gathered[k], self.blocks[k], async_op=True)
+            if self.host_staged:
+                self.host_blocks[k].copy_(self.blocks[k], non_blocking=True)
+                torch.cuda.current_stream(self.blocks[k].device).synchronize()      # the host copy is complete before gloo reads it
+                self.pending[k] = dist.all_gather_into_tensor(self.gathered_host[k], self.host_blocks[k], async_op=True)
+            else:
+                self.pending[k] = dist.all_gather_into_tensor(self.gathered[k], self.blocks[k], async_op=True)
             self.completed += 1
             return k
         return None
+
+    def result(self, k):
+        """The gathered [world * T, n, 87] buffer of slot k (device tensor, or the host tensor on the host-staged path)."""
+        return self.gathered_host[k] if self.host_staged else self.gathered[k]
 
     def drain(self):
         for k in range(len(self.pending)):

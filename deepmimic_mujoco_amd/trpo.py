@@ -314,8 +314,16 @@ def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max
             break
         if max_iters and iters_so_far >= max_iters:
             break
-        if max_seconds and time.time() - tstart >= max_seconds:
-            break
+        if max_seconds:
+            # the deadline is a per-process wall clock: decide collectively (MAX over ranks), or a rank that breaks first leaves
+            # the others waiting forever in the next update's all-reduces
+            stop = time.time() - tstart >= max_seconds
+            if world > 1:
+                flag = torch.tensor([1.0 if stop else 0.0], dtype=torch.float32, device=pi.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+                stop = bool(flag.item() > 0)
+            if stop:
+                break
         seg = next(seg_gen)
         stats = learner.update(seg)
         lens, rets = seg["ep_lens"], seg["ep_rets"]

@@ -132,7 +132,7 @@ void emu_set_state(void* h, const double* qpos, const double* qvel, const int* f
       load_env(e->M, e->B, e->sh, env, lane, (const double*)0);
       if (lane < NQ) e->sh.qpos[lane] = qpos[(size_t)env * NQ + lane];
       if (lane < NV) e->sh.qvel[lane] = qvel[(size_t)env * NV + lane];
-      if (fidx && lane == 0) { e->B.frame_idx[env] = fidx[env]; e->B.frame_init[env] = fidx[env]; e->B.cycle[env] = 0; }
+      if (fidx && lane == 0) set_frame(e->B, env, fidx[env]);
       dmw::sync();
       store_state(e->B, e->sh, env, lane);
       { const LaneTopo lt = lane_topo(lane); stage_tables(e->sh, lane); dmw::sync(); forward(e->M, e->sh, lane, lt, (const DebugOut*)0); }

@@ -95,17 +95,19 @@ def compare_forward(batch, om, idx, q, v, ws, ctrl, tol=1e-9):
     return worst
 
 
-def compare_rollout(batch, om, idx, q, v, steps, seed=0, reward_mode=0, n_substeps=1, tol=1e-9, action_scale=0.9):
-    """Lock-step rollout of every env against its own oracle instance; checks obs, reward, done, frame index."""
+def compare_rollout(batch, om, idx, q, v, steps, seed=0, reward_mode=0, n_substeps=1, tol=1e-9, action_scale=0.9, clip="walk"):
+    """Lock-step rollout of every env against its own oracle instance; checks obs, reward, done, frame index.
+    `clip` must be the clip the batch was created with (its data_config is the oracle's reward table)."""
     from oracle import oracle as O
     n = q.shape[0]
-    mc = mocap()
+    mc = mocap(clip)
     batch.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); batch.set(A.F_TIME, np.zeros(n))
     batch.set_state(q, v, frame_idx=idx)
     ods = [O.Data(om) for _ in range(n)]
     for e in range(n):
         ods[e].reset(); ods[e].set_state(q[e], v[e])
-    fidx = idx.astype(np.int64).copy()
+    # dp_env_v2's cursor counts steps from 0 and adds idx_init at look-up (src/dp_env_v2.py:68-70,128-129); dp_env_v3's starts at the draw
+    fidx = np.zeros(n, dtype=np.int64) if reward_mode == 2 else idx.astype(np.int64).copy()
     finit = idx.astype(np.int64).copy()
     rng = np.random.RandomState(seed)
     worst = 0.0
@@ -152,3 +154,25 @@ def many_row_states(lo, hi, want=4, seed=13, pool=80):
     assert len(keep) >= min(want, 2), "no states with %d < nefc <= %d in the pool" % (lo, hi)
     k = np.asarray(keep)
     return idx[k], q[k], v[k]
+
+
+# ---- host mirror of the device's counter-based RNG (csrc/env_step.h: mix64 / rng_uniform) ---------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def device_rng_uniform(seed, genv, episode, k):
+    h = _mix64((seed & _M64) ^ _mix64(((genv & 0xFFFFFFFF) * 0x100000001B3 + 0x1234567) & _M64))
+    h = _mix64(h ^ ((((episode & 0xFFFFFFFF) << 32) | (k & 0xFFFFFFFF)) & _M64))
+    return float(h >> 11) * (1.0 / 9007199254740992.0)
+
+
+def device_rsi_frame(seed, genv, episode, n_frames):
+    """The mocap frame reset_env draws for (seed, global env id, episode counter)."""
+    return min(int(device_rng_uniform(seed, genv, episode, 0) * float(n_frames)), n_frames - 1)

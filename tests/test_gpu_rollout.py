@@ -138,3 +138,24 @@ def test_bench_prints_one_contract_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and r["peak"] == 8000.0
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1000 and "sample" in c
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """The multi-rank code path of bench.py executed on ONE GPU: two processes (torch.distributed.run), env ranges sharded by
+    rank, the double-buffered per-horizon rollout gather (host-staged over gloo), MAX-reduced timing, rank 0 prints the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--envs", "512", "--steps", "300", "--warmup", "8",
+           "--prewarm-horizons", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["n_ranks_seen"] == 2 and j["config"]["dist_backend"] == "gloo"
+    assert j["config"]["global_envs"] == 1024 and j["config"]["gathers_completed"] >= 1 and j["scaling"] == "weak"
+    assert j["value"] > 1e5 and "cpu_baseline" not in j

@@ -15,21 +15,69 @@ def _spec():
 
 def test_reward_is_one_on_the_reference_and_weights_are_normalised():
     sp = _spec(); mc = H.mocap()
-    T = sp.build_table(mc.data_config, mc.data_vel)
+    T, _P = sp.table_for(mc)
+    qv = _ref_qvel(sp, mc)
     assert T.shape == (len(mc.data_config), FEAT)
     assert abs(sp.w_joint.sum() + sp.w_root - 1) < 1e-12 and abs(TERM_W.sum() - 1) < 1e-12     # code.md:1025-1031
     for k in (0, 7, 20, len(T) - 1):
-        f = sp.features(mc.data_config[k], mc.data_vel[k])
+        f = sp.features(mc.data_config[k], qv[k])
         assert np.array_equal(f, T[k]) and abs(sp.reward(f, T[k]) - 1) < 1e-12
     # a shifted reference root (completed cycles) is matched by shifting the simulated root
     q = mc.data_config[3].copy(); q[0:2] += [2.5, -0.4]
-    assert abs(sp.reward(sp.features(q, mc.data_vel[3]), T[3], root_shift=(2.5, -0.4)) - 1) < 1e-12
+    assert abs(sp.reward(sp.features(q, qv[3]), T[3], root_shift=(2.5, -0.4)) - 1) < 1e-12
+
+
+def _ref_qvel(sp, mc):
+    return sp.reference_qvel(mc.data_config, np.asarray(mc.data)[:, 0], mc.loop)
+
+
+def test_reference_velocities_run_forward_in_time():
+    """The reward's velocity targets must be the clip's real rates, not `MocapDM.data_vel` with the reference's
+    calc_rot_vel(current, previous) sign quirk (root / 3-hinge angular rates negated): hinge rates equal finite differences
+    of the Euler hinge angles of data_config, the root's world angular velocity turns q_{k-1} into q_k, and integrating the
+    table's COM velocity reproduces the COM displacement between frames."""
+    from deepmimic_mujoco_amd.imitation import quat_mul, quat_rot, O_RANG, O_JW
+    sp = _spec()
+    for clip in ("walk", "dance_b"):
+        mc = H.mocap(clip)
+        cfg = mc.data_config; dura = np.asarray(mc.data)[:, 0]
+        qv = _ref_qvel(sp, mc)
+        fd = (cfg[1:, 7:] - cfg[:-1, 7:]) / dura[1:, None]
+        ok = np.abs(cfg[1:, 7:] - cfg[:-1, 7:]).max(1) < 0.2               # frames without Euler-branch jumps
+        close = np.abs(qv[1:, 6:] - fd)[ok]
+        assert np.median(close) < 0.02 and (close < 0.15 * (1 + np.abs(fd[ok]))).mean() > 0.97, clip
+        # the reference's table has the opposite sign on 3-hinge joints and the root's angular rate, the same on 1-hinge joints
+        k = 10
+        assert np.allclose(qv[k, 3:6], -mc.data_vel[k, 3:6], atol=1e-9)
+        assert np.allclose(qv[k, 0:3], mc.data_vel[k, 0:3], atol=1e-12)
+        assert abs(qv[k, 6 + 9] - mc.data_vel[k, 6 + 9]) < 1e-12             # right elbow (1 hinge)
+        big = np.abs(mc.data_vel[k, 6:9]).argmax()
+        assert np.sign(qv[k, 6 + big]) == -np.sign(mc.data_vel[k, 6 + big])  # chest triple
+        # root: exp(dt w_local) takes q_{k-1} to q_k
+        w = qv[k, 3:6] * dura[k]; th = np.linalg.norm(w)
+        dq = np.concatenate([[np.cos(th / 2)], np.sin(th / 2) * w / th])
+        qn = quat_mul(cfg[k - 1, 3:7] / np.linalg.norm(cfg[k - 1, 3:7]), dq)
+        qk = cfg[k, 3:7] / np.linalg.norm(cfg[k, 3:7])
+        assert min(np.abs(qn - qk).max(), np.abs(qn + qk).max()) < 1e-9
+        # COM: velocity feature x dt ~ displacement of the mass centre (first order in dt)
+        cm = sp.cm
+        def com(q):
+            xipos = cm.kinematics(q)[2]
+            return (cm.body_mass[1:, None] * xipos[1:]).sum(0) / cm.body_mass[1:].sum()
+        T = sp.build_table(cfg, qv)
+        for k in (5, 20):
+            assert np.abs(T[k, O_COMV:O_COMV + 3] * dura[k] - (com(cfg[k]) - com(cfg[k - 1]))).max() < 0.004
+        # looping clip: frame 0 carries the last frame's rates (same pose one cycle later)
+        assert np.array_equal(qv[0], qv[-1])
+    mc = H.mocap("getup_facedown")
+    qv = _ref_qvel(sp, mc)
+    assert mc.loop == "none" and np.array_equal(qv[0], qv[1]) and np.isfinite(qv).all()
 
 
 def test_each_term_reacts_to_its_own_perturbation():
     sp = _spec(); mc = H.mocap()
     k = 11
-    q0, v0 = mc.data_config[k], mc.data_vel[k]
+    q0, v0 = mc.data_config[k], _ref_qvel(sp, mc)[k]
     ref = sp.features(q0, v0)
     z = np.zeros(34)
     q = q0.copy(); q[7 + 14] += 0.3                                     # one right-hip hinge (at rest): pose + that foot's end effector
@@ -80,8 +128,7 @@ def test_oracle_features_and_reward_match_the_numpy_definition():
     from oracle import oracle as O
     sp = _spec(); mc = H.mocap()
     om = H.oracle_model()
-    params = sp.params(mc.data_config, mc.loop)
-    T = sp.build_table(mc.data_config, mc.data_vel)
+    T, params = sp.table_for(mc)
     rng = np.random.RandomState(0)
     idx, q, v, _w, _c = H.varied_states(12, seed=2)
     for e in range(12):
@@ -97,8 +144,7 @@ def test_oracle_imitation_episode_wraps_with_cycle_shift_and_ends_non_looping_cl
     from oracle import oracle as O
     sp = _spec(); mc = H.mocap()
     om = H.oracle_model(); d = O.Data(om)
-    params = sp.params(mc.data_config, mc.loop)
-    T = sp.build_table(mc.data_config, mc.data_vel)
+    T, params = sp.table_for(mc)
     F = len(T)
     d.reset(); d.set_state(mc.data_config[F - 3], mc.data_vel[F - 3])
     idx, cyc = F - 3, 0
@@ -119,7 +165,7 @@ def test_oracle_batched_imitation_step_equals_the_single_env_loop():
     """bench.py's cpu_baseline loop (OpenMP over envs) is the same computation as env_step_imitation, env by env."""
     from oracle import oracle as O
     sp = _spec(); mc = H.mocap()
-    T = sp.build_table(mc.data_config, mc.data_vel); P = sp.params(mc.data_config, mc.loop); F = len(T)
+    T, P = sp.table_for(mc); F = len(T)
     om = H.oracle_model(); n = 6
     rng = np.random.RandomState(3)
     start = np.array([F - 2, 0, 5, 11, 17, 30], dtype=np.int32)
@@ -139,15 +185,15 @@ def test_oracle_batched_imitation_step_equals_the_single_env_loop():
     assert cyc[0] == 1
 
 
-def _imit_inputs():
-    sp = _spec(); mc = H.mocap()
-    return sp, mc, sp.build_table(mc.data_config, mc.data_vel), sp.params(mc.data_config, mc.loop)
+def _imit_inputs(clip="walk"):
+    sp = _spec(); mc = H.mocap(clip)
+    return (sp, mc) + sp.table_for(mc)
 
 
-def _rollout_vs_oracle(batch, n, steps, nsub, seed, params=None):
+def _rollout_vs_oracle(batch, n, steps, nsub, seed, params=None, clip="walk"):
     """Reward mode 3 on a batch implementation (testbench or GPU) against the oracle's env_step_imitation, env by env."""
     from oracle import oracle as O
-    sp, mc, T, P = _imit_inputs()
+    sp, mc, T, P = _imit_inputs(clip)
     if params is not None:
         P = params
     F = len(T)
@@ -183,7 +229,7 @@ def test_imitation_reward_on_the_wave_testbench_matches_oracle():
     worst, cyc = _rollout_vs_oracle(b, n, steps=4, nsub=2, seed=3)
     assert worst < 1e-10 and cyc[0] == 1 and cyc[1] == 1
     # on the reference state itself the reward is 1 before any step has perturbed it: evaluate via a zero-length check
-    f = sp.features(mc.data_config[4], mc.data_vel[4])
+    f = sp.features(mc.data_config[4], _ref_qvel(sp, mc)[4])
     assert abs(sp.reward(f, T[4]) - 1) < 1e-12
 
 
@@ -196,29 +242,56 @@ def test_imitation_non_looping_clip_ends_on_the_testbench():
 
 
 @pytest.mark.gpu
-def test_imitation_reward_on_gpu_matches_oracle():
+@pytest.mark.parametrize("clip", ["walk", "spinkick", "dance_b"])       # BASELINE.json configs[2], [3], [4]
+def test_imitation_reward_on_gpu_matches_oracle(clip):
     from deepmimic_mujoco_amd import Batch
-    sp, mc, T, P = _imit_inputs()
+    sp, mc, T, P = _imit_inputs(clip)
     n = 24
     b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
-    worst, cyc = _rollout_vs_oracle(b, n, steps=6, nsub=2, seed=3)
-    print("imitation reward rollout: worst |diff| %.2e" % worst)
-    assert worst < 1e-9 and cyc[0] == 1
+    nsub = max(1, int(float(mc.dt) / 0.0166))                             # frame_skip="mocap": 2 for walk, 1 for the 60 Hz clips
+    worst, cyc = _rollout_vs_oracle(b, n, steps=6, nsub=nsub, seed=3, clip=clip)
+    print("imitation reward rollout (%s, %d sim steps per frame): worst |diff| %.2e" % (clip, nsub, worst))
+    assert worst < 1e-9 and cyc[0] == 1 and P[15] == 1.0
+    b.close()
+
+
+@pytest.mark.gpu
+def test_imitation_non_looping_clip_ends_the_episode_on_gpu():
+    """`Loop: none` clips (getup_facedown, src/mujoco/motions/humanoid3d_getup_facedown.txt) hold their last frame and end the
+    episode there (env_step.h, reward mode 3): the envs started at F-3 / F-2 must report done when the cursor reaches F-1."""
+    from deepmimic_mujoco_amd import Batch
+    clip = "getup_facedown"
+    sp, mc, T, P = _imit_inputs(clip)
+    assert mc.loop == "none" and P[15] == 0.0
+    n = 6
+    b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
+    worst, cyc = _rollout_vs_oracle(b, n, steps=4, nsub=1, seed=5, clip=clip)      # done flags are compared step by step inside
+    assert worst < 1e-9 and np.all(cyc == 0)
+    assert b.get(A.F_FRAME_IDX)[0] == len(T) - 1 and b.get(A.F_FRAME_IDX)[1] == len(T) - 1
     b.close()
 
 
 @pytest.mark.gpu
 def test_imitation_vec_env_and_frame_skip_on_gpu():
     from deepmimic_mujoco_amd import DPVecEnv
-    env = DPVecEnv(64, motion="walk", device=0, reward="imitation", autoreset="rsi", seed=1, frame_skip="mocap")
+    env = DPVecEnv(64, motion="walk", device=0, reward="imitation", autoreset="rsi", seed=1)     # default frame_skip: "mocap"
     assert env.frame_skip == 2                                           # walk: 0.0333 s per frame / 0.0166 s per step
     env.reset("rsi")
-    q = env.batch.get(A.F_QPOS); v = env.batch.get(A.F_QVEL); k = env.batch.get(A.F_FRAME_IDX)
     obs, rew, done, _ = env.step(np.zeros((64, 28)))
     assert rew.min() > 0.3 and rew.max() <= 1.0                          # one passive step off the reference: still close to it
     with pytest.raises(Exception):
         DPVecEnv(4, motion="walk", device=0, reward="alive").batch.set_option(A.OPT_REWARD_MODE, 3)   # no table provided
     env.close()
+    for clip in ("spinkick", "dance_b"):                                 # 60 Hz clips: one sim step per mocap frame
+        e = DPVecEnv(32, motion=clip, device=0, reward="imitation", autoreset="rsi", seed=2)
+        assert e.frame_skip == 1
+        e.reset("rsi")
+        k0 = e.batch.get(A.F_FRAME_IDX).copy()
+        obs, rew, done, _ = e.step(np.zeros((32, 28)))
+        alive = ~done.astype(bool)
+        F = e.mocap_data_len
+        assert np.array_equal(e.batch.get(A.F_FRAME_IDX)[alive], ((k0 + 1) % F)[alive]) and np.isfinite(rew).all() and rew.max() <= 1.0
+        e.close()
 
 
 def test_reference_tables_for_every_clip():
@@ -229,11 +302,10 @@ def test_reference_tables_for_every_clip():
     loops = set()
     for clip in ALL_CLIPS:
         mc = MocapDM(); mc.load_mocap(clip)
-        T = sp.build_table(mc.data_config, mc.data_vel)
-        P = sp.params(mc.data_config, mc.loop)
+        T, P = sp.table_for(mc); qv = _ref_qvel(sp, mc)
         assert T.shape == (len(mc.data_config), FEAT) and np.isfinite(T).all() and np.isfinite(P).all()
         for k in (0, len(T) // 2, len(T) - 1):
-            assert abs(sp.reward(sp.features(mc.data_config[k], mc.data_vel[k]), T[k]) - 1) < 1e-12
+            assert abs(sp.reward(sp.features(mc.data_config[k], qv[k]), T[k]) - 1) < 1e-12
         assert P[15] == (1.0 if mc.loop == "wrap" else 0.0)
         assert max(1, int(float(mc.dt) / 0.0166)) >= 1
         loops.add(mc.loop)
