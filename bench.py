@@ -271,10 +271,14 @@ def main():
                     help="reward of the full-contact workloads: the 5-term DeepMimic imitation reward (default), dp_env_v3's config reward, or the constant 1.0")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged gather, ranks may share a GPU (LOCAL_RANK modulo the visible devices)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="DM_OPT_PIPELINE: sub-batches per GPU stepped on their own streams so that one's drain overlaps the next one's ramp "
+                         "across consecutive steps (1 = one launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (N = 1 only; they add about a minute)")
     ap.add_argument("--no-gym-loop", action="store_true", help="skip the single-env Python DPEnv.step loop (N = 1 only; ~3 s)")
     ap.add_argument("--prewarm-horizons", type=int, default=6, help="untimed 256-step horizons before the warm-up steps (cold-box clock ramp, ~1 s)")
+    ap.add_argument("--no-reorder", action="store_true", help="experiment: identity dispatch order instead of longest-first (DM option 104 = 0)")
     ap.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)   # profiled child of pmc_passes: GPU loop only, prints nothing
     args = ap.parse_args()
 
@@ -324,6 +328,9 @@ def main():
                        action_mode="raw" if full else "p-control", env_offset=shard * n, frame_skip=1)
     stream = torch.cuda.Stream(device=dev)
     env.batch.set_stream(stream.cuda_stream)
+    env.batch.set_option(A.OPT_PIPELINE, max(1, min(args.pipeline, A.MAX_PIPELINE)))
+    if args.no_reorder:
+        env.batch.set_option(104, 0)
 
     with torch.cuda.stream(stream):
         gen = torch.Generator(device=dev); gen.manual_seed(1234 + shard)
@@ -349,6 +356,7 @@ def main():
             k = t % HORIZON
             env.batch.step(actions[t % pool], 1, (obs_T[k], rew_T[k], done_T[k]))
             if k == HORIZON - 1:
+                env.batch.join()                                              # pipelined sub-batches: this stream now consumes their outputs
                 blk = dbg.block(t)
                 blk[:, :, :56] = obs_T; blk[:, :, 56:84] = actions[(tidx + (t - k)) % pool]
                 blk[:, :, 84] = rew_T; blk[:, :, 85] = done_T
@@ -361,11 +369,11 @@ def main():
         for _ in range(args.prewarm_horizons):
             for t in range(HORIZON):
                 one_step(t)
-            drain(); stream.synchronize()
+            drain(); env.batch.sync()
         for t in range(args.warmup):
             one_step(t)
         drain()
-        stream.synchronize()
+        env.batch.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -374,6 +382,7 @@ def main():
         ev0.record(stream)
         for t in range(args.steps):
             one_step(t)
+        env.batch.join()                                                   # every sub-batch launch is inside the events
         drain()                                                            # outstanding gathers finish inside the timed region
         ev1.record(stream)
         stream.synchronize()
@@ -385,7 +394,7 @@ def main():
         if not args._child:
             for t in range(args.steps, args.steps + 8):
                 one_step(t)
-                stream.synchronize()
+                env.batch.sync()
                 stat_nefc.append(env.batch.get(A.F_NEFC)); stat_iter.append(env.batch.get(A.F_SOLVER_ITER))
             drain()
     elapsed = t1 - t0
@@ -418,13 +427,15 @@ def main():
                        "parallelism": "env-shard x%d" % max(world, wl["shards"]), "n_ranks_seen": n_ranks_seen,
                        "dist_backend": args.dist_backend if world > 1 else None,
                        "rollout_allgather_every": HORIZON if world > 1 else None, "gathers_completed": dbg.completed,
+                       "pipeline_sub_batches": max(1, min(args.pipeline, A.MAX_PIPELINE)),
                        "sim_steps_per_env_step": 1,
                        "mean_nefc": round(float(nefc.mean()), 2), "mean_pgs_sweeps": round(float(iters.mean()), 2),
                        "overflow_envs": int((status & 1).sum())},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                          "kernel": "k_step_narrow", "kernel_ms": round(kernel_ms, 4),
-                         "kernel_ms_covers": "one dm_batch_step on the launch stream: k_step_narrow + k_order (~0.01 ms) + 1/256 of a horizon's block packing",
+                         "kernel_ms_covers": "HIP events around the timed region / steps: one dm_batch_step = k_step_narrow (all sub-batches) + k_order + 1/256 of a horizon's block packing; "
+                                             "with --pipeline > 1 consecutive steps overlap, so this is the per-step issue interval, not a lone launch's latency",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                          "note": "latency / fp64-issue bound path, not an HBM stream: see the fp64 and VALU fields",
                          "fp64_flops_per_env_step": round(flops, 0),
@@ -434,7 +445,7 @@ def main():
         }
         if world == 1 and not args.no_pmc:
             tail = ["--workload", args.workload, "--reward", args.reward, "--steps", "48", "--warmup", "8", "--prewarm-horizons", "1",
-                    "--envs", str(n), "--_child", "--no-pmc", "--no-cpu-baseline", "--no-gym-loop"] + (["--clip", args.clip] if args.clip else [])
+                    "--envs", str(n), "--_child", "--no-pmc", "--no-cpu-baseline", "--no-gym-loop", "--pipeline", str(args.pipeline)] + (["--clip", args.clip] if args.clip else [])
             pmc, err = pmc_passes(tail, "k_step_narrow")
             r = out["roofline"]
             if pmc is None:
@@ -451,7 +462,8 @@ def main():
                 if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("sq_pass_avg_us"):
                     cyc = pmc["sq_pass_avg_us"] * 1e-6 * MAX_CLOCK_HZ
                     if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("trace", {}).get("avg_us"):
-                        r["effective_clock_ghz"] = round(pmc["GRBM_GUI_ACTIVE"] / (pmc["trace"]["avg_us"] * 1e-6) / 1e9, 3)
+                        # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                        r["effective_clock_ghz"] = round(pmc["GRBM_GUI_ACTIVE"] / 8.0 / (pmc["trace"]["avg_us"] * 1e-6) / 1e9, 3)
                     # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs
                     r["valu_issue_frac"] = round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * cyc), 4)
                     r["valu_issue_frac_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel duration of the same pass x 2.4 GHz)"

@@ -162,3 +162,8 @@ class Batch(object):
 
     def sync(self):
         A.check(self._L.dm_batch_sync(self._h), self._L)
+
+    def join(self):
+        """Pipelined sub-batches (OPT_PIPELINE > 1): make the batch's stream wait for every step launch still in flight, without
+        a host wait.  Call before consuming the outputs of pipelined `step` calls on that stream."""
+        A.check(self._L.dm_batch_join(self._h), self._L)

@@ -32,11 +32,12 @@ constexpr int NARROW_ROWS = 32;
 static_assert(AOVF_COLS >= MAXEFC, "memory strip too small");
 __global__ __launch_bounds__(64, 2) void k_step_narrow(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ action,
                                                     Real* __restrict__ obs, Real* __restrict__ reward, unsigned char* __restrict__ done,
-                                                    int n_substeps) {
+                                                    int n_substeps, int first) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
-  if ((int)blockIdx.x >= B.n_envs) return;
-  const int env = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
+  const int slot = first + (int)blockIdx.x;          // position in the dispatch order (a pipelined sub-batch starts at `first`)
+  if (slot >= B.n_envs) return;
+  const int env = B.order ? B.order[slot] : slot;
   env_step<Real, NARROW_ROWS>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
 }
 __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ action,
@@ -53,9 +54,9 @@ __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ 
 // shader ticks from 0 to 32 rows) first.  4096 envs are two rounds of resident waves, so the launch ends when the last wave
 // of round two does; longest-first list scheduling trims that tail (measured -9 % kernel time).  Counting sort by
 // min(nefc, 63), descending; the order inside a bucket is arbitrary — results never depend on the dispatch order.
-__global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__ order) {
+__global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__ order, int first, int count) {
   __shared__ int hist[64], start[64];
-  const int tid = threadIdx.x, n = B.n_envs;
+  const int tid = threadIdx.x, n = count;                // envs first .. first + count - 1 are sorted into order[first ..]
   if (tid < 64) hist[tid] = 0;
   __syncthreads();
   constexpr int PER = 8;                 // keys of up to 8192 envs stay in registers between the two passes
@@ -64,15 +65,15 @@ __global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__
   for (int j = 0; j < PER; j++) {
     const int e = tid + j * 1024;
     key[j] = -1;
-    if (e < n) { const int k = B.nefc[e] + (B.solver_iter[e] >> 2); key[j] = k < 0 ? 0 : (k > 63 ? 63 : k); atomicAdd(&hist[key[j]], 1); }
+    if (e < n) { const int k = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); key[j] = k < 0 ? 0 : (k > 63 ? 63 : k); atomicAdd(&hist[key[j]], 1); }
   }
-  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k = B.nefc[e] + (B.solver_iter[e] >> 2); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
+  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
   __syncthreads();
   if (tid == 0) { int acc = 0; for (int k = 63; k >= 0; k--) { start[k] = acc; acc += hist[k]; } }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < PER; j++) if (key[j] >= 0) order[atomicAdd(&start[key[j]], 1)] = tid + j * 1024;
-  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k0 = B.nefc[e] + (B.solver_iter[e] >> 2); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[atomicAdd(&start[k], 1)] = e; }
+  for (int j = 0; j < PER; j++) if (key[j] >= 0) order[first + atomicAdd(&start[key[j]], 1)] = first + tid + j * 1024;
+  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k0 = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[first + atomicAdd(&start[k], 1)] = first + e; }
 }
 
 // same step with per-stage shader-clock accounting (DM_OPT 101); not used on the timed path
@@ -150,12 +151,24 @@ struct dm_batch {
   Real *d_cfg = nullptr, *d_vel = nullptr, *d_imit = nullptr; int* d_order = nullptr;
   // staging for DM_PTR_HOST callers
   Real *d_action = nullptr, *d_obs = nullptr, *d_reward = nullptr; unsigned char *d_done = nullptr, *d_mask = nullptr;
+  // host-pointer steps: obs | reward | done are ONE device block (d_obs points at its start) mirrored in pinned host memory, so a
+  // step costs one H2D (action, from the pinned mirror) and one D2H instead of one pageable copy per array
+  unsigned char* h_out = nullptr; Real* h_action = nullptr; size_t out_bytes = 0;
   Real *d_qpos_in = nullptr, *d_qvel_in = nullptr; int* d_fidx_in = nullptr;
   double* d_debug = nullptr;
   long long* d_prof = nullptr; bool prof = false;
   bool two_tier = true, reorder = true, has_rows = true; int resident_waves = 2048;   // CUs x 8 single-wave workgroups (LDS-limited)
   bool timing = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f; bool ev_pending = false;
+  // pipelined sub-batches (DM_OPT_PIPELINE): the env range is cut into `pipe` contiguous parts, each stepped on its own stream
+  int pipe = 1; hipStream_t ps[DM_MAX_PIPELINE] = {}; hipEvent_t ev_in = nullptr, ev_done[DM_MAX_PIPELINE] = {}; bool pipe_pending = false;
 };
+// make the batch's stream wait for every sub-batch launch still in flight (no host wait)
+static int pipe_join(dm_batch* b) {
+  if (!b->pipe_pending) return DM_OK;
+  for (int h = 0; h < b->pipe; h++) if (hipStreamWaitEvent(b->stream, b->ev_done[h], 0) != hipSuccess) return DM_EHIP;
+  b->pipe_pending = false;
+  return DM_OK;
+}
 
 extern "C" const char* dm_last_error(void) { return g_err.c_str(); }
 extern "C" int dm_abi_version(void) { return DM_ABI_VERSION; }
@@ -196,11 +209,16 @@ template <class T> static hipError_t dalloc(T** p, size_t n) { hipError_t e = hi
 extern "C" void dm_batch_destroy(dm_batch* b) {
   if (!b) return;
   hipSetDevice(b->device);
+  pipe_join(b);
   if (b->stream) hipStreamSynchronize(b->stream);
+  for (int h = 0; h < DM_MAX_PIPELINE; h++) { if (b->ps[h]) hipStreamDestroy(b->ps[h]); if (b->ev_done[h]) hipEventDestroy(b->ev_done[h]); }
+  if (b->ev_in) hipEventDestroy(b->ev_in);
   void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
                   b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
-                  b->d_reward, b->d_done, b->d_mask, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order};
+                  b->d_mask, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (b->h_out) hipHostFree(b->h_out);
+  if (b->h_action) hipHostFree(b->h_action);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
@@ -231,7 +249,12 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   A(b->B.cong, (size_t)n * MAXEFC * 2); A(b->B.status, n); A(b->B.solver_iter, n); A(b->B.episode, n); A(b->B.cycle, n); A(b->d_order, n);
   A(b->d_cfg, (size_t)mc->n_frames * NQ); A(b->d_vel, (size_t)mc->n_frames * NV);
   if (!mc->imit_table.empty()) A(b->d_imit, mc->imit_table.size() + 32);   // [32 parameters][F x 112 feature rows]
-  A(b->d_action, (size_t)n * NU); A(b->d_obs, (size_t)n * NOBS); A(b->d_reward, n); A(b->d_done, n); A(b->d_mask, n);
+  A(b->d_action, (size_t)n * NU); A(b->d_mask, n);
+  b->out_bytes = (size_t)n * (NOBS + 1) * sizeof(Real) + (size_t)n;
+  { unsigned char* blk = nullptr; ok = ok && (dalloc(&blk, b->out_bytes) == hipSuccess);
+    b->d_obs = (Real*)blk; b->d_reward = b->d_obs + (size_t)n * NOBS; b->d_done = (unsigned char*)(b->d_reward + n); }
+  ok = ok && hipHostMalloc((void**)&b->h_out, b->out_bytes, hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&b->h_action, (size_t)n * NU * sizeof(Real), hipHostMallocDefault) == hipSuccess;
   A(b->B.aovf, (size_t)n * AOVF_COLS * 64);
   A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
 #undef A
@@ -252,7 +275,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   ok = ok && hipMemcpy(b->B.qpos, q0.data(), q0.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { dm_batch_destroy(b); return fail(DM_EHIP, "dm_batch_create: upload failed"); }
   b->B.mocap_cfg = b->d_cfg; b->B.mocap_vel = b->d_vel; b->B.n_frames = mc->n_frames; b->B.n_envs = n; b->B.env_offset = 0;
-  b->B.reward_mode = 0; b->B.autoreset = 0; b->B.action_mode = 0; b->B.seed = 0;
+  b->B.reward_mode = 0; b->B.autoreset = 0; b->B.action_mode = 0; b->B.seed = 0; b->B.diag = 1;
   hipEventCreate(&b->ev0); hipEventCreate(&b->ev1);
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) == hipSuccess && cus > 0) b->resident_waves = cus * 8; }
   *out = b;
@@ -261,6 +284,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
 
 extern "C" int dm_batch_set_stream(dm_batch* b, void* s) {
   if (!b) return fail(DM_EINVAL, "null batch");
+  pipe_join(b);
   hipStreamSynchronize(b->stream);   /* keep ordering with work already queued on the previous stream */
   if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
   b->stream = (hipStream_t)s; b->own_stream = false;
@@ -277,6 +301,20 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
     case DM_OPT_AUTORESET: if (v < 0 || v > 2) return fail(DM_EINVAL, "autoreset must be 0..2"); b->B.autoreset = (int)v; break;
     case DM_OPT_ACTION_MODE: if (v < 0 || v > 2) return fail(DM_EINVAL, "action mode must be 0..2"); b->B.action_mode = (int)v; break;
     case DM_OPT_SEED: b->B.seed = (unsigned long long)v; break;
+    case DM_OPT_DIAGNOSTICS: b->B.diag = v != 0; break;
+    case DM_OPT_PIPELINE: {
+      if (v < 1 || v > DM_MAX_PIPELINE) return fail(DM_EINVAL, "pipeline depth must be 1..DM_MAX_PIPELINE");
+      HIPCHK(hipSetDevice(b->device));
+      if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+      for (int h = 0; h < (int)v && v > 1; h++) {
+        if (!b->ps[h]) HIPCHK(hipStreamCreateWithFlags(&b->ps[h], hipStreamNonBlocking));
+        if (!b->ev_done[h]) HIPCHK(hipEventCreateWithFlags(&b->ev_done[h], hipEventDisableTiming));
+      }
+      if (v > 1 && !b->ev_in) HIPCHK(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
+      b->pipe = (int)v;
+      b->B.order = nullptr;   /* the stored dispatch order belongs to the previous partition: identity for the next launch */
+      break;
+    }
     case 104: b->reorder = v != 0; if (!b->reorder) b->B.order = nullptr; break;   /* 1 (default): longest-first dispatch order (k_order) */
     case 100: b->B.env_offset = (int)v; break;  /* global id of env 0 (multi-GPU sharding) */
     case 102: b->two_tier = v != 0; break;       /* 1 (default): register tier of NARROW_ROWS columns + overflow strip; 0: all 64 columns in registers */
@@ -306,6 +344,7 @@ static int stage_in(dm_batch* b, void* dst, const void* src, size_t bytes, int k
 extern "C" int dm_batch_set_state(dm_batch* b, const double* qpos, const double* qvel, const int32_t* fidx, const uint8_t* mask, int32_t kind) {
   if (!b || !qpos || !qvel) return fail(DM_EINVAL, "dm_batch_set_state: null argument");
   HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
   const void *q, *v, *f, *mk; int rc;
   if ((rc = stage_in(b, b->d_qpos_in, qpos, (size_t)b->n * NQ * 8, kind, &q))) return rc;
   if ((rc = stage_in(b, b->d_qvel_in, qvel, (size_t)b->n * NV * 8, kind, &v))) return rc;
@@ -320,6 +359,7 @@ extern "C" int dm_batch_set_state(dm_batch* b, const double* qpos, const double*
 extern "C" int dm_batch_reset(dm_batch* b, int32_t mode, int32_t hard, const uint8_t* mask, int32_t kind) {
   if (!b || mode < 0 || mode > 2) return fail(DM_EINVAL, "dm_batch_reset: bad argument");
   HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
   const void* mk; int rc;
   if ((rc = stage_in(b, b->d_mask, mask, (size_t)b->n, kind, &mk))) return rc;
   hipLaunchKernelGGL(k_reset, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (int)mode, (int)hard, (const unsigned char*)mk);
@@ -331,27 +371,50 @@ extern "C" int dm_batch_reset(dm_batch* b, int32_t mode, int32_t hard, const uin
 extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t nsub, int32_t kind) {
   if (!b || !action || !obs || !reward || !done || nsub < 1) return fail(DM_EINVAL, "dm_batch_step: bad argument");
   HIPCHK(hipSetDevice(b->device));
-  const void* a; int rc;
-  if ((rc = stage_in(b, b->d_action, action, (size_t)b->n * NU * 8, kind, &a))) return rc;
+  const void* a = action;
+  if (kind == DM_PTR_HOST) {
+    memcpy(b->h_action, action, (size_t)b->n * NU * sizeof(Real));
+    HIPCHK(hipMemcpyAsync(b->d_action, b->h_action, (size_t)b->n * NU * sizeof(Real), hipMemcpyHostToDevice, b->stream));
+    a = b->d_action;
+  }
   Real* o = kind == DM_PTR_DEVICE ? obs : b->d_obs;
   Real* r = kind == DM_PTR_DEVICE ? reward : b->d_reward;
   unsigned char* dn = kind == DM_PTR_DEVICE ? done : b->d_done;
+  const bool piped = b->pipe > 1 && kind == DM_PTR_DEVICE && !b->prof && b->two_tier;
+  if (!piped && pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
   if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } HIPCHK(hipEventRecord(b->ev0, b->stream)); }
+  const bool reorder = b->reorder && b->has_rows && b->n > b->resident_waves;   // more envs than resident waves: later rounds exist, their tail matters
   if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, b->d_prof);
-  else if (b->two_tier) {
-    hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub);
-    if (b->reorder && b->has_rows && b->n > b->resident_waves) {   // more envs than resident waves: a second round exists, its tail matters
-      hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order);
+  else if (piped) {
+    // Sub-batch h's launch of THIS call depends on its own launch of the previous call (stream order on ps[h]) and on the
+    // caller's inputs (ev_in), not on the other sub-batches: while the last, cheap workgroups of one sub-batch drain, the
+    // next sub-batch's fill the freed wave slots, across calls.  Nothing is inserted into the caller's stream here — it joins
+    // (dm_batch_join, or any other entry point) when it needs the outputs.
+    HIPCHK(hipEventRecord(b->ev_in, b->stream));
+    for (int h = 0; h < b->pipe; h++) {
+      const int lo = (int)((long long)b->n * h / b->pipe), hi = (int)((long long)b->n * (h + 1) / b->pipe);
+      if (hi <= lo) continue;
+      HIPCHK(hipStreamWaitEvent(b->ps[h], b->ev_in, 0));
+      hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, lo);
+      if (reorder) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->ps[h], b->B, b->d_order, lo, hi - lo);
+      HIPCHK(hipEventRecord(b->ev_done[h], b->ps[h]));
+    }
+    if (reorder) b->B.order = b->d_order;  // valid from the next launch on (same streams: ordered after each part's k_order)
+    b->pipe_pending = true;
+  } else if (b->two_tier) {
+    hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, 0);
+    if (reorder) {
+      hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order, 0, b->n);
       b->B.order = b->d_order;             // valid from the next launch on (same stream: ordered after k_order)
     }
   } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub);
   HIPCHK(hipGetLastError());
   if (b->timing) { HIPCHK(hipEventRecord(b->ev1, b->stream)); b->ev_pending = true; }
   if (kind == DM_PTR_HOST) {
-    HIPCHK(hipMemcpyAsync(obs, b->d_obs, (size_t)b->n * NOBS * 8, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipMemcpyAsync(reward, b->d_reward, (size_t)b->n * 8, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipMemcpyAsync(done, b->d_done, (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(b->h_out, b->d_obs, b->out_bytes, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    const size_t ob = (size_t)b->n * NOBS * sizeof(Real), rb = (size_t)b->n * sizeof(Real);
+    memcpy(obs, b->h_out, ob); memcpy(reward, b->h_out + ob, rb); memcpy(done, b->h_out + ob + rb, (size_t)b->n);
   }
   return DM_OK;
 }
@@ -359,6 +422,7 @@ extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, dou
 extern "C" int dm_batch_get_obs(dm_batch* b, double* obs, int32_t kind) {
   if (!b || !obs) return fail(DM_EINVAL, "dm_batch_get_obs: null argument");
   HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
   Real* o = kind == DM_PTR_DEVICE ? obs : b->d_obs;
   const int tot = b->n * NOBS;
   hipLaunchKernelGGL(k_get_obs, dim3((tot + 255) / 256), dim3(256), 0, b->stream, b->B, o);
@@ -393,6 +457,7 @@ static int field_ptr(dm_batch* b, int field, void** p, size_t* bytes) {
 extern "C" int dm_batch_get(dm_batch* b, int32_t field, void* out, size_t bytes, int32_t kind) {
   if (!b || !out) return fail(DM_EINVAL, "dm_batch_get: null argument");
   HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
   void* p; size_t need; int rc;
   if ((rc = field_ptr(b, field, &p, &need))) return rc;
   if (bytes != need) return fail(DM_EINVAL, "dm_batch_get: buffer size does not match the field");
@@ -403,6 +468,7 @@ extern "C" int dm_batch_get(dm_batch* b, int32_t field, void* out, size_t bytes,
 extern "C" int dm_batch_set(dm_batch* b, int32_t field, const void* in, size_t bytes, int32_t kind) {
   if (!b || !in) return fail(DM_EINVAL, "dm_batch_set: null argument");
   HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
   void* p; size_t need; int rc;
   if ((rc = field_ptr(b, field, &p, &need))) return rc;
   if (bytes != need) return fail(DM_EINVAL, "dm_batch_set: buffer size does not match the field");
@@ -416,6 +482,7 @@ extern "C" int dm_batch_set(dm_batch* b, int32_t field, const void* in, size_t b
 extern "C" int dm_batch_debug_forward(dm_batch* b, int32_t env, double* out_host) {
   if (!b || !out_host || env < 0 || env >= b->n) return fail(DM_EINVAL, "dm_batch_debug_forward: bad argument");
   HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
   HIPCHK(hipMemsetAsync(b->d_debug, 0, DM_DEBUG_DOUBLES * 8, b->stream));
   hipLaunchKernelGGL(k_debug_forward, dim3(1), dim3(64), 0, b->stream, b->d_model, b->B, (int)env, b->d_debug);
   HIPCHK(hipGetLastError());
@@ -456,4 +523,16 @@ extern "C" int dm_gae(const float* rew, const float* vpred, const int32_t* isnew
   HIPCHK(hipGetLastError());
   return DM_OK;
 }
-extern "C" int dm_batch_sync(dm_batch* b) { if (!b) return fail(DM_EINVAL, "null batch"); HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return DM_OK; }
+extern "C" int dm_batch_join(dm_batch* b) {
+  if (!b) return fail(DM_EINVAL, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  return DM_OK;
+}
+extern "C" int dm_batch_sync(dm_batch* b) {
+  if (!b) return fail(DM_EINVAL, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return DM_OK;
+}

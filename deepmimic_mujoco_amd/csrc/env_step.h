@@ -37,6 +37,7 @@ struct Batch {
   int n_envs;
   int env_offset;      // global id of env 0 of this shard (multi-GPU: RNG streams do not depend on the sharding)
   int reward_mode, autoreset, action_mode;
+  int diag;            // 1: k_step also stores the per-step diagnostics (xipos, contact geom list); 0: state, obs and the row counts only
   unsigned long long seed;
 };
 
@@ -138,12 +139,16 @@ DM_DEV R com_z(const DevModel<R>& M, const Shared<R>& s) {  // src/dp_env_v3.py:
   return sz / sm;
 }
 
+// `full`: also the diagnostic arrays (sim.data.xipos, the contact geom list): 848 B per env that nothing on the training path
+// reads back; set_state / reset / debug always store them, the step only when DM_OPT_DIAGNOSTICS is on.
 template <class R>
-DM_DEV void store_derived(const Batch<R>& B, const DevModel<R>& M, Shared<R>& s, int env, int lane) {
-  if (lane < NB * 3) B.xipos[(size_t)env * NB * 3 + lane] = s.xipos[lane / 3][lane % 3];
-  for (int k = lane; k < MAXEFC * 2; k += 64) {
-    const int c = k >> 1;
-    B.cong[(size_t)env * MAXEFC * 2 + k] = (c < s.ncon && c < MAXEFC) ? s.cong[c][k & 1] : -1;
+DM_DEV void store_derived(const Batch<R>& B, const DevModel<R>& M, Shared<R>& s, int env, int lane, bool full = true) {
+  if (full) {
+    if (lane < NB * 3) B.xipos[(size_t)env * NB * 3 + lane] = s.xipos[lane / 3][lane % 3];
+    for (int k = lane; k < MAXEFC * 2; k += 64) {
+      const int c = k >> 1;
+      B.cong[(size_t)env * MAXEFC * 2 + k] = (c < s.ncon && c < MAXEFC) ? s.cong[c][k & 1] : -1;
+    }
   }
   if (lane == 0) {
     B.comz[env] = com_z(M, s);
@@ -304,7 +309,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     if (!rk4_step<R, ROWS, PROF>(M, s, x, lane, lt, prof)) return false;
   const R z = com_z(M, s);
   bool dn = (z < R(0.7)) || (z > R(2.0));
-  store_derived(B, M, s, env, lane);          // sim.data.* as they stand after sim.step(): 4th-stage quantities
+  store_derived(B, M, s, env, lane, B.diag != 0);   // sim.data.* as they stand after sim.step(): 4th-stage quantities
   // reward
   R rew = 1;
   if (B.reward_mode == REW_V3_CONFIG) {          // src/dp_env_v3.py:89-104

@@ -250,12 +250,14 @@ class DPVecEnv(object):
     """N DeepMimic humanoids in lock step on one GPU (one wavefront per environment)."""
 
     def __init__(self, num_envs, motion="walk", xml_path=None, device=0, reward="alive", autoreset="rsi", seed=0,
-                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=None):
+                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=None, diagnostics=False):
         """reward="imitation": the 5-term reward of code.md:1017-1143 (imitation.py) against the frame after the current one.
         frame_skip: sim steps per env step (src/dp_env_v3.py:108-112 hard-codes 1); "mocap" = floor(mocap_dt / timestep), the
         commented intent of :107-110, so that one env step spans one mocap frame.  Default (None): 1, except "mocap" for the
         imitation reward — its reference advances one mocap frame per env step and its velocity features are per second, so any
-        other value plays the clip at the wrong speed (a warning says so when one is given)."""
+        other value plays the clip at the wrong speed (a warning says so when one is given).
+        diagnostics: keep `sim.data.xipos` / the contact geom list up to date after every step (DM_OPT_DIAGNOSTICS; the batched
+        training path does not read them, `DPEnv` and raw `Batch` objects default to on)."""
         self.num_envs = int(num_envs)
         self.mocap = MocapDM()
         self.mocap.load_mocap(motion)
@@ -291,6 +293,7 @@ class DPVecEnv(object):
         b.set_option(A.OPT_ACTION_MODE, {"raw": 0, "p-control": 1, "pd": 2}[action_mode])
         b.set_option(A.OPT_SEED, int(seed))
         b.set_option(A.OPT_ENV_OFFSET, int(env_offset))
+        b.set_option(A.OPT_DIAGNOSTICS, 1 if diagnostics else 0)
         cr = self._cm.actuator_ctrlrange
         self.action_space = Box(low=cr[:, 0], high=cr[:, 1], dtype=np.float32)
         self.observation_space = Box(low=-np.inf, high=np.inf, shape=(A.NOBS,), dtype=np.float32)

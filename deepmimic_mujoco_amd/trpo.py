@@ -149,6 +149,8 @@ class TrpoLearner:
         self.vfadam = MpiAdam(self.vf, group=group)
         self._perm_gen = torch.Generator(device=pi.device)
         self._perm_gen.manual_seed(int(seed))
+        self.perm_source = None        # tests: callable(n) -> index tensor replacing the shuffles of `dataset.iterbatches` (:289)
+        self.last = {}                 # flat g / stepdir / fullstep of the last update (diagnostics, parity tests)
         self.sync_from_root()
 
     # ---- flat parameter access (U.GetFlat / U.SetFromFlat, :144-145) ----------------------------------------------------
@@ -236,6 +238,8 @@ class TrpoLearner:
             lm = torch.sqrt(shs / self.max_kl)
             fullstep = stepdir / lm
             expectedimprove = float(g.dot(fullstep))
+            self.last = {"g": g.detach().clone(), "stepdir": stepdir.detach().clone(), "fullstep": fullstep.detach().clone(),
+                         "shs": float(shs), "lm": float(lm)}
             del klgrads
             surrbefore = float(lossbefore[0])
             stepsize = 1.0
@@ -265,7 +269,7 @@ class TrpoLearner:
         n = ob.shape[0]
         bs = min(self.vf_batch_size, n)
         for _ in range(self.vf_iters):
-            inds = torch.randperm(n, device=ob.device, generator=self._perm_gen)
+            inds = self.perm_source(n).to(ob.device) if self.perm_source is not None else torch.randperm(n, device=ob.device, generator=self._perm_gen)
             for o in range(0, n - bs + 1, bs):                              # include_final_partial_batch=False
                 mb = inds[o:o + bs]
                 mbob, mbret = ob[mb], tdlamret[mb]

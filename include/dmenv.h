@@ -112,8 +112,19 @@ enum {
   DM_OPT_AUTORESET = 2,   /* 0 off (default), 1 RSI on done, 2 noisy-init on done (DummyVecEnv convention) */
   DM_OPT_ACTION_MODE = 3, /* 0 raw ctrl (dp_env_v3.py:112, default), 1 P-control 0.8*(mocap_cfg - q) + action (env_torque_test.py:20),
                              2 PD kp*(mocap_cfg - q) + kd*(mocap_vel - v) + action (setting_states.py:207-226, gains mocap_util.py:22-24) */
-  DM_OPT_SEED = 4
+  DM_OPT_SEED = 4,
+  DM_OPT_DIAGNOSTICS = 5, /* 1 (default): every step also stores sim.data.xipos and the contact (geom1, geom2) list (DM_F_XIPOS,
+                             DM_F_CONTACT_GEOMS: 848 B per env-step); 0: state, obs, reward, done and the row / contact counts only —
+                             those two fields then keep the values of the last set_state / reset (DPVecEnv's default) */
+  DM_OPT_PIPELINE = 6     /* 1 (default): a step is one launch on the batch's stream.  P = 2..DM_MAX_PIPELINE: the env range is cut
+                             into P contiguous sub-batches, each stepped on its own internal stream.  With DEVICE pointers a
+                             sub-batch's launch of call k+1 waits only for its own launch of call k and for the caller's stream
+                             at the time of the call (the inputs), so consecutive calls overlap: the next sub-batch's workgroups
+                             take the wave slots freed while the previous one drains.  The outputs of such calls are complete
+                             once the caller's stream has joined: dm_batch_join() (no host wait), dm_batch_sync(), or any other
+                             entry point of the batch.  Results are identical for every P. */
 };
+#define DM_MAX_PIPELINE 8
 /* further option ids (diagnostics / tests; defaults are what the timed path uses):
  *   100 global id of env 0 of this batch (multi-GPU sharding: RNG streams are keyed by the global env id)
  *   101 per-stage shader-clock profile (k_step_prof + dm_batch_read_profile)
@@ -195,6 +206,8 @@ int dm_gae(const float* rew, const float* vpred, const int32_t* isnew, const flo
            int32_t T, int32_t n, double gamma, double lam, void* hip_stream);
 
 int dm_batch_sync(dm_batch* b);
+/* Make the batch's stream wait (device-side, no host wait) for every pipelined sub-batch launch in flight (DM_OPT_PIPELINE). */
+int dm_batch_join(dm_batch* b);
 const char* dm_last_error(void);
 int dm_abi_version(void);
 int dm_device_count(void);

@@ -99,6 +99,12 @@ class EmuBatch(object):
     def close(self):
         pass
 
+    def join(self):
+        pass
+
+    def sync(self):
+        pass
+
     def debug_forward(self, env=0):
         buf = np.zeros(A.DEBUG_DOUBLES)
         lib().emu_debug_forward(self.h, env, buf.ctypes.data_as(A._dp))

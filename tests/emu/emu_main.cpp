@@ -81,7 +81,7 @@ void* emu_create(const dm_model_desc* d, const double* cfg, const double* vel, i
   B.ncon = e->ncon.data(); B.nefc = e->nefc.data(); B.cong = e->cong.data(); B.status = e->status.data();
   B.aovf = e->aovf.data(); B.cycle = e->cycle.data(); B.imit_table = nullptr; B.imit_pdev = nullptr; B.order = nullptr;
   B.solver_iter = e->siter.data(); B.episode = e->episode.data(); B.mocap_cfg = e->cfg.data(); B.mocap_vel = e->vel.data();
-  B.n_frames = F; B.n_envs = n; B.env_offset = 0; B.reward_mode = 0; B.autoreset = 0; B.action_mode = 0; B.seed = 0;
+  B.n_frames = F; B.n_envs = n; B.env_offset = 0; B.reward_mode = 0; B.autoreset = 0; B.action_mode = 0; B.seed = 0; B.diag = 1;
   return e;
 }
 void emu_set_imitation(void* h, const double* table, const double* params) {
@@ -98,6 +98,7 @@ void emu_set_option(void* h, int opt, long long v) {
   else if (opt == DM_OPT_AUTORESET) e->B.autoreset = (int)v;
   else if (opt == DM_OPT_ACTION_MODE) e->B.action_mode = (int)v;
   else if (opt == DM_OPT_SEED) e->B.seed = (unsigned long long)v;
+  else if (opt == DM_OPT_DIAGNOSTICS) e->B.diag = v != 0;
   else if (opt == 100) e->B.env_offset = (int)v;
   else if (opt == 102) e->two_tier = v != 0;
   else if (opt == 103) e->M.pgs_detect = v ? -1e300 : 1e-10;

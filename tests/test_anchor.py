@@ -1,0 +1,128 @@
+"""Statistical anchors of the parity-unpinned physics (tooling and rationale: tests/anchor.py).
+
+The reference ships 112 numbers measured inside real MuJoCo 2.0 — the observation filter of its TRPO checkpoint, the first two
+moments of the 56 observation dimensions over the 11 673 600 samples its 2-worker training run saw up to iteration 1 900 — and the
+log of that run.  tests/golden/anchor/protocol_seed*.json are replays of the same protocol in the oracle's physics
+(tests/golden/gen/make_anchor.py, ~15 min each); here their moments and learning curves are held against the reference's."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import anchor as AN
+
+ADIR = os.path.join(AN.GOLD, "anchor")
+
+
+def _runs(pattern):
+    return [json.load(open(f)) for f in sorted(glob.glob(os.path.join(ADIR, pattern)))]
+
+
+def test_checkpoint_filter_count_is_the_two_worker_protocol():
+    """count = 1 900 iterations x 3 g-steps x 2 workers x (256 rollout + 3 x 256 value-fit samples) + the 1e-2 initialisation:
+    the moments are the mixture over the whole run (src/trpo.py:228-296, save_per_iter 100), which fixes the replay protocol."""
+    mean, std, cnt = AN.checkpoint_moments()
+    assert abs(cnt - (1900 * 3 * 2 * (256 + 3 * 256) + 1e-2)) < 1e-6
+    assert mean.shape == (56,) and np.all(std >= 0.1 - 1e-12) and np.all(np.isfinite(mean))
+    assert 1.5 < std[28:].mean() / std[:28].mean() < 10            # joint rates (rad/s) are wider than joint angles (rad)
+
+
+def test_protocol_replay_moments_match_the_reference_filter():
+    """Three seeds of the replay vs the checkpoint's 56 means + 56 stds, in units of the checkpoint's std per dimension.
+    Joint-RATE dimensions are set by the dynamics (contact, limits, actuators, damping, inertia): means within 0.25 sigma,
+    spreads within -25 % / +35 %.  Joint-ANGLE dimensions also reflect which posture a run's policy settles into (the three
+    replays differ from each other by up to 0.5 sigma): means within 2 sigma, spreads within a factor 1.8."""
+    runs = _runs("protocol_seed[0-9].json")
+    assert len(runs) >= 3
+    ref_mean, ref_std, cnt = AN.checkpoint_moments()
+    for r in runs:
+        assert abs(r["count"] - cnt) < 1e-6 and r["iterations"] == 1900          # same protocol, same number of filter samples
+        d, ratio = AN.compare_moments(r["mean"], r["std"])
+        assert np.abs(d[28:]).max() < 0.25 and 0.75 < ratio[28:].min() and ratio[28:].max() < 1.35, (np.abs(d[28:]).max(), ratio[28:].min(), ratio[28:].max())
+        assert np.abs(d[:28]).max() < 2.0 and 0.55 < ratio[:28].min() and ratio[:28].max() < 1.8, (np.abs(d[:28]).max(), ratio[:28].min(), ratio[:28].max())
+    M = np.mean([r["mean"] for r in runs], 0); S = np.mean([r["std"] for r in runs], 0)
+    d, ratio = AN.compare_moments(M, S)
+    assert np.sqrt((d[28:] ** 2).mean()) < 0.06 and abs(np.exp(np.log(ratio[28:]).mean()) - 1) < 0.06       # rates: 4 % rms, 2 % mean spread error
+    assert np.sqrt((d[:28] ** 2).mean()) < 0.6 and abs(np.exp(np.log(ratio[:28]).mean()) - 1) < 0.12
+
+
+def test_protocol_replay_learning_curve_tracks_the_reference_log():
+    """EpLenMean of the replays against the reference's own log (tests/golden/trpo_walk0_log.npz): an untrained policy falls after
+    ~35 steps in both, and both learn to stand at the same pace over the first ~1 000 iterations; late in training single runs
+    scatter (replays 176 .. 227 at iteration 1 900, the reference's one run 263)."""
+    ref = np.load(os.path.join(AN.GOLD, "trpo_walk0_log.npz"))
+    curve, steps = ref["EpLenMean"], ref["TimestepsSoFar"]
+    runs = _runs("protocol_seed[0-9].json")
+    C = np.array([r["EpLenMean"] for r in runs])
+    for it, tol in ((10, 6), (100, 12), (500, 25), (1000, 35)):
+        assert abs(C[:, it - 1].mean() - curve[it - 1]) < tol, (it, C[:, it - 1], curve[it - 1])
+    assert np.all(C[:, 1899] > 4 * C[:, 4]) and curve[1899] > 4 * curve[4]            # both physics can be learnt in: 35 -> 180+ steps
+    assert 0.6 < C[:, 1899].mean() / curve[1850:1942].mean() < 1.1
+    T = np.array([r["TimestepsSoFar"][-1] for r in runs])
+    assert np.all(np.abs(T / steps[1899] - 1) < 0.03)                                 # same sample budget per iteration
+
+
+def test_regulariser_variants_are_not_resolved_by_the_anchor():
+    """The two low-confidence items of the contact regulariser (oracle switches `pyramid_diag_mu2`, `pyramid_r_rescale`; either
+    one halves R of the pyramid rows) give the SAME physics, and their replay lies inside the seed-to-seed scatter of the
+    default: 112 moments + the curve cannot tell a factor 2 in R apart.  Kept as a recorded negative result."""
+    a = _runs("protocol_seed0_pyramid_diag_mu20.json")[0]; b = _runs("protocol_seed0_pyramid_r_rescale0.json")[0]
+    assert a["mean"] == b["mean"] and a["EpLenMean"] == b["EpLenMean"]
+    d, ratio = AN.compare_moments(a["mean"], a["std"])
+    assert np.abs(d[28:]).max() < 0.25 and np.abs(d[:28]).max() < 2.0
+
+
+def test_replay_protocol_runs_and_is_deterministic():
+    r1 = AN.run_reference_protocol(seed=5, iterations=2)
+    r2 = AN.run_reference_protocol(seed=5, iterations=2)
+    assert r1["mean"] == r2["mean"] and r1["EpLenMean"] == r2["EpLenMean"]
+    assert abs(r1["count"] - (2 * 3 * 2 * 1024 + 1e-2)) < 1e-9 and 25 < r1["EpLenMean"][-1] < 50
+
+
+def test_shipped_policy_stationary_moments_on_the_oracle():
+    """The shipped policy alone (stochastic, trainer's episode protocol) in the oracle: it balances for ~270 steps as in its own log,
+    its observation means sit inside the training mixture (within 1 sigma of the filter's means) and its spreads are narrower
+    than the mixture's (one good policy vs. every policy of the run).  Fixture: shipped_policy_oracle.json (256 envs x 600 steps);
+    a smaller live sample must agree with it."""
+    fx = json.load(open(os.path.join(ADIR, "shipped_policy_oracle.json")))
+    d, ratio = AN.compare_moments(fx["mean"], fx["std"])
+    assert np.abs(d).max() < 1.0 and ratio.max() <= 1.05 and ratio.min() > 0.15 and 200 < fx["first_len"] < 340
+    mean, std, cnt, first = AN.shipped_policy_moments(n=48, steps=200, seed=1)
+    assert cnt == 48 * 200 and np.abs((mean - np.array(fx["mean"])) / AN.checkpoint_moments()[1]).max() < 0.5
+
+
+@pytest.mark.gpu
+def test_shipped_policy_stationary_moments_on_gpu_match_oracle_and_filter():
+    """The same statistic on the HIP kernel at scale (2048 envs x 600 steps = 1.2 M samples): equal to the oracle's within
+    sampling error, inside the reference filter's mixture."""
+    import torch
+    from deepmimic_mujoco_amd import DPVecEnv, MlpPolicy
+    n, steps = 2048, 600
+    env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=3)
+    pol = MlpPolicy.from_tf_checkpoint(AN.CKPT, device="cuda:0"); pol.seed(3)
+    ob = torch.as_tensor(env.reset("init"), device="cuda:0", dtype=torch.float64)
+    s = torch.zeros(56, dtype=torch.float64, device="cuda:0"); s2 = torch.zeros_like(s)
+    first = torch.full((n,), -1, dtype=torch.int64, device="cuda:0")
+    out = (torch.empty((n, 56), dtype=torch.float64, device="cuda:0"), torch.empty(n, dtype=torch.float64, device="cuda:0"),
+           torch.empty(n, dtype=torch.uint8, device="cuda:0"))
+    for t in range(steps):
+        s += ob.sum(0); s2 += (ob * ob).sum(0)
+        ac, _ = pol.act(True, ob)
+        ob, rew, done, _ = env.step(ac.contiguous(), out)
+        newly = (first < 0) & (done != 0)
+        first[newly] = t + 1
+        ob = ob.clone()
+    cnt = n * steps
+    mean = (s / cnt).cpu().numpy(); std = np.sqrt(np.maximum((s2 / cnt).cpu().numpy() - mean ** 2, 1e-2))
+    first = torch.where(first < 0, torch.full_like(first, steps), first).double().mean().item()
+    env.close()
+    fx = json.load(open(os.path.join(ADIR, "shipped_policy_oracle.json")))
+    ref_mean, ref_std, _ = AN.checkpoint_moments()
+    print("GPU shipped-policy moments: first-episode length %.1f (oracle %.1f); max |mean - oracle| / sigma_ref %.3f; std ratio to oracle %.2f..%.2f"
+          % (first, fx["first_len"], np.abs((mean - np.array(fx["mean"])) / ref_std).max(), (std / np.array(fx["std"])).min(), (std / np.array(fx["std"])).max()))
+    assert np.abs((mean - np.array(fx["mean"])) / ref_std).max() < 0.2                 # kernel == oracle, statistically
+    assert 0.8 < (std / np.array(fx["std"])).min() and (std / np.array(fx["std"])).max() < 1.25
+    d, ratio = AN.compare_moments(mean, std)
+    assert np.abs(d).max() < 1.0 and ratio.max() <= 1.05 and ratio.min() > 0.15 and 200 < first < 340

@@ -366,3 +366,36 @@ def test_full_size_shard_properties_cfg4_cfg5(clip, n):
     assert len(fresh) > 0 and np.array_equal(full["q"][fresh], mc.data_config[full["fi"][fresh]])
     assert (full["status"] & 1).mean() < 0.01 and full["nefc"].max() > 8
     assert 0 < full["rew"].min() and full["rew"].max() <= 1.0
+
+
+@pytest.mark.parametrize("n", [1000, 4096 + 37])
+def test_pipelined_sub_batches_do_not_change_results(n):
+    """DM_OPT_PIPELINE cuts the env range into sub-batches stepped on their own streams, consecutive calls overlapping; it only
+    changes WHEN an env is stepped: obs / reward / done of every step and the final state must be bit-identical for every depth,
+    including a depth change in mid-run and host-pointer calls in between (which join)."""
+    import torch
+    steps = 24
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    acts = torch.randn((steps, n, 28), generator=g, device="cuda", dtype=torch.float64) * 0.9
+    outs = []
+    for depth in (1, 2, 3, 8):
+        b = make_batch(n)
+        b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, 5); b.set_option(A.OPT_PIPELINE, depth)
+        b.reset(0, 1)
+        obs = torch.zeros((steps, n, 56), dtype=torch.float64, device="cuda"); rew = torch.zeros((steps, n), dtype=torch.float64, device="cuda")
+        done = torch.zeros((steps, n), dtype=torch.uint8, device="cuda")
+        for t in range(steps):
+            if depth == 3 and t == 9:
+                b.set_option(A.OPT_PIPELINE, 2)                        # depth change in mid-run
+            b.step(acts[t], 1, (obs[t], rew[t], done[t]))              # no join between calls: consecutive steps overlap
+        b.join()
+        torch.cuda.current_stream().synchronize()
+        outs.append((obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), b.get(A.F_QPOS), b.get(A.F_QACC_WARMSTART), b.get(A.F_EPISODE)))
+        # a host-pointer step joins and runs as one launch: still the same trajectory as an unpipelined batch
+        b.close()
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert np.array_equal(x, y)
+    assert outs[0][2].sum() > 0 and outs[0][5].max() > 1, "no early termination / auto-reset inside the run"
+    with pytest.raises(A.DmenvError):
+        make_batch(8).set_option(A.OPT_PIPELINE, 9)

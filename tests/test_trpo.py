@@ -152,3 +152,88 @@ def test_learn_improves_return_on_a_scripted_env(tmp_path):
 def test_explained_variance():
     y = torch.tensor([1.0, 2.0, 3.0, 4.0])
     assert explained_variance(y, y) == 1.0 and abs(explained_variance(torch.zeros(4), y)) < 1e-12
+
+
+# ---- numeric pin of one update against the analytic float64 restatement (tests/trpo_numpy.py, fixture trpo_update_golden.npz) ----
+def _golden_update(device):
+    """Run TrpoLearner.update on the fixture's segment; return (learner, policy, stats, fixture)."""
+    import os
+    from deepmimic_mujoco_amd.trpo import TrpoLearner, POL_KEYS, VF_KEYS
+    from deepmimic_mujoco_amd.policy import MlpPolicy
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trpo_update_golden.npz"))
+    pi = MlpPolicy(device=device, seed=0)
+    with torch.no_grad():
+        for k in POL_KEYS + VF_KEYS:
+            pi.params[k].copy_(torch.as_tensor(g["p0/" + k], dtype=torch.float32).reshape(pi.params[k].shape))
+    pi.ob_rms.sum = torch.as_tensor(g["rms0_sum"], dtype=torch.float64, device=device)
+    pi.ob_rms.sumsq = torch.as_tensor(g["rms0_sumsq"], dtype=torch.float64, device=device)
+    pi.ob_rms.count = torch.as_tensor(float(g["rms0_count"]), dtype=torch.float64, device=device)
+    pi.ob_rms._refresh()
+    learner = TrpoLearner(pi, vf_batch_size=128)
+    perms = [torch.as_tensor(p, dtype=torch.int64) for p in g["perms"]]
+    learner.perm_source = lambda n, it=iter(perms): next(it)
+    t = lambda a, dt: torch.as_tensor(a, dtype=dt, device=device)
+    seg = {"ob": t(g["ob"], torch.float32), "ac": t(g["ac"], torch.float32), "rew": t(g["rew"], torch.float32), "vpred": t(g["vpred"], torch.float32),
+           "new": t(g["new"], torch.int32), "nextvpred": t(g["nextvpred"], torch.float32), "ep_lens": [], "ep_rets": []}
+    stats = learner.update(seg)
+    return learner, pi, stats, g, seg
+
+
+def _check_against_golden(learner, pi, stats, g, seg):
+    from deepmimic_mujoco_amd.trpo import POL_KEYS, VF_KEYS, flat
+    from tests import trpo_numpy as TN
+    T, N = int(g["T"]), int(g["N"])
+    # GAE of the segment (src/trpo.py:83-94)
+    assert np.allclose(seg["adv"].cpu().numpy(), g["adv"], rtol=2e-5, atol=2e-4) and np.allclose(seg["tdlamret"].cpu().numpy(), g["tdlamret"], rtol=2e-5, atol=2e-4)
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / np.linalg.norm(b))
+    cos = lambda a, b: float(np.dot(np.asarray(a, dtype=np.float64), b) / (np.linalg.norm(a) * np.linalg.norm(b)))
+    L = learner.last
+    # surrogate gradient, CG step direction (10 iterations amplify float32 rounding), scaled step
+    assert rel(L["g"].cpu().numpy(), g["st/g"]) < 2e-4, rel(L["g"].cpu().numpy(), g["st/g"])
+    assert cos(L["stepdir"].cpu().numpy(), g["st/stepdir"]) > 0.9999 and rel(L["stepdir"].cpu().numpy(), g["st/stepdir"]) < 2e-2
+    assert abs(L["shs"] / float(g["st/shs"]) - 1) < 2e-2 and abs(L["lm"] / float(g["st/lm"]) - 1) < 1e-2
+    assert cos(L["fullstep"].cpu().numpy(), g["st/fullstep"]) > 0.9999
+    # line search: same number of halvings, same KL / surrogate at the accepted point
+    assert stats["stepsize"] == float(g["st/stepsize"]) == 0.5
+    assert abs(stats["expectedimprove"] / float(g["st/expectedimprove"]) - 1) < 1e-2
+    assert abs(stats["meankl"] - float(g["st/kl"])) < 2e-4 and abs(stats["surrgain"] - float(g["st/surr"])) < 2e-3
+    assert stats["meankl"] <= 0.015
+    # parameters after the update: policy (theta + stepsize * fullstep) and value function (3 epochs x 4 Adam steps)
+    p1 = {k: g["p1/" + k] for k in POL_KEYS + VF_KEYS}
+    th = flat([pi.params[k].detach() for k in POL_KEYS]).cpu().numpy()
+    assert rel(th - TN.flat({k: g["p0/" + k] for k in POL_KEYS}, POL_KEYS), TN.flat(p1, POL_KEYS) - TN.flat({k: g["p0/" + k] for k in POL_KEYS}, POL_KEYS)) < 2e-2
+    vf = flat([pi.params[k].detach() for k in VF_KEYS]).cpu().numpy()
+    dv_ref = TN.flat(p1, VF_KEYS) - TN.flat({k: g["p0/" + k] for k in VF_KEYS}, VF_KEYS)
+    assert rel(vf - TN.flat({k: g["p0/" + k] for k in VF_KEYS}, VF_KEYS), dv_ref) < 2e-2 and np.abs(dv_ref).max() > 5e-3
+    # the observation filter saw the batch once and every value-fit minibatch once (src/trpo.py:242,293)
+    assert abs(float(pi.ob_rms.count) - float(g["rms1_count"])) < 1e-6 and float(g["rms1_count"]) - float(g["rms0_count"]) == 4 * T * N
+    assert np.allclose(pi.ob_rms.sum.cpu().numpy(), g["rms1_sum"], rtol=1e-9, atol=1e-6)
+
+
+def test_numpy_restatement_reproduces_its_committed_fixture():
+    """tests/golden/trpo_update_golden.npz was written by tests/golden/gen/make_trpo_fixture.py from tests/trpo_numpy.py: re-running
+    the analytic float64 update on the fixture's inputs gives the stored outputs (the fixture is not stale), and its pieces satisfy
+    their definitions: F is symmetric positive, CG reduces the residual, the accepted step respects the trust region."""
+    import os
+    from tests import trpo_numpy as TN
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trpo_update_golden.npz"))
+    T, N = int(g["T"]), int(g["N"])
+    p0 = {k[3:]: g[k] for k in g.files if k.startswith("p0/")}
+    rms = TN.Rms(); rms.sum = g["rms0_sum"].copy(); rms.sumsq = g["rms0_sumsq"].copy(); rms.count = float(g["rms0_count"])
+    fl = lambda a: np.swapaxes(a, 0, 1).reshape((T * N,) + a.shape[2:])
+    p1, st = TN.update(p0, rms, fl(g["ob"]), fl(g["ac"]), fl(g["adv"]), fl(g["tdlamret"]), list(g["perms"]), vf_batch=128)
+    for k in ("g", "stepdir", "fullstep"):
+        assert np.array_equal(st[k], g["st/" + k])
+    assert st["stepsize"] == float(g["st/stepsize"]) and st["kl"] == float(g["st/kl"]) and all(np.array_equal(p1[k], g["p1/" + k]) for k in p1)
+    assert st["kl"] <= 0.015 and st["surr"] >= st["surrbefore"] and st["expectedimprove"] > 0
+
+
+def test_learner_update_matches_the_float64_restatement_on_cpu():
+    _check_against_golden(*_golden_update("cpu"))
+
+
+@pytest.mark.gpu
+def test_learner_update_matches_the_float64_restatement_on_gpu():
+    """src/trpo.py:235-296 on torch-ROCm: gradient, CG direction, step scaling, line-search outcome, KL and value-fit parameters
+    against the analytic float64 restatement (committed fixture), float32 tolerances."""
+    _check_against_golden(*_golden_update("cuda:0"))

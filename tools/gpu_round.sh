@@ -1,0 +1,24 @@
+#!/bin/bash
+# One gpurun call's worth of judged artefacts (run from the repo root on the GPU box): tests, bench lines, stage profile,
+# contact exposure.  Outputs under gpurun_out/<tag>/ ; copy the summaries into profiles/ afterwards.
+set -u
+TAG=${1:-r02}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 ) > $OUT/pytest_gpu.log
+tail -5 $OUT/pytest_gpu.log
+timeout 600 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-600 $OUT/bench_cfg3.json
+for wl in cfg4 cfg5 cfg2; do
+  timeout 300 python bench.py --workload $wl --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; cut -c1-300 $OUT/bench_$wl.json
+done
+timeout 300 python bench.py --workload rollout --steps 1024 --warmup 256 > $OUT/bench_rollout.json 2> $OUT/bench_rollout.err; cut -c1-200 $OUT/bench_rollout.json
+DM_PROF_REWARD=imitation timeout 300 python tools/profile_stages.py > $OUT/stage_cycles.txt 2>&1; head -30 $OUT/stage_cycles.txt
+timeout 300 python tools/contact_exposure.py --out $OUT/contact_exposure_cfg3.json > /dev/null 2> $OUT/contact_exposure.err
+timeout 300 python tools/contact_exposure.py --policy shipped --envs 2048 --steps 400 --out $OUT/contact_exposure_policy.json > /dev/null 2>> $OUT/contact_exposure.err
+python - <<'PY'
+import json,sys,os
+for f in ("contact_exposure_cfg3.json","contact_exposure_policy.json"):
+    p=os.path.join(os.environ.get("OUTDIR", "gpurun_out"), f)
+PY
+grep -h "own_algorithm\|env_steps_with" $OUT/contact_exposure_*.json

@@ -1,7 +1,9 @@
 """Diagnostic: per-stage shader-clock profile of k_step on the GPU (uses DM_OPT 101)."""
 import os
 import sys
+import warnings
 import numpy as np
+warnings.simplefilter("ignore", UserWarning)   # frame_skip = 1 with the imitation reward: one mj_step per env step, as bench.py times it
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from deepmimic_mujoco_amd import DPVecEnv, _abi as A
 
@@ -9,7 +11,7 @@ for wl in ("cfg3", "cfg2"):
     full = wl == "cfg3"
     n = 4096
     env = DPVecEnv(n, motion="walk", device=0, reward=os.environ.get("DM_PROF_REWARD", "v3-config") if full else "alive", autoreset="rsi", seed=0,
-                   contacts=full, limits=full, action_mode="raw" if full else "p-control")
+                   contacts=full, limits=full, action_mode="raw" if full else "p-control", frame_skip=1)
     env.reset("rsi")
     rng = np.random.RandomState(0)
     for t in range(40):
