@@ -93,40 +93,44 @@ def physical_cores():
     return len(cores), len(avail)
 
 
+def cpu_quota_cores():
+    """CPU bandwidth the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota); None = unlimited / unknown."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()[:2]
+            return None if q == "max" else round(float(q) / float(per), 2)
+        except (OSError, ValueError):
+            pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline_worker(clip, reward, nthreads, seconds):
     """Runs in a fresh process whose OpenMP runtime was configured by the parent (OMP_NUM_THREADS / OMP_PROC_BIND / OMP_PLACES):
-    time the CPU oracle (oracle/, float64 C, OpenMP over envs) on a bounded sample of the same workload."""
+    time the CPU oracle (oracle/, float64 C) on a bounded sample of the same workload.  The whole loop — actions, steps, rewards,
+    RSI resets on done — runs in C (`dmo_bench_rollout`), whole trajectories per OpenMP thread: round 1's Python-side loop (action
+    sampling, per-env resets through ctypes) serialised the run beyond a few dozen threads."""
     from oracle import oracle as O
     from deepmimic_mujoco_amd import MocapDM, CompiledModel, humanoid_spec
     from deepmimic_mujoco_amd.imitation import ImitationSpec
     mc = MocapDM(); mc.load_mocap(clip)
-    F = mc.data_config.shape[0]
     om = O.Model()
-    rng = np.random.RandomState(0)
-    imit = reward == "imitation"
-    if imit:
+    table = params = None
+    if reward == "imitation":
         table, params = ImitationSpec(CompiledModel(humanoid_spec())).table_for(mc)
-    n = max(8, nthreads * 8)                     # >= 4 envs per thread so that the static OpenMP schedule is balanced
+    n = max(8, nthreads * 4)
     ds = [O.Data(om) for _ in range(n)]
-    idx = (np.arange(n) % F).astype(np.int32); cyc = np.zeros(n, dtype=np.int32)
-    for e, d in enumerate(ds):
-        d.reset(); d.set_state(mc.data_config[e % F], mc.data_vel[e % F])
-    steps = 0
     t0 = time.perf_counter()
-    while True:
-        a = rng.randn(n, 28) * 0.9
-        if imit:
-            _o, _r, done = O.batch_step_imitation(om, ds, a, 1, table, params, idx, cyc, nthreads)
-        else:
-            _o, _r, done = O.batch_step(om, ds, a, 1, nthreads)
-        steps += 1
-        for e in np.nonzero(done)[0]:
-            k = rng.randint(F)
-            ds[e].reset(); ds[e].set_state(mc.data_config[k], mc.data_vel[k]); idx[e] = k; cyc[e] = 0
-        el = time.perf_counter() - t0
-        if el > seconds and steps >= 4:
-            break
-    print(json.dumps({"rate": n * steps / el, "n": n, "steps": steps, "el": el}))
+    tot, _nd, _rs = O.bench_rollout(om, ds, 40, mc.data_config, mc.data_vel, table, params, 0.9, 1, nthreads)    # calibration (and page-in)
+    rate = tot / (time.perf_counter() - t0)
+    steps = int(max(40, min(20000, seconds * rate / n)))
+    t0 = time.perf_counter()
+    tot, nd, rs = O.bench_rollout(om, ds, steps, mc.data_config, mc.data_vel, table, params, 0.9, 2, nthreads)
+    el = time.perf_counter() - t0
+    print(json.dumps({"rate": tot / el, "n": n, "steps": steps, "el": el, "episodes": nd, "mean_reward": rs / max(1, tot)}))
 
 
 def cpu_baseline(clip, reward="imitation", budget_s=14.0):
@@ -134,11 +138,11 @@ def cpu_baseline(clip, reward="imitation", budget_s=14.0):
     (OMP_PROC_BIND=close, OMP_PLACES=cores): un-pinned, the runtime piles threads of a 256-logical-CPU host onto a few cores
     (round 1: 129 k env-steps/s at 32 threads, 14 k at 256).  Reported: the physical-core run, next to one core."""
     ncores, nlogical = physical_cores()
-    counts = sorted({1, min(32, ncores), ncores})
+    counts = sorted({1, min(32, ncores), ncores, nlogical})
     per = budget_s / len(counts)
     res = {}
     for c in counts:
-        env = dict(os.environ, OMP_NUM_THREADS=str(c), OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_WAIT_POLICY="active", OMP_DYNAMIC="false")
+        env = dict(os.environ, OMP_NUM_THREADS=str(c), OMP_PROC_BIND="close", OMP_PLACES="cores" if c <= ncores else "threads", OMP_DYNAMIC="false")
         try:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--_cpu-worker", clip, reward, str(c), str(per)], env=env,
                                  capture_output=True, text=True, timeout=per * 6 + 120)
@@ -149,8 +153,10 @@ def cpu_baseline(clip, reward="imitation", budget_s=14.0):
     b = res[best]
     return {"value": round(b["rate"], 1), "unit": "env-steps/s", "cores": best, "kind": "port", "single_core_value": round(res[1]["rate"], 1),
             "by_threads": {str(c): round(res[c]["rate"], 1) for c in counts}, "physical_cores": ncores, "logical_cpus": nlogical,
-            "sample": "%d envs x %d steps of the same workload (%s, contacts+limits, %s reward, N(0,0.9^2) actions, RSI reset on done), "
-                      "oracle/dm_oracle.c fp64, OpenMP over envs, %d pinned threads (OMP_PROC_BIND=close, OMP_PLACES=cores; tried %s), %.1f s"
+            "cgroup_cpu_quota_cores": cpu_quota_cores(),
+            "sample": "%d envs x %d steps of the same workload (%s, contacts+limits, %s reward, N(0,0.9^2) actions, RSI reset on done) run entirely "
+                      "in C (oracle/dm_oracle.c dmo_bench_rollout, fp64), one trajectory per OpenMP task, %d threads (OMP_PROC_BIND=close, "
+                      "OMP_PLACES=cores unless threads > cores; tried %s), %.1f s"
                       % (b["n"], b["steps"], clip, reward, best, counts, b["el"])}
 
 
@@ -232,13 +238,22 @@ def pmc_passes(argv_tail, kernel_prefix, timeout_s=150):
 
 def rollout_bench(args, dev, rank, world, local_dev):
     """Informational: the learner-facing loop of src/trpo.py:27-94 kept on the device — 2x100 tanh policy + value forward,
-    Gaussian sampling, env kernel, segment bookkeeping, GAE per 256-step segment.  Not the judged metric line."""
+    Gaussian sampling, env kernel, segment bookkeeping, GAE per 256-step segment.  Not the judged metric line.
+    --pipeline P > 1: the rank's envs are P batches whose policy -> env chains run concurrently on their own streams."""
     import torch
-    from deepmimic_mujoco_amd import DPVecEnv, MlpPolicy, traj_segment_generator, add_vtarg_and_adv
+    from deepmimic_mujoco_amd import DPVecEnv, MlpPolicy, traj_segment_generator, pipelined_segment_generator, add_vtarg_and_adv
     n = args.envs or 4096
-    env = DPVecEnv(n, motion=args.clip or "walk", device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n)
+    P = max(1, min(args.pipeline, 8))
+    clip = args.clip or "walk"
     pol = MlpPolicy(device=dev, seed=0); pol.seed(rank)
-    gen = traj_segment_generator(pol, env, HORIZON, stochastic=True)
+    if P > 1:
+        cuts = [n * h // P for h in range(P + 1)]
+        envs = [DPVecEnv(cuts[h + 1] - cuts[h], motion=clip, device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n + cuts[h])
+                for h in range(P)]
+        gen = pipelined_segment_generator(pol, envs, HORIZON, stochastic=True)
+    else:
+        env = DPVecEnv(n, motion=clip, device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n)
+        gen = traj_segment_generator(pol, env, HORIZON, stochastic=True)
     segs = max(1, args.steps // HORIZON)
     for _ in range(max(1, args.warmup // HORIZON)):
         add_vtarg_and_adv(next(gen), 0.995, 0.97)
@@ -253,8 +268,8 @@ def rollout_bench(args, dev, rank, world, local_dev):
     if rank == 0:
         print(json.dumps({"metric": "rollout env-steps/sec (policy in the loop + GAE)", "value": round(world * n * segs * HORIZON / el, 1),
                           "unit": "env-steps/s", "n_gpus": world, "steps": segs * HORIZON, "ms_per_step": round(el / (segs * HORIZON) * 1e3, 4),
-                          "episodes": eps, "config": {"workload": "rollout: %d envs/GPU, untrained 2x100 tanh policy, alive reward, noisy-init autoreset, "
-                                                                  "%d-step segments + GAE(0.995, 0.97)" % (n, HORIZON)}}))
+                          "episodes": eps, "config": {"workload": "rollout: %d envs/GPU in %d concurrently stepped batch(es), untrained 2x100 tanh policy, alive reward, "
+                                                                  "noisy-init autoreset, %d-step segments + GAE(0.995, 0.97)" % (n, P, HORIZON)}}))
 
 
 def main():

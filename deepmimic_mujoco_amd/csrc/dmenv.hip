@@ -274,7 +274,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   for (int e2 = 0; e2 < n; e2++) for (int k = 0; k < NQ; k++) q0[(size_t)e2 * NQ + k] = hm.qpos0[k];
   ok = ok && hipMemcpy(b->B.qpos, q0.data(), q0.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { dm_batch_destroy(b); return fail(DM_EHIP, "dm_batch_create: upload failed"); }
-  b->B.mocap_cfg = b->d_cfg; b->B.mocap_vel = b->d_vel; b->B.n_frames = mc->n_frames; b->B.n_envs = n; b->B.env_offset = 0;
+  b->B.mocap_cfg = b->d_cfg; b->B.mocap_vel = b->d_vel; b->B.mocap_dt = mc->dt; b->B.n_frames = mc->n_frames; b->B.n_envs = n; b->B.env_offset = 0;
   b->B.reward_mode = 0; b->B.autoreset = 0; b->B.action_mode = 0; b->B.seed = 0; b->B.diag = 1;
   hipEventCreate(&b->ev0); hipEventCreate(&b->ev1);
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) == hipSuccess && cus > 0) b->resident_waves = cus * 8; }
@@ -295,8 +295,8 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
   if (!b) return fail(DM_EINVAL, "null batch");
   switch (opt) {
     case DM_OPT_REWARD_MODE:
-      if (v < 0 || v > 3) return fail(DM_EINVAL, "reward mode must be 0..3");
-      if (v == 3 && !b->d_imit) return fail(DM_EINVAL, "reward mode 3 needs dm_mocap_set_imitation() before dm_batch_create()");
+      if (v < 0 || v > 4) return fail(DM_EINVAL, "reward mode must be 0..4");
+      if (v >= 3 && !b->d_imit) return fail(DM_EINVAL, "reward modes 3 and 4 need dm_mocap_set_imitation() before dm_batch_create()");
       b->B.reward_mode = (int)v; break;
     case DM_OPT_AUTORESET: if (v < 0 || v > 2) return fail(DM_EINVAL, "autoreset must be 0..2"); b->B.autoreset = (int)v; break;
     case DM_OPT_ACTION_MODE: if (v < 0 || v > 2) return fail(DM_EINVAL, "action mode must be 0..2"); b->B.action_mode = (int)v; break;

@@ -40,7 +40,7 @@ DM_CONSTANT Topo TOPO = make_topo();
 #define DM_MINVAL 1e-15
 
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_BOX = 6 };
-enum { REW_ALIVE = 0, REW_V3_CONFIG = 1, REW_V2_POSE = 2, REW_IMITATION = 3 };
+enum { REW_ALIVE = 0, REW_V3_CONFIG = 1, REW_V2_POSE = 2, REW_IMITATION = 3, REW_V1_QUAT = 4 };
 constexpr int IMIT_FEAT = 112;   // doubles per reference feature row (deepmimic_mujoco_amd/imitation.py)
 enum { ROW_NONE = 0, ROW_LIMIT = 1, ROW_CONTACT = 2 };
 

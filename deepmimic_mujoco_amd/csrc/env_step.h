@@ -33,6 +33,7 @@ struct Batch {
   const R* imit_table; // [F,112] reference feature rows of the 5-term imitation reward (nullptr: not provided)
   const R* imit_pdev;  // the same 32 parameters in device memory (the reward indexes them per lane)
   R imit_params[32];   // joint weights [12], root weight, cycle shift x y, loop flag, end-effector bodies [4], offsets [4][3]
+  R mocap_dt;          // duration of a mocap frame (MocapDM.dt): dp_env_v1's update interval (reward mode 4)
   int n_frames;
   int n_envs;
   int env_offset;      // global id of env 0 of this shard (multi-GPU: RNG streams do not depend on the sharding)
@@ -164,11 +165,11 @@ DM_DEV void store_state(const Batch<R>& B, Shared<R>& s, int env, int lane) {
 
 // DPEnv.reference_state_init for one env: `idx` is the drawn mocap frame.  dp_env_v3 (src/dp_env_v3.py:67-71) starts its frame
 // cursor AT the drawn frame; dp_env_v2 (src/dp_env_v2.py:68-70) keeps the draw in idx_init and counts steps from 0 in idx_curr
-// (its target frame is (idx_curr + idx_init) % F, :128-129).
+// (its target frame is (idx_curr + idx_init) % F, :128-129); dp_env_v1 does the same (src/dp_env_v1.py:58-60,94-96).
 template <class R>
 DM_DEV void set_frame(const Batch<R>& B, int env, int idx) {
   B.frame_init[env] = idx;
-  B.frame_idx[env] = B.reward_mode == REW_V2_POSE ? 0 : idx;
+  B.frame_idx[env] = (B.reward_mode == REW_V2_POSE || B.reward_mode == REW_V1_QUAT) ? 0 : idx;
   B.cycle[env] = 0;
 }
 
@@ -293,6 +294,53 @@ DM_DEV R imitation_reward(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s,
   return dmw::wave_sum(term);
 }
 
+// ---- dp_env_v1's reward (src/dp_env_v1.py:82-141) on the hinge-triple model, from the same features as the 5-term reward ------------
+//   err_pose = sum_j JOINT_WEIGHT_j |rotation angle of q_sim^* q_ref|   (MujocoInterface.calc_config_errs, mujoco_interface.py:169-190;
+//              |angle difference| for the 1-hinge joints; un-normalised weights = P[g] / P[12])
+//   err_vel  = L1 distance of the angular rates (root, joints) from the clip's rates frame k -> k + 1 (row `refv`)       (:205-210)
+//   err_root = L1 distance of the root positions                                                                          (:192-199)
+//   r = 0.5 e^(-2 err_pose) + 0.05 e^(-0.1 err_vel) + 0.2 e^(-5 err_root)
+// Lane = body - 1 as in imitation_reward (lane 0 root, lanes 1..12 joint groups); one acos per lane, three exps on three lanes.
+template <class R>
+DM_DEV R v1_reward(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int lane, const LaneTopo& lt, const R* ref, const R* refv) {
+  R qloc[4], aloc[3][3];
+  stage_kinematics(M, s, lane, lt, qloc, aloc);          // ends with a sync
+  const R* P = B.imit_pdev;
+  R pose = 0, vel = 0, root = 0;
+  if (lane < 13) {
+    const int g = lane - 1;
+    const int da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum);
+    const bool isroot = lane == 0, ball = !isroot && nd == 3;
+    R rq[4] = {s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
+    normalize4(rq);
+    const R* rquat = ref + (isroot ? 3 : 13 + 4 * g);
+    const R ident[4] = {1, 0, 0, 0};
+    R q0[4], q1[4];
+    for (int k = 0; k < 4; k++) { q0[k] = isroot ? rq[k] : (ball ? qloc[k] : ident[k]); q1[k] = (isroot || ball) ? rquat[k] : ident[k]; }
+    R pe = fabs(quat_diff_theta(q0, q1)), ve = 0;
+    if (isroot) {
+      R wv[3];
+      const R wloc[3] = {s.qvel[3], s.qvel[4], s.qvel[5]};
+      quat_rot(wv, rq, wloc);
+      for (int k = 0; k < 3; k++) { ve += fabs(refv[10 + k] - wv[k]); root += fabs(s.qpos[k] - ref[k]); }
+    } else if (ball) {
+      R wl[3] = {0, 0, 0};
+      for (int k = 0; k < 3; k++) { const R rate = s.qvel[da + k]; wl[0] += aloc[k][0] * rate; wl[1] += aloc[k][1] * rate; wl[2] += aloc[k][2] * rate; }
+      for (int k = 0; k < 3; k++) ve += fabs(refv[61 + 3 * g + k] - wl[k]);
+    } else {
+      pe = fabs(ref[13 + 4 * g] - s.qpos[da + 1]);
+      ve = fabs(refv[61 + 3 * g] - s.qvel[da]) + fabs(refv[61 + 3 * g + 1]) + fabs(refv[61 + 3 * g + 2]);   // (the two unused slots of the row are 0)
+    }
+    pose = (isroot ? R(1) : P[g] / P[12]) * pe; vel = ve;
+  }
+  pose = dmw::wave_sum(pose); vel = dmw::wave_sum(vel); root = dmw::bcast(root, 0);
+  const R arg = lane == 0 ? R(-2) * pose : lane == 1 ? R(-0.1) * vel : R(-5) * root;
+  const R wgt = lane == 0 ? R(0.5) : lane == 1 ? R(0.05) : R(0.2);
+  R term = 0;
+  if (lane < 3) term = wgt * exp_once(arg);
+  return dmw::wave_sum(term);
+}
+
 // DPEnv.step for one environment
 // ROWS = columns of A = J M^-1 J^T + R that this instantiation keeps in registers; an evaluation with more constraint rows
 // (up to MAXEFC) keeps the remaining columns in the env's global-memory strip s.aovf (see stage_constraint).
@@ -336,6 +384,21 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     dn = dn || ended;                            // a "Loop: none" clip holds its last frame and ends the episode there
     dmw::sync_mem();
     if (lane == 0) { B.frame_idx[env] = k; B.cycle[env] = cyc; }
+  }
+  else if (B.reward_mode == REW_V1_QUAT) {     // src/dp_env_v1.py:82-158: cursor counts steps, reward every `upd` steps, minus the control cost
+    const int idx = dmw::uniform(B.frame_idx[env]) + 1;
+    int upd = (int)floor(B.mocap_dt / (M.timestep * n_substeps));
+    if (upd < 1) upd = 1;
+    R robs = 0;
+    if (idx % upd == 0) {
+      const int k = (idx / upd + dmw::uniform(B.frame_init[env])) % B.n_frames, kv = k + 1 < B.n_frames ? k + 1 : B.n_frames - 1;
+      robs = v1_reward(M, B, s, lane, lt, B.imit_table + (size_t)k * IMIT_FEAT, B.imit_table + (size_t)kv * IMIT_FEAT);
+    }
+    R acs = 0;
+    for (int u = 0; u < NU; u++) { const R c = B.ctrl[(size_t)env * NU + u]; acs += c * c; }
+    rew = robs - R(0.1) * acs;
+    dmw::sync_mem();
+    if (lane == 0) B.frame_idx[env] = idx;
   }
   if (lane == 0) { B.time[env] += M.timestep * n_substeps; reward[env] = rew; done[env] = dn ? 1 : 0; }
   if (dn && B.autoreset) {                        // DummyVecEnv convention: obs of the fresh episode is returned

@@ -32,7 +32,7 @@ from .mocap import MocapDM
 from .model import CompiledModel
 from .spaces import Box
 
-REWARD_MODES = {"alive": 0, "v3-config": 1, "v2-pose": 2, "imitation": 3}
+REWARD_MODES = {"alive": 0, "v3-config": 1, "v2-pose": 2, "imitation": 3, "v1-quat": 4}
 
 
 def _load_model(xml_path=None, explicit=True):
@@ -175,7 +175,7 @@ class DPEnv(object):
         self.idx_init = random.randint(0, self.mocap_data_len - 1)
         # dp_env_v3 starts its frame cursor at the draw (src/dp_env_v3.py:67-71); dp_env_v2 counts steps from 0 and adds idx_init
         # when it looks the target frame up (src/dp_env_v2.py:68-70,128-129)
-        self.idx_curr = 0 if self._reward_mode == REWARD_MODES["v2-pose"] else self.idx_init
+        self.idx_curr = 0 if self._reward_mode in (REWARD_MODES["v2-pose"], REWARD_MODES["v1-quat"]) else self.idx_init
         self.idx_tmp_count = 0
 
     def early_termination(self):
@@ -276,7 +276,7 @@ class DPVecEnv(object):
                           "%.4f s; use frame_skip='mocap' (= %d) to play it in sim time"
                           % (self.frame_skip, float(self.mocap_dt), self.frame_skip * float(self._cm.timestep), per_frame))
         imit = None
-        if reward == "imitation":
+        if reward in ("imitation", "v1-quat"):
             from .imitation import ImitationSpec
             self.imitation = ImitationSpec(self._cm)
             imit = self.imitation.table_for(self.mocap)

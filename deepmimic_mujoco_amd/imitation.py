@@ -157,6 +157,35 @@ class ImitationSpec:
         w = TERM_W / TERM_W.sum()
         return float((w * np.exp(-TERM_SCALE * self.reward_terms(f0, f1, root_shift))).sum())
 
+    def v1_reward_terms(self, f0, f1, f1v):
+        """(err_pose, err_vel, err_root) of `dp_env_v1.calc_reward` (src/dp_env_v1.py:82-141) on this model's features:
+        err_pose = `MujocoInterface.calc_config_errs` (src/mujoco/mujoco_interface.py:169-190): sum over the root and the 12 joints
+        of JOINT_WEIGHT (mocap_util.py:26-29, un-normalised; = w / w_root here) x |rotation angle of q_sim^* q_ref| (|angle
+        difference| for the 1-hinge joints); err_vel = `calc_vel_errs` (:205-210): L1 distance between the simulated angular rates
+        (root, then joints) and the clip's rates from frame k to k + 1 (`f1v` = the feature row that carries them: row k + 1, or the
+        last row); err_root = `calc_root_errs` (:192-199): L1 distance of the root positions (no cycle shift: v1 wraps the frame
+        index only).  The v1 environment's own model has ball joints and a 43-number quaternion pose; this is the same reward on the
+        hinge-triple model of dp_env_v3 (child-in-parent rotations composed from the triples)."""
+        wr = self.w_root
+        th_root = quat_diff_theta(f0[O_RQUAT:O_RQUAT + 4], f1[O_RQUAT:O_RQUAT + 4])
+        err_pose = abs(th_root)
+        err_vel = np.abs(f1v[O_RANG:O_RANG + 3] - f0[O_RANG:O_RANG + 3]).sum()
+        for g, b in enumerate(self.bodies):
+            if self.cm.body_dofnum[b] == 1:
+                pe = abs(f1[O_JQ + 4 * g] - f0[O_JQ + 4 * g])
+            else:
+                pe = abs(quat_diff_theta(f0[O_JQ + 4 * g:O_JQ + 4 * g + 4], f1[O_JQ + 4 * g:O_JQ + 4 * g + 4]))
+            err_pose += self.w_joint[g] / wr * pe
+            err_vel += np.abs(f1v[O_JW + 3 * g:O_JW + 3 * g + 3] - f0[O_JW + 3 * g:O_JW + 3 * g + 3]).sum()
+        err_root = np.abs(f0[O_RPOS:O_RPOS + 3] - f1[O_RPOS:O_RPOS + 3]).sum()
+        return np.array([err_pose, err_vel, err_root])
+
+    def v1_reward(self, f0, f1, f1v, ctrl=None):
+        """0.5 e^(-2 err_pose) + 0.05 e^(-0.1 err_vel) + 0.2 e^(-5 err_root) [- 0.1 sum ctrl^2]   (src/dp_env_v1.py:42-53,130-139,147-150)"""
+        e = self.v1_reward_terms(f0, f1, f1v)
+        r = 0.5 * np.exp(-2.0 * e[0]) + 0.05 * np.exp(-0.1 * e[1]) + 0.2 * np.exp(-5.0 * e[2])
+        return float(r - (0.1 * np.square(ctrl).sum() if ctrl is not None else 0.0))
+
     def reference_qvel(self, data_config, dura, loop="none"):
         """[F, 34] generalized velocity of the clip with the signs a tracking character must reproduce.
 

@@ -135,6 +135,25 @@ class MlpPolicy:
     def save_npz(self, path):
         np.savez(path, **self.state_dict())
 
+    def save_tf_checkpoint(self, prefix, old=None):
+        """Write the policy as the `tf.train.Saver` bundle the reference saves (src/trpo.py:220-224) and restores
+        (`U.load_state`, src/utils/tf_util.py:314-319; `--task evaluate`, src/trpo.py:367): variables `pi/...` and `oldpi/...`
+        (the learner's two MlpPolicy scopes, :128-129) with the reference's names, dtypes and shapes — float32 weights, `logstd`
+        [1, ac], float64 filter sums, scalar count.  `old`: state dict for the `oldpi` scope (default: a copy of `pi`, which is
+        what `assign_old_eq_new` leaves behind at every update, :247)."""
+        from .tf_checkpoint import save_checkpoint
+        def cast(d):
+            out = {}
+            for k, v in d.items():
+                v = np.asarray(v)
+                out[k] = v.astype(np.float64) if k.startswith("obfilter/") else v.astype(np.float32)
+            out["obfilter/count"] = np.asarray(out["obfilter/count"], dtype=np.float64).reshape(())
+            return out
+        cur = cast(self.state_dict()); prev = cast(old) if old is not None else cur
+        tensors = {"pi/" + k: v for k, v in cur.items()}
+        tensors.update({"oldpi/" + k: v for k, v in prev.items()})
+        return save_checkpoint(prefix, tensors)
+
     # ---- forward ----------------------------------------------------------------------------------------------------
     def _obz(self, ob):
         ob = ob.to(torch.float32)

@@ -88,54 +88,69 @@ def add_vtarg_and_adv(seg, gamma, lam):
     return seg
 
 
-def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first_reset="rsi"):
-    """Batched `traj_segment_generator` (src/trpo.py:27-80): N envs advance in lock step on the device.
+class SegmentCollector(object):
+    """One env batch's side of `traj_segment_generator`, split into `launch()` (enqueue T policy + env steps, no host wait) and
+    `collect()` (episode bookkeeping, the one host transfer per segment) so that several env batches can be in flight at once.
+    With `stream` (a torch CUDA stream) everything this collector enqueues runs on that stream."""
 
-    pi: policy.MlpPolicy; env: DPVecEnv created with autoreset="init" — the kernel then applies, on `done`, exactly what
-    the reference does on the host (`env.reset(); ob = env.env.reset_model_init()`, :77-79) and returns the fresh
-    episode's observation.  Yields, every `horizon` steps, the reference's segment dict with a leading [T, N] shape:
-    ob [T,N,56] f32, ac / prevac [T,N,28] f32, rew / vpred [T,N] f32, new [T,N] int32 (new[t] = ob[t] starts an episode),
-    nextvpred [N], ep_rets / ep_lens (lists of finished episodes, host numbers — the only host transfer, once per segment).
+    def __init__(self, pi, env, horizon, stochastic=True, device=None, first_reset="rsi", stream=None):
+        import torch
+        self.pi, self.env, self.T, self.stochastic, self.stream = pi, env, int(horizon), stochastic, stream
+        n, T = env.num_envs, self.T
+        self.n = n
+        device = torch.device(pi.device if device is None else device)
+        self.device = device
+        f32, f64 = torch.float32, torch.float64
+        self.ob64 = torch.zeros((T + 1, n, 56), dtype=f64, device=device)         # row t: observation the policy sees at step t
+        self.ac64 = torch.zeros((T, n, 28), dtype=f64, device=device)
+        self.rew64 = torch.zeros((T, n), dtype=f64, device=device)
+        self.done8 = torch.zeros((T, n), dtype=torch.uint8, device=device)
+        self.vpreds = torch.zeros((T + 1, n), dtype=f32, device=device)
+        self.first = torch.ones(n, dtype=torch.int32, device=device)               # `new` of row 0: carried over from the last segment
+        self.last_ac = torch.zeros((n, 28), dtype=f32, device=device)              # prevac of row 0 (trpo.py:29 samples a random one)
+        self.cur_ret = torch.zeros(n, dtype=f64, device=device)                    # running return / length of the open episodes
+        self.cur_len = torch.zeros(n, dtype=torch.int64, device=device)
+        self.as_buf = (lambda x: x) if device.type == "cuda" else (lambda x: x.numpy())   # host tensors: shared-memory views
+        self.step_idx = torch.arange(1, T + 1, device=device, dtype=torch.int64)[:, None]
+        with self._on_stream():
+            env.reset(first_reset, out=self.as_buf(self.ob64[0]))                  # trpo.py:32 `ob = env.reset()` (RSI); later episodes: noisy init
 
-    Per step the loop issues only the policy forward and ONE env launch: the policy writes its action and value straight
-    into row t of the segment buffers, and `dm_batch_step` reads that action row and writes the next observation, the
-    reward and the done flag straight into rows t+1 / t / t of theirs (float64, as the C ABI produces them).  The float32
-    segment views, `new`, `prevac` and the episode statistics are derived once per segment with [T, N]-wide ops.
-    Nothing leaves the device or the stream."""
-    import torch
-    n, T = env.num_envs, int(horizon)
-    if device is None:
-        device = pi.device
-    device = torch.device(device)
-    f32, f64 = torch.float32, torch.float64
-    ob64 = torch.zeros((T + 1, n, 56), dtype=f64, device=device)         # row t: observation the policy sees at step t
-    ac64 = torch.zeros((T, n, 28), dtype=f64, device=device)
-    rew64 = torch.zeros((T, n), dtype=f64, device=device)
-    done8 = torch.zeros((T, n), dtype=torch.uint8, device=device)
-    vpreds = torch.zeros((T + 1, n), dtype=f32, device=device)
-    first = torch.ones(n, dtype=torch.int32, device=device)               # `new` of row 0: carried over from the last segment
-    last_ac = torch.zeros((n, 28), dtype=f32, device=device)              # prevac of row 0 (trpo.py:29 samples a random one)
-    cur_ret = torch.zeros(n, dtype=f64, device=device)                    # running return / length of the open episodes
-    cur_len = torch.zeros(n, dtype=torch.int64, device=device)
-    as_buf = (lambda x: x) if device.type == "cuda" else (lambda x: x.numpy())   # host tensors: shared-memory views
-    env.reset(first_reset, out=as_buf(ob64[0]))                           # trpo.py:32 `ob = env.reset()` (RSI); later episodes: noisy init
-    step_idx = torch.arange(1, T + 1, device=device, dtype=torch.int64)[:, None]
-    while True:
-        with torch.no_grad():                                              # (the learner may hold the parameters with requires_grad)
+    def _on_stream(self):
+        import contextlib
+        import torch
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def launch(self):
+        import torch
+        pi, env, T, as_buf = self.pi, self.env, self.T, self.as_buf
+        ob64, ac64, rew64, done8, vpreds = self.ob64, self.ac64, self.rew64, self.done8, self.vpreds
+        fs = getattr(env, "frame_skip", 1)
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))         # parameters / filter updated by the learner are visible
+        with self._on_stream(), torch.no_grad():                                    # (the learner may hold the parameters with requires_grad)
             for t in range(T):
-                pi.act(stochastic, ob64[t], out=ac64[t], vpred_out=vpreds[t])                       # :49
-                env.batch.step(as_buf(ac64[t]), getattr(env, "frame_skip", 1), (as_buf(ob64[t + 1]), as_buf(rew64[t]), as_buf(done8[t])))   # :66, one launch
-            vpreds[T] = pi.forward(ob64[T])[1]                             # value of the observation after the segment (:49-52);
+                pi.act(self.stochastic, ob64[t], out=ac64[t], vpred_out=vpreds[t])                       # :49
+                env.batch.step(as_buf(ac64[t]), fs, (as_buf(ob64[t + 1]), as_buf(rew64[t]), as_buf(done8[t])))   # :66, one launch
+            vpreds[T] = pi.forward(ob64[T])[1]                                      # value of the observation after the segment (:49-52);
         # the action for it is sampled at the top of the next segment, i.e. from the policy as updated in between
+
+    def collect(self):
+        import torch
+        T, n, device = self.T, self.n, self.device
+        f32 = torch.float32
+        if self.stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        ob64, ac64, rew64, done8, vpreds = self.ob64, self.ac64, self.rew64, self.done8, self.vpreds
         done = done8.to(torch.bool)
-        new = torch.cat([first[None], done8[:-1].to(torch.int32)], 0)
+        new = torch.cat([self.first[None], done8[:-1].to(torch.int32)], 0)
         acs = ac64.to(f32)
-        prevacs = torch.cat([last_ac[None], acs[:-1]], 0)
+        prevacs = torch.cat([self.last_ac[None], acs[:-1]], 0)
         # episode statistics: return / length of every episode that ended inside the segment, in time-major order
         # (= the order in which a single-env loop would have appended them, :72-76)
         csum = torch.cumsum(rew64, 0)
         ends = done.nonzero()                                              # [K, 2] (t, env), sorted by t then env
         ep_rets, ep_lens = [], []
+        cur_ret, cur_len = self.cur_ret, self.cur_len
         if ends.numel():
             te, ee = ends[:, 0], ends[:, 1]
             # previous end of the same env inside the segment (or -1): sort by (env, t) and shift
@@ -152,15 +167,63 @@ def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first
             inv = torch.empty_like(order); inv[order] = torch.arange(order.numel(), device=device)
             ep_rets = seg_ret[inv].tolist(); ep_lens = seg_len[inv].tolist()
         # carry the open episodes into the next segment
-        last_end = torch.where(done, step_idx.expand(T, n), torch.zeros((T, n), dtype=torch.int64, device=device)).amax(0)   # 1-based
+        last_end = torch.where(done, self.step_idx.expand(T, n), torch.zeros((T, n), dtype=torch.int64, device=device)).amax(0)   # 1-based
         tail_ret = csum[-1] - torch.where(last_end > 0, csum[(last_end - 1).clamp(min=0), torch.arange(n, device=device)], torch.zeros_like(csum[-1]))
-        cur_ret = torch.where(last_end > 0, tail_ret, cur_ret + tail_ret)
-        cur_len = torch.where(last_end > 0, T - last_end, cur_len + T)
-        yield {"ob": ob64[:T].to(f32), "rew": rew64.to(f32), "vpred": vpreds[:T].clone(), "new": new, "ac": acs, "prevac": prevacs,
+        self.cur_ret = torch.where(last_end > 0, tail_ret, cur_ret + tail_ret)
+        self.cur_len = torch.where(last_end > 0, T - last_end, cur_len + T)
+        seg = {"ob": ob64[:T].to(f32), "rew": rew64.to(f32), "vpred": vpreds[:T].clone(), "new": new, "ac": acs, "prevac": prevacs,
                "nextvpred": vpreds[T] * (1 - done8[-1].to(f32)), "ep_rets": ep_rets, "ep_lens": ep_lens}
-        first = done8[-1].to(torch.int32)
-        last_ac = acs[-1].clone()
+        self.first = done8[-1].to(torch.int32)
+        self.last_ac = acs[-1].clone()
         ob64[0].copy_(ob64[T])
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))   # the copies above are ordered before the next launch
+        return seg
+
+
+def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first_reset="rsi"):
+    """Batched `traj_segment_generator` (src/trpo.py:27-80): N envs advance in lock step on the device.
+
+    pi: policy.MlpPolicy; env: DPVecEnv created with autoreset="init" — the kernel then applies, on `done`, exactly what
+    the reference does on the host (`env.reset(); ob = env.env.reset_model_init()`, :77-79) and returns the fresh
+    episode's observation.  Yields, every `horizon` steps, the reference's segment dict with a leading [T, N] shape:
+    ob [T,N,56] f32, ac / prevac [T,N,28] f32, rew / vpred [T,N] f32, new [T,N] int32 (new[t] = ob[t] starts an episode),
+    nextvpred [N], ep_rets / ep_lens (lists of finished episodes, host numbers — the only host transfer, once per segment).
+
+    Per step the loop issues only the policy forward and ONE env launch: the policy writes its action and value straight
+    into row t of the segment buffers, and `dm_batch_step` reads that action row and writes the next observation, the
+    reward and the done flag straight into rows t+1 / t / t of theirs (float64, as the C ABI produces them).  The float32
+    segment views, `new`, `prevac` and the episode statistics are derived once per segment with [T, N]-wide ops.
+    Nothing leaves the device or the stream."""
+    c = SegmentCollector(pi, env, horizon, stochastic, device, first_reset)
+    while True:
+        c.launch()
+        yield c.collect()
+
+
+def pipelined_segment_generator(pi, envs, horizon, stochastic=True, first_reset="rsi"):
+    """The same segments from SEVERAL env batches (e.g. two halves of a GPU's envs) stepped concurrently, each on its own CUDA
+    stream: the whole T-step chain of every batch (policy forward -> env step -> policy forward ...) is enqueued without a host
+    wait, so while one batch's env kernel drains its last, cheap workgroups the other batch's policy / env kernels fill the freed
+    wave slots — the overlap `DM_OPT_PIPELINE` gives open-loop stepping, for the closed loop.  Yields one segment dict whose env
+    axis is the concatenation of the batches (episode lists concatenated in batch order)."""
+    import torch
+    cols = [SegmentCollector(pi, e, horizon, stochastic, None, first_reset, stream=torch.cuda.Stream(device=pi.device)) for e in envs]
+    while True:
+        if getattr(pi, "_dirty", False) or getattr(pi, "_packed", None) is None:
+            pi.pack()                                  # once, on the current stream, before the side streams fork from it
+        for c in cols:
+            c.launch()
+        segs = [c.collect() for c in cols]
+        out = {}
+        for k in segs[0]:
+            if k in ("ep_rets", "ep_lens"):
+                out[k] = [x for sg in segs for x in sg[k]]
+            elif k == "nextvpred":
+                out[k] = torch.cat([sg[k] for sg in segs], 0)
+            else:
+                out[k] = torch.cat([sg[k] for sg in segs], 1)
+        yield out
 
 
 def flatten_segment(seg):

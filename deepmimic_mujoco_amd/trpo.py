@@ -27,7 +27,7 @@ from collections import deque
 
 import torch
 
-from .rollout import add_vtarg_and_adv, flatten_segment, traj_segment_generator
+from .rollout import add_vtarg_and_adv, flatten_segment, traj_segment_generator, pipelined_segment_generator
 
 POL_KEYS = ("polfc1/w", "polfc1/b", "polfc2/w", "polfc2/b", "polfinal/w", "polfinal/b", "logstd")   # var_list   (:139)
 VF_KEYS = ("vffc1/w", "vffc1/b", "vffc2/w", "vffc2/b", "vffinal/w", "vffinal/b")                     # vf_var_list (:140)
@@ -288,7 +288,7 @@ class TrpoLearner:
 
 def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max_seconds=0, callback=None, log=print,
           group=None, log_dir=None, **learner_kwargs):
-    """`learn()` of src/trpo.py:97-319 over a DPVecEnv (autoreset="init") and an MlpPolicy.  Stops after `max_iters`
+    """`learn()` of src/trpo.py:97-319 over a DPVecEnv (autoreset="init"; or a list of them: pipelined rollouts) and an MlpPolicy.  Stops after `max_iters`
     iterations, `max_timesteps` env steps (global) or `max_seconds`.  Returns the list of per-iteration stat dicts, with
     the reference's log keys (EpLenMean / EpRewMean over the last 40 episodes, EpThisIter, EpisodesSoFar, TimestepsSoFar,
     TimeElapsed, entropy, meankl, optimgain, surrgain, ev_tdlam_before).  With `log_dir`, rank 0 also writes the reference's
@@ -297,7 +297,12 @@ def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max
     import torch.distributed as dist
     assert sum([max_iters > 0, max_timesteps > 0, max_seconds > 0]) >= 1
     learner = TrpoLearner(pi, group=group, **learner_kwargs)
-    seg_gen = traj_segment_generator(pi, env, timesteps_per_batch, stochastic=True)
+    if isinstance(env, (list, tuple)):          # several env batches of this rank, stepped concurrently on their own streams
+        seg_gen = pipelined_segment_generator(pi, list(env), timesteps_per_batch, stochastic=True)
+        n_envs_local = sum(e.num_envs for e in env)
+    else:
+        seg_gen = traj_segment_generator(pi, env, timesteps_per_batch, stochastic=True)
+        n_envs_local = env.num_envs
     world = _world(group)
     rank = dist.get_rank(group) if world > 1 else 0
     episodes_so_far = timesteps_so_far = iters_so_far = 0
@@ -335,7 +340,7 @@ def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max
         if world > 1:                                            # :300-302 allgather of (ep_lens, ep_rets): the sums suffice here
             dist.all_reduce(n_eps, group=group)
         lenbuffer.extend(lens[-40:]); rewbuffer.extend(rets[-40:])
-        episodes_so_far += int(n_eps[0]); timesteps_so_far += timesteps_per_batch * env.num_envs * world
+        episodes_so_far += int(n_eps[0]); timesteps_so_far += timesteps_per_batch * n_envs_local * world
         iters_so_far += 1
         stats.update(EpLenMean=float(sum(lenbuffer) / max(1, len(lenbuffer))), EpRewMean=float(sum(rewbuffer) / max(1, len(rewbuffer))),
                      EpLenMeanIter=float(n_eps[1] / max(1.0, float(n_eps[0]))), EpThisIter=int(n_eps[0]), EpisodesSoFar=episodes_so_far,

@@ -108,7 +108,10 @@ int dm_batch_set_stream(dm_batch* b, void* hip_stream); /* default: a stream own
 /* options */
 enum {
   DM_OPT_REWARD_MODE = 1, /* 0 alive=1.0 (dp_env_v3.py:117-128, default), 1 v3-config (:89-104), 2 v2-pose (dp_env_v2.py:116-183),
-                             3 imitation: pose/velocity/end-effector/root/COM terms of code.md:1017-1143 against frame idx+1 */
+                             3 imitation: pose/velocity/end-effector/root/COM terms of code.md:1017-1143 against frame idx+1,
+                             4 v1-quat: dp_env_v1's reward (dp_env_v1.py:82-158: JOINT_WEIGHT-ed |quaternion difference angle| pose error,
+                               L1 angular-rate and root errors, every int(mocap_dt // dt) steps, minus 0.1 sum ctrl^2) on this model's
+                               hinge triples; modes 3 and 4 need dm_mocap_set_imitation() */
   DM_OPT_AUTORESET = 2,   /* 0 off (default), 1 RSI on done, 2 noisy-init on done (DummyVecEnv convention) */
   DM_OPT_ACTION_MODE = 3, /* 0 raw ctrl (dp_env_v3.py:112, default), 1 P-control 0.8*(mocap_cfg - q) + action (env_torque_test.py:20),
                              2 PD kp*(mocap_cfg - q) + kd*(mocap_vel - v) + action (setting_states.py:207-226, gains mocap_util.py:22-24) */

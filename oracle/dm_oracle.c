@@ -1158,6 +1158,41 @@ double dmo_imitation_reward(const dmo_model* m, const double* f0, const double* 
   for (int k = 0; k < 5; k++) { if (terms) terms[k] = e[k]; r += w[k] * exp(-sc[k] * e[k]); }
   return r;
 }
+/* dp_env_v1's reward (src/dp_env_v1.py:82-141) on the feature rows: weighted |quaternion-difference angle| pose error (JOINT_WEIGHT
+ * un-normalised = params[g] / params[12]), L1 angular-rate error against the rates of row f1v, L1 root position error. */
+double dmo_v1_reward(const dmo_model* m, const double* f0, const double* f1, const double* f1v, const double* params, double* terms) {
+  double pose = fabs(quat_diff_theta(f0 + 3, f1 + 3)), vel = 0, root = 0;
+  for (int k = 0; k < 3; k++) { vel += fabs(f1v[10 + k] - f0[10 + k]); root += fabs(f0[k] - f1[k]); }
+  for (int g = 0; g < 12; g++) {
+    double pe = m->body_jntnum[g + 2] == 1 ? fabs(f1[13 + 4 * g] - f0[13 + 4 * g]) : fabs(quat_diff_theta(f0 + 13 + 4 * g, f1 + 13 + 4 * g));
+    pose += params[g] / params[12] * pe;
+    for (int k = 0; k < 3; k++) vel += fabs(f1v[61 + 3 * g + k] - f0[61 + 3 * g + k]);
+  }
+  if (terms) { terms[0] = pose; terms[1] = vel; terms[2] = root; }
+  return 0.5 * exp(-2.0 * pose) + 0.05 * exp(-0.1 * vel) + 0.2 * exp(-5.0 * root);
+}
+/* one env step with dp_env_v1's reward and cursor (src/dp_env_v1.py:143-158,88-96): idx_curr counts steps; the reward is
+ * evaluated when idx_curr is a multiple of update_interval = int(mocap_dt // dt) (else 0), against frame (idx_curr // interval +
+ * idx_init) % F, rates from the following frame; minus 0.1 sum ctrl^2. */
+void dmo_env_step_v1(const dmo_model* m, dmo_data* d, const double* action, int n_substeps, const double* table, int F,
+                     const double* params, double mocap_dt, int* idx_curr, int idx_init, double* obs, double* reward, int* done) {
+  double acs = 0;
+  for (int u = 0; u < m->s.nu; u++) { d->ctrl[u] = action[u]; acs += action[u] * action[u]; }
+  for (int k = 0; k < n_substeps; k++) dmo_step(m, d);
+  dmo_get_obs(m, d, obs);
+  *idx_curr += 1;
+  int upd = (int)floor(mocap_dt / (m->s.timestep * n_substeps));
+  if (upd < 1) upd = 1;
+  double robs = 0;
+  if (*idx_curr % upd == 0) {
+    const int k = (*idx_curr / upd + idx_init) % F, kv = k + 1 < F ? k + 1 : F - 1;
+    double f0[DMO_FEAT];
+    dmo_imitation_features(m, d->qpos, d->qvel, params, f0);
+    robs = dmo_v1_reward(m, f0, table + (size_t)k * DMO_FEAT, table + (size_t)kv * DMO_FEAT, params, 0);
+  }
+  *reward = robs - 0.1 * acs;
+  *done = dmo_is_done(m, d);
+}
 /* one env step in imitation mode: the state after the step is compared with frame idx_curr + 1 (wrapping clips add the
  * cycle shift per completed cycle; "Loop: none" clips hold the last frame and end the episode there). */
 void dmo_env_step_imitation(const dmo_model* m, dmo_data* d, const double* action, int n_substeps, const double* table, int F,
@@ -1202,6 +1237,57 @@ void dmo_batch_step_imitation(const dmo_model* m, dmo_data** ds, int n, const do
                            obs + (size_t)e * 56, reward + e, &dn);
     done[e] = (unsigned char)dn;
   }
+}
+
+/* bench.py's cpu_baseline, entirely in C: every env runs `steps` env-steps of the benchmark's workload — actions ~ N(0, sigma^2)
+ * from a per-env xorshift64* stream (Box-Muller), the 5-term imitation reward when `table` is given (else the alive reward), RSI
+ * reset to a uniformly drawn mocap frame on done.  Envs are independent, so OpenMP runs whole trajectories per thread (no
+ * per-step barrier, nothing serial): the figure is the host's, not the harness'.  Returns the number of env-steps done;
+ * *n_done = episodes ended, *reward_sum = sum of rewards (keeps the loop observable). */
+static inline unsigned long long xs64(unsigned long long* s) {
+  unsigned long long x = *s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; *s = x; return x * 0x2545F4914F6CDD1DULL;
+}
+static inline double xs_uniform(unsigned long long* s) { return (double)(xs64(s) >> 11) * (1.0 / 9007199254740992.0); }
+long dmo_bench_rollout(const dmo_model* m, dmo_data** ds, int n, int steps, const double* cfg, const double* vel, int F, const double* table,
+                       const double* params, double sigma, unsigned long long seed, int nthreads, long* n_done, double* reward_sum) {
+  const int nu = m->s.nu, nq = m->nq, nv = m->nv;
+  long total = 0, dones = 0;
+  double rsum = 0;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : total, dones, rsum)
+#endif
+  for (int e = 0; e < n; e++) {
+    unsigned long long st = seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(e + 1) * 0xD1B54A32D192ED03ULL;
+    if (!st) st = 1;
+    dmo_data* d = ds[e];
+    int idx = (int)(xs_uniform(&st) * F), cyc = 0;
+    if (idx >= F) idx = F - 1;
+    dmo_reset_data(m, d);
+    dmo_set_state(m, d, cfg + (size_t)idx * nq, vel + (size_t)idx * nv);
+    double act[DMO_MAXU], obs[64], rew;
+    for (int t = 0; t < steps; t++) {
+      for (int u = 0; u < nu; u += 2) {
+        const double u1 = 1.0 - xs_uniform(&st), u2 = xs_uniform(&st);
+        const double r = sqrt(-2.0 * log(u1)), a = 6.283185307179586 * u2;
+        act[u] = sigma * r * cos(a);
+        if (u + 1 < nu) act[u + 1] = sigma * r * sin(a);
+      }
+      int dn;
+      if (table) dmo_env_step_imitation(m, d, act, 1, table, F, params, &idx, &cyc, obs, &rew, &dn);
+      else { int ic = idx; dmo_env_step(m, d, act, 1, DMO_REW_ALIVE, 0, 1, &ic, 0, obs, &rew, &dn); }
+      rsum += rew; total++;
+      if (dn) {
+        dones++;
+        idx = (int)(xs_uniform(&st) * F); if (idx >= F) idx = F - 1; cyc = 0;
+        dmo_reset_data(m, d);
+        dmo_set_state(m, d, cfg + (size_t)idx * nq, vel + (size_t)idx * nv);
+      }
+    }
+  }
+  if (n_done) *n_done = dones;
+  if (reward_sum) *reward_sum = rsum;
+  return total;
 }
 
 int dmo_sizeof_model(void) { return (int)sizeof(dmo_model); }

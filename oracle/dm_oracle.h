@@ -146,12 +146,18 @@ void dmo_env_step(const dmo_model* m, dmo_data* d, const double* action, int n_s
 void dmo_imitation_features(const dmo_model* m, const double* qpos, const double* qvel, const double* params, double* feat112);
 double dmo_imitation_reward(const dmo_model* m, const double* f0, const double* f1, const double* params, double shift_x,
                             double shift_y, double* terms5);
+double dmo_v1_reward(const dmo_model* m, const double* f0, const double* f1, const double* f1v, const double* params, double* terms);
+void dmo_env_step_v1(const dmo_model* m, dmo_data* d, const double* action, int n_substeps, const double* table, int F,
+                     const double* params, double mocap_dt, int* idx_curr, int idx_init, double* obs, double* reward, int* done);
 void dmo_env_step_imitation(const dmo_model* m, dmo_data* d, const double* action, int n_substeps, const double* table, int F,
                             const double* params, int* idx_curr, int* cycle, double* obs, double* reward, int* done);
 void dmo_batch_step(const dmo_model* m, dmo_data** ds, int n, const double* actions, int n_substeps,
                     double* obs, double* reward, unsigned char* done, int nthreads);
 void dmo_batch_step_imitation(const dmo_model* m, dmo_data** ds, int n, const double* actions, int n_substeps, const double* table, int F,
                               const double* params, int* idx_curr, int* cycle, double* obs, double* reward, unsigned char* done, int nthreads);
+/* bench.py's cpu_baseline loop in C: per-env action streams, RSI reset on done, OpenMP over whole trajectories. */
+long dmo_bench_rollout(const dmo_model* m, dmo_data** ds, int n, int steps, const double* cfg, const double* vel, int F, const double* table,
+                       const double* params, double sigma, unsigned long long seed, int nthreads, long* n_done, double* reward_sum);
 
 /* heap model + string-keyed accessors for the ctypes test harness (oracle/oracle.py) */
 dmo_model* dmo_model_new(const dmo_spec* s);         /* s == NULL -> the dp_env_v3 humanoid */

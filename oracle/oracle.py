@@ -84,6 +84,13 @@ def lib():
                                      C.POINTER(C.c_ubyte), C.c_int]
         L.dmo_batch_step_imitation.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, dp, C.c_int, dp, C.c_int, dp,
                                                C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp, C.POINTER(C.c_ubyte), C.c_int]
+        L.dmo_v1_reward.restype = C.c_double
+        L.dmo_v1_reward.argtypes = [C.c_void_p, dp, dp, dp, dp, dp]
+        L.dmo_env_step_v1.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_int, dp, C.c_int, dp, C.c_double, C.POINTER(C.c_int), C.c_int, dp, dp,
+                                      C.POINTER(C.c_int)]
+        L.dmo_bench_rollout.restype = C.c_long
+        L.dmo_bench_rollout.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, C.c_double, C.c_ulonglong,
+                                        C.c_int, C.POINTER(C.c_long), dp]
         _LIB = L
     return _LIB
 
@@ -231,3 +238,32 @@ def batch_step_imitation(model, datas, actions, n_substeps, table, params, idx_c
                                    idx_curr.ctypes.data_as(C.POINTER(C.c_int)), cycle.ctypes.data_as(C.POINTER(C.c_int)),
                                    _dp(obs), _dp(rew), done.ctypes.data_as(C.POINTER(C.c_ubyte)), int(nthreads))
     return obs, rew, done
+
+
+def bench_rollout(model, datas, steps, data_config, data_vel, table=None, params=None, sigma=0.9, seed=0, nthreads=1):
+    """bench.py's cpu_baseline workload run entirely in C (see dmo_bench_rollout) -> (env_steps, episodes_ended, reward_sum)."""
+    n = len(datas)
+    arr = (C.c_void_p * n)(*[d.h for d in datas])
+    cfg = np.ascontiguousarray(data_config, dtype=np.float64); vel = np.ascontiguousarray(data_vel, dtype=np.float64)
+    tb = None if table is None else np.ascontiguousarray(table, dtype=np.float64)
+    p = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
+    nd = C.c_long(0); rs = np.zeros(1)
+    tot = lib().dmo_bench_rollout(model.h, arr, n, int(steps), _dp(cfg), _dp(vel), cfg.shape[0], None if tb is None else _dp(tb),
+                                  None if p is None else _dp(p), float(sigma), int(seed), int(nthreads), C.byref(nd), _dp(rs))
+    return int(tot), int(nd.value), float(rs[0])
+
+
+def v1_reward(model, f0, f1, f1v, params):
+    a = np.ascontiguousarray(f0, dtype=np.float64); b = np.ascontiguousarray(f1, dtype=np.float64); c = np.ascontiguousarray(f1v, dtype=np.float64)
+    p = np.ascontiguousarray(params, dtype=np.float64); t = np.zeros(3)
+    return float(lib().dmo_v1_reward(model.h, _dp(a), _dp(b), _dp(c), _dp(p), _dp(t))), t
+
+
+def env_step_v1(model, data, action, n_substeps, table, params, mocap_dt, idx_curr, idx_init):
+    """dp_env_v1's step (reward mode 4) -> (obs, reward, done, idx_curr)"""
+    a = np.ascontiguousarray(action, dtype=np.float64); tb = np.ascontiguousarray(table, dtype=np.float64)
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    o = np.zeros(56); rr = np.zeros(1); dn = C.c_int(0); ic = C.c_int(int(idx_curr))
+    lib().dmo_env_step_v1(model.h, data.h, _dp(a), int(n_substeps), _dp(tb), tb.shape[0], _dp(p), float(mocap_dt), C.byref(ic), int(idx_init),
+                          _dp(o), _dp(rr), C.byref(dn))
+    return o, float(rr[0]), bool(dn.value), ic.value

@@ -18,7 +18,7 @@ def lib():
         subprocess.check_call(["make", "-C", _HERE, "-s"])
         L = C.CDLL(os.path.join(_HERE, "libdmemu.so"))
         L.emu_create.restype = C.c_void_p
-        L.emu_create.argtypes = [C.POINTER(A.ModelDesc), A._dp, A._dp, C.c_int, C.c_int, C.c_uint]
+        L.emu_create.argtypes = [C.POINTER(A.ModelDesc), A._dp, A._dp, C.c_int, C.c_int, C.c_uint, C.c_double]
         L.emu_destroy.argtypes = [C.c_void_p]
         L.emu_set_option.argtypes = [C.c_void_p, C.c_int, C.c_longlong]
         L.emu_set_imitation.argtypes = [C.c_void_p, A._dp, A._dp]
@@ -33,11 +33,11 @@ def lib():
 
 
 class EmuBatch(object):
-    def __init__(self, cm, data_config, data_vel, n_envs, flags=0, imitation=None):
+    def __init__(self, cm, data_config, data_vel, n_envs, flags=0, imitation=None, mocap_dt=0.033332):
         self.n = n_envs
         md, self._keep = A.make_model_desc(cm)
         cfg = np.ascontiguousarray(data_config, dtype=np.float64); vel = np.ascontiguousarray(data_vel, dtype=np.float64)
-        self.h = lib().emu_create(C.byref(md), cfg.ctypes.data_as(A._dp), vel.ctypes.data_as(A._dp), cfg.shape[0], n_envs, flags)
+        self.h = lib().emu_create(C.byref(md), cfg.ctypes.data_as(A._dp), vel.ctypes.data_as(A._dp), cfg.shape[0], n_envs, flags, float(mocap_dt))
         if not self.h:
             raise RuntimeError("emu_create failed")
         if imitation is not None:

@@ -63,7 +63,7 @@ struct EmuBatch {
 }  // namespace
 
 extern "C" {
-void* emu_create(const dm_model_desc* d, const double* cfg, const double* vel, int F, int n, unsigned flags) {
+void* emu_create(const dm_model_desc* d, const double* cfg, const double* vel, int F, int n, unsigned flags, double mocap_dt) {
   EmuBatch* e = new EmuBatch();
   std::string err;
   if (build_dev_model(d, &e->M, &err) != 0) { fprintf(stderr, "emu_create: %s\n", err.c_str()); delete e; return nullptr; }
@@ -81,7 +81,7 @@ void* emu_create(const dm_model_desc* d, const double* cfg, const double* vel, i
   B.ncon = e->ncon.data(); B.nefc = e->nefc.data(); B.cong = e->cong.data(); B.status = e->status.data();
   B.aovf = e->aovf.data(); B.cycle = e->cycle.data(); B.imit_table = nullptr; B.imit_pdev = nullptr; B.order = nullptr;
   B.solver_iter = e->siter.data(); B.episode = e->episode.data(); B.mocap_cfg = e->cfg.data(); B.mocap_vel = e->vel.data();
-  B.n_frames = F; B.n_envs = n; B.env_offset = 0; B.reward_mode = 0; B.autoreset = 0; B.action_mode = 0; B.seed = 0; B.diag = 1;
+  B.mocap_dt = mocap_dt; B.n_frames = F; B.n_envs = n; B.env_offset = 0; B.reward_mode = 0; B.autoreset = 0; B.action_mode = 0; B.seed = 0; B.diag = 1;
   return e;
 }
 void emu_set_imitation(void* h, const double* table, const double* params) {

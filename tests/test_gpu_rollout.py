@@ -159,3 +159,37 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert j["n_gpus"] == 2 and j["config"]["n_ranks_seen"] == 2 and j["config"]["dist_backend"] == "gloo"
     assert j["config"]["global_envs"] == 1024 and j["config"]["gathers_completed"] >= 1 and j["scaling"] == "weak"
     assert j["value"] > 1e5 and "cpu_baseline" not in j
+
+
+@pytest.mark.gpu
+def test_pipelined_rollouts_equal_the_same_batches_stepped_one_after_the_other():
+    """`pipelined_segment_generator`: two env batches whose policy -> env chains run concurrently on their own CUDA streams must
+    produce exactly the segments the same two batches produce when their chains run back to back on one stream."""
+    from deepmimic_mujoco_amd import SegmentCollector, pipelined_segment_generator
+    T, n = 40, 192
+    outs = []
+    for piped in (True, False):
+        envs = [DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=4, env_offset=h * n) for h in range(2)]
+        pol = MlpPolicy.from_tf_checkpoint(CKPT, device=DEV); pol.seed(9)
+        if piped:
+            gen = pipelined_segment_generator(pol, envs, T, stochastic=True)
+            segs = [next(gen) for _ in range(3)]
+        else:
+            cols = [SegmentCollector(pol, e, T, True, None, "rsi") for e in envs]
+            segs = []
+            for _ in range(3):
+                for c in cols:
+                    c.launch()
+                parts = [c.collect() for c in cols]
+                segs.append({k: (torch.cat([p[k] for p in parts], 0 if k == "nextvpred" else 1) if k not in ("ep_rets", "ep_lens")
+                                 else [x for p in parts for x in p[k]]) for k in parts[0]})
+        torch.cuda.synchronize()
+        outs.append(segs)
+        for e in envs:
+            e.close()
+    for a, b in zip(*outs):
+        assert a["ob"].shape == (T, 2 * n, 56) and a["nextvpred"].shape == (2 * n,)
+        for k in ("ob", "ac", "rew", "vpred", "new", "prevac", "nextvpred"):
+            assert torch.equal(a[k], b[k]), k
+        assert a["ep_lens"] == b["ep_lens"] and a["ep_rets"] == b["ep_rets"]
+    assert sum(len(s["ep_lens"]) for s in outs[0]) > 0

@@ -310,3 +310,100 @@ def test_reference_tables_for_every_clip():
         assert max(1, int(float(mc.dt) / 0.0166)) >= 1
         loops.add(mc.loop)
     assert loops == {"wrap", "none"}
+
+
+# ---- reward mode 4: dp_env_v1's reward (src/dp_env_v1.py:82-158) on the hinge-triple model ---------------------------------------
+def test_v1_reward_definition_numpy_vs_oracle_and_known_answers():
+    from oracle import oracle as O
+    from deepmimic_mujoco_amd.mocap import JOINT_WEIGHT
+    sp = _spec(); mc = H.mocap()
+    T, P = sp.table_for(mc)
+    om = H.oracle_model()
+    # un-normalised weights = the reference's JOINT_WEIGHT table (src/mujoco/mocap_util.py:26-29)
+    names = list(sp.cm.body_names)
+    for g, b in enumerate(sp.bodies):
+        assert abs(P[g] / P[12] - JOINT_WEIGHT[names[b]]) < 1e-12
+    assert JOINT_WEIGHT["root"] == 1
+    # on the reference motion itself: zero pose / root error, rates of the following frame
+    qv = _ref_qvel(sp, mc)
+    k = 9
+    from deepmimic_mujoco_amd.imitation import O_RANG, O_JW
+    f = T[k].copy(); f[O_RANG:O_RANG + 3] = T[k + 1][O_RANG:O_RANG + 3]; f[O_JW:O_JW + 36] = T[k + 1][O_JW:O_JW + 36]   # pose of frame k, rates k -> k+1
+    e = sp.v1_reward_terms(f, T[k], T[k + 1])
+    assert e[0] < 1e-12 and e[2] == 0 and e[1] == 0 and abs(sp.v1_reward(f, T[k], T[k + 1]) - 0.75) < 1e-12     # weights 0.5 + 0.05 + 0.2
+    assert sp.v1_reward_terms(T[k], T[k], T[k + 1])[1] > 0.05              # ... and the rate term is about frame k+1's rates, not frame k's
+    # each term reacts to its own perturbation; the pose term is LINEAR in the angle (|theta|, not theta^2)
+    q = mc.data_config[k].copy(); q[7 + 17] += 0.2                          # right knee (1 hinge, weight 0.3)
+    e = sp.v1_reward_terms(sp.features(q, qv[k + 1]), T[k], T[k + 1])
+    assert abs(e[0] - 0.3 * 0.2) < 1e-12 and e[2] == 0
+    q = mc.data_config[k].copy(); q[0] += 0.1; q[2] -= 0.05
+    e = sp.v1_reward_terms(sp.features(q, qv[k + 1]), T[k], T[k + 1])
+    assert abs(e[2] - 0.15) < 1e-12 and e[0] < 1e-12
+    rng = np.random.RandomState(1)
+    idx, qs, vs, _w, _c = H.varied_states(10, seed=4)
+    for e_ in range(10):
+        f0 = sp.features(qs[e_], vs[e_]); kk = int(idx[e_]); kv = min(kk + 1, len(T) - 1)
+        r_c, t_c = O.v1_reward(om, O.imitation_features(om, qs[e_], vs[e_], P), T[kk], T[kv], P)
+        assert np.allclose(t_c, sp.v1_reward_terms(f0, T[kk], T[kv]), rtol=1e-10, atol=1e-12) and abs(r_c - sp.v1_reward(f0, T[kk], T[kv])) < 1e-12
+
+
+def _rollout_v1_vs_oracle(batch, n, steps, nsub, seed, clip="walk"):
+    from oracle import oracle as O
+    sp, mc, T, P = _imit_inputs(clip)
+    F = len(T)
+    om = H.oracle_model()
+    rng = np.random.RandomState(seed)
+    idx = np.concatenate([[F - 2], rng.randint(0, F, size=n - 1)]).astype(np.int32)
+    q = mc.data_config[idx].copy(); v = mc.data_vel[idx].copy()
+    q[n // 2:, 7:] += 0.05 * rng.randn(n - n // 2, 28)
+    batch.set_option(A.OPT_REWARD_MODE, 4)
+    batch.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); batch.set(A.F_TIME, np.zeros(n))
+    batch.set_state(q, v, frame_idx=idx)
+    assert np.all(batch.get(A.F_FRAME_IDX) == 0) and np.array_equal(batch.get(A.F_FRAME_INIT), idx)     # v1's cursor counts steps from 0
+    ods = [O.Data(om) for _ in range(n)]
+    for e in range(n):
+        ods[e].reset(); ods[e].set_state(q[e], v[e])
+    cur = np.zeros(n, int)
+    worst = 0.0; zero_steps = 0
+    for t in range(steps):
+        a = rng.randn(n, 28) * 0.3
+        obs, rew, done = batch.step(a, nsub)[:3]
+        for e in range(n):
+            o, r, d, cur[e] = O.env_step_v1(om, ods[e], a[e], nsub, T, P, float(mc.dt), cur[e], int(idx[e]))
+            worst = max(worst, abs(rew[e] - r), H.rel_err(obs[e], o))
+            assert bool(done[e]) == d, (t, e)
+            zero_steps += int(abs(r + 0.1 * np.square(a[e]).sum()) < 1e-15)
+        assert np.array_equal(batch.get(A.F_FRAME_IDX), cur.astype(np.int32))
+    return worst, zero_steps
+
+
+def test_v1_reward_mode_on_the_wave_testbench_matches_oracle():
+    from tests.emu.emu import EmuBatch
+    sp, mc, T, P = _imit_inputs()
+    n = 4
+    b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0, imitation=(T, P), mocap_dt=float(mc.dt))
+    worst, zeros = _rollout_v1_vs_oracle(b, n, steps=4, nsub=1, seed=2)          # walk: int(0.0333 // 0.0166) = 2 -> reward on even steps only
+    assert worst < 1e-10 and zeros == n * 2
+    b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0, imitation=(T, P), mocap_dt=float(mc.dt))
+    worst, zeros = _rollout_v1_vs_oracle(b, n, steps=3, nsub=2, seed=3)          # two sim steps per env step: interval 1
+    assert worst < 1e-10 and zeros == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", ["walk", "dance_b"])
+def test_v1_reward_mode_on_gpu_matches_oracle(clip):
+    from deepmimic_mujoco_amd import Batch
+    sp, mc, T, P = _imit_inputs(clip)
+    n = 16
+    b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
+    worst, zeros = _rollout_v1_vs_oracle(b, n, steps=8, nsub=1, seed=7, clip=clip)
+    print("v1-quat reward rollout (%s): worst |diff| %.2e, steps without a reward evaluation %d" % (clip, worst, zeros))
+    assert worst < 1e-9 and zeros == (n * 4 if clip == "walk" else 0)
+    b.close()
+    from deepmimic_mujoco_amd import DPVecEnv
+    env = DPVecEnv(8, motion=clip, device=0, reward="v1-quat", autoreset="rsi", seed=1)
+    env.reset("rsi")
+    assert np.all(env.batch.get(A.F_FRAME_IDX) == 0)
+    obs, rew, done, _ = env.step(np.zeros((8, 28)))
+    assert np.isfinite(rew).all() and rew.max() <= 0.75 + 1e-12
+    env.close()

@@ -274,3 +274,44 @@ def test_reference_log_formats_round_trip(tmp_path):
     m.close()
     h2, r2, l2, t2 = read_monitor_csv(str(tmp_path / "run.monitor.csv"))
     assert h2 == hdr and r2 == r and l2 == l and np.allclose(t2, t, atol=1e-6)
+
+
+def test_tf_checkpoint_writer_reproduces_the_shipped_bundle_byte_for_byte(tmp_path):
+    """`save_checkpoint` is the inverse of the reader on the reference's own artefact: re-saving the 32 tensors of
+    src/checkpoint_tmp/DeepMimic/trpo-walk-0 gives identical `.index` (table blocks, prefix compression, restart points, masked
+    crc32c, footer) and `.data` files, so a bundle written here is one `tf.train.Saver.restore` reads."""
+    from deepmimic_mujoco_amd.tf_checkpoint import save_checkpoint
+    d = load_checkpoint(CKPT)
+    out = str(tmp_path / "resaved")
+    save_checkpoint(out, d)
+    for ext in (".index", ".data-00000-of-00001"):
+        assert open(out + ext, "rb").read() == open(CKPT + ext, "rb").read(), ext
+    assert 'model_checkpoint_path: "resaved"' in open(str(tmp_path / "checkpoint")).read()
+
+
+def test_policy_saved_as_tf_bundle_round_trips_and_has_the_reference_layout(tmp_path):
+    pol = MlpPolicy(seed=4)
+    pol.ob_rms.update(torch.randn(300, 56, dtype=torch.float64) * 2 + 0.3)
+    with torch.no_grad():
+        pol.params["logstd"] -= 0.25
+    pre = str(tmp_path / "DeepMimic" / "trpo-walk-7")
+    pol.save_tf_checkpoint(pre)
+    idx = read_index(pre); ref = read_index(CKPT)
+    assert sorted(idx) == sorted(ref)                                           # same 32 variables ...
+    for k in ref:                                                                # ... same dtype, shape, offset and size
+        assert idx[k][:5] == ref[k][:5], k
+    back = MlpPolicy.from_tf_checkpoint(pre)
+    for k, v in pol.params.items():
+        assert torch.equal(back.params[k], v.detach()), k
+    assert torch.equal(back.ob_rms.sum, pol.ob_rms.sum) and torch.equal(back.ob_rms.count, pol.ob_rms.count)
+    ob = torch.randn(5, 56, dtype=torch.float64)
+    assert torch.equal(back.forward(ob)[0], pol.forward(ob)[0])
+    old = load_checkpoint(pre, scope="oldpi")
+    assert np.array_equal(old["polfc1/w"], pol.params["polfc1/w"].detach().numpy())
+    # a bigger bundle spills into several table blocks: still read back exactly (multi-block index, separators)
+    from deepmimic_mujoco_amd.tf_checkpoint import save_checkpoint
+    big = {"scope%03d/some/rather/long/variable/name_%d" % (i, i): np.full((i % 5 + 1, 3), i, dtype=np.float32) for i in range(300)}
+    big["z/i64"] = np.arange(7, dtype=np.int64); big["a/flag"] = np.array([True, False]); big["a/scalar"] = np.float64(3.5)
+    save_checkpoint(str(tmp_path / "big"), big)
+    got = load_checkpoint(str(tmp_path / "big"))
+    assert sorted(got) == sorted(big) and all(np.array_equal(got[k], np.asarray(big[k])) and got[k].dtype == np.asarray(big[k]).dtype for k in big)

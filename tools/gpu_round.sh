@@ -12,13 +12,11 @@ timeout 600 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -
 for wl in cfg4 cfg5 cfg2; do
   timeout 300 python bench.py --workload $wl --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; cut -c1-300 $OUT/bench_$wl.json
 done
-timeout 300 python bench.py --workload rollout --steps 1024 --warmup 256 > $OUT/bench_rollout.json 2> $OUT/bench_rollout.err; cut -c1-200 $OUT/bench_rollout.json
+for p in 1 2; do
+  timeout 300 python bench.py --workload rollout --pipeline $p --steps 1024 --warmup 256 > $OUT/bench_rollout_p$p.json 2> $OUT/bench_rollout_p$p.err; cut -c1-200 $OUT/bench_rollout_p$p.json
+done
+timeout 300 python bench.py --pipeline 1 --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_pipeline1.json 2> $OUT/bench_cfg3_pipeline1.err; cut -c1-200 $OUT/bench_cfg3_pipeline1.json
 DM_PROF_REWARD=imitation timeout 300 python tools/profile_stages.py > $OUT/stage_cycles.txt 2>&1; head -30 $OUT/stage_cycles.txt
 timeout 300 python tools/contact_exposure.py --out $OUT/contact_exposure_cfg3.json > /dev/null 2> $OUT/contact_exposure.err
 timeout 300 python tools/contact_exposure.py --policy shipped --envs 2048 --steps 400 --out $OUT/contact_exposure_policy.json > /dev/null 2>> $OUT/contact_exposure.err
-python - <<'PY'
-import json,sys,os
-for f in ("contact_exposure_cfg3.json","contact_exposure_policy.json"):
-    p=os.path.join(os.environ.get("OUTDIR", "gpurun_out"), f)
-PY
 grep -h "own_algorithm\|env_steps_with" $OUT/contact_exposure_*.json

@@ -33,7 +33,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
     ap.add_argument("--log-dir", default=None, help="write progress.csv and monitor.csv in the reference's formats")
-    ap.add_argument("--save", default=None, help="write the trained policy as .npz (reference variable names)")
+    ap.add_argument("--save", default=None, help="write the trained policy: `x.npz` (reference variable names) or a checkpoint prefix -> "
+                                                 "tf.train.Saver bundle (x.index + x.data-00000-of-00001) the reference's `--task evaluate --load_model_path x` restores")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); lr = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(lr)
@@ -52,7 +53,10 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
             json.dump({"args": vars(args), "world": world, "history": hist}, open(args.out, "w"))
         if args.save:
-            pi.save_npz(args.save)
+            if args.save.endswith(".npz"):
+                pi.save_npz(args.save)
+            else:
+                pi.save_tf_checkpoint(args.save)
         best = max(h["EpLenMeanIter"] for h in hist)
         print("done: %d iterations, %d env steps in %.1f s (%.0f steps/s incl. learner), EpLenMean(last iter) %.1f, best %.1f"
               % (len(hist), hist[-1]["TimestepsSoFar"], hist[-1]["TimeElapsed"], hist[-1]["TimestepsSoFar"] / hist[-1]["TimeElapsed"],
