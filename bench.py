@@ -289,6 +289,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="DM_OPT_PIPELINE: sub-batches per GPU stepped on their own streams so that one's drain overlaps the next one's ramp "
                          "across consecutive steps (1 = one launch per step)")
+    ap.add_argument("--dtype", type=int, default=64, choices=[64, 32],
+                    help="arithmetic of the kernels: 64 (the parity path, the judged line) or 32 (libdmenv32.so, the float32 build: informational)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (N = 1 only; they add about a minute)")
     ap.add_argument("--no-gym-loop", action="store_true", help="skip the single-env Python DPEnv.step loop (N = 1 only; ~3 s)")
@@ -340,7 +342,7 @@ def main():
         warnings.simplefilter("ignore", UserWarning)        # frame_skip = 1 with the imitation reward is this benchmark's definition of a step
         env = DPVecEnv(n, motion=clip, device=local_dev, reward=args.reward if full else "alive",
                        autoreset="rsi", seed=0, contacts=full, limits=full,
-                       action_mode="raw" if full else "p-control", env_offset=shard * n, frame_skip=1)
+                       action_mode="raw" if full else "p-control", env_offset=shard * n, frame_skip=1, dtype=args.dtype)
     stream = torch.cuda.Stream(device=dev)
     env.batch.set_stream(stream.cuda_stream)
     env.batch.set_option(A.OPT_PIPELINE, max(1, min(args.pipeline, A.MAX_PIPELINE)))
@@ -405,6 +407,17 @@ def main():
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
+        # per-launch duration of the step kernel by HIP events on the stream it is launched on (pipelined: sub-batch 0's launch on
+        # its own stream, while the other sub-batches keep the machine busy): untimed, sampled after the clock stopped
+        launch_us = []
+        if not args._child:
+            env.batch.enable_timing(True)
+            for t in range(args.steps, args.steps + 48):
+                one_step(t)
+                if t >= args.steps + 8:
+                    launch_us.append(env.batch.last_step_ms() * 1e3)
+            env.batch.enable_timing(False)
+            env.batch.sync()
         # row / sweep statistics for the flop count: untimed, a few more steps sampled after the clock stopped
         if not args._child:
             for t in range(args.steps, args.steps + 8):
@@ -426,6 +439,7 @@ def main():
     if rank == 0:
         total_steps = world * n * args.steps
         value = total_steps / elapsed
+        P_sub = max(1, min(args.pipeline, A.MAX_PIPELINE))
         kernel_ms = gpu_ms / args.steps       # per-launch duration on the launch stream (incl. k_order and the per-horizon block packing)
         ach_gbs = ALGO_BYTES_PER_STEP * n / (kernel_ms * 1e-3) / 1e9
         rew_name = "5-term DeepMimic imitation" if args.reward == "imitation" else args.reward
@@ -437,7 +451,7 @@ def main():
         out = {
             "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f%d" % args.dtype, "data": "synthetic",
             "config": {"workload": label, "envs_per_gpu": n, "global_envs": world * n if world > 1 else n * wl["shards"], "clip": clip,
                        "parallelism": "env-shard x%d" % max(world, wl["shards"]), "n_ranks_seen": n_ranks_seen,
                        "dist_backend": args.dist_backend if world > 1 else None,
@@ -452,6 +466,13 @@ def main():
                          "kernel_ms_covers": "HIP events around the timed region / steps: one dm_batch_step = k_step_narrow (all sub-batches) + k_order + 1/256 of a horizon's block packing; "
                                              "with --pipeline > 1 consecutive steps overlap, so this is the per-step issue interval, not a lone launch's latency",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
+                         "launch": {"kernel": "k_step_narrow", "envs_per_launch": n // P_sub, "launches_per_step": P_sub,
+                                    "algorithmic_bytes": ALGO_BYTES_PER_STEP * (n // P_sub),
+                                    "avg_us": round(float(np.mean(launch_us)), 1) if launch_us else None,
+                                    "measured": "HIP events on the launch's own stream, %d launches sampled after the timed region" % len(launch_us),
+                                    "launches_in_flight": round(float(np.mean(launch_us)) * 1e-3 * P_sub / kernel_ms, 2) if launch_us else None,
+                                    "note": "`achieved` is the whole-GPU rate, bytes of one step / step interval: with pipelined sub-batches "
+                                            "launches overlap, so bytes / one launch's duration is only that launch's share of the machine"},
                          "note": "latency / fp64-issue bound path, not an HBM stream: see the fp64 and VALU fields",
                          "fp64_flops_per_env_step": round(flops, 0),
                          "fp64_flops_source": "flop count of the kernel's algorithm (bench.py eval_flops) on this run's nefc / PGS-sweep samples (%d env-steps)" % nefc.size,
@@ -460,32 +481,32 @@ def main():
         }
         if world == 1 and not args.no_pmc:
             tail = ["--workload", args.workload, "--reward", args.reward, "--steps", "48", "--warmup", "8", "--prewarm-horizons", "1",
-                    "--envs", str(n), "--_child", "--no-pmc", "--no-cpu-baseline", "--no-gym-loop", "--pipeline", str(args.pipeline)] + (["--clip", args.clip] if args.clip else [])
+                    "--envs", str(n), "--_child", "--no-pmc", "--no-cpu-baseline", "--no-gym-loop", "--pipeline", str(args.pipeline), "--dtype", str(args.dtype)] + (["--clip", args.clip] if args.clip else [])
             pmc, err = pmc_passes(tail, "k_step_narrow")
             r = out["roofline"]
             if pmc is None:
                 r["pmc"] = err
             else:
                 r["pmc"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in pmc.items()}
+                # counters are averages per k_step_narrow LAUNCH; a step is P_sub launches of n / P_sub envs each
                 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-                    # counters are KiB per launch.  The guide's x2 gfx950 correction of FETCH_SIZE was calibrated on 16 B/lane
+                    # FETCH_SIZE / WRITE_SIZE are KiB.  The guide's x2 gfx950 correction of FETCH_SIZE was calibrated on 16 B/lane
                     # streaming reads; this kernel reads 8 B/lane rows, an uncalibrated width: both readings are reported
-                    r["traffic"] = round((pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
-                    r["traffic_fetch_doubled"] = round((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
+                    r["traffic"] = round((pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * P_sub)
+                    r["traffic_fetch_doubled"] = round((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * P_sub)
                     r["traffic_over_algorithmic"] = round(r["traffic"] / (ALGO_BYTES_PER_STEP * n), 3)
-                    r["traffic_source"] = "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (48 launches each), bytes per launch"
-                if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("sq_pass_avg_us"):
-                    cyc = pmc["sq_pass_avg_us"] * 1e-6 * MAX_CLOCK_HZ
-                    if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("trace", {}).get("avg_us"):
-                        # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-                        r["effective_clock_ghz"] = round(pmc["GRBM_GUI_ACTIVE"] / 8.0 / (pmc["trace"]["avg_us"] * 1e-6) / 1e9, 3)
-                    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs
-                    r["valu_issue_frac"] = round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * cyc), 4)
-                    r["valu_issue_frac_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel duration of the same pass x 2.4 GHz)"
+                    r["traffic_source"] = "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, HBM bytes per step (= %d launches)" % P_sub
+                if pmc.get("SQ_ACTIVE_INST_VALU"):
+                    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; the denominator is the un-profiled step interval
+                    r["valu_issue_frac"] = round(P_sub * pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * kernel_ms * 1e-3 * MAX_CLOCK_HZ), 4)
+                    r["valu_issue_frac_note"] = "launches/step x SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x step interval x 2.4 GHz)"
+                if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("trace", {}).get("avg_us"):
+                    r["effective_clock_ghz"] = round(pmc["GRBM_GUI_ACTIVE"] / 8.0 / (pmc["trace"]["avg_us"] * 1e-6) / 1e9, 3)   # summed over the 8 XCDs
                 if pmc.get("SQ_INSTS_VALU"):
-                    r["valu_wave_instr_per_env_step"] = round(pmc["SQ_INSTS_VALU"] / n, 1)
+                    per_env = pmc["SQ_INSTS_VALU"] / (n / P_sub)
+                    r["valu_wave_instr_per_env_step"] = round(per_env, 1)
                     # useful fp64 lane-operations (an FMA lane does 2 flops) over the lane slots of all VALU instructions issued
-                    r["lane_efficiency"] = round((flops / 2.0) / (pmc["SQ_INSTS_VALU"] / n * 64.0), 4)
+                    r["lane_efficiency"] = round((flops / 2.0) / (per_env * 64.0), 4)
                     r["lane_efficiency_note"] = "useful fp64 FMA-lane operations / (VALU wave-instructions x 64 lanes)"
                 if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY"):
                     r["wave_wait_frac"] = round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4)

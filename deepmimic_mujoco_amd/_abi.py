@@ -90,7 +90,7 @@ LIB_PATH = os.environ.get("DMENV_LIB") or os.path.join(_HERE, "csrc", "libdmenv.
 EXPORTS = ["dm_model_create", "dm_model_destroy", "dm_mocap_create", "dm_mocap_set_imitation", "dm_mocap_destroy", "dm_batch_create",
            "dm_batch_destroy", "dm_batch_set_stream", "dm_batch_set_option", "dm_batch_set_state", "dm_batch_reset",
            "dm_batch_step", "dm_batch_get_obs", "dm_batch_get", "dm_batch_set", "dm_batch_debug_forward",
-           "dm_batch_last_step_ms", "dm_batch_enable_timing", "dm_batch_read_profile", "dm_batch_sync", "dm_batch_join", "dm_policy_weight_count", "dm_policy_act", "dm_gae", "dm_last_error", "dm_abi_version",
+           "dm_batch_last_step_ms", "dm_batch_enable_timing", "dm_batch_read_profile", "dm_batch_sync", "dm_batch_join", "dm_policy_weight_count", "dm_policy_act", "dm_gae", "dm_last_error", "dm_abi_version", "dm_real_bits",
            "dm_device_count"]
 _LIB = None
 
@@ -99,15 +99,21 @@ class DmenvError(RuntimeError):
     pass
 
 
-def load():
-    """Load libdmenv.so (built by `__graft_entry__.build()` / csrc/build.py).  No fallback of any kind."""
+def load(dtype=64):
+    """Load libdmenv.so (float64 arithmetic; dtype=32: libdmenv32.so, the float32 build of the same source), built by
+    `__graft_entry__.build()` / csrc/build.py.  Both export the same C ABI (float64 buffers).  No fallback of any kind."""
     global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(LIB_PATH):
-        raise DmenvError("libdmenv.so not found at %s — build the HIP extension first "
-                         "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    if dtype not in (64, 32):
+        raise ValueError("dtype must be 64 or 32")
+    if _LIB is None:
+        _LIB = {}
+    if dtype in _LIB:
+        return _LIB[dtype]
+    path = LIB_PATH if dtype == 64 else LIB_PATH[:-3] + "32.so"
+    if not os.path.exists(path):
+        raise DmenvError("%s not found at %s — build the HIP extension first "
+                         "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % (os.path.basename(path), path))
+    L = C.CDLL(path)
     vp, i32, u8p = C.c_void_p, C.c_int32, C.POINTER(C.c_uint8)
     L.dm_last_error.restype = C.c_char_p
     L.dm_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
@@ -135,7 +141,9 @@ def load():
     L.dm_gae.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, C.c_double, C.c_double, vp]
     if L.dm_abi_version() != ABI_VERSION:
         raise DmenvError("libdmenv.so ABI version %d != %d" % (L.dm_abi_version(), ABI_VERSION))
-    _LIB = L
+    if L.dm_real_bits() != dtype:
+        raise DmenvError("%s computes in float%d, expected float%d" % (os.path.basename(path), L.dm_real_bits(), dtype))
+    _LIB[dtype] = L
     return L
 
 

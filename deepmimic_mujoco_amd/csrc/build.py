@@ -17,16 +17,31 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
+OUT32 = os.path.join(HERE, "libdmenv32.so")
+
+
+def _stale(out, srcs):
+    return not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs)
+
+
 def build(force=False, verbose=False):
+    """libdmenv.so (float64 arithmetic: the parity build) and libdmenv32.so (-DDM_REAL_FLOAT: the same kernels in float32, the
+    `dtype 32` batch), compiled side by side.  Returns the path of libdmenv.so."""
     srcs = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(REPO, "include", "dmenv.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(s) <= os.path.getmtime(OUT) for s in srcs):
-        return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-I" + os.path.join(REPO, "include"), "-I" + HERE, os.path.join(HERE, "dmenv.hip"), "-o", OUT]
-    if verbose:
-        cmd.insert(-2, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    jobs = []
+    for out, defs in ((OUT, []), (OUT32, ["-DDM_REAL_FLOAT"])):
+        if not force and not _stale(out, srcs):
+            continue
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-shift-count-negative",
+               "-Wno-implicit-const-int-float-conversion"] + defs + os.environ.get("DM_BUILD_DEFINES", "").split() + [
+               "-I" + os.path.join(REPO, "include"), "-I" + HERE, os.path.join(HERE, "dmenv.hip"), "-o", out]
+        if verbose:
+            cmd.insert(-2, "-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd))
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     return OUT
 
 

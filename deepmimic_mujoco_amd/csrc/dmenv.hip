@@ -19,7 +19,17 @@
 #include "model_host.h"
 
 using namespace dm;
+// Arithmetic / device-state type of this build: float64 (libdmenv.so, the parity build) or float32 (libdmenv32.so, -DDM_REAL_FLOAT:
+// the `dtype 32` batch of SURVEY.md section 8b — same kernels, half the registers and LDS per env).  Everything that crosses the
+// C ABI (actions, observations, rewards, field reads / writes, mocap tables) stays float64 (`Ext`) in both builds.
+#ifdef DM_REAL_FLOAT
+typedef float Real;
+#define DM_STEP_WAVES 3
+#else
 typedef double Real;
+#define DM_STEP_WAVES 2
+#endif
+typedef double Ext;
 
 // ============================================ kernels ======================================================
 // one 64-lane workgroup (= one wavefront) per environment.
@@ -28,10 +38,13 @@ typedef double Real;
 // columns in a per-env global-memory strip.  k_step holds all 64 columns in registers (512 VGPRs, 1 wave per SIMD) and is
 // the single-tier fallback (DM option 102 = 0) and the profiling / debug instantiation.  Both perform identical
 // arithmetic on the rows that exist.
-constexpr int NARROW_ROWS = 32;
+#ifndef DM_NARROW_ROWS
+#define DM_NARROW_ROWS 32
+#endif
+constexpr int NARROW_ROWS = DM_NARROW_ROWS;
 static_assert(AOVF_COLS >= MAXEFC, "memory strip too small");
-__global__ __launch_bounds__(64, 2) void k_step_narrow(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ action,
-                                                    Real* __restrict__ obs, Real* __restrict__ reward, unsigned char* __restrict__ done,
+__global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_narrow(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
+                                                    Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
                                                     int n_substeps, int first) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
@@ -40,8 +53,8 @@ __global__ __launch_bounds__(64, 2) void k_step_narrow(const DevModel<Real>* __r
   const int env = B.order ? B.order[slot] : slot;
   env_step<Real, NARROW_ROWS>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
 }
-__global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ action,
-                                             Real* __restrict__ obs, Real* __restrict__ reward, unsigned char* __restrict__ done,
+__global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
+                                             Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
                                              int n_substeps) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
@@ -77,8 +90,8 @@ __global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__
 }
 
 // same step with per-stage shader-clock accounting (DM_OPT 101); not used on the timed path
-__global__ __launch_bounds__(64) void k_step_prof(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ action,
-                                                  Real* __restrict__ obs, Real* __restrict__ reward, unsigned char* __restrict__ done,
+__global__ __launch_bounds__(64) void k_step_prof(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
+                                                  Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
                                                   int n_substeps, long long* prof) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
@@ -87,16 +100,16 @@ __global__ __launch_bounds__(64) void k_step_prof(const DevModel<Real>* __restri
   env_step<Real, MAXEFC, true>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps, prof);
 }
 
-__global__ __launch_bounds__(64) void k_set_state(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Real* __restrict__ qpos,
-                                                  const Real* __restrict__ qvel, const int* __restrict__ frame_idx,
+__global__ __launch_bounds__(64) void k_set_state(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ qpos,
+                                                  const Ext* __restrict__ qvel, const int* __restrict__ frame_idx,
                                                   const unsigned char* __restrict__ mask) {
   __shared__ Shared<Real> s;
   const int env = blockIdx.x, lane = dmw::lane();
   if (env >= B.n_envs) return;
   if (mask && !mask[env]) return;
-  load_env(*Mp, B, s, env, lane, (const Real*)0);
-  if (lane < NQ) s.qpos[lane] = qpos[(size_t)env * NQ + lane];
-  if (lane < NV) s.qvel[lane] = qvel[(size_t)env * NV + lane];
+  load_env(*Mp, B, s, env, lane, (const Ext*)0);
+  if (lane < NQ) s.qpos[lane] = (Real)qpos[(size_t)env * NQ + lane];
+  if (lane < NV) s.qvel[lane] = (Real)qvel[(size_t)env * NV + lane];
   if (frame_idx && lane == 0) set_frame(B, env, frame_idx[env]);
   dmw::sync();
   store_state(B, s, env, lane);
@@ -110,24 +123,34 @@ __global__ __launch_bounds__(64) void k_reset(const DevModel<Real>* __restrict__
   const int env = blockIdx.x, lane = dmw::lane();
   if (env >= B.n_envs) return;
   if (mask && !mask[env]) return;
-  load_env(*Mp, B, s, env, lane, (const Real*)0);
+  load_env(*Mp, B, s, env, lane, (const Ext*)0);
   reset_env(*Mp, B, s, env, lane, mode, hard);
   store_state(B, s, env, lane);
   { const LaneTopo lt = lane_topo(lane); stage_tables(s, lane); dmw::sync(); forward(*Mp, s, lane, lt, (const DebugOut*)0); }
   store_derived(B, *Mp, s, env, lane);
 }
 
-__global__ void k_get_obs(Batch<Real> B, Real* __restrict__ obs) {
+__global__ void k_get_obs(Batch<Real> B, Ext* __restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B.n_envs * NOBS) return;
   const int env = i / NOBS, k = i % NOBS;
   obs[i] = k < 28 ? B.qpos[(size_t)env * NQ + 7 + k] : B.qvel[(size_t)env * NV + 6 + (k - 28)];
 }
 
+// field reads / writes of the float32 build: device state is `Real`, the C ABI speaks float64
+__global__ void k_to_ext(const Real* __restrict__ src, Ext* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (Ext)src[i];
+}
+__global__ void k_from_ext(const Ext* __restrict__ src, Real* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (Real)src[i];
+}
+
 __global__ __launch_bounds__(64) void k_debug_forward(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, int env, double* out) {
   __shared__ Shared<Real> s;
   const int lane = dmw::lane();
-  load_env(*Mp, B, s, env, lane, (const Real*)0);
+  load_env(*Mp, B, s, env, lane, (const Ext*)0);
   // actuator forces from the stored ctrl
   if (lane < NU) { const int d = lane + 6; s.act[d] = Mp->gear[d] * clampr(B.ctrl[(size_t)env * NU + lane], Mp->ctrl_lo[d], Mp->ctrl_hi[d]); }
   dmw::sync();
@@ -150,11 +173,12 @@ struct dm_batch {
   Batch<Real> B{};
   Real *d_cfg = nullptr, *d_vel = nullptr, *d_imit = nullptr; int* d_order = nullptr;
   // staging for DM_PTR_HOST callers
-  Real *d_action = nullptr, *d_obs = nullptr, *d_reward = nullptr; unsigned char *d_done = nullptr, *d_mask = nullptr;
+  Ext *d_action = nullptr, *d_obs = nullptr, *d_reward = nullptr; unsigned char *d_done = nullptr, *d_mask = nullptr;
   // host-pointer steps: obs | reward | done are ONE device block (d_obs points at its start) mirrored in pinned host memory, so a
   // step costs one H2D (action, from the pinned mirror) and one D2H instead of one pageable copy per array
-  unsigned char* h_out = nullptr; Real* h_action = nullptr; size_t out_bytes = 0;
-  Real *d_qpos_in = nullptr, *d_qvel_in = nullptr; int* d_fidx_in = nullptr;
+  unsigned char* h_out = nullptr; Ext* h_action = nullptr; size_t out_bytes = 0;
+  Ext* d_cvt = nullptr;   // float32 build: float64 staging for field reads / writes through host pointers
+  Ext *d_qpos_in = nullptr, *d_qvel_in = nullptr; int* d_fidx_in = nullptr;
   double* d_debug = nullptr;
   long long* d_prof = nullptr; bool prof = false;
   bool two_tier = true, reorder = true, has_rows = true; int resident_waves = 2048;   // CUs x 8 single-wave workgroups (LDS-limited)
@@ -172,6 +196,7 @@ static int pipe_join(dm_batch* b) {
 
 extern "C" const char* dm_last_error(void) { return g_err.c_str(); }
 extern "C" int dm_abi_version(void) { return DM_ABI_VERSION; }
+extern "C" int dm_real_bits(void) { return (int)(8 * sizeof(Real)); }   /* 64: libdmenv.so, 32: libdmenv32.so */
 extern "C" int dm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 extern "C" int dm_model_create(const dm_model_desc* d, dm_model** out) {
@@ -215,7 +240,7 @@ extern "C" void dm_batch_destroy(dm_batch* b) {
   if (b->ev_in) hipEventDestroy(b->ev_in);
   void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
                   b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
-                  b->d_mask, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order};
+                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order};
   for (void* p : ptrs) if (p) hipFree(p);
   if (b->h_out) hipHostFree(b->h_out);
   if (b->h_action) hipHostFree(b->h_action);
@@ -250,34 +275,39 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   A(b->d_cfg, (size_t)mc->n_frames * NQ); A(b->d_vel, (size_t)mc->n_frames * NV);
   if (!mc->imit_table.empty()) A(b->d_imit, mc->imit_table.size() + 32);   // [32 parameters][F x 112 feature rows]
   A(b->d_action, (size_t)n * NU); A(b->d_mask, n);
-  b->out_bytes = (size_t)n * (NOBS + 1) * sizeof(Real) + (size_t)n;
+  b->out_bytes = (size_t)n * (NOBS + 1) * sizeof(Ext) + (size_t)n;
   { unsigned char* blk = nullptr; ok = ok && (dalloc(&blk, b->out_bytes) == hipSuccess);
-    b->d_obs = (Real*)blk; b->d_reward = b->d_obs + (size_t)n * NOBS; b->d_done = (unsigned char*)(b->d_reward + n); }
+    b->d_obs = (Ext*)blk; b->d_reward = b->d_obs + (size_t)n * NOBS; b->d_done = (unsigned char*)(b->d_reward + n); }
   ok = ok && hipHostMalloc((void**)&b->h_out, b->out_bytes, hipHostMallocDefault) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&b->h_action, (size_t)n * NU * sizeof(Real), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&b->h_action, (size_t)n * NU * sizeof(Ext), hipHostMallocDefault) == hipSuccess;
   A(b->B.aovf, (size_t)n * AOVF_COLS * 64);
   A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
+  if (sizeof(Real) != sizeof(Ext)) A(b->d_cvt, (size_t)n * NB * 3);   // largest Real field per env: xipos (42)
 #undef A
   if (!ok) { dm_batch_destroy(b); return fail(DM_ENOMEM, "dm_batch_create: hipMalloc failed"); }
   ok = hipMemcpy(b->d_model, &hm, sizeof hm, hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(b->d_cfg, mc->cfg.data(), mc->cfg.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(b->d_vel, mc->vel.data(), mc->vel.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  auto upload = [](Real* dst, const double* src, size_t cnt) {      // host float64 table -> device `Real` array
+    std::vector<Real> tmp(src, src + cnt);
+    return hipMemcpy(dst, tmp.data(), cnt * sizeof(Real), hipMemcpyHostToDevice) == hipSuccess;
+  };
+  ok = ok && upload(b->d_cfg, mc->cfg.data(), mc->cfg.size());
+  ok = ok && upload(b->d_vel, mc->vel.data(), mc->vel.size());
   if (b->d_imit) {
-    ok = ok && hipMemcpy(b->d_imit, mc->imit_params.data(), 32 * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(b->d_imit + 32, mc->imit_table.data(), mc->imit_table.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && upload(b->d_imit, mc->imit_params.data(), 32);
+    ok = ok && upload(b->d_imit + 32, mc->imit_table.data(), mc->imit_table.size());
     for (int k = 0; k < 32; k++) b->B.imit_params[k] = mc->imit_params[k];
   }
   b->B.imit_pdev = b->d_imit;
   b->B.imit_table = b->d_imit ? b->d_imit + 32 : nullptr;
   // initial state = MjSim(model): qpos0, zero velocity
-  std::vector<double> q0((size_t)n * NQ);
+  std::vector<Real> q0((size_t)n * NQ);
   for (int e2 = 0; e2 < n; e2++) for (int k = 0; k < NQ; k++) q0[(size_t)e2 * NQ + k] = hm.qpos0[k];
-  ok = ok && hipMemcpy(b->B.qpos, q0.data(), q0.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(b->B.qpos, q0.data(), q0.size() * sizeof(Real), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { dm_batch_destroy(b); return fail(DM_EHIP, "dm_batch_create: upload failed"); }
   b->B.mocap_cfg = b->d_cfg; b->B.mocap_vel = b->d_vel; b->B.mocap_dt = mc->dt; b->B.n_frames = mc->n_frames; b->B.n_envs = n; b->B.env_offset = 0;
   b->B.reward_mode = 0; b->B.autoreset = 0; b->B.action_mode = 0; b->B.seed = 0; b->B.diag = 1;
   hipEventCreate(&b->ev0); hipEventCreate(&b->ev1);
-  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) == hipSuccess && cus > 0) b->resident_waves = cus * 8; }
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) == hipSuccess && cus > 0) b->resident_waves = cus * 4 * DM_STEP_WAVES; }
   *out = b;
   return DM_OK;
 }
@@ -350,7 +380,7 @@ extern "C" int dm_batch_set_state(dm_batch* b, const double* qpos, const double*
   if ((rc = stage_in(b, b->d_qvel_in, qvel, (size_t)b->n * NV * 8, kind, &v))) return rc;
   if ((rc = stage_in(b, b->d_fidx_in, fidx, (size_t)b->n * 4, kind, &f))) return rc;
   if ((rc = stage_in(b, b->d_mask, mask, (size_t)b->n, kind, &mk))) return rc;
-  hipLaunchKernelGGL(k_set_state, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)q, (const Real*)v, (const int*)f, (const unsigned char*)mk);
+  hipLaunchKernelGGL(k_set_state, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)q, (const Ext*)v, (const int*)f, (const unsigned char*)mk);
   HIPCHK(hipGetLastError());
   if (kind == DM_PTR_HOST) HIPCHK(hipStreamSynchronize(b->stream));
   return DM_OK;
@@ -373,18 +403,18 @@ extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, dou
   HIPCHK(hipSetDevice(b->device));
   const void* a = action;
   if (kind == DM_PTR_HOST) {
-    memcpy(b->h_action, action, (size_t)b->n * NU * sizeof(Real));
-    HIPCHK(hipMemcpyAsync(b->d_action, b->h_action, (size_t)b->n * NU * sizeof(Real), hipMemcpyHostToDevice, b->stream));
+    memcpy(b->h_action, action, (size_t)b->n * NU * sizeof(Ext));
+    HIPCHK(hipMemcpyAsync(b->d_action, b->h_action, (size_t)b->n * NU * sizeof(Ext), hipMemcpyHostToDevice, b->stream));
     a = b->d_action;
   }
-  Real* o = kind == DM_PTR_DEVICE ? obs : b->d_obs;
-  Real* r = kind == DM_PTR_DEVICE ? reward : b->d_reward;
+  Ext* o = kind == DM_PTR_DEVICE ? obs : b->d_obs;
+  Ext* r = kind == DM_PTR_DEVICE ? reward : b->d_reward;
   unsigned char* dn = kind == DM_PTR_DEVICE ? done : b->d_done;
   const bool piped = b->pipe > 1 && kind == DM_PTR_DEVICE && !b->prof && b->two_tier;
   if (!piped && pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
-  if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } HIPCHK(hipEventRecord(b->ev0, b->stream)); }
+  if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } if (!piped) HIPCHK(hipEventRecord(b->ev0, b->stream)); }
   const bool reorder = b->reorder && b->has_rows && b->n > b->resident_waves;   // more envs than resident waves: later rounds exist, their tail matters
-  if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, b->d_prof);
+  if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, b->d_prof);
   else if (piped) {
     // Sub-batch h's launch of THIS call depends on its own launch of the previous call (stream order on ps[h]) and on the
     // caller's inputs (ev_in), not on the other sub-batches: while the last, cheap workgroups of one sub-batch drain, the
@@ -395,25 +425,27 @@ extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, dou
       const int lo = (int)((long long)b->n * h / b->pipe), hi = (int)((long long)b->n * (h + 1) / b->pipe);
       if (hi <= lo) continue;
       HIPCHK(hipStreamWaitEvent(b->ps[h], b->ev_in, 0));
-      hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, lo);
+      if (b->timing && h == 0) HIPCHK(hipEventRecord(b->ev0, b->ps[0]));     // timing: sub-batch 0's kernel on ITS stream
+      hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo);
+      if (b->timing && h == 0) { HIPCHK(hipEventRecord(b->ev1, b->ps[0])); b->ev_pending = true; }
       if (reorder) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->ps[h], b->B, b->d_order, lo, hi - lo);
       HIPCHK(hipEventRecord(b->ev_done[h], b->ps[h]));
     }
     if (reorder) b->B.order = b->d_order;  // valid from the next launch on (same streams: ordered after each part's k_order)
     b->pipe_pending = true;
   } else if (b->two_tier) {
-    hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub, 0);
+    hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0);
     if (reorder) {
       hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order, 0, b->n);
       b->B.order = b->d_order;             // valid from the next launch on (same stream: ordered after k_order)
     }
-  } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Real*)a, o, r, dn, (int)nsub);
+  } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub);
   HIPCHK(hipGetLastError());
-  if (b->timing) { HIPCHK(hipEventRecord(b->ev1, b->stream)); b->ev_pending = true; }
+  if (b->timing && !piped) { HIPCHK(hipEventRecord(b->ev1, b->stream)); b->ev_pending = true; }
   if (kind == DM_PTR_HOST) {
     HIPCHK(hipMemcpyAsync(b->h_out, b->d_obs, b->out_bytes, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
-    const size_t ob = (size_t)b->n * NOBS * sizeof(Real), rb = (size_t)b->n * sizeof(Real);
+    const size_t ob = (size_t)b->n * NOBS * sizeof(Ext), rb = (size_t)b->n * sizeof(Ext);
     memcpy(obs, b->h_out, ob); memcpy(reward, b->h_out + ob, rb); memcpy(done, b->h_out + ob + rb, (size_t)b->n);
   }
   return DM_OK;
@@ -423,7 +455,7 @@ extern "C" int dm_batch_get_obs(dm_batch* b, double* obs, int32_t kind) {
   if (!b || !obs) return fail(DM_EINVAL, "dm_batch_get_obs: null argument");
   HIPCHK(hipSetDevice(b->device));
   if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
-  Real* o = kind == DM_PTR_DEVICE ? obs : b->d_obs;
+  Ext* o = kind == DM_PTR_DEVICE ? obs : b->d_obs;
   const int tot = b->n * NOBS;
   hipLaunchKernelGGL(k_get_obs, dim3((tot + 255) / 256), dim3(256), 0, b->stream, b->B, o);
   HIPCHK(hipGetLastError());
@@ -431,25 +463,27 @@ extern "C" int dm_batch_get_obs(dm_batch* b, double* obs, int32_t kind) {
   return DM_OK;
 }
 
-static int field_ptr(dm_batch* b, int field, void** p, size_t* bytes) {
+// field -> device array, element count, and whether its elements are `Real` (float64 at the ABI) or int32
+static int field_ptr(dm_batch* b, int field, void** p, size_t* count, bool* is_real) {
   const size_t n = b->n;
+  *is_real = false;
   switch (field) {
-    case DM_F_QPOS: *p = b->B.qpos; *bytes = n * NQ * 8; break;
-    case DM_F_QVEL: *p = b->B.qvel; *bytes = n * NV * 8; break;
-    case DM_F_QACC_WARMSTART: *p = b->B.qws; *bytes = n * NV * 8; break;
-    case DM_F_TIME: *p = b->B.time; *bytes = n * 8; break;
-    case DM_F_FRAME_IDX: *p = b->B.frame_idx; *bytes = n * 4; break;
-    case DM_F_FRAME_INIT: *p = b->B.frame_init; *bytes = n * 4; break;
-    case DM_F_XIPOS: *p = b->B.xipos; *bytes = n * NB * 3 * 8; break;
-    case DM_F_COM_Z: *p = b->B.comz; *bytes = n * 8; break;
-    case DM_F_NCON: *p = b->B.ncon; *bytes = n * 4; break;
-    case DM_F_NEFC: *p = b->B.nefc; *bytes = n * 4; break;
-    case DM_F_CONTACT_GEOMS: *p = b->B.cong; *bytes = n * MAXEFC * 2 * 4; break;
-    case DM_F_STATUS: *p = b->B.status; *bytes = n * 4; break;
-    case DM_F_SOLVER_ITER: *p = b->B.solver_iter; *bytes = n * 4; break;
-    case DM_F_CTRL: *p = b->B.ctrl; *bytes = n * NU * 8; break;
-    case DM_F_EPISODE: *p = b->B.episode; *bytes = n * 4; break;
-    case DM_F_CYCLE: *p = b->B.cycle; *bytes = n * 4; break;
+    case DM_F_QPOS: *p = b->B.qpos; *count = n * NQ; *is_real = true; break;
+    case DM_F_QVEL: *p = b->B.qvel; *count = n * NV; *is_real = true; break;
+    case DM_F_QACC_WARMSTART: *p = b->B.qws; *count = n * NV; *is_real = true; break;
+    case DM_F_TIME: *p = b->B.time; *count = n; *is_real = true; break;
+    case DM_F_FRAME_IDX: *p = b->B.frame_idx; *count = n; break;
+    case DM_F_FRAME_INIT: *p = b->B.frame_init; *count = n; break;
+    case DM_F_XIPOS: *p = b->B.xipos; *count = n * NB * 3; *is_real = true; break;
+    case DM_F_COM_Z: *p = b->B.comz; *count = n; *is_real = true; break;
+    case DM_F_NCON: *p = b->B.ncon; *count = n; break;
+    case DM_F_NEFC: *p = b->B.nefc; *count = n; break;
+    case DM_F_CONTACT_GEOMS: *p = b->B.cong; *count = n * MAXEFC * 2; break;
+    case DM_F_STATUS: *p = b->B.status; *count = n; break;
+    case DM_F_SOLVER_ITER: *p = b->B.solver_iter; *count = n; break;
+    case DM_F_CTRL: *p = b->B.ctrl; *count = n * NU; *is_real = true; break;
+    case DM_F_EPISODE: *p = b->B.episode; *count = n; break;
+    case DM_F_CYCLE: *p = b->B.cycle; *count = n; break;
     default: return fail(DM_EINVAL, "unknown field");
   }
   return DM_OK;
@@ -458,10 +492,16 @@ extern "C" int dm_batch_get(dm_batch* b, int32_t field, void* out, size_t bytes,
   if (!b || !out) return fail(DM_EINVAL, "dm_batch_get: null argument");
   HIPCHK(hipSetDevice(b->device));
   if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
-  void* p; size_t need; int rc;
-  if ((rc = field_ptr(b, field, &p, &need))) return rc;
+  void* p; size_t cnt; bool real; int rc;
+  if ((rc = field_ptr(b, field, &p, &cnt, &real))) return rc;
+  const size_t need = cnt * (real ? sizeof(Ext) : 4);
   if (bytes != need) return fail(DM_EINVAL, "dm_batch_get: buffer size does not match the field");
-  HIPCHK(hipMemcpyAsync(out, p, need, kind == DM_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, b->stream));
+  if (real && sizeof(Real) != sizeof(Ext)) {       // float32 build: widen on the device, then copy
+    Ext* dst = kind == DM_PTR_DEVICE ? (Ext*)out : b->d_cvt;
+    hipLaunchKernelGGL(k_to_ext, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, b->stream, (const Real*)p, dst, cnt);
+    HIPCHK(hipGetLastError());
+    if (kind == DM_PTR_HOST) HIPCHK(hipMemcpyAsync(out, dst, need, hipMemcpyDeviceToHost, b->stream));
+  } else HIPCHK(hipMemcpyAsync(out, p, need, kind == DM_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, b->stream));
   if (kind == DM_PTR_HOST) HIPCHK(hipStreamSynchronize(b->stream));
   return DM_OK;
 }
@@ -469,12 +509,18 @@ extern "C" int dm_batch_set(dm_batch* b, int32_t field, const void* in, size_t b
   if (!b || !in) return fail(DM_EINVAL, "dm_batch_set: null argument");
   HIPCHK(hipSetDevice(b->device));
   if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
-  void* p; size_t need; int rc;
-  if ((rc = field_ptr(b, field, &p, &need))) return rc;
+  void* p; size_t cnt; bool real; int rc;
+  if ((rc = field_ptr(b, field, &p, &cnt, &real))) return rc;
+  const size_t need = cnt * (real ? sizeof(Ext) : 4);
   if (bytes != need) return fail(DM_EINVAL, "dm_batch_set: buffer size does not match the field");
   if (field == DM_F_XIPOS || field == DM_F_COM_Z || field == DM_F_NCON || field == DM_F_NEFC || field == DM_F_CONTACT_GEOMS || field == DM_F_SOLVER_ITER)
     return fail(DM_EINVAL, "dm_batch_set: derived field is read-only");
-  HIPCHK(hipMemcpyAsync(p, in, need, kind == DM_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->stream));
+  if (real && sizeof(Real) != sizeof(Ext)) {       // float32 build: copy, then narrow on the device
+    const Ext* src = (const Ext*)in;
+    if (kind == DM_PTR_HOST) { HIPCHK(hipMemcpyAsync(b->d_cvt, in, need, hipMemcpyHostToDevice, b->stream)); src = b->d_cvt; }
+    hipLaunchKernelGGL(k_from_ext, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, b->stream, src, (Real*)p, cnt);
+    HIPCHK(hipGetLastError());
+  } else HIPCHK(hipMemcpyAsync(p, in, need, kind == DM_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->stream));
   if (kind == DM_PTR_HOST) HIPCHK(hipStreamSynchronize(b->stream));
   return DM_OK;
 }

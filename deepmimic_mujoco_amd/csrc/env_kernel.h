@@ -226,7 +226,8 @@ template <class R> struct SinCos { R s, c; };
 #if defined(DM_WAVE_TESTBENCH)
 template <class R> DM_DEV SinCos<R> sincos_once(R x) { return SinCos<R>{sin(x), cos(x)}; }
 #else
-template <class R> __device__ __attribute__((noinline)) SinCos<R> sincos_once(R x) { SinCos<R> r; sincos(x, &r.s, &r.c); return r; }
+__device__ __attribute__((noinline)) inline SinCos<double> sincos_once(double x) { SinCos<double> r; sincos(x, &r.s, &r.c); return r; }
+__device__ __attribute__((noinline)) inline SinCos<float> sincos_once(float x) { SinCos<float> r; sincosf(x, &r.s, &r.c); return r; }
 #endif
 template <class R> DM_DEV void quat_rot(R* r, const R* q, const R* v) { R m[9]; quat2mat(m, q); mat_vec(r, m, v); }
 template <class R> DM_DEV void axisangle2quat(R* q, const R* axis, R angle) {

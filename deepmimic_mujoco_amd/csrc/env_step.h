@@ -111,13 +111,13 @@ DM_DEV bool rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int 
 
 // load one env's row from HBM (coalesced: lane k reads element k) and turn the action into actuator forces
 template <class R>
-DM_DEV void load_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int env, int lane, const R* action) {
+DM_DEV void load_env(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int env, int lane, const double* action) {
   if (lane < NQ) s.qpos[lane] = B.qpos[(size_t)env * NQ + lane];
   if (lane < NV) { s.qvel[lane] = B.qvel[(size_t)env * NV + lane]; s.qws[lane] = B.qws[(size_t)env * NV + lane]; s.act[lane] = 0; }
   if (lane == 0) { s.status = 0; s.nefc = 0; s.ncon = 0; s.solver_iter = 0; s.aovf = B.aovf ? B.aovf + (size_t)env * AOVF_COLS * 64 : (R*)0; }
   dmw::sync();
   if (action && lane < NU) {
-    R a = action[(size_t)env * NU + lane];
+    R a = (R)action[(size_t)env * NU + lane];   // (the C ABI's buffers are float64 whatever the arithmetic type R)
     if (B.action_mode == 1) {  // P-control towards the current mocap frame (src/env_torque_test.py:14-20)
       const int idx = B.frame_idx[env];
       a += R(0.8) * (B.mocap_cfg[(size_t)idx * NQ + 7 + lane] - s.qpos[7 + lane]);
@@ -346,7 +346,7 @@ DM_DEV R v1_reward(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int la
 // (up to MAXEFC) keeps the remaining columns in the env's global-memory strip s.aovf (see stage_constraint).
 template <class R, int ROWS = MAXEFC, bool PROF = false>
 DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, StepScratch<R>& x, int env, int lane,
-                     const R* action, R* obs, R* reward, unsigned char* done, int n_substeps, long long* prof_out = 0) {
+                     const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, long long* prof_out = 0) {
   long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tstart = 0;
   if (PROF) tstart = dmw::clk();

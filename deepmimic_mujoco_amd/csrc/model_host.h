@@ -13,7 +13,8 @@ namespace dm {
 
 inline int mfail(std::string* err, int code, const char* msg) { if (err) *err = msg; return code; }
 
-inline int build_dev_model(const dm_model_desc* d, DevModel<double>* hp, std::string* err) {
+template <class R>
+inline int build_dev_model(const dm_model_desc* d, DevModel<R>* hp, std::string* err) {
   if (!d || !hp) return mfail(err, DM_EINVAL, "dm_model_create: null argument");
   if (d->abi_version != DM_ABI_VERSION) return mfail(err, DM_EINVAL, "dm_model_create: ABI version mismatch");
   if (d->nbody != NB || d->njnt != NJ || d->nq != NQ || d->nv != NV || d->nu != NU || d->ngeom != NG)
@@ -27,7 +28,7 @@ inline int build_dev_model(const dm_model_desc* d, DevModel<double>* hp, std::st
   for (int j = 1; j < NJ; j++)
     if (d->jnt_type[j] != 3 || d->jnt_bodyid[j] != T.dof_body[j + 5]) return mfail(err, DM_EUNSUPPORTED, "dm_model_create: joint layout differs from the humanoid");
   for (int u = 0; u < NU; u++) if (d->actuator_dofid[u] != u + 6) return mfail(err, DM_EUNSUPPORTED, "dm_model_create: actuator u must drive hinge dof u+6");
-  DevModel<double>& h = *hp;
+  DevModel<R>& h = *hp;
   memset(&h, 0, sizeof h);
   for (int b = 0; b < NB; b++) {
     for (int k = 0; k < 3; k++) { h.body_pos[b][k] = d->body_pos[3 * b + k]; h.body_ipos[b][k] = d->body_ipos[3 * b + k]; }
@@ -84,9 +85,9 @@ inline int build_dev_model(const dm_model_desc* d, DevModel<double>* hp, std::st
     const int dim = h.geom_condim[a] > h.geom_condim[b] ? h.geom_condim[a] : h.geom_condim[b];
     r.t1t2 = h.geom_type[a] | (h.geom_type[b] << 8) | (dim << 16);
     r.meta = h.geom_body[a] | (h.geom_body[b] << 8) | ((h.pair_stage[p] + 1) << 16);
-    r.margin = std::fmax(h.geom_margin[a], h.geom_margin[b]);
-    r.mu = std::fmax(h.geom_mu[a], h.geom_mu[b]);
-    r.bound = (h.geom_type[a] == GEOM_PLANE ? 0.0 : h.geom_rbound[a]) + h.geom_rbound[b] + r.margin;
+    r.margin = h.geom_margin[a] > h.geom_margin[b] ? h.geom_margin[a] : h.geom_margin[b];
+    r.mu = h.geom_mu[a] > h.geom_mu[b] ? h.geom_mu[a] : h.geom_mu[b];
+    r.bound = (h.geom_type[a] == GEOM_PLANE ? R(0) : h.geom_rbound[a]) + h.geom_rbound[b] + r.margin;
     r.tran = h.body_invw[h.geom_body[a]] + h.body_invw[h.geom_body[b]];
     for (int k = 0; k < 3; k++) { r.s1[k] = h.geom_size[a][k]; r.s2[k] = h.geom_size[b][k]; }
   }

@@ -54,6 +54,12 @@ DM_DEV double dpp_f64(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+template <int CTRL>
+DM_DEV float dpp_f32(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+DM_DEV float perm_xor1(float v) { return dpp_f32<0xB1>(v); }
+DM_DEV float perm_xor2(float v) { return dpp_f32<0x4E>(v); }
+DM_DEV float perm_half_mirror(float v) { return dpp_f32<0x141>(v); }
+DM_DEV float perm_row_mirror(float v) { return dpp_f32<0x140>(v); }
 DM_DEV double perm_xor1(double v) { return dpp_f64<0xB1>(v); }         // quad_perm [1,0,3,2]
 DM_DEV double perm_xor2(double v) { return dpp_f64<0x4E>(v); }         // quad_perm [2,3,0,1]
 DM_DEV double perm_half_mirror(double v) { return dpp_f64<0x141>(v); } // lane i <-> 7-i within each 8
@@ -110,6 +116,14 @@ DM_DEV double wave_sum(double v) {
   v = sum16(v);
   return ((bcast(v, 0) + bcast(v, 16)) + bcast(v, 32)) + bcast(v, 48);
 }
+#if !defined(DM_WAVE_TESTBENCH)
+DM_DEV float sum8(float v) { v += perm_xor1(v); v += perm_xor2(v); v += perm_half_mirror(v); return v; }
+DM_DEV float sum16(float v) { v = sum8(v); v += perm_row_mirror(v); return v; }
+DM_DEV float wave_sum(float v) {
+  v = sum16(v);
+  return ((bcast(v, 0) + bcast(v, 16)) + bcast(v, 32)) + bcast(v, 48);
+}
+#endif
 // exclusive prefix sum over lanes of a small non-negative int (< 32): one ballot + popcount per bit instead of a
 // 6-step shuffle scan (each shuffle is an LDS-crossbar round trip)
 DM_DEV int wave_exclusive_scan(int v, int lane_id, int* total) {

@@ -250,14 +250,15 @@ class DPVecEnv(object):
     """N DeepMimic humanoids in lock step on one GPU (one wavefront per environment)."""
 
     def __init__(self, num_envs, motion="walk", xml_path=None, device=0, reward="alive", autoreset="rsi", seed=0,
-                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=None, diagnostics=False):
+                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=None, diagnostics=False, dtype=64):
         """reward="imitation": the 5-term reward of code.md:1017-1143 (imitation.py) against the frame after the current one.
         frame_skip: sim steps per env step (src/dp_env_v3.py:108-112 hard-codes 1); "mocap" = floor(mocap_dt / timestep), the
         commented intent of :107-110, so that one env step spans one mocap frame.  Default (None): 1, except "mocap" for the
         imitation reward — its reference advances one mocap frame per env step and its velocity features are per second, so any
         other value plays the clip at the wrong speed (a warning says so when one is given).
         diagnostics: keep `sim.data.xipos` / the contact geom list up to date after every step (DM_OPT_DIAGNOSTICS; the batched
-        training path does not read them, `DPEnv` and raw `Batch` objects default to on)."""
+        training path does not read them, `DPEnv` and raw `Batch` objects default to on).
+        dtype: 64 (default) or 32 — arithmetic of the kernels; observations / actions stay float64 arrays."""
         self.num_envs = int(num_envs)
         self.mocap = MocapDM()
         self.mocap.load_mocap(motion)
@@ -282,7 +283,7 @@ class DPVecEnv(object):
             imit = self.imitation.table_for(self.mocap)
         if batch_factory is None:
             self._batch = Batch(self._cm, self.mocap.data_config, self.mocap.data_vel, self.num_envs, device=device,
-                                flags=flags, mocap_dt=float(self.mocap_dt), imitation=imit)
+                                flags=flags, mocap_dt=float(self.mocap_dt), imitation=imit, dtype=dtype)
         elif imit is not None:
             self._batch = batch_factory(self._cm, self.mocap.data_config, self.mocap.data_vel, self.num_envs, flags, imitation=imit)
         else:

@@ -213,6 +213,9 @@ int dm_batch_sync(dm_batch* b);
 int dm_batch_join(dm_batch* b);
 const char* dm_last_error(void);
 int dm_abi_version(void);
+/* Arithmetic / device-state type of the loaded library: 64 (libdmenv.so) or 32 (libdmenv32.so, the same source built with
+ * -DDM_REAL_FLOAT: SURVEY.md section 8b's `dtype 32`).  Every buffer of this ABI is float64 in both. */
+int dm_real_bits(void);
 int dm_device_count(void);
 
 #ifdef __cplusplus

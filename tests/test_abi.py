@@ -15,15 +15,17 @@ from tests import helpers as H
 HEADER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "dmenv.h")
 
 
-def test_library_exports_every_declared_symbol():
-    L = A.load()
+@pytest.mark.parametrize("dtype", [64, 32])
+def test_library_exports_every_declared_symbol(dtype):
+    """libdmenv.so (float64 arithmetic) and libdmenv32.so (the float32 build of the same source) export the same C ABI."""
+    L = A.load(dtype)
     text = open(HEADER).read()
-    declared = sorted(set(re.findall(r"\b(dm_[a-z_]+)\s*\(", text)))
+    declared = sorted(set(re.findall(r"\b(dm_[a-z_0-9]+)\s*\(", text)))
     assert len(declared) >= 20
     for name in declared:
-        assert hasattr(L, name), "libdmenv.so does not export %s" % name
+        assert hasattr(L, name), "the float%d library does not export %s" % (dtype, name)
     assert sorted(declared) == sorted(A.EXPORTS)
-    assert L.dm_abi_version() == A.ABI_VERSION
+    assert L.dm_abi_version() == A.ABI_VERSION and L.dm_real_bits() == dtype
 
 
 def test_header_constants_match_python_mirror():

@@ -399,3 +399,74 @@ def test_pipelined_sub_batches_do_not_change_results(n):
     assert outs[0][2].sum() > 0 and outs[0][5].max() > 1, "no early termination / auto-reset inside the run"
     with pytest.raises(A.DmenvError):
         make_batch(8).set_option(A.OPT_PIPELINE, 9)
+
+
+# ---- dtype 32: the float32 build of the same kernels (libdmenv32.so) -----------------------------------------
+def test_float32_batch_tracks_the_float64_path():
+    """Same C ABI, float32 arithmetic and device state.  Not a parity path (the bar of the float64 path is 1e-9 against the
+    oracle); it must TRACK it: one step from identical states agrees to ~1e-4 of the observation scale wherever both paths see
+    the same constraint rows, field reads / writes convert at the boundary, results are reproducible."""
+    from deepmimic_mujoco_amd import Batch
+    mc = H.mocap()
+    n = 256
+    idx, q, v, _ws, _c = H.varied_states(n, seed=31)
+    q[:, 3:7] /= np.linalg.norm(q[:, 3:7], axis=1, keepdims=True)
+    rng = np.random.RandomState(2)
+    a = rng.randn(n, 28) * 0.5
+    outs = {}
+    for dt in (64, 32, 32):
+        b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), dtype=dt)
+        assert b.dtype == dt
+        b.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); b.set_state(q, v, frame_idx=idx)
+        if dt == 32:                                          # boundary conversion: float64 in, float32 state, float64 out
+            assert np.array_equal(b.get(A.F_QPOS), q.astype(np.float32).astype(np.float64))
+        nefc0 = b.get(A.F_NEFC).copy()
+        obs, rew, done = b.step(a)
+        outs.setdefault(dt, []).append((obs.copy(), done.copy(), nefc0, b.get(A.F_NEFC).copy(), b.get(A.F_QPOS).copy()))
+        b.close()
+    o64, d64, n64a, n64b, q64 = outs[64][0]
+    o32, d32, n32a, n32b, q32 = outs[32][0]
+    assert np.array_equal(outs[32][0][0], outs[32][1][0]) and np.array_equal(q32, outs[32][1][4])          # reproducible
+    same = (n64a == n32a) & (n64b == n32b)                    # same rows at the first and the last RK stage
+    assert same.mean() > 0.9, same.mean()
+    scale = np.maximum(1.0, np.abs(o64).max(1))
+    err = np.abs(o32 - o64).max(1) / scale
+    print("float32 vs float64 after one step: median rel err %.2e, 99th pct %.2e (envs with equal row counts: %.1f%%)"
+          % (np.median(err[same]), np.percentile(err[same], 99), 100 * same.mean()))
+    assert np.median(err[same]) < 2e-4 and np.percentile(err[same], 95) < 5e-3
+    assert (d64 == d32).mean() > 0.99 and np.isfinite(o32).all()
+
+
+def test_float32_batch_full_size_rollout_and_shipped_policy_anchor():
+    """4096 float32 envs with RSI + early termination stay finite and keep auto-resetting exactly onto mocap frames (rounded to
+    float32); the reference's shipped policy balances in the float32 physics as long as in the float64 one (~270 steps)."""
+    import torch
+    from deepmimic_mujoco_amd import DPVecEnv, MlpPolicy, traj_segment_generator
+    from tests.test_policy import CKPT
+    n = 4096
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        env = DPVecEnv(n, motion="walk", device=0, reward="imitation", autoreset="rsi", seed=5, dtype=32, frame_skip=1)
+    mc = env.mocap
+    env.reset("rsi")
+    rng = np.random.RandomState(0)
+    dones = 0
+    for t in range(20):
+        obs, rew, done, _ = env.step(rng.randn(n, 28) * 0.9)
+        dones += int(done.sum())
+    assert np.isfinite(obs).all() and np.isfinite(rew).all() and 0 < rew.min() and rew.max() <= 1.0 + 1e-6 and dones > 0
+    fresh = np.nonzero(env.batch.get(A.F_TIME) == 0)[0]
+    fi = env.batch.get(A.F_FRAME_IDX)
+    assert len(fresh) > 0 and np.array_equal(env.batch.get(A.F_QPOS)[fresh], mc.data_config[fi[fresh]].astype(np.float32).astype(np.float64))
+    env.close()
+    lens = {}
+    for dt in (64, 32):
+        e = DPVecEnv(1024, motion="walk", device=0, reward="alive", autoreset="init", seed=1, dtype=dt)
+        pol = MlpPolicy.from_tf_checkpoint(CKPT, device="cuda:0"); pol.seed(1)
+        seg = next(traj_segment_generator(pol, e, 1200, stochastic=True, first_reset="init"))
+        new = seg["new"].cpu().numpy()[1:]
+        lens[dt] = float(np.where(new.any(0), new.argmax(0) + 1, 1200).mean())
+        e.close()
+    print("shipped policy, first-episode length: float64 %.1f, float32 %.1f" % (lens[64], lens[32]))
+    assert abs(lens[32] / lens[64] - 1) < 0.15 and 200 < lens[32] < 360

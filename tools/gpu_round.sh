@@ -9,6 +9,10 @@ export TMPDIR=/tmp
 ( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 ) > $OUT/pytest_gpu.log
 tail -5 $OUT/pytest_gpu.log
 timeout 600 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-600 $OUT/bench_cfg3.json
+# rocprofv3 --kernel-trace --stats of the same command (short run, no nested PMC passes), summarised per kernel
+( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace -- python $OLDPWD/bench.py --steps 96 --warmup 16 --no-pmc --no-cpu-baseline --no-gym-loop > /dev/null 2>&1 )
+ROWS=6 python tools/rocprof_summary.py $OUT/kstep_summary.md "k_step_narrow — $TAG, MI355X (bench.py default workload: cfg3 + 5-term imitation reward, 4096 envs as 2 pipelined sub-batches)" \
+  $(find /tmp/p_trace -name "*.db" | head -1) > /dev/null; head -12 $OUT/kstep_summary.md
 for wl in cfg4 cfg5 cfg2; do
   timeout 300 python bench.py --workload $wl --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; cut -c1-300 $OUT/bench_$wl.json
 done
