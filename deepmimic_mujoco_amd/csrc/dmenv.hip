@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ 
   env_step<Real, MAXEFC>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
 }
 
+// (Recomputing the order only every 2 / 4 / 8 steps was measured too: 11.2 / 10.95 / 10.8 M env-steps/s against 11.6 M every step.)
 // Dispatch order for the NEXT step: envs with more constraint rows (a good proxy for their step time: 0.32 .. 0.72 M
 // shader ticks from 0 to 32 rows) first.  4096 envs are two rounds of resident waves, so the launch ends when the last wave
 // of round two does; longest-first list scheduling trims that tail (measured -9 % kernel time).  Counting sort by
@@ -87,6 +88,34 @@ __global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__
 #pragma unroll
   for (int j = 0; j < PER; j++) if (key[j] >= 0) order[first + atomicAdd(&start[key[j]], 1)] = first + tid + j * 1024;
   for (int e = tid + PER * 1024; e < n; e += 1024) { const int k0 = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[first + atomicAdd(&start[k], 1)] = first + e; }
+}
+
+// The same ordering for the pipelined path, where the step kernel of ANOTHER sub-batch is resident while it runs: ONE wave, so that
+// its workgroup is placed into a freed wave slot like any step workgroup.  (k_order's 16-wave workgroup needs a whole CU's worth
+// of free registers at one instant; beside a resident step kernel it waited 67 us on average — rocprofv3 — on its sub-batch's
+// critical path.)  Up to 64 keys per lane stay in registers between the two passes: all loads of a lane are issued together.
+__global__ __launch_bounds__(64) void k_order_wave(Batch<Real> B, int* __restrict__ order, int first, int count) {
+  __shared__ int hist[64], start[64];
+  const int lane = threadIdx.x;
+  hist[lane] = 0;
+  __syncthreads();
+  constexpr int PER = 64;                // 4096 envs per sub-batch in registers; beyond that the keys are read again
+  int key[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int e = lane + j * 64;
+    key[j] = -1;
+    if (e < count) key[j] = B.nefc[first + e] + (B.solver_iter[first + e] >> 2);
+  }
+#pragma unroll
+  for (int j = 0; j < PER; j++) if (key[j] >= 0 || (lane + j * 64) < count) { key[j] = key[j] < 0 ? 0 : (key[j] > 63 ? 63 : key[j]); atomicAdd(&hist[key[j]], 1); }
+  for (int e = lane + PER * 64; e < count; e += 64) { const int k = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
+  __syncthreads();
+  if (lane == 0) { int acc = 0; for (int k = 63; k >= 0; k--) { start[k] = acc; acc += hist[k]; } }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER; j++) if ((lane + j * 64) < count) order[first + atomicAdd(&start[key[j]], 1)] = first + lane + j * 64;
+  for (int e = lane + PER * 64; e < count; e += 64) { const int k0 = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[first + atomicAdd(&start[k], 1)] = first + e; }
 }
 
 // same step with per-stage shader-clock accounting (DM_OPT 101); not used on the timed path
@@ -428,7 +457,7 @@ extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, dou
       if (b->timing && h == 0) HIPCHK(hipEventRecord(b->ev0, b->ps[0]));     // timing: sub-batch 0's kernel on ITS stream
       hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo);
       if (b->timing && h == 0) { HIPCHK(hipEventRecord(b->ev1, b->ps[0])); b->ev_pending = true; }
-      if (reorder) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->ps[h], b->B, b->d_order, lo, hi - lo);
+      if (reorder) hipLaunchKernelGGL(k_order_wave, dim3(1), dim3(64), 0, b->ps[h], b->B, b->d_order, lo, hi - lo);
       HIPCHK(hipEventRecord(b->ev_done[h], b->ps[h]));
     }
     if (reorder) b->B.order = b->d_order;  // valid from the next launch on (same streams: ordered after each part's k_order)

@@ -19,6 +19,7 @@ done
 for p in 1 2; do
   timeout 300 python bench.py --workload rollout --pipeline $p --steps 1024 --warmup 256 > $OUT/bench_rollout_p$p.json 2> $OUT/bench_rollout_p$p.err; cut -c1-200 $OUT/bench_rollout_p$p.json
 done
+timeout 300 python bench.py --dtype 32 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_f32.json 2> $OUT/bench_cfg3_f32.err; cut -c1-200 $OUT/bench_cfg3_f32.json
 timeout 300 python bench.py --pipeline 1 --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_pipeline1.json 2> $OUT/bench_cfg3_pipeline1.err; cut -c1-200 $OUT/bench_cfg3_pipeline1.json
 DM_PROF_REWARD=imitation timeout 300 python tools/profile_stages.py > $OUT/stage_cycles.txt 2>&1; head -30 $OUT/stage_cycles.txt
 timeout 300 python tools/contact_exposure.py --out $OUT/contact_exposure_cfg3.json > /dev/null 2> $OUT/contact_exposure.err
