@@ -63,7 +63,9 @@ __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ 
   env_step<Real, MAXEFC>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
 }
 
-// (Recomputing the order only every 2 / 4 / 8 steps was measured too: 11.2 / 10.95 / 10.8 M env-steps/s against 11.6 M every step.)
+// (Measured alternatives: having the launch's LAST workgroup sort the order before it exits — a device-scope counter, no ordering launch at
+//  all — is no faster at two sub-batches (11.65 M) and slower at one launch per step (8.53 vs 8.93 M: one wave sorting 4096 keys takes longer than
+//  this 16-wave kernel on an idle machine).  Recomputing the order only every 2 / 4 / 8 steps: 11.2 / 10.95 / 10.8 M env-steps/s against 11.6 M every step.)
 // Dispatch order for the NEXT step: envs with more constraint rows (a good proxy for their step time: 0.32 .. 0.72 M
 // shader ticks from 0 to 32 rows) first.  4096 envs are two rounds of resident waves, so the launch ends when the last wave
 // of round two does; longest-first list scheduling trims that tail (measured -9 % kernel time).  Counting sort by

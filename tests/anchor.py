@@ -100,8 +100,9 @@ class OracleVecEnv(object):
         pass
 
 
-def run_reference_protocol(seed=0, iterations=1900, workers=2, horizon=256, g_step=3, log_every=0, **model_opts):
-    """The reference's training run (`mpirun -np 2 python3 trpo.py`: src/trpo.py:338-353) in the oracle's physics.
+def run_reference_protocol(seed=0, iterations=1900, workers=2, horizon=256, g_step=3, log_every=0, backend="oracle", **model_opts):
+    """The reference's training run (`mpirun -np 2 python3 trpo.py`: src/trpo.py:338-353) in the oracle's physics
+    (backend="oracle", CPU) or on the HIP kernel (backend="gpu": a 2-env `DPVecEnv` with the kernel's noisy-init auto-reset).
     Returns {"EpLenMean": per-iteration curve (rolling 40 episodes, logged every g_step updates like src/trpo.py:303-306),
     "TimestepsSoFar", "mean", "std", "count"}."""
     import torch
@@ -110,8 +111,14 @@ def run_reference_protocol(seed=0, iterations=1900, workers=2, horizon=256, g_st
     from deepmimic_mujoco_amd.rollout import traj_segment_generator
     from deepmimic_mujoco_amd.trpo import TrpoLearner
     torch.manual_seed(seed); torch.set_num_threads(1)
-    env = OracleVecEnv(workers, seed=seed, **model_opts)
-    pi = MlpPolicy(device="cpu", seed=seed); pi.seed(seed)
+    if backend == "gpu":
+        from deepmimic_mujoco_amd import DPVecEnv
+        assert not model_opts, "the kernel has no model switches"
+        env = DPVecEnv(workers, motion="walk", device=0, reward="alive", autoreset="init", seed=seed)
+        pi = MlpPolicy(device="cuda:0", seed=seed); pi.seed(seed)
+    else:
+        env = OracleVecEnv(workers, seed=seed, **model_opts)
+        pi = MlpPolicy(device="cpu", seed=seed); pi.seed(seed)
     # value-fit minibatch: each worker walks its own 256 samples in minibatches of 128 and the gradients are all-mean'd,
     # i.e. `workers` x 128 samples per Adam step (src/trpo.py:288-295)
     learner = TrpoLearner(pi, vf_batch_size=128 * workers, seed=seed)
@@ -129,7 +136,7 @@ def run_reference_protocol(seed=0, iterations=1900, workers=2, horizon=256, g_st
             print("seed %d iter %d EpLenMean %.1f steps %d" % (seed, it + 1, curve[-1], tot), flush=True)
     mean, std, cnt = moments_of(pi.ob_rms)
     return {"seed": seed, "iterations": iterations, "EpLenMean": curve, "TimestepsSoFar": steps, "mean": mean.tolist(), "std": std.tolist(),
-            "count": cnt, "entropy": float(pi.entropy()), "model_opts": model_opts}
+            "count": cnt, "entropy": float(pi.entropy()), "model_opts": model_opts, "backend": backend}
 
 
 def shipped_policy_moments(n=64, steps=400, seed=0, nthreads=None, **model_opts):

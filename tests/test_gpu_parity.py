@@ -301,7 +301,7 @@ def test_pgs_guarded_replay_path_gives_identical_results():
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
 
 
-@pytest.mark.parametrize("n", [4096 + 37, 8192 + 101])      # > resident waves, so the reordering is active; > 8192: k_order's second key loop
+@pytest.mark.parametrize("n", [3000, 4096 + 37, 8192 + 101])      # > resident waves, so the reordering is active; <= 4096: sorted by the launch's last workgroup; > 8192: k_order's second key loop
 def test_dispatch_order_does_not_change_results(n):
     """Longest-first dispatch (k_order, option 104) only changes which workgroup steps which env: outputs must be bit-identical."""
     outs = []
