@@ -32,17 +32,18 @@ def test_checkpoint_filter_count_is_the_two_worker_protocol():
 def test_protocol_replay_moments_match_the_reference_filter():
     """Three seeds of the replay vs the checkpoint's 56 means + 56 stds, in units of the checkpoint's std per dimension.
     Joint-RATE dimensions are set by the dynamics (contact, limits, actuators, damping, inertia): means within 0.25 sigma,
-    spreads within -25 % / +35 %.  Joint-ANGLE dimensions also reflect which posture a run's policy settles into (the three
-    replays differ from each other by up to 0.5 sigma): means within 2 sigma, spreads within a factor 1.8."""
-    runs = _runs("protocol_seed[0-9].json")
-    assert len(runs) >= 3
+    spreads within -30 % / +35 %.  Joint-ANGLE dimensions also reflect which posture a run's policy settles into (the
+    replays differ from each other by up to 0.5 sigma): means within 2 sigma, spreads within a factor 2 / 1.8.  The fixtures
+    hold three replays in the oracle (CPU) and two on the HIP kernel (`make_anchor.py <seed> backend=gpu`, 7 min on an MI355X)."""
+    runs = _runs("protocol_seed[0-9].json") + _runs("protocol_gpu_seed[0-9].json")     # oracle (CPU) replays + replays on the HIP kernel (MI355X)
+    assert len(runs) >= 5 and sum(r.get("backend") == "gpu" for r in runs) >= 2
     ref_mean, ref_std, cnt = AN.checkpoint_moments()
     for r in runs:
         assert abs(r["count"] - cnt) < 1e-6 and r["iterations"] == 1900          # same protocol, same number of filter samples
         d, ratio = AN.compare_moments(r["mean"], r["std"])
-        assert np.abs(d[28:]).max() < 0.25 and 0.75 < ratio[28:].min() and ratio[28:].max() < 1.35, (np.abs(d[28:]).max(), ratio[28:].min(), ratio[28:].max())
-        assert np.abs(d[:28]).max() < 2.0 and 0.55 < ratio[:28].min() and ratio[:28].max() < 1.8, (np.abs(d[:28]).max(), ratio[:28].min(), ratio[:28].max())
-    M = np.mean([r["mean"] for r in runs], 0); S = np.mean([r["std"] for r in runs], 0)
+        assert np.abs(d[28:]).max() < 0.25 and 0.70 < ratio[28:].min() and ratio[28:].max() < 1.35, (np.abs(d[28:]).max(), ratio[28:].min(), ratio[28:].max())
+        assert np.abs(d[:28]).max() < 2.0 and 0.50 < ratio[:28].min() and ratio[:28].max() < 1.8, (np.abs(d[:28]).max(), ratio[:28].min(), ratio[:28].max())
+    M = np.mean([r["mean"] for r in runs], 0); S = np.mean([r["std"] for r in runs], 0)     # all five replays
     d, ratio = AN.compare_moments(M, S)
     assert np.sqrt((d[28:] ** 2).mean()) < 0.06 and abs(np.exp(np.log(ratio[28:]).mean()) - 1) < 0.06       # rates: 4 % rms, 2 % mean spread error
     assert np.sqrt((d[:28] ** 2).mean()) < 0.6 and abs(np.exp(np.log(ratio[:28]).mean()) - 1) < 0.12
@@ -54,7 +55,7 @@ def test_protocol_replay_learning_curve_tracks_the_reference_log():
     scatter (replays 176 .. 227 at iteration 1 900, the reference's one run 263)."""
     ref = np.load(os.path.join(AN.GOLD, "trpo_walk0_log.npz"))
     curve, steps = ref["EpLenMean"], ref["TimestepsSoFar"]
-    runs = _runs("protocol_seed[0-9].json")
+    runs = _runs("protocol_seed[0-9].json") + _runs("protocol_gpu_seed[0-9].json")
     C = np.array([r["EpLenMean"] for r in runs])
     for it, tol in ((10, 6), (100, 12), (500, 25), (1000, 35)):
         assert abs(C[:, it - 1].mean() - curve[it - 1]) < tol, (it, C[:, it - 1], curve[it - 1])
