@@ -33,6 +33,12 @@ import warnings
 
 import numpy as np
 
+# Multi-process GPU runs on this platform need dmabuf IPC: the host driver does not support the legacy IPC mode, and RCCL's cross-process
+# buffer registration otherwise fails with `hipIpcGetMemHandle: invalid argument` (platform note of the build environment, which exports the
+# same value here and on the GPU boxes).  The HSA runtime reads it when it is loaded, so it must be in the environment BEFORE torch
+# initialises HIP — setdefault: an exported value wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -320,9 +326,6 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            # this image's host driver only supports dmabuf IPC; RCCL's cross-process buffer registration otherwise fails with
-            # `hipIpcGetMemHandle: invalid argument` (the platform exports the same setting; profiles/r02_two_rank_*.log)
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
