@@ -204,6 +204,8 @@ def pmc_passes(argv_tail, kernel_prefix, timeout_s=150):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "already running under a profiler: nested counter passes skipped"
     groups = [("trace", ["--stats"]),
               ("fetch", ["--pmc", "FETCH_SIZE"]), ("write", ["--pmc", "WRITE_SIZE"]),
               ("sq", ["--pmc", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]),

@@ -193,3 +193,25 @@ def test_pipelined_rollouts_equal_the_same_batches_stepped_one_after_the_other()
             assert torch.equal(a[k], b[k]), k
         assert a["ep_lens"] == b["ep_lens"] and a["ep_rets"] == b["ep_rets"]
     assert sum(len(s["ep_lens"]) for s in outs[0]) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--workload", "cfg4"], ["--workload", "cfg5"], ["--workload", "cfg2", "--pipeline", "1"], ["--dtype", "32"]])
+def test_bench_other_workloads_print_the_contract_line(extra):
+    """The single-shard lines of BASELINE.json configs[3] / [4] ('spinkick', 'dance_b'; an interior shard's global env ids), configs[1]
+    and the float32 build go through the same code path and print the same contract line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "24", "--warmup", "4", "--prewarm-horizons", "0", "--envs", "768",
+                          "--no-pmc", "--no-cpu-baseline", "--no-gym-loop"] + extra, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert j["value"] > 1e5 and j["n_gpus"] == 1 and j["steps"] == 24 and j["config"]["envs_per_gpu"] == 768
+    wl = extra[1] if extra[0] == "--workload" else "cfg3"
+    assert {"cfg4": "spinkick", "cfg5": "dance_b", "cfg2": "walk", "cfg3": "walk"}[wl] == j["config"]["clip"]
+    if wl in ("cfg4", "cfg5"):
+        assert "shard 3 of 8" in j["config"]["workload"] and j["config"]["global_envs"] == 8 * 768
+    assert j["dtype"] == ("f32" if "--dtype" in extra else "f64")
+    assert j["roofline"]["launch"]["launches_per_step"] == (1 if "--pipeline" in extra else 2)
