@@ -8,6 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 ) > $OUT/pytest_gpu.log
 tail -5 $OUT/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log
 timeout 600 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-600 $OUT/bench_cfg3.json
 # rocprofv3 --kernel-trace --stats of the same command (short run, no nested PMC passes), summarised per kernel
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace -- python $OLDPWD/bench.py --steps 96 --warmup 16 --no-pmc --no-cpu-baseline --no-gym-loop > /dev/null 2>&1 )
