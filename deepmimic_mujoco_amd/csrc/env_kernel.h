@@ -1565,6 +1565,9 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   // The termination test of sweep k (a 6-stage cross-lane reduction + compare) is independent of the rows of sweep k + 1,
   // so sweep k + 1 is issued speculatively right behind the reduction and dropped if sweep k turns out to have converged:
   // one discarded sweep per solve buys the reduction latency off the serial chain of every sweep.
+  // (Round 2 measured the generalisation — blocks of K = 2 / 3 / 4 sweeps whose K tests run beside the next block's K speculative sweeps,
+  //  the state after every sweep kept for the roll-back; bit-identical results — at 11.54 / 11.39 / 11.35 M env-steps/s against 11.65 M:
+  //  with two waves per SIMD the partner wave already fills this chain's stalls, so the extra discarded sweeps only add instructions.)
   int iter = 0;
   const int maxiter = dmw::uniform(M.iterations);
   // loop constants pinned in VGPRs: left to itself the compiler re-loads them from memory (s_load + wait) every sweep
