@@ -961,19 +961,30 @@ DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s
       if (c0[k] - half > reach || c0[k] + half < -reach) return;
     }
     auto gfun = [&](R tt) { R acc = 0; for (int k = 0; k < 3; k++) { const R pk = c0[k] + tt * u[k]; acc += u[k] * (pk - clampr(pk, -s2[k], s2[k])); } return acc; };
-    R ta = -s1[1], tb = s1[1], ga = gfun(ta), gb = gfun(tb), ts;
-    if (ga >= 0) ts = ta;
-    else if (gb <= 0) ts = tb;
-    else {
-      for (int k = 0; k < 3; k++) for (int sg = 0; sg < 2; sg++) {
-        if (fabs(u[k]) <= R(1e-12)) continue;
-        const R tc = ((sg ? s2[k] : -s2[k]) - c0[k]) / u[k];
-        if (!(tc > ta && tc < tb)) continue;
-        const R gc = gfun(tc);
-        if (gc <= 0) { ta = tc; ga = gc; } else { tb = tc; gb = gc; }
-      }
-      ts = (gb - ga > R(1e-300)) ? ta - ga * (tb - ta) / (gb - ga) : R(0.5) * (ta + tb);
+    // Where the segment runs through the INSIDE of the box g is zero on a whole interval, and its computed value at the interval's ends
+    // (a face crossing) is +-1 ulp with a rounding-dependent sign: values within eps of zero are therefore a set of their own.  If any
+    // sample point (the two ends, the face crossings inside the segment) lies in it the answer is the middle of that set's extent —
+    // the root itself when it falls on a sample, the middle of the zero plateau otherwise; only when no sample is numerically zero is
+    // the root bracketed between the neighbouring samples and interpolated (the generic case; identical to the oracle's sequence).
+    const R L = s1[1], eps = sizeof(R) == 8 ? R(1e-12) : R(1e-6);
+    R ta = -L, tb = L, ga = gfun(ta), gb = gfun(tb), ts;
+    const R g_lo = ga, g_hi = gb;
+    R z0 = R(1e30), z1 = R(-1e30);
+    if (fabs(ga) <= eps) { z0 = ta; z1 = ta; }
+    if (fabs(gb) <= eps) { if (tb < z0) z0 = tb; if (tb > z1) z1 = tb; }
+    for (int k = 0; k < 3; k++) for (int sg = 0; sg < 2; sg++) {
+      if (fabs(u[k]) <= R(1e-12)) continue;
+      const R tc = ((sg ? s2[k] : -s2[k]) - c0[k]) / u[k];
+      if (!(tc > -L && tc < L)) continue;
+      const R gc = gfun(tc);
+      if (fabs(gc) <= eps) { if (tc < z0) z0 = tc; if (tc > z1) z1 = tc; }
+      else if (gc < 0) { if (tc > ta) { ta = tc; ga = gc; } }
+      else { if (tc < tb) { tb = tc; gb = gc; } }
     }
+    if (z0 <= z1) ts = R(0.5) * (z0 + z1);
+    else if (g_lo > 0) ts = -L;
+    else if (g_hi < 0) ts = L;
+    else ts = (gb - ga > R(1e-300)) ? ta - ga * (tb - ta) / (gb - ga) : R(0.5) * (ta + tb);
     R center[3], clamped[3], nrm[3], pl[3];
     for (int k = 0; k < 3; k++) { center[k] = c0[k] + ts * u[k]; clamped[k] = clampr(center[k], -s2[k], s2[k]); t[k] = center[k] - clamped[k]; }
     const R dist = sqrt(dot3(t, t));

@@ -703,24 +703,37 @@ static int narrowphase(const dmo_model* m, const dmo_data* d, int g1, int g2, do
      * is piecewise linear and non-decreasing, with breakpoints where a coordinate crosses a face plane (at most 6).  The
      * zero of g is bracketed between consecutive breakpoints inside [-L, L] and found by linear interpolation — exact up to
      * rounding, no iteration.  The HIP kernel runs the identical sequence of operations. */
+
     double ax[3] = {m1[2], m1[5], m1[8]}, t[3], c0[3], u[3];
     sub3(t, p1, p2); matT_vec(c0, m2, t); matT_vec(u, m2, ax);
 #define SEGBOX_G(tt, out) do { double g_ = 0; for (int k_ = 0; k_ < 3; k_++) { double pk_ = c0[k_] + (tt) * u[k_]; \
       g_ += u[k_] * (pk_ - clampd(pk_, -s2[k_], s2[k_])); } (out) = g_; } while (0)
-    double ta = -s1[1], tb = s1[1], ga, gb, ts, center[3], clamped[3], nrm[3], pl[3];
+    /* Where the segment runs through the INSIDE of the box, g is zero on a whole interval and its computed value at the interval's
+     * ends (a face crossing) is +-1 ulp with a sign that depends on rounding: a bracket driven by `g <= 0` would then pick one end or
+     * the other at random (and with it the face the contact is pushed out through).  So values within eps of zero are a set of
+     * their own: if any sample point (the two ends, the face crossings inside the segment) lies in it, the answer is the MIDDLE of
+     * that set's extent — the root itself when it falls on a sample point, the middle of the zero plateau otherwise; only when no
+     * sample is numerically zero is the root bracketed between the neighbouring samples and interpolated (the generic case). */
+    const double L = s1[1], eps = 1e-12;
+    double ta = -L, tb = L, ga, gb, ts, center[3], clamped[3], nrm[3], pl[3];
+    double z0 = 1e300, z1 = -1e300;
     SEGBOX_G(ta, ga); SEGBOX_G(tb, gb);
-    if (ga >= 0) ts = ta;
-    else if (gb <= 0) ts = tb;
-    else {
-      for (int k = 0; k < 3; k++) for (int sg = 0; sg < 2; sg++) {
-        if (fabs(u[k]) <= 1e-12) continue;
-        double tc = ((sg ? s2[k] : -s2[k]) - c0[k]) / u[k], gc;
-        if (!(tc > ta && tc < tb)) continue;
-        SEGBOX_G(tc, gc);
-        if (gc <= 0) { ta = tc; ga = gc; } else { tb = tc; gb = gc; }
-      }
-      ts = (gb - ga > 1e-300) ? ta - ga * (tb - ta) / (gb - ga) : 0.5 * (ta + tb);
+    const double g_lo = ga, g_hi = gb;
+    if (fabs(ga) <= eps) { z0 = ta; z1 = ta; }
+    if (fabs(gb) <= eps) { if (tb < z0) z0 = tb; if (tb > z1) z1 = tb; }
+    for (int k = 0; k < 3; k++) for (int sg = 0; sg < 2; sg++) {
+      if (fabs(u[k]) <= 1e-12) continue;
+      double tc = ((sg ? s2[k] : -s2[k]) - c0[k]) / u[k], gc;
+      if (!(tc > -L && tc < L)) continue;
+      SEGBOX_G(tc, gc);
+      if (fabs(gc) <= eps) { if (tc < z0) z0 = tc; if (tc > z1) z1 = tc; }
+      else if (gc < 0) { if (tc > ta) { ta = tc; ga = gc; } }
+      else { if (tc < tb) { tb = tc; gb = gc; } }
     }
+    if (z0 <= z1) ts = 0.5 * (z0 + z1);
+    else if (g_lo > 0) ts = -L;
+    else if (g_hi < 0) ts = L;
+    else ts = (gb - ga > 1e-300) ? ta - ga * (tb - ta) / (gb - ga) : 0.5 * (ta + tb);
 #undef SEGBOX_G
     for (int k = 0; k < 3; k++) { center[k] = c0[k] + ts * u[k]; clamped[k] = clampd(center[k], -s2[k], s2[k]); t[k] = center[k] - clamped[k]; }
     double dist = norm3(t);

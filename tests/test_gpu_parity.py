@@ -41,6 +41,15 @@ def test_capsule_box_contacts_match_oracle():
     b.close()
 
 
+def test_capsule_through_the_box_interior_matches_oracle():
+    """Deep penetration: the capsule's axis passes through the inside of the box (zero-distance plateau; tests/test_wave_testbench.py)."""
+    qs = np.load(H.GOLDEN + "/capsule_box_deep_poses.npy")
+    n = len(qs)
+    b = make_batch(n)
+    H.compare_forward(b, H.oracle_model(), np.zeros(n, dtype=np.int32), qs, np.zeros((n, 34)), np.zeros((n, 34)), np.zeros((n, 28)))
+    b.close()
+
+
 def test_box_box_contacts_match_oracle():
     qs = np.load(H.GOLDEN + "/box_box_poses.npy")
     n = len(qs)

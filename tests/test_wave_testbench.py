@@ -124,6 +124,19 @@ def test_capsule_box_contacts_on_testbench():
     assert all(any((c[0] in (10, 11, 13, 14)) and (c[1] in (12, 15)) for c in cg[e] if c[0] >= 0) for e in range(n))
 
 
+def test_capsule_through_the_box_interior_is_deterministic_on_testbench():
+    """A shin capsule whose axis runs THROUGH the inside of the other foot's box (deep penetration; found by tools/fuzz_parity.py):
+    the segment-to-box distance is zero on a whole interval there and the derivative's computed value at the interval's ends is +-1 ulp
+    with a rounding-dependent sign.  The routine takes the middle of that plateau, so kernel and oracle (different instruction
+    sequences, FMA contraction on one side only) still agree on the contact — before, they picked opposite ends (J off by 0.78)."""
+    qs = np.load(H.GOLDEN + "/capsule_box_deep_poses.npy")
+    n = len(qs)
+    b = make(n)
+    H.compare_forward(b, H.oracle_model(), np.zeros(n, dtype=np.int32), qs, np.zeros((n, 34)), np.zeros((n, 34)), np.zeros((n, 28)))
+    cg = b.get(A.F_CONTACT_GEOMS)
+    assert any(tuple(c) == (11, 15) for c in cg[0])                     # right shin capsule vs left foot box
+
+
 def test_box_box_contacts_on_testbench():
     """Foot box against foot box (face contacts with 2-4 clipped vertices and edge-edge contacts; seeded poses)."""
     qs = np.load(H.GOLDEN + "/box_box_poses.npy")[[0, 1, 2]]
