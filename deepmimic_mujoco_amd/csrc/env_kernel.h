@@ -963,9 +963,10 @@ DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s
     auto gfun = [&](R tt) { R acc = 0; for (int k = 0; k < 3; k++) { const R pk = c0[k] + tt * u[k]; acc += u[k] * (pk - clampr(pk, -s2[k], s2[k])); } return acc; };
     // Where the segment runs through the INSIDE of the box g is zero on a whole interval, and its computed value at the interval's ends
     // (a face crossing) is +-1 ulp with a rounding-dependent sign: values within eps of zero are therefore a set of their own.  If any
-    // sample point (the two ends, the face crossings inside the segment) lies in it the answer is the middle of that set's extent —
-    // the root itself when it falls on a sample, the middle of the zero plateau otherwise; only when no sample is numerically zero is
-    // the root bracketed between the neighbouring samples and interpolated (the generic case; identical to the oracle's sequence).
+    // sample point (the two ends, the face crossings inside the segment) lies in it the answer is the point of that set's extent nearest
+    // the capsule's centre (t = 0) — the root itself when it falls on a sample; only when no sample is numerically zero is the root
+    // bracketed between the neighbouring samples and interpolated (the generic case; identical to the oracle's sequence).  (Not the
+    // plateau's middle: entering through one face and leaving through the opposite one would tie the closest-face choice below.)
     const R L = s1[1], eps = sizeof(R) == 8 ? R(1e-12) : R(1e-6);
     R ta = -L, tb = L, ga = gfun(ta), gb = gfun(tb), ts;
     const R g_lo = ga, g_hi = gb;
@@ -981,7 +982,7 @@ DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s
       else if (gc < 0) { if (tc > ta) { ta = tc; ga = gc; } }
       else { if (tc < tb) { tb = tc; gb = gc; } }
     }
-    if (z0 <= z1) ts = R(0.5) * (z0 + z1);
+    if (z0 <= z1) ts = z0 > 0 ? z0 : (z1 < 0 ? z1 : R(0));   // the point of the zero set nearest the capsule's centre
     else if (g_lo > 0) ts = -L;
     else if (g_hi < 0) ts = L;
     else ts = (gb - ga > R(1e-300)) ? ta - ga * (tb - ta) / (gb - ga) : R(0.5) * (ta + tb);

@@ -730,7 +730,7 @@ static int narrowphase(const dmo_model* m, const dmo_data* d, int g1, int g2, do
       else if (gc < 0) { if (tc > ta) { ta = tc; ga = gc; } }
       else { if (tc < tb) { tb = tc; gb = gc; } }
     }
-    if (z0 <= z1) ts = 0.5 * (z0 + z1);
+    if (z0 <= z1) ts = z0 > 0 ? z0 : (z1 < 0 ? z1 : 0.0);   /* the point of the zero set nearest the capsule's centre */
     else if (g_lo > 0) ts = -L;
     else if (g_hi < 0) ts = L;
     else ts = (gb - ga > 1e-300) ? ta - ga * (tb - ta) / (gb - ga) : 0.5 * (ta + tb);

@@ -62,8 +62,9 @@ def oracle_model(max_efc=63, **opts):
     return om
 
 
-def compare_forward(batch, om, idx, q, v, ws, ctrl, tol=1e-9):
-    """Stage-by-stage comparison of one forward evaluation per env (debug dump vs oracle)."""
+def compare_forward(batch, om, idx, q, v, ws, ctrl, tol=1e-9, failures=None):
+    """Stage-by-stage comparison of one forward evaluation per env (debug dump vs oracle).  With `failures` (a list) a mismatching
+    env is appended to it as (env, message) and the sweep goes on; without, the first mismatch raises."""
     from oracle import oracle as O
     n = q.shape[0]
     batch.set(A.F_QACC_WARMSTART, ws); batch.set(A.F_CTRL, ctrl)
@@ -71,12 +72,13 @@ def compare_forward(batch, om, idx, q, v, ws, ctrl, tol=1e-9):
     cg_all = batch.get(A.F_CONTACT_GEOMS)
     od = O.Data(om)
     worst = {}
-    for e in range(n):
+
+    def one(e):
         od.set("qacc_warmstart", ws[e]); od.set("ctrl", ctrl[e]); od.set_state(q[e], v[e])
         dbg = batch.debug_forward(e)
         nefc, ncon = int(od.get("nefc")[0]), int(od.get("ncon")[0])
         assert dbg["nefc"] == nefc and dbg["ncon"] == ncon, (e, dbg["nefc"], nefc, dbg["ncon"], ncon)
-        assert dbg["solver_iter"] == int(od.get("solver_iter")[0]), e
+        assert dbg["solver_iter"] == int(od.get("solver_iter")[0]), "PGS sweep count differs for env %d" % e
         ocg = od.get("contact_geom").reshape(-1, 2).astype(np.int32)
         k = min(ncon, A.MAXEFC)
         assert np.array_equal(cg_all[e][:k], ocg[:k]), "contact (geom1, geom2) list differs for env %d" % e
@@ -88,10 +90,24 @@ def compare_forward(batch, om, idx, q, v, ws, ctrl, tol=1e-9):
                  ("efc_aref", dbg["efc_aref"], od.get("efc_aref")[:nefc]), ("efc_b", dbg["efc_b"], od.get("efc_b")[:nefc]),
                  ("efc_force", dbg["efc_force"], od.get("efc_force")[:nefc]), ("qacc", dbg["qacc"], od.get("qacc")),
                  ("xipos", dbg["xipos"], od.get("xipos").reshape(14, 3))]
-        for name, a, b in pairs:
-            worst[name] = max(worst.get(name, 0.0), rel_err(a, b))
-    for name, w in worst.items():
-        assert w < tol, "%s: rel err %.3e" % (name, w)
+        errs = {name: rel_err(a, b) for name, a, b in pairs}
+        if failures is not None:
+            bad = [name for name, _a, _b in pairs if not errs[name] < tol]
+            assert not bad, "%s: rel err %.3e (env %d)" % (bad[0], errs[bad[0]], e)
+        for name, w in errs.items():
+            worst[name] = max(worst.get(name, 0.0), w)
+
+    for e in range(n):
+        if failures is None:
+            one(e)
+        else:
+            try:
+                one(e)
+            except AssertionError as ex:
+                failures.append((e, str(ex)))
+    if failures is None:
+        for name, w in worst.items():
+            assert w < tol, "%s: rel err %.3e" % (name, w)
     return worst
 
 

@@ -127,8 +127,9 @@ def test_capsule_box_contacts_on_testbench():
 def test_capsule_through_the_box_interior_is_deterministic_on_testbench():
     """A shin capsule whose axis runs THROUGH the inside of the other foot's box (deep penetration; found by tools/fuzz_parity.py):
     the segment-to-box distance is zero on a whole interval there and the derivative's computed value at the interval's ends is +-1 ulp
-    with a rounding-dependent sign.  The routine takes the middle of that plateau, so kernel and oracle (different instruction
-    sequences, FMA contraction on one side only) still agree on the contact — before, they picked opposite ends (J off by 0.78)."""
+    with a rounding-dependent sign.  The routine takes the plateau's point nearest the capsule's centre, so kernel and oracle (different
+    instruction sequences, FMA contraction on one side only) still agree on the contact — before, they picked opposite ends (J off by
+    0.78); the plateau's MIDDLE would tie the closest-face choice when the axis enters and leaves through opposite faces (pose 1)."""
     qs = np.load(H.GOLDEN + "/capsule_box_deep_poses.npy")
     n = len(qs)
     b = make(n)
