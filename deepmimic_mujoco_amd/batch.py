@@ -158,8 +158,9 @@ class Batch(object):
         return float(ms.value)
 
     def read_profile(self):
-        """[N,8] int64 shader-clock cycles of the last step: kin, mass, bias, rows, constraint, total, nefc, sweeps."""
-        out = np.zeros((self.n, 16), dtype=np.int64)
+        """[N,32] int64 shader-clock cycles of the last step: kin, mass, bias, rows, constraint, total, nefc, sweeps | 8..13 the
+        constraint stage's parts | 16..23 the collision stage's parts, 24..27 its near-pair counts (include/dmenv.h)."""
+        out = np.zeros((self.n, 32), dtype=np.int64)
         A.check(self._L.dm_batch_read_profile(self._h, out.ctypes.data_as(C.POINTER(C.c_longlong))), self._L)
         return out
 

@@ -387,7 +387,7 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
     }
     case 101:                                   /* per-stage cycle profile on/off (diagnostic) */
       b->prof = v != 0;
-      if (b->prof && !b->d_prof) { if (hipMalloc((void**)&b->d_prof, (size_t)b->n * 16 * sizeof(long long)) != hipSuccess) return fail(DM_ENOMEM, "prof alloc"); }
+      if (b->prof && !b->d_prof) { if (hipMalloc((void**)&b->d_prof, (size_t)b->n * dm::PROF_SLOTS * sizeof(long long)) != hipSuccess) return fail(DM_ENOMEM, "prof alloc"); }
       break;
     default: return fail(DM_EINVAL, "unknown option");
   }
@@ -571,7 +571,7 @@ extern "C" int dm_batch_debug_forward(dm_batch* b, int32_t env, double* out_host
 extern "C" int dm_batch_read_profile(dm_batch* b, long long* out_host) {   /* [N,8]: kin, mass, bias, rows, constraint, total, nefc, iters */
   if (!b || !out_host || !b->d_prof) return fail(DM_EINVAL, "profile not enabled");
   HIPCHK(hipStreamSynchronize(b->stream));
-  HIPCHK(hipMemcpy(out_host, b->d_prof, (size_t)b->n * 16 * sizeof(long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out_host, b->d_prof, (size_t)b->n * dm::PROF_SLOTS * sizeof(long long), hipMemcpyDeviceToHost));
   return DM_OK;
 }
 extern "C" int dm_batch_enable_timing(dm_batch* b, int32_t on) { if (!b) return fail(DM_EINVAL, "null batch"); b->timing = on != 0; b->ev_pending = false; return DM_OK; }

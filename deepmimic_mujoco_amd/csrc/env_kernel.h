@@ -41,6 +41,7 @@ DM_CONSTANT Topo TOPO = make_topo();
 
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_BOX = 6 };
 enum { REW_ALIVE = 0, REW_V3_CONFIG = 1, REW_V2_POSE = 2, REW_IMITATION = 3, REW_V1_QUAT = 4 };
+constexpr int PROF_SLOTS = 32;  // per-env profile record (k_step_prof): see dm_batch_read_profile
 constexpr int IMIT_FEAT = 112;   // doubles per reference feature row (deepmimic_mujoco_amd/imitation.py)
 enum { ROW_NONE = 0, ROW_LIMIT = 1, ROW_CONTACT = 2 };
 
@@ -1031,10 +1032,13 @@ DM_DEV void make_frame(R* f, const R* nrm, const R* hint) {
 }
 
 // constraint rows: joint limits first (joint order), then contacts (pair-list order)  [MJ mj_collision, mj_makeConstraint]
-template <class R, int ROWS>
-DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
+template <class R, int ROWS, bool PROF = false>
+DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in, long long* prof = 0) {
   const int lane = dmw::launder(lane_in);
   int nrow = 0;
+  long long rt0 = 0, rt1 = 0;
+  if (PROF) rt0 = dmw::clk();
+#define DM_RSTAMP(k) if (PROF) { rt1 = dmw::clk(); prof[k] += rt1 - rt0; rt0 = rt1; }
   // this lane's two candidate pairs: issued here, consumed after the geom poses and the limit rows are done
   const int npair = dmw::uniform(M.npair);
   // (scalars, not a struct copy: the narrow phase indexes the sizes dynamically, which would pin a local struct in scratch)
@@ -1077,9 +1081,14 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
     }
     nrow = __builtin_popcountll(mask);
   }
+  DM_RSTAMP(16);
   // ---- contacts: lanes over candidate pairs, two passes of 64
   int ncon = 0, firstdrop = 1 << 20;
   if (M.enable_contact) {
+    // (Measured dead ends, round 2: compacting the survivors of both passes onto lanes for ONE narrow-phase / emission trip takes 3 % off
+    //  a lone wave's step — exposed latencies — and is 1 % SLOWER at two waves per SIMD, where those latencies were already covered
+    //  and the two passes mostly run different geometry-type paths anyway; an oriented-bounding-box test behind the spheres cuts the
+    //  pairs entering the narrow phase from 4.9 to 1.7 per evaluation and costs as much as it saves.)
     for (int pass = 0; pass * 64 < npair; pass++) {
       if (pass > 0) {
         pr = pass * 64 + lane < npair ? pass * 64 + lane : 0;
@@ -1105,11 +1114,14 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
           cand = dot3(d, d) <= r_bound * r_bound;
         }
       }
+      DM_RSTAMP(17 + 3 * pass);
       if (dmw::ballot(cand) == 0ull) continue;        // nothing near anything in this pass (the common case for body-body pairs)
+      if (PROF) { prof[24 + pass] += 1; prof[26 + pass] += __builtin_popcountll(dmw::ballot(cand)); }
       if (cand) {
         const R z1[3] = {r_s1a, r_s1b, r_s1c}, z2[3] = {r_s2a, r_s2b, r_s2c};
         narrowphase(s, g1, g2, t1, t2, z1, z2, M.pair_rec[pr].s1, M.pair_rec[pr].s2, ((r_meta >> 16) & 0xff) - 1, margin, pc);
       }
+      DM_RSTAMP(18 + 3 * pass);
       if (dmw::ballot(pc.n > 0) == 0ull) continue;
       const int rows_per = dim == 1 ? 1 : 2 * (dim - 1);
       int tot_rows, tot_con;
@@ -1167,6 +1179,7 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
         }
       }
       nrow += tot_rows; ncon += tot_con;
+      DM_RSTAMP(19 + 3 * pass);
     }
   }
   // first dropped row index over the wave (min), if any
@@ -1179,6 +1192,8 @@ DM_DEV void stage_rows(const DevModel<R>& M, Shared<R>& s, int lane_in) {
   if (firstdrop < nrow) { status = 1; nrow = firstdrop; }
   if (lane == 0) { s.nefc = nrow; s.ncon = ncon; s.status |= status; }
   dmw::sync();
+  DM_RSTAMP(23);
+#undef DM_RSTAMP
 }
 
 // [MJ getimpedance]
@@ -1701,7 +1716,7 @@ DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo
     dbg->out[34 * 34 + lane] = bias;
   }
   DM_MARK("rows");
-  stage_rows<R, ROWS>(M, s, lane);
+  stage_rows<R, ROWS, PROF>(M, s, lane, prof);
   if (PROF) { t1 = dmw::clk(); prof[3] += t1 - t0; t0 = t1; }
   DM_MARK("constraint");
   stage_constraint<R, ROWS, PROF>(M, s, lane, dbg, prof);

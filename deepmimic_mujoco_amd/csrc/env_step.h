@@ -347,7 +347,8 @@ DM_DEV R v1_reward(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int la
 template <class R, int ROWS = MAXEFC, bool PROF = false>
 DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, StepScratch<R>& x, int env, int lane,
                      const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, long long* prof_out = 0) {
-  long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long prof[PROF_SLOTS];
+  for (int k = 0; k < PROF_SLOTS; k++) prof[k] = 0;
   long long tstart = 0;
   if (PROF) tstart = dmw::clk();
   const LaneTopo lt = lane_topo(lane);
@@ -412,7 +413,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
   if (PROF && lane == 0) {
     prof[5] = dmw::clk() - tstart;
     prof[6] = s.nefc; prof[7] = s.solver_iter;
-    for (int k = 0; k < 16; k++) prof_out[(size_t)env * 16 + k] = prof[k];
+    for (int k = 0; k < PROF_SLOTS; k++) prof_out[(size_t)env * PROF_SLOTS + k] = prof[k];
   }
   return true;
 }

@@ -191,7 +191,10 @@ int dm_batch_last_step_ms(dm_batch* b, float* ms);
 int dm_batch_enable_timing(dm_batch* b, int32_t on);
 
 /* diagnostic: per-env shader-clock cycles of the last step by stage (enable with dm_batch_set_option(b, 101, 1)):
- * out [N,8] int64 = kinematics, mass matrix+factor, bias, rows(collision), constraint, whole step, nefc, PGS sweeps */
+ * out [N,32] int64 = kinematics, mass matrix+factor, bias, rows(collision), constraint, whole step, nefc, PGS sweeps;
+ * [8..13] the constraint stage's parts (smooth solve, J rows, impedance + half solve, A, warm start + PGS, assembly);
+ * [16] geom poses + limit rows, [17,18,19] / [20,21,22] broad phase, narrow phase, row emission of pair pass 0 / 1, [23] tail,
+ * [24,25] evaluations in which a pair of pass 0 / 1 passed the bounding spheres, [26,27] such pairs (summed over the step) */
 int dm_batch_read_profile(dm_batch* b, long long* out_host);
 
 /* Replaces: MlpPolicy.act(stochastic, ob) (src/mlp_policy_trpo.py:63-65; network :35-58, DiagGaussianPd src/distributions.py:220-245)

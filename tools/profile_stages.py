@@ -33,9 +33,16 @@ for wl in ("cfg3", "cfg2"):
     sub = ["smooth solve", "J rows", "imp + half-solve", "A build", "warm start + PGS", "force assembly + back-solve"]
     for k, nme in enumerate(sub):  # slots 8..15
         print("      constraint/%-28s %9.0f" % (nme, p[:, 8 + k].mean()))
+    rsub = ["geom poses + limit rows", "pass 0 broad phase", "pass 0 narrow phase", "pass 0 row emission", "pass 1 broad phase", "pass 1 narrow phase",
+            "pass 1 row emission", "tail"]
+    for k, nme in enumerate(rsub):  # slots 16..23
+        print("      rows/%-34s %9.0f" % (nme, p[:, 16 + k].mean()))
+    print("      rows/evaluations (of 4) with a pair past the bounding spheres: pass 0 %.2f, pass 1 %.2f; such pairs per evaluation: pass 0 %.2f, pass 1 %.2f"
+          % (p[:, 24].mean(), p[:, 25].mean(), p[:, 26].mean() / 4, p[:, 27].mean() / 4))
     for lo, hi in [(0, 1), (1, 8), (8, 16), (16, 32), (32, 64)]:
         m = (p[:, 6] >= lo) & (p[:, 6] < hi)
         if m.any():
             print("   nefc [%d,%d): %5d envs, constraint %8.0f rows %8.0f total %8.0f | sweeps %.1f ybuild %6.0f half %6.0f A %6.0f ws %6.0f pgs %7.0f fin %6.0f" % (
                 lo, hi, m.sum(), p[m, 4].mean(), p[m, 3].mean(), p[m, 5].mean(), p[m, 7].mean(), *[p[m, 8 + k].mean() for k in range(6)]))
+            print("        rows parts: %s | evaluations with near pairs %.2f %.2f" % (" ".join("%6.0f" % p[m, 16 + k].mean() for k in range(8)), p[m, 24].mean(), p[m, 25].mean()))
     env.close()
