@@ -1387,6 +1387,42 @@ struct ACol {        // column I of A = Y Y^T + diag(R); precondition: I < nefc
     }
   }
 };
+// A = Y Y^T + diag(R) for an evaluation with at most 16 rows (95 % of those with any), on the matrix core: the 16 x 34 block of Y
+// goes through the broadcast buffer once, nine 16x16x4 MFMA blocks (both operands the same register: the product is symmetric)
+// leave the 16 x 16 result spread over the wave, and a second trip through LDS hands lane r its row.  ~75 instructions whatever the
+// row count, against 34 FMAs + 17 LDS reads PER COLUMN on the vector unit with a handful of its 64 lanes doing useful work.
+// Rows past nefc have Y = 0, so their rows / columns of A come out as exact zeros, as the sweeps expect.
+template <class R, int ROWS>
+DM_DEV void a_block16(R* AR, const R* y, Shared<R>& s, int lane, bool active, R Rr, R& diag) {
+  constexpr int LD = 18;                       // row stride of the result in LDS: 16-byte aligned rows, two-way bank conflicts at worst
+  dmw::sync();
+  if (lane < 16) {
+#pragma unroll
+    for (int d = 0; d < NV; d++) s.u.ybuf[lane][d] = y[d];
+  }
+  dmw::sync();
+  R acc[4] = {0, 0, 0, 0};
+  {
+    const int i = lane & 15, k = lane >> 4;
+    const R* src = &s.u.ybuf[i][k];
+#pragma unroll
+    for (int st = 0; st < 8; st++) { const R a = src[4 * st]; dmw::mfma_16x16x4(a, a, acc); }
+    const R a = k < 2 ? src[32] : R(0);        // dofs 32, 33; the block's last two k are padding
+    dmw::mfma_16x16x4(a, a, acc);
+  }
+  dmw::sync();                                 // every lane has read its operands: rows 0 .. 8 of the buffer become the result tile
+  R* ab = &s.u.ybuf[0][0];
+#pragma unroll
+  for (int v = 0; v < 4; v++) ab[dmw::mfma_row(lane, v, R(0)) * LD + (lane & 15)] = acc[v];
+  dmw::sync();
+  const int r = lane & 15;
+  if (active) { const R dg = ab[r * (LD + 1)] + Rr; diag = dg; ab[r * (LD + 1)] = dg; }
+  dmw::sync();
+#pragma unroll
+  for (int j = 0; j < 16; j++) { AR[j] = lane < 16 ? ab[r * LD + j] : R(0); dmw::pin_value(AR[j]); }
+#pragma unroll
+  for (int j = 16; j < ROWS; j++) { AR[j] = 0; dmw::pin_value(AR[j]); }
+}
 template <int B, int ROWS, class R>
 struct WarmBlock {   // A[:, 8B .. 8B+7] scaled in place (row j by -1 / A_jj);  t += A_scaled[:, 8B .. 8B+7] f   (slots past nefc: f = 0, zero column)
   static DM_DEV void run(R* AR, R& t, R f, R ndinv, int nefc) {
@@ -1555,9 +1591,12 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     // ---- A = Y Y^T + diag(R): rows of Y broadcast through LDS, 16 at a time ---------------------------------
     // columns past nefc are exact zeros (the row groups of the sweeps may touch them); zeroed here, not earlier, so that
     // the array is not live during the row build and the half solve
+    if (nefc <= 16) a_block16<R, ROWS>(AR, y, s, lane, active, Rr, diag);
+    else {
 #pragma unroll
-    for (int i = 0; i < ROWS; i++) { AR[i] = 0; dmw::pin_value(AR[i]); }   // (opaque zeros stay in their registers: as known constants
-    ACol<0, ROWS, R>::run(AR, y, s, lane, nefc, Rr, diag);              //  they would be re-materialised before every early-exit test)
+      for (int i = 0; i < ROWS; i++) { AR[i] = 0; dmw::pin_value(AR[i]); }   // (opaque zeros stay in their registers: as known constants
+      ACol<0, ROWS, R>::run(AR, y, s, lane, nefc, Rr, diag);              //  they would be re-materialised before every early-exit test)
+    }
   }
   const R dinvr = R(1) / diag;
   DM_STAMP(11)

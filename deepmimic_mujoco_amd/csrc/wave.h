@@ -77,6 +77,22 @@ DM_DEV double rcp_fast(double x) {
   return r;
 }
 DM_DEV float rcp_fast(float x) { return 1.0f / x; }
+// D += A B on the matrix core, one 16x16x4 block: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; it holds, in d[v],
+// D[mfma_row(l, v)][l & 15].  (v_mfma_f64_16x16x4_f64: row = (l >> 4) + 4 v; the f32 form: row = 4 (l >> 4) + v.)
+DM_DEV void mfma_16x16x4(double a, double b, double (&d)[4]) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  v4d c = {d[0], d[1], d[2], d[3]};
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; d[3] = c[3];
+}
+DM_DEV void mfma_16x16x4(float a, float b, float (&d)[4]) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f c = {d[0], d[1], d[2], d[3]};
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; d[3] = c[3];
+}
+DM_DEV int mfma_row(int lane_id, int v, double) { return (lane_id >> 4) + 4 * v; }
+DM_DEV int mfma_row(int lane_id, int v, float) { return 4 * (lane_id >> 4) + v; }
 // max(a, b) as the bare instruction.  fmax() first quiets each operand (`v_max x, x`) for signalling NaNs: one more
 // instruction on the PGS row-to-row chain, where no NaN can be signalling (operands come straight from arithmetic).
 DM_DEV double max_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }

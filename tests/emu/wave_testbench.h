@@ -65,6 +65,33 @@ inline int shfl_up_i(int v, int d) { const int l = lane(); return exchange(v, l 
 inline double bcast(double v, int src) { return exchange(v, src); }
 inline float bcast(float v, int src) { return exchange(v, src); }
 inline int bcast_i(int v, int src) { return exchange(v, src); }
+// one 16x16x4 matrix-core block (see wave.h): a collective; every fibre gathers the operands of all lanes, then forms its own four
+// results with the k index innermost
+template <class T> inline void mfma_16x16x4(T a, T b, T (&d)[4]) {
+  T A[64], B[64];
+  {
+    WaveBench& w = bench();
+    const int p = (int)(w.gen & 1ull);
+    w.slot[p][w.cur_lane] = to_bits(a);
+    rendezvous();
+    for (int l = 0; l < 64; l++) A[l] = from_bits<T>(bench().slot[p][l]);
+  }
+  {
+    WaveBench& w = bench();
+    const int p = (int)(w.gen & 1ull);
+    w.slot[p][w.cur_lane] = to_bits(b);
+    rendezvous();
+    for (int l = 0; l < 64; l++) B[l] = from_bits<T>(bench().slot[p][l]);
+  }
+  const int l = lane();
+  for (int v = 0; v < 4; v++) {
+    const int row = (l >> 4) + 4 * v, col = l & 15;
+    T acc = d[v];
+    for (int k = 0; k < 4; k++) acc = std::fma(A[row + 16 * k], B[col + 16 * k], acc);
+    d[v] = acc;
+  }
+}
+template <class T> inline int mfma_row(int lane_id, int v, T) { return (lane_id >> 4) + 4 * v; }
 inline long long clk() { return 0; }
 template <class T> inline T max_raw(T a, T b) { return std::fmax(a, b); }
 template <class T> inline T rcp_fast(T x) { return T(1) / x; }
