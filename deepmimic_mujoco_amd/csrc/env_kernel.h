@@ -1634,6 +1634,9 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   // (Round 2 measured the generalisation — blocks of K = 2 / 3 / 4 sweeps whose K tests run beside the next block's K speculative sweeps,
   //  the state after every sweep kept for the roll-back; bit-identical results — at 11.54 / 11.39 / 11.35 M env-steps/s against 11.65 M:
   //  with two waves per SIMD the partner wave already fills this chain's stalls, so the extra discarded sweeps only add instructions.)
+  // (Also measured: lane i's `tsave = t` as a v_mov under EXEC = 1 << i (two scalar instructions around one move) instead of the compare and
+  //  the two selects: two vector instructions fewer per row and 1.3 % SLOWER — 11.65 / 11.67 against 11.80 / 11.84 M; an EXEC write costs the
+  //  vector pipe more than the selects.)
   int iter = 0;
   const int maxiter = dmw::uniform(M.iterations);
   // loop constants pinned in VGPRs: left to itself the compiler re-loads them from memory (s_load + wait) every sweep
