@@ -1636,7 +1636,8 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   //  with two waves per SIMD the partner wave already fills this chain's stalls, so the extra discarded sweeps only add instructions.)
   // (Also measured: lane i's `tsave = t` as a v_mov under EXEC = 1 << i (two scalar instructions around one move) instead of the compare and
   //  the two selects: two vector instructions fewer per row and 1.3 % SLOWER — 11.65 / 11.67 against 11.80 / 11.84 M; an EXEC write costs the
-  //  vector pipe more than the selects.)
+  //  vector pipe more than the selects; the lane mask made by the scalar unit (s_lshl_b64) feeding the two selects, no v_cmp: 11.69 M — the
+  //  scalar-write -> mask-read hazard puts a wait state in front of every select.)
   int iter = 0;
   const int maxiter = dmw::uniform(M.iterations);
   // loop constants pinned in VGPRs: left to itself the compiler re-loads them from memory (s_load + wait) every sweep
