@@ -17,8 +17,9 @@
 //   * collision runs lanes over the 104 candidate geom pairs with deterministic prefix-sum compaction, so
 //     the contact list (and hence the PGS row order) is bit-identical to a serial walk of the pair list.
 // fp64 throughout (the reference computes in float64; parity bar 1e-5 relative, test bar 1e-9).
-// f64 MFMA is deliberately not used: on gfx950 v_mfma_f64 runs at the f64 VALU rate (78.6 TF both), and the
-// only GEMM-shaped piece (64x34x64 for A) would need a fragment->row-per-lane re-layout on top.
+// The matrix core is used in one place: A = Y Y^T of an evaluation with at most 16 rows (a_block16: nine v_mfma_f64_16x16x4
+// blocks).  On gfx950 v_mfma_f64 runs at the f64 VALU rate (78.6 TF both), so a block only pays where its padding is cheaper than
+// the vector unit's idle lanes; the same treatment of the Jacobian rows was measured and is exactly as fast as the vector loop.
 #pragma once
 
 #include "topology.h"
