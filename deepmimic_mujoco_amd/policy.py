@@ -159,17 +159,28 @@ class MlpPolicy:
         ob = ob.to(torch.float32)
         return torch.clamp((ob - self.ob_rms.mean) / self.ob_rms.std, -5.0, 5.0)
 
-    def forward(self, ob):
-        """ob [N, ob_dim] -> (mean [N, ac_dim] f32, vpred [N] f32)."""
+    def forward_value(self, ob, z=None):
+        """ob [N, ob_dim] -> vpred [N] f32 (the value net alone: the learner's value fit needs nothing else)."""
         p = self.params
-        z = self._obz(ob)
+        if z is None:
+            z = self._obz(ob)
         h = torch.tanh(torch.addmm(p["vffc1/b"], z, p["vffc1/w"]))
         h = torch.tanh(torch.addmm(p["vffc2/b"], h, p["vffc2/w"]))
-        vpred = torch.addmm(p["vffinal/b"], h, p["vffinal/w"])[:, 0]
+        return torch.addmm(p["vffinal/b"], h, p["vffinal/w"])[:, 0]
+
+    def forward_mean(self, ob, z=None):
+        """ob [N, ob_dim] -> action mean [N, ac_dim] f32 (the policy net alone: surrogate, KL and Fisher products)."""
+        p = self.params
+        if z is None:
+            z = self._obz(ob)
         h = torch.tanh(torch.addmm(p["polfc1/b"], z, p["polfc1/w"]))
         h = torch.tanh(torch.addmm(p["polfc2/b"], h, p["polfc2/w"]))
-        mean = torch.addmm(p["polfinal/b"], h, p["polfinal/w"])
-        return mean, vpred
+        return torch.addmm(p["polfinal/b"], h, p["polfinal/w"])
+
+    def forward(self, ob):
+        """ob [N, ob_dim] -> (mean [N, ac_dim] f32, vpred [N] f32)."""
+        z = self._obz(ob)
+        return self.forward_mean(ob, z), self.forward_value(ob, z)
 
     def seed(self, seed):
         self._noise_gen = torch.Generator(device=self.device)

@@ -131,16 +131,97 @@ class MpiAdam:
                 raise AssertionError("value-function parameters diverged across ranks")
 
 
+class _VfGraph:
+    """One value-fit minibatch step (TrpoLearner._vf_step) captured as a hipGraph.  The epoch's shuffled samples sit in static
+    [nb, bs, .] buffers; a device-side counter picks the minibatch and the step's Adam scale (precomputed on the host for the
+    whole epoch), so a replay needs no host-side work at all."""
+
+    def __init__(self, learner, ob, ret, bs):
+        self.ok = False
+        self.L = learner
+        pi, ad = learner.pi, learner.vfadam
+        n = ob.shape[0]
+        self.bs, self.nb, self.n = bs, n // bs, n
+        dev = ob.device
+        self.ob_s = torch.zeros((self.nb, bs) + tuple(ob.shape[1:]), dtype=ob.dtype, device=dev)
+        self.ret_s = torch.zeros((self.nb, bs), dtype=ret.dtype, device=dev)
+        self.a_s = torch.zeros(self.nb, dtype=torch.float32, device=dev)
+        self.ctr = torch.zeros(1, dtype=torch.long, device=dev)
+        self.one = torch.ones(1, dtype=torch.long, device=dev)
+        self.cnt_add = torch.tensor(float(bs), dtype=torch.float64, device=dev)
+        rms = pi.ob_rms
+        # snapshot: warm-up and capture run the step for real
+        saved = [t.clone() for t in (rms.sum, rms.sumsq, rms.count, ad.m, ad.v)] + [p.detach().clone() for p in ad.params]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        with torch.no_grad():
+            for t, sv in zip([rms.sum, rms.sumsq, rms.count, ad.m, ad.v] + list(ad.params), saved):
+                t.copy_(sv)
+            rms._refresh()
+        self.ok = True
+
+    def matches(self, ob, ret, bs):
+        return ob.shape[0] == self.n and bs == self.bs and ob.dtype == self.ob_s.dtype and ob.device == self.ob_s.device
+
+    def _body(self):
+        L = self.L
+        pi, ad, rms = L.pi, L.vfadam, L.pi.ob_rms
+        mbob = torch.index_select(self.ob_s, 0, self.ctr)[0]
+        mbret = torch.index_select(self.ret_s, 0, self.ctr)[0]
+        a = torch.index_select(self.a_s, 0, self.ctr)[0]
+        # RunningMeanStd.update, device-only
+        x = mbob.to(torch.float64)
+        with torch.no_grad():
+            rms.sum += x.sum(0).reshape(rms.shape)
+            rms.sumsq += (x * x).sum(0).reshape(rms.shape)
+            rms.count += self.cnt_add
+            rms._refresh()
+        vpred = pi.forward_value(mbob)
+        vferr = ((vpred - mbret) ** 2).mean()
+        g = flat(torch.autograd.grad(vferr, L.vf)).to(torch.float32)
+        with torch.no_grad():                                              # MpiAdam.update with the step scale from the table
+            ad.m.mul_(ad.beta1).add_(g, alpha=1 - ad.beta1)
+            ad.v.mul_(ad.beta2).addcmul_(g, g, value=1 - ad.beta2)
+            step = (-a) * ad.m / (torch.sqrt(ad.v) + ad.epsilon)
+            ad.setfromflat(ad.getflat() + step)
+            self.ctr += self.one
+
+    def run_epoch(self, ob, ret, inds):
+        L, ad = self.L, self.L.vfadam
+        used = inds[:self.nb * self.bs]
+        self.ob_s.view(self.nb * self.bs, *ob.shape[1:]).copy_(ob[used])
+        self.ret_s.view(-1).copy_(ret[used])
+        a = []
+        for k in range(self.nb):
+            t = ad.t + 1 + k
+            a.append(L.vf_stepsize * math.sqrt(1 - ad.beta2 ** t) / (1 - ad.beta1 ** t))
+        self.a_s.copy_(torch.tensor(a, dtype=torch.float32), non_blocking=False)
+        self.ctr.zero_()
+        for _ in range(self.nb):
+            self.graph.replay()
+        ad.t += self.nb
+
+
 class TrpoLearner:
     """One policy/value update per segment; the reference's `learn()` body between `seg_gen.__next__()` and the logging."""
 
     def __init__(self, pi, *, max_kl=0.01, cg_iters=10, cg_damping=0.1, gamma=0.995, lam=0.97, entcoeff=0.0,
-                 vf_iters=3, vf_stepsize=1e-3, vf_batch_size=128, fvp_subsample=5, group=None, seed=0):
+                 vf_iters=3, vf_stepsize=1e-3, vf_batch_size=128, fvp_subsample=5, group=None, seed=0, vf_graph=None):
         self.pi = pi
         self.max_kl, self.cg_iters, self.cg_damping = max_kl, cg_iters, cg_damping
         self.gamma, self.lam, self.entcoeff = gamma, lam, entcoeff
         self.vf_iters, self.vf_stepsize, self.vf_batch_size = vf_iters, vf_stepsize, vf_batch_size
         self.fvp_subsample = fvp_subsample
+        # value-fit minibatch steps as one captured hipGraph each (single-process GPU runs; None = when possible)
+        self.vf_graph = vf_graph
+        self._vfg = None
         self.group = group
         for k in POL_KEYS + VF_KEYS:
             pi.params[k].requires_grad_(True)
@@ -176,8 +257,7 @@ class TrpoLearner:
 
     # ---- losses (:118-134) -------------------------------------------------------------------------------------------------
     def _pd(self, ob):
-        mean, _ = self.pi.forward(ob)
-        return mean, self.pi.params["logstd"]
+        return self.pi.forward_mean(ob), self.pi.params["logstd"]
 
     @staticmethod
     def _kl(mean0, logstd0, mean1, logstd1):
@@ -200,6 +280,40 @@ class TrpoLearner:
 
     loss_names = ("optimgain", "meankl", "entloss", "surrgain", "entropy")
 
+    # ---- value fit (:288-296) --------------------------------------------------------------------------------------------
+    def _vf_step(self, mbob, mbret):
+        """One minibatch of the value fit: obs-filter update (:293), squared-error gradient, MpiAdam step."""
+        self.pi.ob_rms.update(mbob, group=self.group)
+        vpred = self.pi.forward_value(mbob)
+        vferr = ((vpred - mbret) ** 2).mean()
+        gv = flat(torch.autograd.grad(vferr, self.vf))
+        self.vfadam.update(gv, self.vf_stepsize)
+
+    def _vf_graph_ready(self, ob, ret, bs):
+        """The minibatch step is ~60 launches of tiny kernels (CPU-bound: 0.7 ms each, 384 of them per update at 4 096 envs x 128
+        steps).  On a single-process GPU run it is captured once as a hipGraph and replayed; multi-rank runs (collectives inside the
+        step) and CPU runs keep the eager loop.  Same operations in the same order: results are identical."""
+        if self.vf_graph is False or ob.device.type != "cuda" or _world(self.group) > 1:
+            return False
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return False
+        g = self._vfg
+        if g is not None and g.ok and g.matches(ob, ret, bs):
+            return True
+        if g is not None and not g.ok:
+            return False
+        try:
+            self._vfg = _VfGraph(self, ob, ret, bs)
+        except Exception as ex:                                            # capture not possible here: stay eager, say so once
+            import warnings
+            warnings.warn("value-fit graph capture failed (%s: %s); using the eager loop" % (type(ex).__name__, ex))
+            self._vfg = _VfGraph.__new__(_VfGraph); self._vfg.ok = False
+            if self.vf_graph is True:
+                raise
+            return False
+        return True
+
     # ---- one update ----------------------------------------------------------------------------------------------------------
     def update(self, seg):
         pi = self.pi
@@ -209,7 +323,7 @@ class TrpoLearner:
         atarg = (atarg - atarg.mean()) / atarg.std(unbiased=False)          # :240
         pi.ob_rms.update(ob, group=self.group)                              # :242
         with torch.no_grad():                                               # :247 oldpi <- pi
-            old_mean, _ = pi.forward(ob)
+            old_mean = pi.forward_mean(ob)
             old_logstd = pi.params["logstd"].detach().clone()
         sub = slice(None, None, self.fvp_subsample)                         # :245 fvpargs = [arr[::5] ...]
         ob_f, om_f = ob[sub], old_mean[sub]
@@ -268,16 +382,15 @@ class TrpoLearner:
         # ---- value function (:288-296) ------------------------------------------------------------------------------------
         n = ob.shape[0]
         bs = min(self.vf_batch_size, n)
+        graphed = self._vf_graph_ready(ob, tdlamret, bs)
         for _ in range(self.vf_iters):
             inds = self.perm_source(n).to(ob.device) if self.perm_source is not None else torch.randperm(n, device=ob.device, generator=self._perm_gen)
+            if graphed:
+                self._vfg.run_epoch(ob, tdlamret, inds)
+                continue
             for o in range(0, n - bs + 1, bs):                              # include_final_partial_batch=False
                 mb = inds[o:o + bs]
-                mbob, mbret = ob[mb], tdlamret[mb]
-                pi.ob_rms.update(mbob, group=self.group)                    # :293
-                _, vpred = pi.forward(mbob)
-                vferr = ((vpred - mbret) ** 2).mean()
-                gv = flat(torch.autograd.grad(vferr, self.vf))
-                self.vfadam.update(gv, self.vf_stepsize)
+                self._vf_step(ob[mb], tdlamret[mb])
 
         pi.mark_dirty()                                                     # parameters / obs filter changed in place: the native act() repacks
         for name, val in zip(self.loss_names, meanlosses.tolist()):

@@ -155,7 +155,7 @@ def test_explained_variance():
 
 
 # ---- numeric pin of one update against the analytic float64 restatement (tests/trpo_numpy.py, fixture trpo_update_golden.npz) ----
-def _golden_update(device):
+def _golden_update(device, **learner_kw):
     """Run TrpoLearner.update on the fixture's segment; return (learner, policy, stats, fixture)."""
     import os
     from deepmimic_mujoco_amd.trpo import TrpoLearner, POL_KEYS, VF_KEYS
@@ -169,7 +169,7 @@ def _golden_update(device):
     pi.ob_rms.sumsq = torch.as_tensor(g["rms0_sumsq"], dtype=torch.float64, device=device)
     pi.ob_rms.count = torch.as_tensor(float(g["rms0_count"]), dtype=torch.float64, device=device)
     pi.ob_rms._refresh()
-    learner = TrpoLearner(pi, vf_batch_size=128)
+    learner = TrpoLearner(pi, vf_batch_size=128, **learner_kw)
     perms = [torch.as_tensor(p, dtype=torch.int64) for p in g["perms"]]
     learner.perm_source = lambda n, it=iter(perms): next(it)
     t = lambda a, dt: torch.as_tensor(a, dtype=dt, device=device)
@@ -237,3 +237,17 @@ def test_learner_update_matches_the_float64_restatement_on_gpu():
     """src/trpo.py:235-296 on torch-ROCm: gradient, CG direction, step scaling, line-search outcome, KL and value-fit parameters
     against the analytic float64 restatement (committed fixture), float32 tolerances."""
     _check_against_golden(*_golden_update("cuda:0"))
+
+
+@pytest.mark.gpu
+def test_value_fit_as_captured_graph_equals_the_eager_loop_on_gpu():
+    """The value fit's minibatch step replayed as a captured hipGraph (single-process GPU runs) against the eager loop on the same
+    update: same value parameters, same obs-filter moments, same Adam state; and the graph path really ran."""
+    from deepmimic_mujoco_amd.trpo import VF_KEYS, flat
+    le, pe, se, g, _ = _golden_update("cuda:0", vf_graph=False)
+    lg, pg, sg, _, _ = _golden_update("cuda:0", vf_graph=True)
+    assert le._vfg is None and lg._vfg is not None and lg._vfg.ok
+    ve = flat([pe.params[k].detach() for k in VF_KEYS]); vg = flat([pg.params[k].detach() for k in VF_KEYS])
+    assert float((ve - vg).abs().max()) < 1e-6 * max(1.0, float(ve.abs().max()))
+    assert torch.allclose(pe.ob_rms.sum, pg.ob_rms.sum, rtol=1e-12, atol=1e-9) and float(pe.ob_rms.count) == float(pg.ob_rms.count)
+    assert le.vfadam.t == lg.vfadam.t == 12 and float((le.vfadam.m - lg.vfadam.m).abs().max()) < 1e-7
