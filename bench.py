@@ -254,7 +254,12 @@ def rollout_bench(args, dev, rank, world, local_dev):
     P = max(1, min(args.pipeline, 8))
     clip = args.clip or "walk"
     pol = MlpPolicy(device=dev, seed=0); pol.seed(rank)
-    if P > 1:
+    if not args.unfused:        # one batch, P pipelined sub-batches, the policy step inside the env step kernel: one launch per step
+        from deepmimic_mujoco_amd import _abi as A
+        env = DPVecEnv(n, motion=clip, device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n)
+        env.batch.set_option(A.OPT_PIPELINE, min(P, A.MAX_PIPELINE))
+        gen = traj_segment_generator(pol, env, HORIZON, stochastic=True, fused=True)
+    elif P > 1:
         cuts = [n * h // P for h in range(P + 1)]
         envs = [DPVecEnv(cuts[h + 1] - cuts[h], motion=clip, device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n + cuts[h])
                 for h in range(P)]
@@ -263,7 +268,7 @@ def rollout_bench(args, dev, rank, world, local_dev):
         env = DPVecEnv(n, motion=clip, device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n)
         gen = traj_segment_generator(pol, env, HORIZON, stochastic=True)
     segs = max(1, args.steps // HORIZON)
-    for _ in range(max(1, args.warmup // HORIZON)):
+    for _ in range(max(3, args.warmup // HORIZON)):            # (the first segments carry one-time costs: allocator growth, lazy kernel loads)
         add_vtarg_and_adv(next(gen), 0.995, 0.97)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -276,8 +281,10 @@ def rollout_bench(args, dev, rank, world, local_dev):
     if rank == 0:
         print(json.dumps({"metric": "rollout env-steps/sec (policy in the loop + GAE)", "value": round(world * n * segs * HORIZON / el, 1),
                           "unit": "env-steps/s", "n_gpus": world, "steps": segs * HORIZON, "ms_per_step": round(el / (segs * HORIZON) * 1e3, 4),
-                          "episodes": eps, "config": {"workload": "rollout: %d envs/GPU in %d concurrently stepped batch(es), untrained 2x100 tanh policy, alive reward, "
-                                                                  "noisy-init autoreset, %d-step segments + GAE(0.995, 0.97)" % (n, P, HORIZON)}}))
+                          "episodes": eps, "config": {"workload": "rollout: %d envs/GPU, %s, untrained 2x100 tanh policy, alive reward, "
+                                                                  "noisy-init autoreset, %d-step segments + GAE(0.995, 0.97)"
+                                                                  % (n, ("%d concurrently stepped batch(es), one policy launch + one env launch per step" % P) if args.unfused
+                                                                     else ("policy step fused into the env step kernel (one launch per step), %d pipelined sub-batch(es)" % P), HORIZON)}}))
 
 
 def main():
@@ -297,6 +304,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="DM_OPT_PIPELINE: sub-batches per GPU stepped on their own streams so that one's drain overlaps the next one's ramp "
                          "across consecutive steps (1 = one launch per step)")
+    ap.add_argument("--unfused", action="store_true", help="rollout workload: separate policy launch per step (the round-1 form) instead of the fused step")
     ap.add_argument("--dtype", type=int, default=64, choices=[64, 32],
                     help="arithmetic of the kernels: 64 (the parity path, the judged line) or 32 (libdmenv32.so, the float32 build: informational)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -23,7 +23,7 @@ from .tf_checkpoint import load_checkpoint  # noqa: F401
 from .policy import MlpPolicy, RunningMeanStd  # noqa: F401
 from .trpo import TrpoLearner, learn  # noqa: F401
 from . import logio  # noqa: F401
-from .rollout import traj_segment_generator, pipelined_segment_generator, SegmentCollector, add_vtarg_and_adv, flatten_segment, RolloutBlock, shard_range  # noqa: F401
+from .rollout import traj_segment_generator, pipelined_segment_generator, SegmentCollector, can_fuse, add_vtarg_and_adv, flatten_segment, RolloutBlock, shard_range  # noqa: F401
 
 __all__ = ["Config", "MocapDM", "CompiledModel", "humanoid_spec", "load_mjcf", "to_mjcf", "Batch", "DPEnv", "DPVecEnv",
            "load_checkpoint", "MlpPolicy", "RunningMeanStd", "traj_segment_generator", "pipelined_segment_generator", "SegmentCollector", "add_vtarg_and_adv", "flatten_segment",

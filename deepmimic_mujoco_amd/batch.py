@@ -107,6 +107,28 @@ class Batch(object):
         A.check(self._L.dm_batch_step(self._h, ap, op, rp, dp, int(n_substeps), kind), self._L)
         return obs, rew, done
 
+    def step_act(self, action, n_substeps, out, weights, next_action, next_vpred, stochastic, seed, counter):
+        """`step` followed, inside the step kernel, by the policy's step on the new observations (dm_batch_step_act): device tensors
+        only.  action [n, 28] f64 -> out = (obs [n, 56] f64, rew [n] f64, done [n] u8); next_action [n, 28] f64 and next_vpred [n] f32
+        receive the action / value for those observations; `weights` is MlpPolicy.pack()'s float32 block."""
+        n = self.n
+        ap, kind, _ka = self._ptr(action, np.float64, (n, A.NU))
+        obs, rew, done = out
+        op, k1, _ = self._ptr(obs, np.float64, (n, A.NOBS), out=True)
+        rp, k2, _ = self._ptr(rew, np.float64, (n,), out=True)
+        dp, k3, _ = self._ptr(done, np.uint8, (n,), out=True)
+        np_, k4, _ = self._ptr(next_action, np.float64, (n, A.NU), out=True)
+        if not (kind == k1 == k2 == k3 == k4 == A.PTR_DEVICE):
+            raise ValueError("step_act works on device tensors")
+        import torch
+        if not (weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous() and weights.numel() == self._L.dm_policy_weight_count()):
+            raise ValueError("weights: the packed float32 policy block (MlpPolicy.pack()) on the device")
+        if not (next_vpred.is_cuda and next_vpred.dtype == torch.float32 and next_vpred.is_contiguous() and next_vpred.numel() == n):
+            raise ValueError("next_vpred: float32 [n] on the device")
+        A.check(self._L.dm_batch_step_act(self._h, ap, op, rp, dp, int(n_substeps), C.c_void_p(weights.data_ptr()), np_,
+                                          C.c_void_p(next_vpred.data_ptr()), 1 if stochastic else 0, int(seed) & (2 ** 64 - 1), int(counter)), self._L)
+        return obs, rew, done
+
     def get_obs(self, out=None):
         if out is None:
             out = np.empty((self.n, A.NOBS))

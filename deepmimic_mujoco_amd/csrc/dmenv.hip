@@ -53,6 +53,22 @@ __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_narrow(const DevMode
   const int env = B.order ? B.order[slot] : slot;
   env_step<Real, NARROW_ROWS>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
 }
+// the same step followed, in the same wave, by the policy's step on the observation it produced (dm_batch_step_act)
+__global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_act(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
+                                                 Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
+                                                 int n_substeps, int first, dmp::PolicyArgs pa) {
+  __shared__ Shared<Real> s;
+  __shared__ StepScratch<Real> x;
+  const int slot = first + (int)blockIdx.x;
+  if (slot >= B.n_envs) return;
+  const int env = B.order ? B.order[slot] : slot;
+  env_step<Real, NARROW_ROWS>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
+  // s.qpos / s.qvel hold the state the observation was written from (the fresh episode's after an auto-reset); the row-descriptor
+  // region is free
+  static_assert(sizeof(s.u) >= 464 * sizeof(float), "policy scratch");
+  dmw::sync();
+  dmp::policy_wave(pa, env, dmw::lane(), &s.qpos[7], &s.qvel[6], reinterpret_cast<float*>(&s.u));
+}
 __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                              Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
                                              int n_substeps) {
@@ -429,8 +445,9 @@ extern "C" int dm_batch_reset(dm_batch* b, int32_t mode, int32_t hard, const uin
   return DM_OK;
 }
 
-extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t nsub, int32_t kind) {
+static int step_impl(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t nsub, int32_t kind, const dmp::PolicyArgs* pol) {
   if (!b || !action || !obs || !reward || !done || nsub < 1) return fail(DM_EINVAL, "dm_batch_step: bad argument");
+  if (pol && (kind != DM_PTR_DEVICE || b->prof || !b->two_tier)) return fail(DM_EINVAL, "dm_batch_step_act: device pointers, the two-tier kernel and no profiling");
   HIPCHK(hipSetDevice(b->device));
   const void* a = action;
   if (kind == DM_PTR_HOST) {
@@ -457,7 +474,8 @@ extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, dou
       if (hi <= lo) continue;
       HIPCHK(hipStreamWaitEvent(b->ps[h], b->ev_in, 0));
       if (b->timing && h == 0) HIPCHK(hipEventRecord(b->ev0, b->ps[0]));     // timing: sub-batch 0's kernel on ITS stream
-      hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo);
+      if (pol) hipLaunchKernelGGL(k_step_act, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, *pol);
+      else hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo);
       if (b->timing && h == 0) { HIPCHK(hipEventRecord(b->ev1, b->ps[0])); b->ev_pending = true; }
       if (reorder) hipLaunchKernelGGL(k_order_wave, dim3(1), dim3(64), 0, b->ps[h], b->B, b->d_order, lo, hi - lo);
       HIPCHK(hipEventRecord(b->ev_done[h], b->ps[h]));
@@ -465,7 +483,8 @@ extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, dou
     if (reorder) b->B.order = b->d_order;  // valid from the next launch on (same streams: ordered after each part's k_order)
     b->pipe_pending = true;
   } else if (b->two_tier) {
-    hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0);
+    if (pol) hipLaunchKernelGGL(k_step_act, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, *pol);
+    else hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0);
     if (reorder) {
       hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order, 0, b->n);
       b->B.order = b->d_order;             // valid from the next launch on (same stream: ordered after k_order)
@@ -480,6 +499,16 @@ extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, dou
     memcpy(obs, b->h_out, ob); memcpy(reward, b->h_out + ob, rb); memcpy(done, b->h_out + ob + rb, (size_t)b->n);
   }
   return DM_OK;
+}
+
+extern "C" int dm_batch_step(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t nsub, int32_t kind) {
+  return step_impl(b, action, obs, reward, done, nsub, kind, nullptr);
+}
+extern "C" int dm_batch_step_act(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t nsub,
+                                 const float* weights, double* next_action, float* next_vpred, int32_t stochastic, uint64_t seed, uint64_t counter) {
+  if (!weights || !next_action || !next_vpred) return fail(DM_EINVAL, "dm_batch_step_act: null policy argument");
+  dmp::PolicyArgs pa{weights, next_action, next_vpred, (int)stochastic, (unsigned long long)seed, (unsigned long long)counter};
+  return step_impl(b, action, obs, reward, done, nsub, DM_PTR_DEVICE, &pa);
 }
 
 extern "C" int dm_batch_get_obs(dm_batch* b, double* obs, int32_t kind) {

@@ -99,6 +99,83 @@ __global__ __launch_bounds__(256) void k_policy_act(const float* __restrict__ P,
   }
 }
 
+// The same policy step for ONE environment by ONE wave, as the epilogue of the env step kernel (dm_batch_step_act): the wave that
+// has just produced an observation turns it into the next action and its value estimate before it exits, so a rollout step is one
+// launch and consecutive steps of a pipelined batch overlap exactly like open-loop stepping (the separate launch sat on every
+// step's critical path: policy 20..40 us + launch gaps against an env step of ~310 us).  Lane l < 50 owns four consecutive hidden
+// units (lanes 0..24 the policy net, 25..49 the value net): one 16-byte weight load per input and lane, 14 / 20 of them in flight —
+// every wave streams the 87 KB of weights from L2 itself, so the epilogue is bound by those loads' latency, not by its ~1 k FMAs;
+// activations go through `scr` (LDS, >= 464 floats).
+struct PolicyArgs {
+  const float* P;            // packed weights (layout above); nullptr: no policy step
+  double* action;            // [N, 28] out: action for the observation just produced
+  float* vpred;              // [N] out
+  int stochastic;
+  unsigned long long seed, counter;
+};
+template <int K, int UNROLL>
+__device__ inline float4 dense4_wave(const float* __restrict__ W, const float* __restrict__ bias, const float* in) {
+  // four consecutive hidden units of one net: one 16-byte weight load per input (coalesced across lanes), UNROLL of them in flight
+  float4 acc = *reinterpret_cast<const float4*>(bias);
+#pragma unroll 1
+  for (int k0 = 0; k0 < K; k0 += UNROLL) {
+    float4 w[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) if (k0 + u < K) w[u] = *reinterpret_cast<const float4*>(W + (size_t)(k0 + u) * HID);
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) if (k0 + u < K) {
+      const float x = in[k0 + u];
+      acc.x += x * w[u].x; acc.y += x * w[u].y; acc.z += x * w[u].z; acc.w += x * w[u].w;
+    }
+  }
+  return acc;
+}
+template <class T>
+__device__ inline void policy_wave(const PolicyArgs& pa, int env, int lane, const T* ob_q /* qpos + 7: 28 */, const T* ob_v /* qvel + 6: 28 */, float* scr) {
+  const float* __restrict__ P = pa.P;
+  float* z = scr; float* h1 = scr + 64; float* h2 = scr + 264;
+  if (lane < OB) {
+    const float o = lane < 28 ? (float)ob_q[lane] : (float)ob_v[lane - 28];
+    z[lane] = fminf(fmaxf((o - P[O_MEAN + lane]) / P[O_STD + lane], -5.0f), 5.0f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+  // lanes 0..24: units 4 l .. 4 l + 3 of the policy net; lanes 25..49: of the value net
+  const bool hid = lane < 2 * (HID / 4);
+  const int net = lane >= HID / 4 ? 1 : 0, j4 = 4 * (lane - net * (HID / 4));
+  const int jj = hid ? j4 : 0;
+  {
+    const float4 a = dense4_wave<OB, 14>(P + (net ? O_VW1 : O_PW1) + jj, P + (net ? O_VB1 : O_PB1) + jj, z);
+    if (hid) *reinterpret_cast<float4*>(h1 + net * HID + j4) = make_float4(tanhf(a.x), tanhf(a.y), tanhf(a.z), tanhf(a.w));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+  {
+    const float4 a = dense4_wave<HID, 20>(P + (net ? O_VW2 : O_PW2) + jj, P + (net ? O_VB2 : O_PB2) + jj, h1 + net * HID);
+    if (hid) *reinterpret_cast<float4*>(h2 + net * HID + j4) = make_float4(tanhf(a.x), tanhf(a.y), tanhf(a.z), tanhf(a.w));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+  // output layer: lanes 0..27 the action means, lane 28 the value
+  {
+    const bool isv = lane == AC, on = lane <= AC;
+    const float* W = P + (isv ? O_VW3 : O_PW3);
+    const int ws = isv ? 1 : AC, wo = (isv || !on) ? 0 : lane;
+    const float* h = h2 + (isv ? HID : 0);
+    float sacc = isv ? P[O_VB3] : P[O_PB3 + wo];
+#pragma unroll 1
+    for (int k0 = 0; k0 < HID; k0 += 20) {
+      float w[20];
+#pragma unroll
+      for (int u = 0; u < 20; u++) w[u] = W[(k0 + u) * ws + wo];
+#pragma unroll
+      for (int u = 0; u < 20; u++) sacc += h[k0 + u] * w[u];
+    }
+    if (isv) pa.vpred[env] = sacc;
+    else if (on) {
+      if (pa.stochastic) sacc += expf(P[O_LOGSTD + lane]) * normal_from(pa.seed, pa.counter, (unsigned)(env * AC + lane));
+      pa.action[(size_t)env * AC + lane] = (double)sacc;
+    }
+  }
+}
+
 // GAE(lambda) of src/trpo.py:83-94 for N environments: thread = env, a backward loop over the T rows of the [T, N] segment
 // (coalesced across envs), instead of T small launches.
 __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, const float* __restrict__ vpred, const int* __restrict__ isnew,

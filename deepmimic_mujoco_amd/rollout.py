@@ -88,12 +88,20 @@ def add_vtarg_and_adv(seg, gamma, lam):
     return seg
 
 
+def can_fuse(pi, env, device=None):
+    """True when `SegmentCollector(fused=True)` is possible: the policy step can run inside the env step kernel (dm_batch_step_act)."""
+    import torch
+    device = torch.device(pi.device if device is None else device)
+    return (device.type == "cuda" and getattr(pi, "native", False) and hasattr(getattr(env, "batch", None), "step_act")
+            and getattr(pi, "ob_dim", 0) == 56 and getattr(pi, "ac_dim", 0) == 28 and getattr(pi, "hid_size", 0) == 100)
+
+
 class SegmentCollector(object):
     """One env batch's side of `traj_segment_generator`, split into `launch()` (enqueue T policy + env steps, no host wait) and
     `collect()` (episode bookkeeping, the one host transfer per segment) so that several env batches can be in flight at once.
     With `stream` (a torch CUDA stream) everything this collector enqueues runs on that stream."""
 
-    def __init__(self, pi, env, horizon, stochastic=True, device=None, first_reset="rsi", stream=None):
+    def __init__(self, pi, env, horizon, stochastic=True, device=None, first_reset="rsi", stream=None, fused=False):
         import torch
         self.pi, self.env, self.T, self.stochastic, self.stream = pi, env, int(horizon), stochastic, stream
         n, T = env.num_envs, self.T
@@ -102,7 +110,7 @@ class SegmentCollector(object):
         self.device = device
         f32, f64 = torch.float32, torch.float64
         self.ob64 = torch.zeros((T + 1, n, 56), dtype=f64, device=device)         # row t: observation the policy sees at step t
-        self.ac64 = torch.zeros((T, n, 28), dtype=f64, device=device)
+        self.ac64 = torch.zeros((T + 1, n, 28), dtype=f64, device=device)         # row T: the action already drawn for ob64[T] (fused path)
         self.rew64 = torch.zeros((T, n), dtype=f64, device=device)
         self.done8 = torch.zeros((T, n), dtype=torch.uint8, device=device)
         self.vpreds = torch.zeros((T + 1, n), dtype=f32, device=device)
@@ -112,6 +120,13 @@ class SegmentCollector(object):
         self.cur_len = torch.zeros(n, dtype=torch.int64, device=device)
         self.as_buf = (lambda x: x) if device.type == "cuda" else (lambda x: x.numpy())   # host tensors: shared-memory views
         self.step_idx = torch.arange(1, T + 1, device=device, dtype=torch.int64)[:, None]
+        # fused path: the env step kernel also runs the policy on the observation it produced (dm_batch_step_act), one launch per step.
+        # As in the reference's generator (src/trpo.py:47-56) the action for the first observation of a segment was then drawn BEFORE the
+        # update in between (by the policy that finished the last segment) and only its value is re-evaluated afterwards.
+        if fused and not can_fuse(pi, env, device):
+            raise ValueError("fused rollout steps need the native policy kernel (56-100-100-28) and a device-resident env batch")
+        self.fused = bool(fused)
+        self.have_ac0 = False
         with self._on_stream():
             env.reset(first_reset, out=self.as_buf(self.ob64[0]))                  # trpo.py:32 `ob = env.reset()` (RSI); later episodes: noisy init
 
@@ -127,7 +142,22 @@ class SegmentCollector(object):
         fs = getattr(env, "frame_skip", 1)
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))         # parameters / filter updated by the learner are visible
+        if self.fused and (getattr(pi, "_dirty", False) or getattr(pi, "_packed", None) is None):
+            pi.pack()                                                               # (on the caller's stream, before the side stream forks)
+            if self.stream is not None:
+                self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with self._on_stream(), torch.no_grad():                                    # (the learner may hold the parameters with requires_grad)
+            if self.fused:
+                if not self.have_ac0:
+                    pi.act(self.stochastic, ob64[0], out=ac64[0], vpred_out=vpreds[0])                   # very first step: :49
+                else:
+                    vpreds[0] = pi.forward_value(ob64[0])                                                 # :56, the updated policy's value
+                for t in range(T):                                                                       # :49 + :66, one launch
+                    pi._counter += 1
+                    env.batch.step_act(ac64[t], fs, (ob64[t + 1], rew64[t], done8[t]), pi._packed, ac64[t + 1], vpreds[t + 1],
+                                       self.stochastic, pi._seed, pi._counter)
+                env.batch.join()
+                return
             for t in range(T):
                 pi.act(self.stochastic, ob64[t], out=ac64[t], vpred_out=vpreds[t])                       # :49
                 env.batch.step(as_buf(ac64[t]), fs, (as_buf(ob64[t + 1]), as_buf(rew64[t]), as_buf(done8[t])))   # :66, one launch
@@ -143,7 +173,7 @@ class SegmentCollector(object):
         ob64, ac64, rew64, done8, vpreds = self.ob64, self.ac64, self.rew64, self.done8, self.vpreds
         done = done8.to(torch.bool)
         new = torch.cat([self.first[None], done8[:-1].to(torch.int32)], 0)
-        acs = ac64.to(f32)
+        acs = ac64[:T].to(f32)
         prevacs = torch.cat([self.last_ac[None], acs[:-1]], 0)
         # episode statistics: return / length of every episode that ended inside the segment, in time-major order
         # (= the order in which a single-env loop would have appended them, :72-76)
@@ -176,12 +206,14 @@ class SegmentCollector(object):
         self.first = done8[-1].to(torch.int32)
         self.last_ac = acs[-1].clone()
         ob64[0].copy_(ob64[T])
+        if self.fused:
+            ac64[0].copy_(ac64[T]); self.have_ac0 = True
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))   # the copies above are ordered before the next launch
         return seg
 
 
-def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first_reset="rsi"):
+def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first_reset="rsi", fused=False):
     """Batched `traj_segment_generator` (src/trpo.py:27-80): N envs advance in lock step on the device.
 
     pi: policy.MlpPolicy; env: DPVecEnv created with autoreset="init" — the kernel then applies, on `done`, exactly what
@@ -192,23 +224,25 @@ def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first
 
     Per step the loop issues only the policy forward and ONE env launch: the policy writes its action and value straight
     into row t of the segment buffers, and `dm_batch_step` reads that action row and writes the next observation, the
-    reward and the done flag straight into rows t+1 / t / t of theirs (float64, as the C ABI produces them).  The float32
+    reward and the done flag straight into rows t+1 / t / t of theirs (float64, as the C ABI produces them).  With `fused=True`
+    (see `can_fuse`) even the policy forward is gone: the env step kernel runs it on the observation it has just produced
+    (`dm_batch_step_act`), a step is ONE launch, and with `DM_OPT_PIPELINE` on the batch consecutive steps overlap.  The float32
     segment views, `new`, `prevac` and the episode statistics are derived once per segment with [T, N]-wide ops.
     Nothing leaves the device or the stream."""
-    c = SegmentCollector(pi, env, horizon, stochastic, device, first_reset)
+    c = SegmentCollector(pi, env, horizon, stochastic, device, first_reset, fused=fused)
     while True:
         c.launch()
         yield c.collect()
 
 
-def pipelined_segment_generator(pi, envs, horizon, stochastic=True, first_reset="rsi"):
+def pipelined_segment_generator(pi, envs, horizon, stochastic=True, first_reset="rsi", fused=False):
     """The same segments from SEVERAL env batches (e.g. two halves of a GPU's envs) stepped concurrently, each on its own CUDA
     stream: the whole T-step chain of every batch (policy forward -> env step -> policy forward ...) is enqueued without a host
     wait, so while one batch's env kernel drains its last, cheap workgroups the other batch's policy / env kernels fill the freed
     wave slots — the overlap `DM_OPT_PIPELINE` gives open-loop stepping, for the closed loop.  Yields one segment dict whose env
     axis is the concatenation of the batches (episode lists concatenated in batch order)."""
     import torch
-    cols = [SegmentCollector(pi, e, horizon, stochastic, None, first_reset, stream=torch.cuda.Stream(device=pi.device)) for e in envs]
+    cols = [SegmentCollector(pi, e, horizon, stochastic, None, first_reset, stream=torch.cuda.Stream(device=pi.device), fused=fused) for e in envs]
     while True:
         if getattr(pi, "_dirty", False) or getattr(pi, "_packed", None) is None:
             pi.pack()                                  # once, on the current stream, before the side streams fork from it

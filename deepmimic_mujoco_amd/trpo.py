@@ -400,7 +400,7 @@ class TrpoLearner:
 
 
 def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max_seconds=0, callback=None, log=print,
-          group=None, log_dir=None, **learner_kwargs):
+          group=None, log_dir=None, fused=None, **learner_kwargs):
     """`learn()` of src/trpo.py:97-319 over a DPVecEnv (autoreset="init"; or a list of them: pipelined rollouts) and an MlpPolicy.  Stops after `max_iters`
     iterations, `max_timesteps` env steps (global) or `max_seconds`.  Returns the list of per-iteration stat dicts, with
     the reference's log keys (EpLenMean / EpRewMean over the last 40 episodes, EpThisIter, EpisodesSoFar, TimestepsSoFar,
@@ -414,7 +414,10 @@ def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max
         seg_gen = pipelined_segment_generator(pi, list(env), timesteps_per_batch, stochastic=True)
         n_envs_local = sum(e.num_envs for e in env)
     else:
-        seg_gen = traj_segment_generator(pi, env, timesteps_per_batch, stochastic=True)
+        # fused (default when possible): the policy step runs inside the env step kernel, one launch per rollout step
+        from .rollout import can_fuse
+        use_fused = can_fuse(pi, env) if fused is None else bool(fused)
+        seg_gen = traj_segment_generator(pi, env, timesteps_per_batch, stochastic=True, fused=use_fused)
         n_envs_local = env.num_envs
     world = _world(group)
     rank = dist.get_rank(group) if world > 1 else 0

@@ -206,6 +206,14 @@ int dm_policy_weight_count(void);
 int dm_policy_act(const float* weights, const double* obs, double* action, float* vpred, int32_t n, int32_t stochastic,
                   uint64_t seed, uint64_t counter, void* hip_stream);
 
+/* dm_batch_step followed, INSIDE the step kernel, by dm_policy_act on the observations it produced: the wave that steps env e writes
+ * obs / reward / done as dm_batch_step does and then next_action[e] (28) and next_vpred[e] for that observation (the fresh episode's
+ * after an auto-reset).  One launch per rollout step (src/trpo.py:47-66: `ac, vpred = pi.act(ob)`; `ob, rew, new, _ = env.step(ac)`),
+ * so consecutive steps of a pipelined batch (DM_OPT_PIPELINE) overlap although every step's action depends on the last one's
+ * observation: that dependency stays inside a sub-batch's stream.  Device pointers only; same noise stream as dm_policy_act. */
+int dm_batch_step_act(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t n_substeps,
+                      const float* weights, double* next_action, float* next_vpred, int32_t stochastic, uint64_t seed, uint64_t counter);
+
 /* Replaces: add_vtarg_and_adv (src/trpo.py:83-94) for N environments at once: rew, vpred, adv, tdlamret [T, N] float32,
  * isnew [T, N] int32 (isnew[t] = the observation of step t starts an episode), nextvpred [N]; device pointers. */
 int dm_gae(const float* rew, const float* vpred, const int32_t* isnew, const float* nextvpred, float* adv, float* tdlamret,

@@ -215,3 +215,73 @@ def test_bench_other_workloads_print_the_contract_line(extra):
         assert "shard 3 of 8" in j["config"]["workload"] and j["config"]["global_envs"] == 8 * 768
     assert j["dtype"] == ("f32" if "--dtype" in extra else "f64")
     assert j["roofline"]["launch"]["launches_per_step"] == (1 if "--pipeline" in extra else 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_fused_policy_step_equals_step_then_act(pipeline):
+    """dm_batch_step_act == dm_batch_step followed by dm_policy_act on the observations it produced: same obs / reward / done
+    (bit-exact: the same env kernel code), same actions and values (the per-wave MLP sums in a different order: 1e-5), over
+    closed-loop steps with auto-resets (an untrained policy: episodes of ~34 steps), at one launch per step and with pipelined
+    sub-batches."""
+    from deepmimic_mujoco_amd import _abi as A
+    n, steps = 640, 48
+    pol = MlpPolicy(device=DEV, seed=2); pol.seed(5)
+    outs = []
+    for fused in (False, True):
+        env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=3)
+        env.batch.set_option(A.OPT_PIPELINE, pipeline)
+        ob = torch.zeros((steps + 1, n, 56), dtype=torch.float64, device=DEV)
+        ac = torch.zeros((steps + 1, n, 28), dtype=torch.float64, device=DEV)
+        vp = torch.zeros((steps + 1, n), dtype=torch.float32, device=DEV)
+        rew = torch.zeros((steps, n), dtype=torch.float64, device=DEV); dn = torch.zeros((steps, n), dtype=torch.uint8, device=DEV)
+        env.reset("init", out=ob[0])
+        pol._counter = 100
+        pol.act(True, ob[0], out=ac[0], vpred_out=vp[0])
+        for t in range(steps):
+            if fused:
+                pol._counter += 1
+                env.batch.step_act(ac[t], 1, (ob[t + 1], rew[t], dn[t]), pol._packed, ac[t + 1], vp[t + 1], True, pol._seed, pol._counter)
+            else:
+                env.batch.step(ac[t], 1, (ob[t + 1], rew[t], dn[t]))
+                env.batch.join()
+                pol.act(True, ob[t + 1], out=ac[t + 1], vpred_out=vp[t + 1])
+        env.batch.sync()
+        outs.append((ob.clone(), ac.clone(), vp.clone(), rew.clone(), dn.clone()))
+        env.close()
+    (ob0, ac0, vp0, r0, d0), (ob1, ac1, vp1, r1, d1) = outs
+    # the first step is bit-identical (same actions in); its policy outputs differ by float32 rounding; later steps inherit that
+    assert torch.equal(ob0[1], ob1[1]) and torch.equal(d0[0], d1[0])
+    assert float((ac0[1] - ac1[1]).abs().max()) < 1e-5 and float((vp0[1] - vp1[1]).abs().max()) < 1e-4 * max(1.0, float(vp0[1].abs().max()))
+    assert float((ob0[:9] - ob1[:9]).abs().max()) < 1e-4 and float((ac0[:9] - ac1[:9]).abs().max()) < 1e-4
+    same = (d0 == d1).all(0)                                  # envs whose episodes ended at the same steps in both runs
+    assert float(same.float().mean()) > 0.9 and int(d0.sum()) > n // 2 and abs(int(d0.sum()) - int(d1.sum())) <= n // 20
+    # an auto-reset env's next action is the policy's on the FRESH episode's observation
+    t, e = [int(x) for x in d1.nonzero()[0]]
+    assert float(ob1[t + 1, e, :28].abs().max()) < 0.0101
+    ref_ac, ref_vp = pol.forward(ob1[t + 1, e][None])
+    assert abs(float(ref_vp[0]) - float(vp1[t + 1, e])) < 1e-4 * max(1.0, abs(float(ref_vp[0])))
+
+
+@pytest.mark.gpu
+def test_fused_segment_generator_follows_the_reference_protocol():
+    """`traj_segment_generator(fused=True)`: segments of the same shape and statistics as the two-launch form; the first action of a
+    segment is the one drawn for that observation at the end of the previous segment (src/trpo.py:47-56), `new` / `prevac` / episode
+    bookkeeping hold across segment boundaries, and the shipped policy balances as long as in the two-launch form."""
+    from deepmimic_mujoco_amd import _abi as A
+    n, T = 512, 64
+    pol = MlpPolicy.from_tf_checkpoint(CKPT, device=DEV); pol.seed(1)
+    env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=0)
+    env.batch.set_option(A.OPT_PIPELINE, 2)
+    gen = traj_segment_generator(pol, env, T, stochastic=True, first_reset="init", fused=True)
+    segs = [next(gen) for _ in range(8)]
+    lens = [x for s in segs for x in s["ep_lens"]]
+    for a, b in zip(segs[:-1], segs[1:]):
+        assert torch.equal(b["prevac"][0], a["ac"][-1])                     # prevac of row 0 = last action of the previous segment
+        assert a["ob"].shape == (T, n, 56) and a["ac"].shape == (T, n, 28) and a["vpred"].shape == (T, n)
+    for s in segs:
+        assert bool((s["rew"] == 1).all()) and bool(torch.isfinite(s["ac"]).all()) and bool(torch.isfinite(s["vpred"]).all())
+        fresh = s["ob"][1:][s["new"][1:].bool()]
+        assert fresh.numel() == 0 or bool((fresh[:, :28].abs() < 0.0101).all())      # a fresh episode starts at the noisy default pose
+    assert len(lens) > 50 and 150 < np.mean(lens) < 450                     # the checkpoint's policy: ~270 steps (DESIGN.md section 5)
+    env.close()

@@ -17,8 +17,9 @@ ROWS=6 python tools/rocprof_summary.py $OUT/kstep_summary.md "k_step_narrow — 
 for wl in cfg4 cfg5 cfg2; do
   timeout 300 python bench.py --workload $wl --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; cut -c1-300 $OUT/bench_$wl.json
 done
+timeout 300 python bench.py --workload rollout --steps 2048 --warmup 256 > $OUT/bench_rollout_fused.json 2> $OUT/bench_rollout_fused.err; cut -c1-200 $OUT/bench_rollout_fused.json
 for p in 1 2; do
-  timeout 300 python bench.py --workload rollout --pipeline $p --steps 1024 --warmup 256 > $OUT/bench_rollout_p$p.json 2> $OUT/bench_rollout_p$p.err; cut -c1-200 $OUT/bench_rollout_p$p.json
+  timeout 300 python bench.py --workload rollout --unfused --pipeline $p --steps 2048 --warmup 256 > $OUT/bench_rollout_p$p.json 2> $OUT/bench_rollout_p$p.err; cut -c1-200 $OUT/bench_rollout_p$p.json
 done
 timeout 300 python bench.py --dtype 32 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_f32.json 2> $OUT/bench_cfg3_f32.err; cut -c1-200 $OUT/bench_cfg3_f32.json
 timeout 300 python bench.py --pipeline 1 --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_pipeline1.json 2> $OUT/bench_cfg3_pipeline1.err; cut -c1-200 $OUT/bench_cfg3_pipeline1.json

@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--reward", default="alive", help="alive | v3-config | v2-pose | imitation")
     ap.add_argument("--autoreset", default="init", help="init (the reference's trpo.py protocol) | rsi (DeepMimic reference-state initialisation)")
     ap.add_argument("--frame-skip", default=None, help="sim steps per env step, or 'mocap' (default: 1; 'mocap' with --reward imitation)")
-    ap.add_argument("--pipeline", type=int, default=1, help="step the rank's envs as this many batches on their own streams (policy -> env chains overlap)")
+    ap.add_argument("--pipeline", type=int, default=2, help="sub-batches whose step launches overlap across consecutive steps (DM_OPT_PIPELINE; with "
+                                                            "--unfused: that many env batches on their own streams, policy -> env chains overlap)")
+    ap.add_argument("--unfused", action="store_true", help="separate policy launch per step instead of the policy step inside the env step kernel")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
     ap.add_argument("--log-dir", default=None, help="write progress.csv and monitor.csv in the reference's formats")
@@ -46,13 +48,20 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     fs = args.frame_skip if args.frame_skip in (None, "mocap") else int(args.frame_skip)
     P = max(1, args.pipeline)
-    cuts = [args.envs * h // P for h in range(P + 1)]
-    envs = [DPVecEnv(cuts[h + 1] - cuts[h], motion=args.motion, device=lr, reward=args.reward, autoreset=args.autoreset, seed=args.seed + 10000 * rank,
-                     env_offset=rank * args.envs + cuts[h], frame_skip=fs) for h in range(P)]
-    env = envs if P > 1 else envs[0]
+    if args.unfused:
+        cuts = [args.envs * h // P for h in range(P + 1)]
+        envs = [DPVecEnv(cuts[h + 1] - cuts[h], motion=args.motion, device=lr, reward=args.reward, autoreset=args.autoreset, seed=args.seed + 10000 * rank,
+                         env_offset=rank * args.envs + cuts[h], frame_skip=fs) for h in range(P)]
+        env = envs if P > 1 else envs[0]
+    else:
+        from deepmimic_mujoco_amd import _abi as A
+        env = DPVecEnv(args.envs, motion=args.motion, device=lr, reward=args.reward, autoreset=args.autoreset, seed=args.seed + 10000 * rank,
+                       env_offset=rank * args.envs, frame_skip=fs)
+        env.batch.set_option(A.OPT_PIPELINE, min(P, A.MAX_PIPELINE))
     pi = MlpPolicy(device=dev, seed=args.seed); pi.seed(args.seed + 10000 * rank)
     hist = learn(env, pi, timesteps_per_batch=args.horizon, max_seconds=args.seconds if not args.iters else 0, max_iters=args.iters,
-                 vf_batch_size=args.vf_batch, vf_stepsize=args.vf_stepsize, max_kl=args.max_kl, seed=args.seed, log_dir=args.log_dir)
+                 vf_batch_size=args.vf_batch, vf_stepsize=args.vf_stepsize, max_kl=args.max_kl, seed=args.seed, log_dir=args.log_dir,
+                 fused=False if args.unfused else None)
     if rank == 0:
         if args.out:
             os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
