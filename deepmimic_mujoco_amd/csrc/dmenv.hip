@@ -15,6 +15,7 @@
 
 #include "dmenv.h"
 #include "policy_kernel.h"
+#include "vf_kernel.h"
 #include "env_step.h"
 #include "model_host.h"
 
@@ -626,6 +627,35 @@ extern "C" int dm_gae(const float* rew, const float* vpred, const int32_t* isnew
   if (!rew || !vpred || !isnew || !nextvpred || !adv || !tdlamret || T <= 0 || n <= 0) return fail(DM_EINVAL, "dm_gae: bad argument");
   hipLaunchKernelGGL(dmp::k_gae, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, rew, vpred, (const int*)isnew, nextvpred, adv,
                      tdlamret, (int)T, (int)n, (float)gamma, (float)lam);
+  HIPCHK(hipGetLastError());
+  return DM_OK;
+}
+extern "C" int dm_vf_param_count(void) { return dmv::NP; }
+extern "C" size_t dm_vf_scratch_bytes(int32_t bs) {
+  const size_t nblk = (size_t)((bs + dmv::SB - 1) / dmv::SB);
+  return nblk * dmv::NPAD * sizeof(float) + (size_t)dmv::RMS_BLOCKS * 2 * dmv::OB * sizeof(double) + 256;
+}
+extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, int32_t bs, float* theta, float* adam_m, float* adam_v,
+                               const float* step_scale_host, double beta1, double beta2, double eps, double* rms_sum, double* rms_sumsq,
+                               double* rms_count, float* rms_mean, float* rms_std, void* scratch, void* hip_stream) {
+  if (!ob || !ret || !theta || !adam_m || !adam_v || !step_scale_host || !rms_sum || !rms_sumsq || !rms_count || !rms_mean || !rms_std || !scratch ||
+      nb < 1 || bs < 1)
+    return fail(DM_EINVAL, "dm_vf_fit_epoch: bad argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int nblk = (bs + dmv::SB - 1) / dmv::SB;
+  float* partial = (float*)scratch;
+  double* rpart = (double*)((char*)scratch + (((size_t)nblk * dmv::NPAD * sizeof(float) + 255) / 256) * 256);
+  unsigned* ticket = (unsigned*)(rpart + dmv::RMS_BLOCKS * 2 * dmv::OB);
+  HIPCHK(hipMemsetAsync(ticket, 0, sizeof(unsigned), st));
+  for (int i = 0; i < nb; i++) {
+    const float* mbob = ob + (size_t)i * bs * dmv::OB;
+    const float* mbret = ret + (size_t)i * bs;
+    hipLaunchKernelGGL(dmv::k_vf_rms, dim3(dmv::RMS_BLOCKS), dim3(256), 0, st, mbob, (int)bs, rpart, ticket, rms_sum, rms_sumsq, rms_count, rms_mean, rms_std);
+    hipLaunchKernelGGL(dmv::k_vf_grad, dim3(nblk), dim3(256), 0, st, mbob, mbret, (int)bs, (const float*)theta, (const float*)rms_mean,
+                       (const float*)rms_std, partial);
+    hipLaunchKernelGGL(dmv::k_vf_adam, dim3((dmv::NP + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk, theta, adam_m, adam_v,
+                       step_scale_host[i], (float)beta1, (float)beta2, (float)eps);
+  }
   HIPCHK(hipGetLastError());
   return DM_OK;
 }

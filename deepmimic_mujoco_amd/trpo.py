@@ -213,7 +213,7 @@ class TrpoLearner:
     """One policy/value update per segment; the reference's `learn()` body between `seg_gen.__next__()` and the logging."""
 
     def __init__(self, pi, *, max_kl=0.01, cg_iters=10, cg_damping=0.1, gamma=0.995, lam=0.97, entcoeff=0.0,
-                 vf_iters=3, vf_stepsize=1e-3, vf_batch_size=128, fvp_subsample=5, group=None, seed=0, vf_graph=None):
+                 vf_iters=3, vf_stepsize=1e-3, vf_batch_size=128, fvp_subsample=5, group=None, seed=0, vf_graph=None, vf_native=None):
         self.pi = pi
         self.max_kl, self.cg_iters, self.cg_damping = max_kl, cg_iters, cg_damping
         self.gamma, self.lam, self.entcoeff = gamma, lam, entcoeff
@@ -222,6 +222,9 @@ class TrpoLearner:
         # value-fit minibatch steps as one captured hipGraph each (single-process GPU runs; None = when possible)
         self.vf_graph = vf_graph
         self._vfg = None
+        # ... or as the hand-written kernels of csrc/vf_kernel.h (three launches per minibatch, one C call per epoch; None = when possible)
+        self.vf_native = vf_native
+        self._vf_scratch = None
         self.group = group
         for k in POL_KEYS + VF_KEYS:
             pi.params[k].requires_grad_(True)
@@ -288,6 +291,44 @@ class TrpoLearner:
         vferr = ((vpred - mbret) ** 2).mean()
         gv = flat(torch.autograd.grad(vferr, self.vf))
         self.vfadam.update(gv, self.vf_stepsize)
+
+    def _vf_native_ready(self, ob, ret):
+        """The value fit as csrc/vf_kernel.h's kernels (dm_vf_fit_epoch): single-process GPU runs with the reference's 56-100-100-1 value
+        net.  Same arithmetic as `_vf_step` in float32 (obs-filter sums in float64), sums in a fixed order."""
+        if self.vf_native is False or ob.device.type != "cuda" or _world(self.group) > 1:
+            return False
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return False
+        p = self.pi.params
+        ok = (ob.dtype == torch.float32 and ob.dim() == 2 and ob.shape[1] == 56 and ret.dtype == torch.float32 and getattr(self.pi, "native", False)
+              and tuple(p["vffc1/w"].shape) == (56, 100) and tuple(p["vffc2/w"].shape) == (100, 100) and tuple(p["vffinal/w"].shape) == (100, 1)
+              and all(p[k].dtype == torch.float32 for k in VF_KEYS) and tuple(self.pi.ob_rms.shape) == (56,))
+        if not ok and self.vf_native is True:
+            raise ValueError("the native value fit needs float32 [n, 56] observations and the 56-100-100-1 value net on a GPU")
+        return ok
+
+    def _vf_native_epoch(self, ob, ret, inds, bs):
+        import ctypes as C
+        from . import _abi as A
+        L = A.load()
+        ad, rms = self.vfadam, self.pi.ob_rms
+        n = ob.shape[0]
+        nb = n // bs                                                        # include_final_partial_batch=False
+        used = inds[:nb * bs]
+        ob_s = ob[used].contiguous(); ret_s = ret[used].contiguous()
+        theta = ad.getflat().to(torch.float32).contiguous()
+        assert theta.numel() == L.dm_vf_param_count()
+        need = int(L.dm_vf_scratch_bytes(int(bs)))
+        if self._vf_scratch is None or self._vf_scratch.numel() < need or self._vf_scratch.device != ob.device:
+            self._vf_scratch = torch.empty(need, dtype=torch.uint8, device=ob.device)
+        scale = (C.c_float * nb)(*[self.vf_stepsize * math.sqrt(1 - ad.beta2 ** (ad.t + 1 + k)) / (1 - ad.beta1 ** (ad.t + 1 + k)) for k in range(nb)])
+        pp = lambda t: C.c_void_p(t.data_ptr())
+        A.check(L.dm_vf_fit_epoch(pp(ob_s), pp(ret_s), nb, int(bs), pp(theta), pp(ad.m), pp(ad.v), scale, float(ad.beta1), float(ad.beta2), float(ad.epsilon),
+                                  pp(rms.sum), pp(rms.sumsq), pp(rms.count), pp(rms.mean), pp(rms.std), pp(self._vf_scratch),
+                                  C.c_void_p(torch.cuda.current_stream(ob.device).cuda_stream)), L)
+        ad.setfromflat(theta)
+        ad.t += nb
 
     def _vf_graph_ready(self, ob, ret, bs):
         """The minibatch step is ~60 launches of tiny kernels (CPU-bound: 0.7 ms each, 384 of them per update at 4 096 envs x 128
@@ -382,9 +423,13 @@ class TrpoLearner:
         # ---- value function (:288-296) ------------------------------------------------------------------------------------
         n = ob.shape[0]
         bs = min(self.vf_batch_size, n)
-        graphed = self._vf_graph_ready(ob, tdlamret, bs)
+        native = self._vf_native_ready(ob, tdlamret)
+        graphed = (not native) and self._vf_graph_ready(ob, tdlamret, bs)
         for _ in range(self.vf_iters):
             inds = self.perm_source(n).to(ob.device) if self.perm_source is not None else torch.randperm(n, device=ob.device, generator=self._perm_gen)
+            if native:
+                self._vf_native_epoch(ob, tdlamret, inds, bs)
+                continue
             if graphed:
                 self._vfg.run_epoch(ob, tdlamret, inds)
                 continue

@@ -219,6 +219,19 @@ int dm_batch_step_act(dm_batch* b, const double* action, double* obs, double* re
 int dm_gae(const float* rew, const float* vpred, const int32_t* isnew, const float* nextvpred, float* adv, float* tdlamret,
            int32_t T, int32_t n, double gamma, double lam, void* hip_stream);
 
+/* Replaces: one epoch of the value fit of src/trpo.py:288-296 — for each of `nb` minibatches of `bs` samples (already shuffled:
+ * ob [nb*bs, 56] float32, ret [nb*bs] float32): `pi.ob_rms.update(mbob)` (src/utils/misc_util.py:53-70: rms_sum / rms_sumsq [56] and
+ * rms_count float64, rms_mean / rms_std [56] float32 refreshed), the gradient of mean((vpred - ret)^2) w.r.t. the 56-100-100-1 tanh
+ * value net (theta: dm_vf_param_count() floats = vffc1/w, vffc1/b, vffc2/w, vffc2/b, vffinal/w, vffinal/b, weights row-major
+ * [in][out]) and the MpiAdam step (src/mpi_adam.py:21-35) with the caller's per-step scale a_i = stepsize sqrt(1 - b2^t) / (1 - b1^t)
+ * (step_scale_host: HOST array [nb]).  Three launches per minibatch, all enqueued by this one call; device pointers otherwise;
+ * `scratch`: dm_vf_scratch_bytes(bs) bytes on the device. */
+int dm_vf_param_count(void);
+size_t dm_vf_scratch_bytes(int32_t bs);
+int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, int32_t bs, float* theta, float* adam_m, float* adam_v,
+                    const float* step_scale_host, double beta1, double beta2, double eps, double* rms_sum, double* rms_sumsq,
+                    double* rms_count, float* rms_mean, float* rms_std, void* scratch, void* hip_stream);
+
 int dm_batch_sync(dm_batch* b);
 /* Make the batch's stream wait (device-side, no host wait) for every pipelined sub-batch launch in flight (DM_OPT_PIPELINE). */
 int dm_batch_join(dm_batch* b);

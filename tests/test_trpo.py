@@ -240,12 +240,48 @@ def test_learner_update_matches_the_float64_restatement_on_gpu():
 
 
 @pytest.mark.gpu
+def test_native_value_fit_equals_the_eager_loop_on_gpu():
+    """csrc/vf_kernel.h (dm_vf_fit_epoch: obs filter, forward / backward of the value net, MpiAdam, three launches per minibatch)
+    against the eager torch loop on the same update (3 epochs x 4 minibatches of 128): same value parameters, Adam moments and
+    obs-filter state to float32 rounding; then a large minibatch (4 096 samples, 128 blocks of partial gradients) on random data."""
+    from deepmimic_mujoco_amd.trpo import VF_KEYS, flat, TrpoLearner
+    from deepmimic_mujoco_amd.policy import MlpPolicy
+    le, pe, _, g, _ = _golden_update("cuda:0", vf_graph=False, vf_native=False)
+    ln, pn, _, _, _ = _golden_update("cuda:0", vf_native=True)
+    assert ln._vf_scratch is not None and le._vf_scratch is None
+    ve = flat([pe.params[k].detach() for k in VF_KEYS]); vn = flat([pn.params[k].detach() for k in VF_KEYS])
+    dv = ve - flat([torch.as_tensor(g["p0/" + k], dtype=torch.float32, device="cuda:0").reshape(-1) for k in VF_KEYS])
+    assert float((ve - vn).abs().max()) < 2e-3 * float(dv.abs().max()) and float(dv.abs().max()) > 5e-3      # the 12 Adam steps agree to 0.2 %
+    assert torch.allclose(pe.ob_rms.sum, pn.ob_rms.sum, rtol=1e-12, atol=1e-8) and float(pe.ob_rms.count) == float(pn.ob_rms.count)
+    assert torch.allclose(pe.ob_rms.std, pn.ob_rms.std, rtol=1e-6) and le.vfadam.t == ln.vfadam.t == 12
+    assert float((le.vfadam.m - ln.vfadam.m).abs().max()) < 1e-5 * max(1e-3, float(le.vfadam.m.abs().max())) + 1e-7
+    # one big minibatch: gradient (through the first Adam step: m = 0.1 g) against autograd
+    torch.manual_seed(0)
+    n = 4096
+    ob = torch.randn(n, 56, device="cuda:0") * 2.0; ret = torch.randn(n, device="cuda:0") * 3.0
+    outs = []
+    for native in (False, True):
+        pi = MlpPolicy(device="cuda:0", seed=3)
+        L = TrpoLearner(pi, vf_batch_size=n, vf_iters=1, vf_graph=False, vf_native=native)
+        L.perm_source = lambda k: torch.arange(k)
+        if native:
+            assert L._vf_native_ready(ob, ret)
+            L._vf_native_epoch(ob, ret, torch.arange(n, device="cuda:0"), n)
+        else:
+            L._vf_step(ob, ret)
+        outs.append((L.vfadam.m.clone(), flat([pi.params[k].detach() for k in VF_KEYS]), pi.ob_rms.mean.clone(), pi.ob_rms.std.clone()))
+    (m0, t0, mu0, sd0), (m1, t1, mu1, sd1) = outs
+    assert float((m0 - m1).abs().max()) < 2e-5 * float(m0.abs().max()) + 1e-8, float((m0 - m1).abs().max()) / float(m0.abs().max())
+    assert float((t0 - t1).abs().max()) < 1e-5 and torch.allclose(mu0, mu1, atol=1e-6) and torch.allclose(sd0, sd1, rtol=1e-6)
+
+
+@pytest.mark.gpu
 def test_value_fit_as_captured_graph_equals_the_eager_loop_on_gpu():
     """The value fit's minibatch step replayed as a captured hipGraph (single-process GPU runs) against the eager loop on the same
     update: same value parameters, same obs-filter moments, same Adam state; and the graph path really ran."""
     from deepmimic_mujoco_amd.trpo import VF_KEYS, flat
-    le, pe, se, g, _ = _golden_update("cuda:0", vf_graph=False)
-    lg, pg, sg, _, _ = _golden_update("cuda:0", vf_graph=True)
+    le, pe, se, g, _ = _golden_update("cuda:0", vf_graph=False, vf_native=False)
+    lg, pg, sg, _, _ = _golden_update("cuda:0", vf_graph=True, vf_native=False)
     assert le._vfg is None and lg._vfg is not None and lg._vfg.ok
     ve = flat([pe.params[k].detach() for k in VF_KEYS]); vg = flat([pg.params[k].detach() for k in VF_KEYS])
     assert float((ve - vg).abs().max()) < 1e-6 * max(1.0, float(ve.abs().max()))
