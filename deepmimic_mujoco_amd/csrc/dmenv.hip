@@ -288,7 +288,7 @@ extern "C" void dm_batch_destroy(dm_batch* b) {
   if (b->ev_in) hipEventDestroy(b->ev_in);
   void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
                   b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
-                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order};
+                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order, b->B.kin, b->B.kin_ok};
   for (void* p : ptrs) if (p) hipFree(p);
   if (b->h_out) hipHostFree(b->h_out);
   if (b->h_action) hipHostFree(b->h_action);
@@ -329,6 +329,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   ok = ok && hipHostMalloc((void**)&b->h_out, b->out_bytes, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&b->h_action, (size_t)n * NU * sizeof(Ext), hipHostMallocDefault) == hipSuccess;
   A(b->B.aovf, (size_t)n * AOVF_COLS * 64);
+  A(b->B.kin, (size_t)n * KIN_DOUBLES); A(b->B.kin_ok, n);
   A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
   if (sizeof(Real) != sizeof(Ext)) A(b->d_cvt, (size_t)n * NB * 3);   // largest Real field per env: xipos (42)
 #undef A
@@ -428,6 +429,7 @@ extern "C" int dm_batch_set_state(dm_batch* b, const double* qpos, const double*
   if ((rc = stage_in(b, b->d_qvel_in, qvel, (size_t)b->n * NV * 8, kind, &v))) return rc;
   if ((rc = stage_in(b, b->d_fidx_in, fidx, (size_t)b->n * 4, kind, &f))) return rc;
   if ((rc = stage_in(b, b->d_mask, mask, (size_t)b->n, kind, &mk))) return rc;
+  HIPCHK(hipMemsetAsync(b->B.kin_ok, 0, (size_t)b->n, b->stream));          // parked kinematics belong to the old states
   hipLaunchKernelGGL(k_set_state, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)q, (const Ext*)v, (const int*)f, (const unsigned char*)mk);
   HIPCHK(hipGetLastError());
   if (kind == DM_PTR_HOST) HIPCHK(hipStreamSynchronize(b->stream));
@@ -440,6 +442,7 @@ extern "C" int dm_batch_reset(dm_batch* b, int32_t mode, int32_t hard, const uin
   if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
   const void* mk; int rc;
   if ((rc = stage_in(b, b->d_mask, mask, (size_t)b->n, kind, &mk))) return rc;
+  HIPCHK(hipMemsetAsync(b->B.kin_ok, 0, (size_t)b->n, b->stream));
   hipLaunchKernelGGL(k_reset, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (int)mode, (int)hard, (const unsigned char*)mk);
   HIPCHK(hipGetLastError());
   if (kind == DM_PTR_HOST) HIPCHK(hipStreamSynchronize(b->stream));
@@ -576,6 +579,7 @@ extern "C" int dm_batch_set(dm_batch* b, int32_t field, const void* in, size_t b
   if (bytes != need) return fail(DM_EINVAL, "dm_batch_set: buffer size does not match the field");
   if (field == DM_F_XIPOS || field == DM_F_COM_Z || field == DM_F_NCON || field == DM_F_NEFC || field == DM_F_CONTACT_GEOMS || field == DM_F_SOLVER_ITER)
     return fail(DM_EINVAL, "dm_batch_set: derived field is read-only");
+  if (field == DM_F_QPOS) HIPCHK(hipMemsetAsync(b->B.kin_ok, 0, (size_t)b->n, b->stream));   // parked kinematics belong to the old positions
   if (real && sizeof(Real) != sizeof(Ext)) {       // float32 build: copy, then narrow on the device
     const Ext* src = (const Ext*)in;
     if (kind == DM_PTR_HOST) { HIPCHK(hipMemcpyAsync(b->d_cvt, in, need, hipMemcpyHostToDevice, b->stream)); src = b->d_cvt; }

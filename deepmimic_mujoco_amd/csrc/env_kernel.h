@@ -42,6 +42,7 @@ DM_CONSTANT Topo TOPO = make_topo();
 
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_BOX = 6 };
 enum { REW_ALIVE = 0, REW_V3_CONFIG = 1, REW_V2_POSE = 2, REW_IMITATION = 3, REW_V1_QUAT = 4 };
+constexpr int KIN_A = NB * 3 + NB * 9 + NB * 3 + NV * 6, KIN_B = 2 * NB * 10, KIN_DOUBLES = KIN_A + KIN_B;   // see env_step.h save_kin
 constexpr int PROF_SLOTS = 32;  // per-env profile record (k_step_prof): see dm_batch_read_profile
 constexpr int IMIT_FEAT = 112;   // doubles per reference feature row (deepmimic_mujoco_amd/imitation.py)
 enum { ROW_NONE = 0, ROW_LIMIT = 1, ROW_CONTACT = 2 };
@@ -1742,11 +1743,11 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
 // one forward-dynamics evaluation: s.qpos, s.qvel, s.act, s.qws  ->  s.ua.f.qacc (+ s.xipos, contact bookkeeping)
 // PROF: accumulate shader-clock cycles per stage into prof[0..4] (profiling kernel only).
 template <class R, int ROWS = MAXEFC, bool PROF = false>
-DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt, const DebugOut* dbg, long long* prof = 0) {
+DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo& lt, const DebugOut* dbg, long long* prof = 0, bool kin = false) {
   long long t0 = 0, t1 = 0;
   if (PROF) t0 = dmw::clk();
   DM_MARK("kinematics");
-  stage_kinematics(M, s, lane, lt);
+  if (!kin) stage_kinematics(M, s, lane, lt);   // (kin: this state's kinematics are already in LDS — env_step.h load_kin)
   if (PROF) { t1 = dmw::clk(); prof[0] += t1 - t0; t0 = t1; }
   if (dbg) { for (int e = lane; e < NV * NV; e += 64) dbg->out[e] = 0; dmw::sync(); }
   DM_MARK("mass_factor");

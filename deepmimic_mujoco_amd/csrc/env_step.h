@@ -28,6 +28,8 @@ struct Batch {
   int* episode;     // [N]
   int* order;       // [N] dispatch order: workgroup w steps env order[w] (nullptr: identity) — costly envs first shortens the tail
   int* cycle;       // [N] completed motion cycles since the episode started (imitation reward: root advance of the reference)
+  R* kin;           // [N, KIN_DOUBLES] kinematics of the state an env was left in (see save_kin), valid where kin_ok[env] != 0
+  unsigned char* kin_ok;   // [N]
   const R* mocap_cfg;  // [F,35]
   const R* mocap_vel;  // [F,34]
   const R* imit_table; // [F,112] reference feature rows of the 5-term imitation reward (nullptr: not provided)
@@ -79,7 +81,7 @@ struct StepScratch {
 // [MJ mj_step, integrator RK4] on the state in s.qpos / s.qvel / s.qws / s.act.  Returns with the new state in
 // s.qpos / s.qvel / s.qws and the derived quantities of the 4th stage evaluation in `s` (as sim.data after sim.step()).
 template <class R, int ROWS = MAXEFC, bool PROF = false>
-DM_DEV bool rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int lane, const LaneTopo& lt, long long* prof = 0) {
+DM_DEV bool rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int lane, const LaneTopo& lt, long long* prof = 0, bool kin0 = false) {
   const R h = M.timestep;
   const R A[3] = {R(0.5), R(0.5), R(1)};
   const R Bw[4] = {R(1) / 6, R(1) / 3, R(1) / 3, R(1) / 6};
@@ -95,7 +97,7 @@ DM_DEV bool rk4_step(const DevModel<R>& M, Shared<R>& s, StepScratch<R>& x, int 
       if (lane < NV) { const R vi = x.x0v[lane] + h * (c * x.aprev[lane]); x.vprev[lane] = vi; s.qvel[lane] = vi; }
       dmw::sync();
     }
-    forward<R, ROWS, PROF>(M, s, lane, lt, (const DebugOut*)0, prof);
+    forward<R, ROWS, PROF>(M, s, lane, lt, (const DebugOut*)0, prof, i == 0 && kin0);
     if (lane < NV) {
       const R a = s.ua.f.qacc[lane];
       x.aprev[lane] = a; x.sumv[lane] += Bw[i] * x.vprev[lane]; x.suma[lane] += Bw[i] * a;
@@ -341,6 +343,32 @@ DM_DEV R v1_reward(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, int la
   return dmw::wave_sum(term);
 }
 
+// The imitation rewards end the step with a kinematics pass on the state the env is left in — exactly the pass the NEXT step's first
+// evaluation starts with.  Its results (body frames, motion axes, inertias: 694 numbers) are parked in the env's HBM strip and read
+// back instead of being recomputed: ~25 memory instructions against ~1 000, bit-identical values.  Whoever changes an env's state
+// from outside (reset, set_state, field writes) clears its flag.
+constexpr int KIN_PER_LANE = (KIN_DOUBLES + 63) / 64;
+template <class R>
+DM_DEV void save_kin(const Shared<R>& s, R* dst, int lane) {
+  static_assert(sizeof(s.xpos) + sizeof(s.xmat) + sizeof(s.xipos) + sizeof(s.cdof) == KIN_A * sizeof(R) && sizeof(s.ub.i) == KIN_B * sizeof(R), "kinematics block layout");
+  const R* a = &s.xpos[0][0];
+  const R* b = &s.ub.i.sin[0][0];
+#pragma unroll
+  for (int c = 0; c < KIN_PER_LANE; c++) { const int i = lane + 64 * c; if (i < KIN_DOUBLES) dst[i] = i < KIN_A ? a[i] : b[i - KIN_A]; }
+}
+template <class R>
+DM_DEV void fetch_kin(R* reg, const R* src, int lane) {          // issued at the top of the step, consumed after the state has been loaded
+#pragma unroll
+  for (int c = 0; c < KIN_PER_LANE; c++) { const int i = lane + 64 * c; reg[c] = i < KIN_DOUBLES ? src[i] : R(0); }
+}
+template <class R>
+DM_DEV void place_kin(Shared<R>& s, const R* reg, int lane) {
+  R* a = &s.xpos[0][0];
+  R* b = &s.ub.i.sin[0][0];
+#pragma unroll
+  for (int c = 0; c < KIN_PER_LANE; c++) { const int i = lane + 64 * c; if (i < KIN_A) a[i] = reg[c]; else if (i < KIN_DOUBLES) b[i - KIN_A] = reg[c]; }
+}
+
 // DPEnv.step for one environment
 // ROWS = columns of A = J M^-1 J^T + R that this instantiation keeps in registers; an evaluation with more constraint rows
 // (up to MAXEFC) keeps the remaining columns in the env's global-memory strip s.aovf (see stage_constraint).
@@ -353,9 +381,14 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
   if (PROF) tstart = dmw::clk();
   const LaneTopo lt = lane_topo(lane);
   stage_tables(s, lane);
+  const bool kin0 = B.kin && dmw::uniform((int)B.kin_ok[env]) != 0;
+  R kreg[KIN_PER_LANE];
+  if (kin0) fetch_kin(kreg, B.kin + (size_t)env * KIN_DOUBLES, lane);
   load_env(M, B, s, env, lane, action);
+  if (kin0) { place_kin(s, kreg, lane); dmw::sync(); }
   for (int k = 0; k < n_substeps; k++)   // do_simulation(action, n)
-    if (!rk4_step<R, ROWS, PROF>(M, s, x, lane, lt, prof)) return false;
+    if (!rk4_step<R, ROWS, PROF>(M, s, x, lane, lt, prof, k == 0 && kin0)) return false;
+  bool kin_saved = false;
   const R z = com_z(M, s);
   bool dn = (z < R(0.7)) || (z > R(2.0));
   store_derived(B, M, s, env, lane, B.diag != 0);   // sim.data.* as they stand after sim.step(): 4th-stage quantities
@@ -385,6 +418,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     dn = dn || ended;                            // a "Loop: none" clip holds its last frame and ends the episode there
     dmw::sync_mem();
     if (lane == 0) { B.frame_idx[env] = k; B.cycle[env] = cyc; }
+    if (B.kin && !(dn && B.autoreset)) { save_kin(s, B.kin + (size_t)env * KIN_DOUBLES, lane); kin_saved = true; }   // (after the fence: the stores drain behind the rest of the epilogue)
   }
   else if (B.reward_mode == REW_V1_QUAT) {     // src/dp_env_v1.py:82-158: cursor counts steps, reward every `upd` steps, minus the control cost
     const int idx = dmw::uniform(B.frame_idx[env]) + 1;
@@ -394,6 +428,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     if (idx % upd == 0) {
       const int k = (idx / upd + dmw::uniform(B.frame_init[env])) % B.n_frames, kv = k + 1 < B.n_frames ? k + 1 : B.n_frames - 1;
       robs = v1_reward(M, B, s, lane, lt, B.imit_table + (size_t)k * IMIT_FEAT, B.imit_table + (size_t)kv * IMIT_FEAT);
+      if (B.kin) { save_kin(s, B.kin + (size_t)env * KIN_DOUBLES, lane); kin_saved = true; }
     }
     R acs = 0;
     for (int u = 0; u < NU; u++) { const R c = B.ctrl[(size_t)env * NU + u]; acs += c * c; }
@@ -401,7 +436,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
     dmw::sync_mem();
     if (lane == 0) B.frame_idx[env] = idx;
   }
-  if (lane == 0) { B.time[env] += M.timestep * n_substeps; reward[env] = rew; done[env] = dn ? 1 : 0; }
+  if (lane == 0) { B.time[env] += M.timestep * n_substeps; reward[env] = rew; done[env] = dn ? 1 : 0; if (B.kin) B.kin_ok[env] = (kin_saved && !(dn && B.autoreset)) ? 1 : 0; }
   if (dn && B.autoreset) {                        // DummyVecEnv convention: obs of the fresh episode is returned
     dmw::sync_mem();
     reset_env(M, B, s, env, lane, B.autoreset == 1 ? 0 : 1, 1);

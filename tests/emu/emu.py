@@ -20,6 +20,7 @@ def lib():
         L.emu_create.restype = C.c_void_p
         L.emu_create.argtypes = [C.POINTER(A.ModelDesc), A._dp, A._dp, C.c_int, C.c_int, C.c_uint, C.c_double]
         L.emu_destroy.argtypes = [C.c_void_p]
+        L.emu_invalidate_kin.argtypes = [C.c_void_p]
         L.emu_set_option.argtypes = [C.c_void_p, C.c_int, C.c_longlong]
         L.emu_set_imitation.argtypes = [C.c_void_p, A._dp, A._dp]
         L.emu_field.restype = C.c_void_p
@@ -62,6 +63,8 @@ class EmuBatch(object):
 
     def set(self, field, value):
         self._view(field)[...] = np.asarray(value).reshape(self._view(field).shape)
+        if field == A.F_QPOS:
+            lib().emu_invalidate_kin(self.h)          # as dm_batch_set does: parked kinematics belong to the old positions
 
     def step(self, action, n_substeps=1, out=None):
         a = np.ascontiguousarray(action, dtype=np.float64).reshape(self.n, A.NU)

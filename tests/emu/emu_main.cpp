@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <functional>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "wave_testbench.h"
@@ -54,7 +55,8 @@ using namespace dm;
 struct EmuBatch {
   DevModel<double> M;
   Batch<double> B;
-  std::vector<double> qpos, qvel, qws, time, ctrl, xipos, comz, cfg, vel, aovf, imit;
+  std::vector<double> qpos, qvel, qws, time, ctrl, xipos, comz, cfg, vel, aovf, imit, kin;
+  std::vector<unsigned char> kin_ok;
   bool two_tier = true;
   std::vector<int> fidx, finit, ncon, nefc, cong, status, siter, episode, cycle;
   Shared<double> sh;
@@ -81,6 +83,7 @@ void* emu_create(const dm_model_desc* d, const double* cfg, const double* vel, i
   B.ncon = e->ncon.data(); B.nefc = e->nefc.data(); B.cong = e->cong.data(); B.status = e->status.data();
   B.aovf = e->aovf.data(); B.cycle = e->cycle.data(); B.imit_table = nullptr; B.imit_pdev = nullptr; B.order = nullptr;
   B.solver_iter = e->siter.data(); B.episode = e->episode.data(); B.mocap_cfg = e->cfg.data(); B.mocap_vel = e->vel.data();
+  e->kin.assign((size_t)n * KIN_DOUBLES, 0); e->kin_ok.assign(n, 0); B.kin = e->kin.data(); B.kin_ok = e->kin_ok.data();
   B.mocap_dt = mocap_dt; B.n_frames = F; B.n_envs = n; B.env_offset = 0; B.reward_mode = 0; B.autoreset = 0; B.action_mode = 0; B.seed = 0; B.diag = 1;
   return e;
 }
@@ -92,6 +95,7 @@ void emu_set_imitation(void* h, const double* table, const double* params) {
   e->B.imit_pdev = e->B.imit_params;
 }
 void emu_destroy(void* h) { delete (EmuBatch*)h; }
+void emu_invalidate_kin(void* h) { EmuBatch* e = (EmuBatch*)h; std::fill(e->kin_ok.begin(), e->kin_ok.end(), 0); }   // as the device entry points do
 void emu_set_option(void* h, int opt, long long v) {
   EmuBatch* e = (EmuBatch*)h;
   if (opt == DM_OPT_REWARD_MODE) e->B.reward_mode = (int)v;
@@ -127,6 +131,7 @@ void emu_step(void* h, const double* action, double* obs, double* reward, unsign
 }
 void emu_set_state(void* h, const double* qpos, const double* qvel, const int* fidx, const unsigned char* mask) {
   EmuBatch* e = (EmuBatch*)h;
+  std::fill(e->kin_ok.begin(), e->kin_ok.end(), 0);
   for (int env = 0; env < e->B.n_envs; env++) {
     if (mask && !mask[env]) continue;
     run_wave([&](int lane) {
@@ -143,6 +148,7 @@ void emu_set_state(void* h, const double* qpos, const double* qvel, const int* f
 }
 void emu_reset(void* h, int mode, int hard, const unsigned char* mask) {
   EmuBatch* e = (EmuBatch*)h;
+  std::fill(e->kin_ok.begin(), e->kin_ok.end(), 0);
   for (int env = 0; env < e->B.n_envs; env++) {
     if (mask && !mask[env]) continue;
     run_wave([&](int lane) {

@@ -233,6 +233,31 @@ def test_imitation_reward_on_the_wave_testbench_matches_oracle():
     assert abs(sp.reward(f, T[4]) - 1) < 1e-12
 
 
+def test_parked_kinematics_are_bit_identical_to_recomputing_them_on_the_testbench():
+    """In the imitation modes a step ends with the kinematics of the state it leaves behind; the next step reads them back instead
+    of recomputing them (env_step.h save_kin).  Same rollout with the parked results discarded before every step: identical bits."""
+    from tests.emu.emu import EmuBatch, lib
+    sp, mc, T, P = _imit_inputs()
+    n = 4
+    rng = np.random.RandomState(11)
+    idx = rng.randint(0, len(mc.data_config), size=n).astype(np.int32)
+    acts = rng.randn(5, n, 28) * 0.4
+    outs = []
+    for discard in (False, True):
+        b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0, imitation=(T, P))
+        b.set_option(A.OPT_REWARD_MODE, 3); b.set_option(A.OPT_AUTORESET, 1)
+        b.set_state(mc.data_config[idx].copy(), mc.data_vel[idx].copy(), frame_idx=idx)
+        rows = []
+        for t in range(5):
+            if discard:
+                lib().emu_invalidate_kin(b.h)
+            o, r, d = b.step(acts[t], 1)[:3]
+            rows.append((o.copy(), r.copy(), d.copy()))
+        outs.append(rows)
+    for (o0, r0, d0), (o1, r1, d1) in zip(*outs):
+        assert np.array_equal(o0, o1) and np.array_equal(r0, r1) and np.array_equal(d0, d1)
+
+
 def test_imitation_non_looping_clip_ends_on_the_testbench():
     from tests.emu.emu import EmuBatch
     sp, mc, T, P = _imit_inputs()
