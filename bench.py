@@ -509,6 +509,10 @@ def main():
                     r["traffic_fetch_doubled"] = round((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * P_sub)
                     r["traffic_over_algorithmic"] = round(r["traffic"] / (ALGO_BYTES_PER_STEP * n), 3)
                     r["traffic_source"] = "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, HBM bytes per step (= %d launches)" % P_sub
+                    if full and args.reward == "imitation":
+                        r["traffic_note"] = ("includes the parked kinematics of the imitation modes: 694 doubles written by a step's reward pass and read back by the "
+                                             "next step instead of recomputing one kinematics pass in five (5 552 B each way per env-step = %.1f MB per step; +2 %% "
+                                             "env-steps/s for 0.6 %% of the HBM peak)" % (2 * 694 * 8 * n / 1e6))
                 if pmc.get("SQ_ACTIVE_INST_VALU"):
                     # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; the denominator is the un-profiled step interval
                     r["valu_issue_frac"] = round(P_sub * pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * kernel_ms * 1e-3 * MAX_CLOCK_HZ), 4)
