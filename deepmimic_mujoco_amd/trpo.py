@@ -518,3 +518,31 @@ def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max
     if progress is not None:
         progress.close(); monitor.close()
     return history
+
+
+def runner(env, pi, timesteps_per_batch=1024, stochastic_policy=False, log=print):
+    """`runner()` + `traj_1_generator()` of src/trpo.py:356-436 (`--task evaluate`), one trajectory per env of the batch at once: from
+    `env.reset(); env.reset_model_init()` each env runs `pi.act(stochastic, ob)` -> `env.step(ac)` until its first `done` or until
+    `timesteps_per_batch + 1` steps.  Returns (average length, average return) as the reference prints them, plus the per-trajectory
+    arrays.  `pi` comes from `MlpPolicy.from_tf_checkpoint(path)` (= U.load_state) or `from_npz`."""
+    n = env.num_envs
+    dev = pi.device
+    with torch.no_grad():
+        ob = torch.zeros((n, 56), dtype=torch.float64, device=dev)
+        env.reset("init", out=ob if ob.is_cuda else ob.numpy())
+        alive = torch.ones(n, dtype=torch.bool, device=dev)
+        ep_len = torch.zeros(n, dtype=torch.int64, device=dev); ep_ret = torch.zeros(n, dtype=torch.float64, device=dev)
+        for t in range(int(timesteps_per_batch) + 1):
+            ac, _ = pi.act(stochastic_policy, ob)
+            res = env.step(ac if ac.is_cuda else ac.numpy())
+            ob = torch.as_tensor(res[0], dtype=torch.float64, device=dev)
+            rew = torch.as_tensor(res[1], dtype=torch.float64, device=dev); done = torch.as_tensor(res[2], device=dev).to(torch.bool)
+            ep_ret += torch.where(alive, rew, torch.zeros_like(rew)); ep_len += alive.to(torch.int64)
+            alive &= ~done
+            if not bool(alive.any()):
+                break
+    lens, rets = ep_len.cpu().numpy(), ep_ret.cpu().numpy()
+    log("stochastic policy:" if stochastic_policy else "deterministic policy:")
+    log("Average length: %s" % (lens.sum() / len(lens)))
+    log("Average return: %s" % (rets.sum() / len(rets)))
+    return float(lens.mean()), float(rets.mean()), lens, rets

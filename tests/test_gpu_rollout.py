@@ -285,3 +285,19 @@ def test_fused_segment_generator_follows_the_reference_protocol():
         assert fresh.numel() == 0 or bool((fresh[:, :28].abs() < 0.0101).all())      # a fresh episode starts at the noisy default pose
     assert len(lens) > 50 and 150 < np.mean(lens) < 450                     # the checkpoint's policy: ~270 steps
     env.close()
+
+
+@pytest.mark.gpu
+def test_evaluate_task_runs_the_shipped_checkpoint():
+    """`tools/train_trpo.py --task evaluate --load-model-path <the reference's checkpoint>` = src/trpo.py:480-487 (`runner`): prints the
+    reference's three lines; the shipped policy stays up for hundreds of steps (its own log: 264 on average, stochastic)."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "train_trpo.py"), "--task", "evaluate", "--load-model-path", CKPT,
+                          "--number-trajs", "64", "--stochastic-policy"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert lines[-3] == "stochastic policy:" and lines[-2].startswith("Average length:") and lines[-1].startswith("Average return:")
+    avg = float(lines[-2].split(":")[1])
+    assert 150 < avg < 500 and abs(float(lines[-1].split(":")[1]) - avg) < 1e-6          # alive reward: return == length

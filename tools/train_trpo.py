@@ -33,6 +33,10 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2, help="sub-batches whose step launches overlap across consecutive steps (DM_OPT_PIPELINE; with "
                                                             "--unfused: that many env batches on their own streams, policy -> env chains overlap)")
     ap.add_argument("--unfused", action="store_true", help="separate policy launch per step instead of the policy step inside the env step kernel")
+    ap.add_argument("--task", default="train", choices=["train", "evaluate"], help="evaluate: the reference's `trpo.py --task evaluate --load_model_path ...`")
+    ap.add_argument("--load-model-path", default=None, help="evaluate: a tf.train.Saver checkpoint prefix (the reference's or one written by --save) or an .npz")
+    ap.add_argument("--number-trajs", type=int, default=10, help="evaluate: trajectories (one env each; src/trpo.py:483)")
+    ap.add_argument("--stochastic-policy", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
     ap.add_argument("--log-dir", default=None, help="write progress.csv and monitor.csv in the reference's formats")
@@ -47,6 +51,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     fs = args.frame_skip if args.frame_skip in (None, "mocap") else int(args.frame_skip)
+    if args.task == "evaluate":                     # src/trpo.py:480-487
+        from deepmimic_mujoco_amd.trpo import runner
+        assert args.load_model_path, "--task evaluate needs --load-model-path"
+        pi = MlpPolicy.from_npz(args.load_model_path, device=dev) if args.load_model_path.endswith(".npz") else MlpPolicy.from_tf_checkpoint(args.load_model_path, device=dev)
+        pi.seed(args.seed)
+        env = DPVecEnv(args.number_trajs, motion=args.motion, device=lr, reward=args.reward, autoreset="init", seed=args.seed, frame_skip=fs)
+        runner(env, pi, timesteps_per_batch=1024, stochastic_policy=args.stochastic_policy)
+        return
     P = max(1, args.pipeline)
     if args.unfused:
         cuts = [args.envs * h // P for h in range(P + 1)]
