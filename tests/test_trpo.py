@@ -149,6 +149,35 @@ def test_learn_improves_return_on_a_scripted_env(tmp_path):
     assert all(h["meankl"] <= 0.0151 for h in hist)
 
 
+def test_runner_counts_each_envs_first_episode():
+    """`runner` (src/trpo.py:356-436 for a batch): every env contributes its FIRST episode — steps and rewards stop counting at its
+    first `done` although the env goes on — and the cap is `timesteps_per_batch + 1` steps."""
+    from deepmimic_mujoco_amd.trpo import runner
+
+    class Scripted:
+        num_envs = 4
+
+        def __init__(self):
+            self.t = 0
+
+        def reset(self, mode, out=None):
+            assert mode == "init"
+            self.t = 0
+            out[...] = 0.0
+            return out
+
+        def step(self, ac):
+            self.t += 1
+            done = np.array([self.t == 3, self.t == 5, self.t in (2, 4), False])         # env 2 "ends" twice: only the first counts
+            return np.full((4, 56), float(self.t)), np.array([1.0, 2.0, 0.5, 1.0]), done, [{}] * 4
+
+    pi = MlpPolicy(seed=0); pi.seed(0)
+    lines = []
+    avg_len, avg_ret, lens, rets = runner(Scripted(), pi, timesteps_per_batch=9, stochastic_policy=True, log=lines.append)
+    assert list(lens) == [3, 5, 2, 10] and list(rets) == [3.0, 10.0, 1.0, 10.0]
+    assert avg_len == 5.0 and avg_ret == 6.0 and lines[0] == "stochastic policy:" and lines[1] == "Average length: 5.0"
+
+
 def test_explained_variance():
     y = torch.tensor([1.0, 2.0, 3.0, 4.0])
     assert explained_variance(y, y) == 1.0 and abs(explained_variance(torch.zeros(4), y)) < 1e-12
