@@ -22,6 +22,8 @@
 // the vector unit's idle lanes; the same treatment of the Jacobian rows was measured and is exactly as fast as the vector loop.
 #pragma once
 
+#include <type_traits>
+
 #include "topology.h"
 #include "wave.h"
 
@@ -1649,30 +1651,36 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
   dmw::pin_value(pgs_detect);
   const R f_ws = f, t_ws = t;
   bool anybad = false;
-  auto sweep = [&](R& myimp) {
-    // fresh opaque copies per sweep: otherwise the 64 row-exists tests and 64 lane==row masks are hoisted out of the
-    // sweep loop as 128 SGPR pairs, spilled to VGPR lanes and read back with v_readlane on every row
-    const int ne = dmw::launder_uniform(nefc);
-    const int ln = dmw::launder(lane);
-    const R f0 = f, nf0 = -f;
-    R tsave = t;
-    SweepGroup<0, ROWS, R>::run(AR, t, tsave, nf0, ln, ne, (const R*)0, ndinv, &s);
-    {   // every lane, unpredicated: a lane without a row has f = 0 and t = 0 throughout, so its step, its new force and its
-        // cost change are exact zeros (a branch around this block costs more than the block)
-      const R delta = dmw::max_raw(nf0, tsave);
-      const R fn = f0 + delta;
-      const R change = (delta * diag) * (R(0.5) * delta - tsave);      // = delta (delta A_ii / 2 + r)
-      f = fn; myimp = -change; anybad = anybad || (change > pgs_detect);
-    }
-  };
-  if (maxiter > 0) {
+  // Two instantiations of the sweep loop, chosen once per solve: with at most 16 rows (95 % of the solves) the row nest stops at four
+  // groups and the improvement of a sweep is lane 0's 16-lane sum alone — rows 16.. hold exact zeros, so the value is the wave sum's
+  // to the bit, without the three cross-row broadcasts and additions of every sweep's termination test.
+  auto solve = [&](auto small_tag) {
+    constexpr bool SMALL = decltype(small_tag)::value;
+    constexpr int NEST = SMALL ? (ROWS < 16 ? ROWS : 16) : ROWS;
+    auto sweep = [&](R& myimp) {
+      // fresh opaque copies per sweep: otherwise the 64 row-exists tests and 64 lane==row masks are hoisted out of the
+      // sweep loop as 128 SGPR pairs, spilled to VGPR lanes and read back with v_readlane on every row
+      const int ne = dmw::launder_uniform(nefc);
+      const int ln = dmw::launder(lane);
+      const R f0 = f, nf0 = -f;
+      R tsave = t;
+      SweepGroup<0, NEST, R>::run(AR, t, tsave, nf0, ln, ne, (const R*)0, ndinv, &s);
+      {   // every lane, unpredicated: a lane without a row has f = 0 and t = 0 throughout, so its step, its new force and its
+          // cost change are exact zeros (a branch around this block costs more than the block)
+        const R delta = dmw::max_raw(nf0, tsave);
+        const R fn = f0 + delta;
+        const R change = (delta * diag) * (R(0.5) * delta - tsave);      // = delta (delta A_ii / 2 + r)
+        f = fn; myimp = -change; anybad = anybad || (change > pgs_detect);
+      }
+    };
     R myimp;
     sweep(myimp);
     iter = 1;
     bool more = iter < maxiter;
     while (more) {                                                                  // (one exit test per sweep)
       const R fprev = f, tprev = t;
-      const R improvement = dmw::wave_sum(myimp) * pgs_scale;                     // of sweep `iter` (idle lanes hold 0)
+      const R total = SMALL ? dmw::bcast(dmw::sum16(myimp), 0) : dmw::wave_sum(myimp);   // of sweep `iter` (idle lanes hold 0)
+      const R improvement = total * pgs_scale;
       R myimp_next;
       sweep(myimp_next);                                                          // sweep iter + 1, speculative
       const bool conv = dmw::uniform(improvement < pgs_tol);
@@ -1681,6 +1689,9 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
       iter += conv ? 0 : 1;
       more = !conv && iter < maxiter;
     }
+  };
+  if (maxiter > 0) {
+    if (nefc <= 16) solve(std::true_type{}); else solve(std::false_type{});
   }
   if (dmw::ballot(anybad) != 0) {
     // guarded re-solve (cold): the (scaled) register columns are parked in the env's memory strip so that one compact loop
