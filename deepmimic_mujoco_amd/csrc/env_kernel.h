@@ -1676,19 +1676,20 @@ DM_DEV void stage_constraint(const DevModel<R>& M, Shared<R>& s, int lane_in, co
     R myimp;
     sweep(myimp);
     iter = 1;
-    bool more = iter < maxiter;
+    bool more = iter < maxiter, conv = false;
+    R fprev = f, tprev = t;
     while (more) {                                                                  // (one exit test per sweep)
-      const R fprev = f, tprev = t;
+      fprev = f; tprev = t;
       const R total = SMALL ? dmw::bcast(dmw::sum16(myimp), 0) : dmw::wave_sum(myimp);   // of sweep `iter` (idle lanes hold 0)
       const R improvement = total * pgs_scale;
       R myimp_next;
       sweep(myimp_next);                                                          // sweep iter + 1, speculative
-      const bool conv = dmw::uniform(improvement < pgs_tol);
-      f = conv ? fprev : f; t = conv ? tprev : t;                                   // converged: the speculative sweep is dropped
+      conv = dmw::uniform(improvement < pgs_tol);
       myimp = myimp_next;
-      iter += conv ? 0 : 1;
+      iter += 1;
       more = !conv && iter < maxiter;
     }
+    if (conv) { f = fprev; t = tprev; iter -= 1; }                                  // converged: the speculative sweep is dropped (once, after the loop)
   };
   if (maxiter > 0) {
     if (nefc <= 16) solve(std::true_type{}); else solve(std::false_type{});
