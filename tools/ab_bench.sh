@@ -1,0 +1,36 @@
+#!/bin/bash
+# A/B of two builds of libdmenv.so inside ONE gpurun call (same box, alternating runs): how every kernel change of round 2 was judged.
+#   here (no GPU):   tools/ab_bench.sh build <git-ref-A> [<git-ref-B, default: the working tree>]     -> build_ab/A.so, build_ab/B.so
+#   on the GPU box:  gpurun -- 'bash tools/ab_bench.sh run [bench.py arguments]'                      -> alternating A / B bench lines
+# build_ab/ is git-ignored but travels to the GPU box with the snapshot.
+set -eu
+cd "$(dirname "$0")/.."
+LIB=deepmimic_mujoco_amd/csrc/libdmenv.so
+case "${1:-}" in
+  build)
+    mkdir -p build_ab
+    A=${2:?git ref of build A}; B=${3:-}
+    cp $LIB build_ab/keep.so 2>/dev/null || true
+    build_ref() {   # $1 ref ('' = working tree), $2 output
+      if [ -n "$1" ]; then
+        tmp=$(mktemp -d); git archive "$1" deepmimic_mujoco_amd/csrc include | tar -x -C "$tmp"
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-shift-count-negative \
+          -Wno-implicit-const-int-float-conversion -I"$tmp/include" -I"$tmp/deepmimic_mujoco_amd/csrc" "$tmp/deepmimic_mujoco_amd/csrc/dmenv.hip" -o "$2"
+        rm -rf "$tmp"
+      else
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-shift-count-negative \
+          -Wno-implicit-const-int-float-conversion -Iinclude -Ideepmimic_mujoco_amd/csrc deepmimic_mujoco_amd/csrc/dmenv.hip -o "$2"
+      fi
+    }
+    build_ref "$A" build_ab/A.so & build_ref "$B" build_ab/B.so & wait
+    ls -la build_ab/A.so build_ab/B.so ;;
+  run)
+    shift
+    cp $LIB build_ab/keep.so
+    for rep in 1 2; do for v in A B; do
+      cp build_ab/$v.so $LIB
+      echo "$v $(timeout 300 python bench.py --no-pmc --no-cpu-baseline --no-gym-loop "$@" 2>/dev/null | cut -c1-110)"
+    done; done
+    cp build_ab/keep.so $LIB ;;
+  *) sed -n 2,6p "$0" ;;
+esac
