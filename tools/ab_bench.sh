@@ -2,7 +2,8 @@
 # A/B of two builds of libdmenv.so inside ONE gpurun call (same box, alternating runs): how every kernel change of round 2 was judged.
 #   here (no GPU):   tools/ab_bench.sh build <git-ref-A> [<git-ref-B, default: the working tree>]     -> build_ab/A.so, build_ab/B.so
 #   on the GPU box:  gpurun -- 'bash tools/ab_bench.sh run [bench.py arguments]'                      -> alternating A / B bench lines
-# build_ab/ is git-ignored but travels to the GPU box with the snapshot.
+# build_ab/ is git-ignored but travels to the GPU box with the snapshot.  Both builds must export the C ABI the working tree's _abi.py binds
+# (a ref from before an entry point was added fails to load: its line then shows the loader's message).
 set -eu
 cd "$(dirname "$0")/.."
 LIB=deepmimic_mujoco_amd/csrc/libdmenv.so
@@ -29,7 +30,8 @@ case "${1:-}" in
     cp $LIB build_ab/keep.so
     for rep in 1 2; do for v in A B; do
       cp build_ab/$v.so $LIB
-      echo "$v $(timeout 300 python bench.py --no-pmc --no-cpu-baseline --no-gym-loop "$@" 2>/dev/null | cut -c1-110)"
+      out=$(timeout 300 python bench.py --no-pmc --no-cpu-baseline --no-gym-loop "$@" 2>build_ab/err.txt | cut -c1-110)
+      echo "$v ${out:-$(tail -1 build_ab/err.txt | cut -c1-160)}"
     done; done
     cp build_ab/keep.so $LIB ;;
   *) sed -n 2,6p "$0" ;;
