@@ -27,3 +27,5 @@ DM_PROF_REWARD=imitation timeout 300 python tools/profile_stages.py > $OUT/stage
 timeout 300 python tools/contact_exposure.py --out $OUT/contact_exposure_cfg3.json > /dev/null 2> $OUT/contact_exposure.err
 timeout 300 python tools/contact_exposure.py --policy shipped --envs 2048 --steps 400 --out $OUT/contact_exposure_policy.json > /dev/null 2>> $OUT/contact_exposure.err
 grep -h "own_algorithm\|env_steps_with" $OUT/contact_exposure_*.json
+# randomised HIP == oracle sweep (three seeds here; more: tools/fuzz_parity.py <states-per-clip> <seed>)
+for sd in 1 2 3; do timeout 300 python tools/fuzz_parity.py 320 $sd 2>&1 | grep -E "FAIL|fuzz seed"; done | tee $OUT/fuzz.log
