@@ -305,6 +305,35 @@ def test_native_value_fit_equals_the_eager_loop_on_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bs", [1000, 37])
+def test_native_value_fit_handles_ragged_minibatches_on_gpu(bs):
+    """Minibatch sizes that are not a multiple of the 32-sample blocks (a partial last block, partial row groups of the filter sums):
+    two epochs of three minibatches against the eager loop."""
+    from deepmimic_mujoco_amd.trpo import VF_KEYS, flat, TrpoLearner
+    from deepmimic_mujoco_amd.policy import MlpPolicy
+    torch.manual_seed(1)
+    n = 3 * bs + 5                                               # the last 5 samples are dropped (include_final_partial_batch=False)
+    ob = torch.randn(n, 56, device="cuda:0") * 1.5 + 0.3; ret = torch.randn(n, device="cuda:0") * 2.0
+    outs = []
+    for native in (False, True):
+        pi = MlpPolicy(device="cuda:0", seed=5)
+        L = TrpoLearner(pi, vf_batch_size=bs, vf_iters=2, vf_graph=False, vf_native=native)
+        perms = [torch.randperm(n, generator=torch.Generator().manual_seed(k)) for k in (7, 8)]
+        for pm in perms:
+            inds = pm.to("cuda:0")
+            if native:
+                L._vf_native_epoch(ob, ret, inds, bs)
+            else:
+                for o in range(0, n - bs + 1, bs):
+                    mb = inds[o:o + bs]
+                    L._vf_step(ob[mb], ret[mb])
+        outs.append((flat([pi.params[k].detach() for k in VF_KEYS]), L.vfadam.m.clone(), pi.ob_rms.sum.clone(), float(pi.ob_rms.count), L.vfadam.t))
+    (t0, m0, s0, c0, k0), (t1, m1, s1, c1, k1) = outs
+    assert k0 == k1 == 6 and c0 == c1 and torch.allclose(s0, s1, rtol=1e-12, atol=1e-9)
+    assert float((m0 - m1).abs().max()) < 1e-4 * float(m0.abs().max()) + 1e-8 and float((t0 - t1).abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
 def test_value_fit_as_captured_graph_equals_the_eager_loop_on_gpu():
     """The value fit's minibatch step replayed as a captured hipGraph (single-process GPU runs) against the eager loop on the same
     update: same value parameters, same obs-filter moments, same Adam state; and the graph path really ran."""
