@@ -301,3 +301,32 @@ def test_evaluate_task_runs_the_shipped_checkpoint():
     assert lines[-3] == "stochastic policy:" and lines[-2].startswith("Average length:") and lines[-1].startswith("Average return:")
     avg = float(lines[-2].split(":")[1])
     assert 150 < avg < 500 and abs(float(lines[-1].split(":")[1]) - avg) < 1e-6          # alive reward: return == length
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,pipeline", [(1, 2), (3, 2), (65, 1)])
+def test_fused_policy_step_on_tiny_and_odd_batches(n, pipeline):
+    """dm_batch_step_act with fewer envs than sub-batches / odd sizes: same observations as dm_batch_step (bit-exact) and the policy
+    kernel's actions / values on them."""
+    from deepmimic_mujoco_amd import _abi as A
+    pol = MlpPolicy(device=DEV, seed=4); pol.seed(4)
+    res = []
+    for fused in (False, True):
+        env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=8)
+        env.batch.set_option(A.OPT_PIPELINE, pipeline)
+        ob0 = torch.zeros((n, 56), dtype=torch.float64, device=DEV); env.reset("init", out=ob0)
+        ac0 = torch.zeros((n, 28), dtype=torch.float64, device=DEV); vp0 = torch.zeros(n, dtype=torch.float32, device=DEV)
+        pol._counter = 10; pol.act(True, ob0, out=ac0, vpred_out=vp0)
+        ob1 = torch.zeros_like(ob0); rew = torch.zeros(n, dtype=torch.float64, device=DEV); dn = torch.zeros(n, dtype=torch.uint8, device=DEV)
+        ac1 = torch.zeros_like(ac0); vp1 = torch.zeros_like(vp0)
+        if fused:
+            pol._counter += 1
+            env.batch.step_act(ac0, 1, (ob1, rew, dn), pol._packed, ac1, vp1, True, pol._seed, pol._counter)
+        else:
+            env.batch.step(ac0, 1, (ob1, rew, dn)); env.batch.join()
+            pol.act(True, ob1, out=ac1, vpred_out=vp1)
+        env.batch.sync()
+        res.append((ob1.clone(), ac1.clone(), vp1.clone()))
+        env.close()
+    assert torch.equal(res[0][0], res[1][0])
+    assert float((res[0][1] - res[1][1]).abs().max()) < 1e-5 and float((res[0][2] - res[1][2]).abs().max()) < 1e-4
