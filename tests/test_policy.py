@@ -315,3 +315,21 @@ def test_policy_saved_as_tf_bundle_round_trips_and_has_the_reference_layout(tmp_
     save_checkpoint(str(tmp_path / "big"), big)
     got = load_checkpoint(str(tmp_path / "big"))
     assert sorted(got) == sorted(big) and all(np.array_equal(got[k], np.asarray(big[k])) and got[k].dtype == np.asarray(big[k]).dtype for k in big)
+
+
+def test_fused_rollout_step_is_refused_without_the_native_path():
+    """`SegmentCollector(fused=True)` needs the HIP policy epilogue: on CPU tensors / without a device-resident env batch it raises
+    instead of silently running something else; `can_fuse` says so beforehand."""
+    from deepmimic_mujoco_amd.rollout import SegmentCollector, can_fuse
+
+    class Env:
+        num_envs = 2
+        batch = object()
+
+        def reset(self, mode, out=None):
+            return out
+
+    pi = MlpPolicy(seed=0)
+    assert not can_fuse(pi, Env())
+    with pytest.raises(ValueError):
+        SegmentCollector(pi, Env(), 4, fused=True)
