@@ -49,6 +49,10 @@ __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_narrow(const DevMode
                                                     int n_substeps, int first) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
+#ifdef DM_LDS_PAD      // experiment (profiles/r02_slot16_ubench.md): extra LDS per workgroup lowers the residency (6 880 -> 6 envs per CU,
+  __shared__ volatile char lds_pad[DM_LDS_PAD];   // 20 500 -> 4) without touching the code path; build with DM_BUILD_DEFINES=-DDM_LDS_PAD=...
+  if (n_substeps < 0) lds_pad[threadIdx.x] = 1;
+#endif
   const int slot = first + (int)blockIdx.x;          // position in the dispatch order (a pipelined sub-batch starts at `first`)
   if (slot >= B.n_envs) return;
   const int env = B.order ? B.order[slot] : slot;
