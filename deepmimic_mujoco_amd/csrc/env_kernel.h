@@ -1773,7 +1773,8 @@ DM_DEV void forward(const DevModel<R>& M, Shared<R>& s, int lane, const LaneTopo
     dbg->out[34 * 34 + lane] = bias;
   }
   DM_MARK("rows");
-  stage_rows<R, ROWS, PROF>(M, s, lane, prof);
+  if (M.enable_contact || M.enable_limit) stage_rows<R, ROWS, PROF>(M, s, lane, prof);
+  else { if (lane == 0) { s.nefc = 0; s.ncon = 0; } dmw::sync(); }      // contact-free, limit-free model: no row can exist
   if (PROF) { t1 = dmw::clk(); prof[3] += t1 - t0; t0 = t1; }
   DM_MARK("constraint");
   stage_constraint<R, ROWS, PROF>(M, s, lane, dbg, prof);
