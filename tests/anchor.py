@@ -101,6 +101,7 @@ class OracleVecEnv(object):
 
 
 def run_reference_protocol(seed=0, iterations=1900, workers=2, horizon=256, g_step=3, log_every=0, backend="oracle", **model_opts):
+    model_opts = {("iterations" if k == "pgs_iterations" else k): v for k, v in model_opts.items()}      # (the oracle's PGS sweep limit shares a name with the protocol's)
     """The reference's training run (`mpirun -np 2 python3 trpo.py`: src/trpo.py:338-353) in the oracle's physics
     (backend="oracle", CPU) or on the HIP kernel (backend="gpu": a 2-env `DPVecEnv` with the kernel's noisy-init auto-reset).
     Returns {"EpLenMean": per-iteration curve (rolling 40 episodes, logged every g_step updates like src/trpo.py:303-306),

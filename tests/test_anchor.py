@@ -95,6 +95,31 @@ def test_regulariser_variant_is_not_resolved_by_eight_seeds_either():
     assert abs(a[:, 0].mean() - 1) < 0.03 and abs(b[:, 0].mean() - 1) < 0.03          # both reproduce the checkpoint's rate scales
 
 
+def test_anchor_detects_gross_physics_errors_but_not_solver_details():
+    """Negative controls (tests/golden/anchor/controls/: the same protocol with a deliberately wrong model, two seeds each).  What the
+    asserted bands / the eight default replays' scatter DO catch: joint limits switched off (a rate spread of 1.8-1.9 x, angle spreads
+    15 % low), gravity 20 % low (rate spreads 5-11 % high, an angle mean beyond 2 sigma), half the time step (rate spreads 20-25 % low,
+    episodes twice as long).  What they do NOT catch: PGS cut to 5 sweeps, or the factor 2 in the pyramid regulariser (test above).
+    This is the resolving power of the reference's only physics artefacts — and the sense in which 'the anchors agree' is to be read."""
+    cdir = os.path.join(ADIR, "controls")
+    base = _runs("protocol_seed[0-9].json")
+    geo = np.array([np.exp(np.log(AN.compare_moments(r["mean"], r["std"])[1][28:]).mean()) for r in base])      # per-seed rate-spread scale
+
+    def ctl(tag):
+        out = []
+        for f in sorted(glob.glob(os.path.join(cdir, "protocol_seed[0-9]_%s*.json" % tag))):
+            r = json.load(open(f)); d, ratio = AN.compare_moments(r["mean"], r["std"])
+            out.append((np.abs(d[28:]).max(), ratio[28:].max(), np.exp(np.log(ratio[28:]).mean()), np.abs(d[:28]).max(), np.exp(np.log(ratio[:28]).mean()), r["EpLenMean"][99]))
+        assert len(out) == 2, tag
+        return np.array(out)
+
+    lim, grav, dt, pgs = ctl("enable_limit0"), ctl("gravity_z"), ctl("timestep"), ctl("pgs_iterations5")
+    assert np.all(lim[:, 1] > 1.45) and np.all(lim[:, 4] < 0.90)                     # outside the asserted spread band
+    assert np.all((grav[:, 2] - geo.mean()) / geo.std(ddof=1) > 1.5) and grav[:, 3].max() > 2.0
+    assert np.all((dt[:, 2] - geo.mean()) / geo.std(ddof=1) < -4) and np.all(dt[:, 5] > 100)
+    assert np.all(pgs[:, 1] < 1.45) and np.all(np.abs(pgs[:, 2] - geo.mean()) < 2 * geo.std(ddof=1)) and np.all(pgs[:, 3] < 2.0)   # invisible
+
+
 def test_replay_protocol_runs_and_is_deterministic():
     r1 = AN.run_reference_protocol(seed=5, iterations=2)
     r2 = AN.run_reference_protocol(seed=5, iterations=2)
