@@ -57,9 +57,30 @@ class OracleVecEnv(object):
         from oracle import oracle as O
         self.O = O
         self.num_envs = int(num_envs)
-        self.om = O.Model()
+        # `spec_*` options scale / replace entries of the model SPECIFICATION before it is compiled (negative controls of the anchors):
+        # spec_solref0 / spec_solref1 (replace), spec_gear / spec_damping / spec_friction / spec_armature (scale factors)
+        spec_opts = {k: v for k, v in model_opts.items() if k.startswith("spec_")}
+        if spec_opts:
+            sp = O.humanoid_spec()
+            for k, v in spec_opts.items():
+                if k in ("spec_solref0", "spec_solref1"):
+                    sp.solref[int(k[-1])] = v
+                elif k == "spec_gear":
+                    for i in range(sp.nu): sp.act_gear[i] *= v
+                elif k == "spec_damping":
+                    for i in range(sp.njnt): sp.jnt_damping[i] *= v
+                elif k == "spec_armature":
+                    for i in range(sp.njnt): sp.jnt_armature[i] *= v
+                elif k == "spec_friction":
+                    for i in range(sp.ngeom): sp.geom_friction[i][0] *= v
+                else:
+                    raise KeyError(k)
+            self.om = O.Model(sp)
+        else:
+            self.om = O.Model()
         for k, v in model_opts.items():
-            self.om.set(k, v)
+            if not k.startswith("spec_"):
+                self.om.set(k, v)
         self.ds = [O.Data(self.om) for _ in range(self.num_envs)]
         # one np_random per env = per MPI worker of the reference (workerseed = seed + 10000 rank, src/trpo.py:341-343)
         self.rngs = [np.random.RandomState(seed + 10000 * e) for e in range(self.num_envs)]

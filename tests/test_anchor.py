@@ -99,7 +99,8 @@ def test_anchor_detects_gross_physics_errors_but_not_solver_details():
     """Negative controls (tests/golden/anchor/controls/: the same protocol with a deliberately wrong model, two seeds each).  What the
     asserted bands / the eight default replays' scatter DO catch: joint limits switched off (a rate spread of 1.8-1.9 x, angle spreads
     15 % low), gravity 20 % low (rate spreads 5-11 % high, an angle mean beyond 2 sigma), half the time step (rate spreads 20-25 % low,
-    episodes twice as long).  What they do NOT catch: PGS cut to 5 sweeps, or the factor 2 in the pyramid regulariser (test above).
+    episodes twice as long), actuator gears 30 % weak (rate spreads 28 % low).  What they do NOT catch: PGS cut to 5 sweeps, contact friction
+    halved, the constraint time constant doubled, or the factor 2 in the pyramid regulariser (test above); joint damping doubled is marginal.
     This is the resolving power of the reference's only physics artefacts — and the sense in which 'the anchors agree' is to be read."""
     cdir = os.path.join(ADIR, "controls")
     base = _runs("protocol_seed[0-9].json")
@@ -114,10 +115,14 @@ def test_anchor_detects_gross_physics_errors_but_not_solver_details():
         return np.array(out)
 
     lim, grav, dt, pgs = ctl("enable_limit0"), ctl("gravity_z"), ctl("timestep"), ctl("pgs_iterations5")
+    gear, fric, sref = ctl("spec_gear"), ctl("spec_friction"), ctl("spec_solref0")
     assert np.all(lim[:, 1] > 1.45) and np.all(lim[:, 4] < 0.90)                     # outside the asserted spread band
     assert np.all((grav[:, 2] - geo.mean()) / geo.std(ddof=1) > 1.5) and grav[:, 3].max() > 2.0
     assert np.all((dt[:, 2] - geo.mean()) / geo.std(ddof=1) < -4) and np.all(dt[:, 5] > 100)
     assert np.all(pgs[:, 1] < 1.45) and np.all(np.abs(pgs[:, 2] - geo.mean()) < 2 * geo.std(ddof=1)) and np.all(pgs[:, 3] < 2.0)   # invisible
+    assert np.all((gear[:, 2] - geo.mean()) / geo.std(ddof=1) < -5)                 # actuators 30 % weak: caught
+    for c in (fric, sref):                                                          # friction x 0.5, constraint time constant x 2: invisible
+        assert np.all(np.abs(c[:, 2] - geo.mean()) < 2 * geo.std(ddof=1)) and np.all(c[:, 1] < 1.45) and np.all(c[:, 3] < 2.0)
 
 
 def test_replay_protocol_runs_and_is_deterministic():
