@@ -81,6 +81,13 @@ class Batch(object):
 
     def set_option(self, opt, value):
         A.check(self._L.dm_batch_set_option(self._h, int(opt), int(value)), self._L)
+        self.__dict__.setdefault("options", {})[int(opt)] = int(value)
+
+    @property
+    def can_step_act(self):
+        """dm_batch_step_act needs the two-tier kernel (option 102, default on) and no per-stage profiling (option 101)."""
+        o = self.__dict__.get("options", {})
+        return o.get(102, 1) != 0 and o.get(101, 0) == 0
 
     def set_stream(self, stream_handle):
         A.check(self._L.dm_batch_set_stream(self._h, C.c_void_p(int(stream_handle))), self._L)

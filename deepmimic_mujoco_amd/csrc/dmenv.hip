@@ -494,7 +494,13 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     if (pol) hipLaunchKernelGGL(k_step_act, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, *pol);
     else hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0);
     if (reorder) {
-      hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order, 0, b->n);
+      // (with a pipeline depth configured, every sub-batch's range is sorted on its own: a later pipelined launch reads order[lo..hi)
+      //  of ITS part only, which must then name exactly that part's envs — otherwise two streams could step one env at once)
+      const int parts = b->pipe > 1 ? b->pipe : 1;
+      for (int h = 0; h < parts; h++) {
+        const int lo = (int)((long long)b->n * h / parts), hi = (int)((long long)b->n * (h + 1) / parts);
+        if (hi > lo) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order, lo, hi - lo);
+      }
       b->B.order = b->d_order;             // valid from the next launch on (same stream: ordered after k_order)
     }
   } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub);
@@ -650,6 +656,11 @@ extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, in
       nb < 1 || bs < 1)
     return fail(DM_EINVAL, "dm_vf_fit_epoch: bad argument");
   hipStream_t st = (hipStream_t)hip_stream;
+  { // launch on the device that owns the parameters (the caller's stream belongs to it), whatever the thread's current device is
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, theta) == hipSuccess) HIPCHK(hipSetDevice(at.device));
+    else (void)hipGetLastError();
+  }
   const int nblk = (bs + dmv::SB - 1) / dmv::SB;
   float* partial = (float*)scratch;
   double* rpart = (double*)((char*)scratch + (((size_t)nblk * dmv::NPAD * sizeof(float) + 255) / 256) * 256);
@@ -663,8 +674,8 @@ extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, in
                        (const float*)rms_std, partial);
     hipLaunchKernelGGL(dmv::k_vf_adam, dim3((dmv::NP + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk, theta, adam_m, adam_v,
                        step_scale_host[i], (float)beta1, (float)beta2, (float)eps);
+    HIPCHK(hipGetLastError());
   }
-  HIPCHK(hipGetLastError());
   return DM_OK;
 }
 extern "C" int dm_batch_join(dm_batch* b) {

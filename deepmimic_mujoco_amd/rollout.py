@@ -93,7 +93,7 @@ def can_fuse(pi, env, device=None):
     import torch
     device = torch.device(pi.device if device is None else device)
     return (device.type == "cuda" and getattr(pi, "native", False) and hasattr(getattr(env, "batch", None), "step_act")
-            and getattr(pi, "ob_dim", 0) == 56 and getattr(pi, "ac_dim", 0) == 28 and getattr(pi, "hid_size", 0) == 100)
+            and getattr(env.batch, "can_step_act", True) and getattr(pi, "ob_dim", 0) == 56 and getattr(pi, "ac_dim", 0) == 28 and getattr(pi, "hid_size", 0) == 100)
 
 
 class SegmentCollector(object):

@@ -152,20 +152,28 @@ class _VfGraph:
         rms = pi.ob_rms
         # snapshot: warm-up and capture run the step for real
         saved = [t.clone() for t in (rms.sum, rms.sumsq, rms.count, ad.m, ad.v)] + [p.detach().clone() for p in ad.params]
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):
+        # Whatever happens in warm-up or capture (an exception sends the learner to its eager loop), the parameters, the Adam moments and
+        # the observation filter go back to the snapshot: the fallback must not train on state the throw-away steps have moved.
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self.ctr.zero_()              # always minibatch 0: the warm-up must not index past nb (nb may be < 3)
+                    self._body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.ctr.zero_()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
                 self._body()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._body()
-        with torch.no_grad():
-            for t, sv in zip([rms.sum, rms.sumsq, rms.count, ad.m, ad.v] + list(ad.params), saved):
-                t.copy_(sv)
-            rms._refresh()
-        self.ok = True
+            self.ok = True
+        finally:
+            torch.cuda.synchronize(dev)
+            with torch.no_grad():
+                for t, sv in zip([rms.sum, rms.sumsq, rms.count, ad.m, ad.v] + list(ad.params), saved):
+                    t.copy_(sv)
+                rms._refresh()
+            self.ctr.zero_()
 
     def matches(self, ob, ret, bs):
         return ob.shape[0] == self.n and bs == self.bs and ob.dtype == self.ob_s.dtype and ob.device == self.ob_s.device

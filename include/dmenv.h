@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 1
+#define DM_ABI_VERSION 2
 
 /* fixed sizes of the DeepMimic humanoid (dp_env_v3.xml:21-156): the kernels are specialised to this tree */
 #define DM_NBODY 14

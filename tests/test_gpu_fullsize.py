@@ -1,0 +1,98 @@
+"""Full-size oracle parity (run with -m gpu): the REAL per-GPU shard of BASELINE.json configs[2], [3], [4] — 4 096 'walk', 4 096
+'spinkick', 8 192 'dance_b' environments — stepped exactly as bench.py steps it (5-term imitation reward, RSI auto-reset from the
+device's counter-based RNG, two pipelined sub-batches, longest-first dispatch order, an interior shard's global env ids) against the
+CPU oracle's OpenMP batch step, EVERY env, every step: observations and rewards to 1e-9, done flags, frame cursors, cycle counters,
+constraint-row counts, contact counts and contact (geom1, geom2) lists identical.  The oracle side mirrors the device's auto-reset
+on the host (tests/helpers.device_rsi_frame: the frame `reset_env` draws for (seed, global env id, episode)).
+Reference semantics: src/dp_env_v3.py:106-156 (step, is_done, reset_model)."""
+import os
+
+import numpy as np
+import pytest
+
+from deepmimic_mujoco_amd import _abi as A
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+SEED = 11
+STEPS = 16
+
+
+@pytest.mark.parametrize("clip,n", [("walk", 4096), ("spinkick", 4096), ("dance_b", 8192)])
+def test_full_shard_matches_oracle_every_env_every_step(clip, n):
+    import torch
+    from deepmimic_mujoco_amd import Batch
+    from deepmimic_mujoco_amd.imitation import ImitationSpec
+    from oracle import oracle as O
+    mc = H.mocap(clip)
+    sp = ImitationSpec(H.compiled_model())
+    T, P = sp.table_for(mc)
+    F = len(T)
+    off = 3 * n                                                   # shard 3 of 8: global env ids do not start at 0
+    b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
+    b.set_option(A.OPT_REWARD_MODE, 3); b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, SEED)
+    b.set_option(A.OPT_ENV_OFFSET, off); b.set_option(A.OPT_DIAGNOSTICS, 1); b.set_option(A.OPT_PIPELINE, 2)
+    b.reset(0, 1)                                                 # env.reset(): sim.reset() + RSI
+    fidx = b.get(A.F_FRAME_IDX).copy()
+    expect0 = np.array([H.device_rsi_frame(SEED, off + e, 0, F) for e in range(n)], dtype=np.int32)
+    assert np.array_equal(fidx, expect0), "device RSI draw differs from the host mirror of its RNG"
+    om = H.oracle_model()
+    ods = [O.Data(om) for _ in range(n)]
+    for e in range(n):
+        ods[e].reset(); ods[e].set_state(mc.data_config[fidx[e]], mc.data_vel[fidx[e]])
+    cyc = np.zeros(n, dtype=np.int32)
+    episode = np.ones(n, dtype=np.int64)                          # the initial reset consumed episode 0
+    nthreads = max(1, len(os.sched_getaffinity(0)))
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    dev = torch.device("cuda:0")
+    obs_t = torch.empty((n, 56), dtype=torch.float64, device=dev); rew_t = torch.empty(n, dtype=torch.float64, device=dev)
+    done_t = torch.empty(n, dtype=torch.uint8, device=dev)
+    worst = 0.0; ndone = 0; max_nefc = 0; reordered = False
+    for t in range(STEPS):
+        a_t = torch.randn((n, 28), generator=g, device=dev, dtype=torch.float64) * 0.9
+        b.step(a_t, 1, (obs_t, rew_t, done_t))                   # pipelined: two sub-batch launches on their own streams
+        b.join(); torch.cuda.current_stream().synchronize()
+        a = a_t.cpu().numpy(); obs = obs_t.cpu().numpy(); rew = rew_t.cpu().numpy(); done = done_t.cpu().numpy()
+        o_obs, o_rew, o_done = O.batch_step_imitation(om, ods, a, 1, T, P, fidx, cyc, nthreads=nthreads)
+        assert np.array_equal(done, o_done), "done flags differ at step %d: envs %s" % (t, np.nonzero(done != o_done)[0][:8])
+        # sim.data.* as they stand after sim.step(): row / contact counts and the contact list of the 4th RK stage, every env
+        nefc = b.get(A.F_NEFC); ncon = b.get(A.F_NCON); cg = b.get(A.F_CONTACT_GEOMS)
+        o_nefc = np.array([int(d.get("nefc")[0]) for d in ods], dtype=np.int32)
+        o_ncon = np.array([int(d.get("ncon")[0]) for d in ods], dtype=np.int32)
+        assert np.array_equal(nefc, o_nefc), "nefc differs at step %d: envs %s" % (t, np.nonzero(nefc != o_nefc)[0][:8])
+        assert np.array_equal(ncon, o_ncon), "ncon differs at step %d" % t
+        for e in range(n):
+            k = min(int(o_ncon[e]), A.MAXEFC)
+            if k:
+                ocg = ods[e].get("contact_geom").reshape(-1, 2).astype(np.int32)
+                assert np.array_equal(cg[e][:k], ocg[:k]), "contact (geom1, geom2) list differs: step %d env %d" % (t, e)
+            assert np.all(cg[e][k:] == -1)
+        max_nefc = max(max_nefc, int(nefc.max()))
+        # mirror of the device's auto-reset: hard reset onto the frame its RNG draws for (seed, global id, episode)
+        dn = np.nonzero(done)[0]
+        for e in dn:
+            k = H.device_rsi_frame(SEED, off + int(e), int(episode[e]), F)
+            episode[e] += 1
+            ods[e].reset(); ods[e].set_state(mc.data_config[k], mc.data_vel[k])
+            fidx[e] = k; cyc[e] = 0
+            o_obs[e] = np.concatenate([mc.data_config[k][7:], mc.data_vel[k][6:]])      # DummyVecEnv convention: the fresh episode's obs
+        ndone += len(dn)
+        err_o = np.abs(obs - o_obs).max(1) / np.maximum(1.0, np.abs(o_obs).max(1))
+        err_r = np.abs(rew - o_rew) / np.maximum(1.0, np.abs(o_rew))
+        worst = max(worst, float(err_o.max()), float(err_r.max()))
+        assert err_o.max() < 1e-9, "obs differ at step %d: env %d rel err %.3e" % (t, int(err_o.argmax()), err_o.max())
+        assert err_r.max() < 1e-9, "reward differs at step %d: env %d" % (t, int(err_r.argmax()))
+        assert np.array_equal(b.get(A.F_FRAME_IDX), fidx), "frame cursors differ at step %d" % t
+        assert np.array_equal(b.get(A.F_CYCLE), cyc), "cycle counters differ at step %d" % t
+        assert np.array_equal(b.get(A.F_EPISODE), episode.astype(np.int32))
+    q = b.get(A.F_QPOS); w = b.get(A.F_QACC_WARMSTART); tm = b.get(A.F_TIME)
+    oq = np.stack([d.get("qpos") for d in ods]); ow = np.stack([d.get("qacc_warmstart") for d in ods]); ot = np.array([d.get("time")[0] for d in ods])
+    assert np.abs(q - oq).max() / max(1.0, np.abs(oq).max()) < 1e-9
+    assert np.abs(w - ow).max() / max(1.0, np.abs(ow).max()) < 1e-7      # accelerations: conditioned like the contact solve
+    assert np.abs(tm - ot).max() < 1e-12
+    assert ndone > 0 and max_nefc > 16, "the run must contain early terminations and heavy contact (%d done, max nefc %d)" % (ndone, max_nefc)
+    assert (b.get(A.F_STATUS) & 1).sum() == 0
+    print("full shard %s x %d, %d steps: worst rel err %.2e, %d auto-resets, max nefc %d, oracle threads %d"
+          % (clip, n, STEPS, worst, ndone, max_nefc, nthreads))
+    b.close()
