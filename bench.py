@@ -194,6 +194,30 @@ def single_env_gym_loop(device, seconds=2.0):
                     "one packed obs+reward+done D2H), reset() + reset_model_init() on done as src/trpo.py:78-79"}
 
 
+def _export_raw(cur, name, outdir, max_rows=4000):
+    """DM_PROFILE_KEEP=<dir>: keep a trimmed raw export of a rocprofv3 pass (per-launch kernel rows; per-launch counter values) as CSV,
+    so that every figure the line derives from it can be re-derived from the repository (profiles/raw/)."""
+    import csv
+    os.makedirs(outdir, exist_ok=True)
+    rows = cur.execute("select name, start, end, end - start, grid_size_x, workgroup_size_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
+                       "from kernels order by start limit ?", (max_rows,)).fetchall()
+    with open(os.path.join(outdir, "%s_kernels.csv" % name), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "start_ns", "end_ns", "duration_ns", "grid_x", "workgroup_x", "vgpr_count(db)", "accum_vgpr_count(db)", "sgpr_count", "lds_bytes", "scratch_bytes"])
+        for r in rows:
+            w.writerow([str(r[0]).split("(")[0][:60]] + list(r[1:]))
+    if name != "trace":
+        try:
+            rows = cur.execute("select kernel_name, counter_name, value from counters_collection where kernel_name like 'k_%' limit ?", (4 * max_rows,)).fetchall()
+            with open(os.path.join(outdir, "%s_counters.csv" % name), "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["kernel", "counter", "value (one row per launch and counter)"])
+                for r in rows:
+                    w.writerow([str(r[0]).split("(")[0][:60], r[1], r[2]])
+        except Exception as e:
+            open(os.path.join(outdir, "%s_counters.err" % name), "w").write(repr(e))
+
+
 def pmc_passes(argv_tail, kernel_prefix, timeout_s=150):
     """Live rocprofv3 passes of THIS workload (short run, child processes): kernel trace, HBM bytes, SQ instruction mix.
     Counters are collected in separate passes with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC section)."""
@@ -227,6 +251,9 @@ def pmc_passes(argv_tail, kernel_prefix, timeout_s=150):
                 res[name + "_error"] = "no output database"
                 continue
             cur = sqlite3.connect(dbs[0]).cursor()
+            keep = os.environ.get("DM_PROFILE_KEEP")
+            if keep:
+                _export_raw(cur, name, keep)
             if name == "trace":
                 r = cur.execute("select count(*), avg(end-start), max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) "
                                 "from kernels where name like ?", (kernel_prefix + "%",)).fetchone()
@@ -341,6 +368,13 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         n_ranks_seen = dist.get_world_size()
         assert n_ranks_seen == args.gpus, "process group has %d ranks, --gpus says %d" % (n_ranks_seen, args.gpus)
+        if rank == 0:       # start-up line for the scaling log (stderr: stdout carries exactly one JSON line)
+            n_log = args.envs or WORKLOADS.get(args.workload, WORKLOADS["cfg3"])["envs"]
+            sys.stderr.write("bench.py: %s process group up, %d ranks (backend reports %s), device %s; rollout gather every %d steps: "
+                             "[%d, %d, 87] f32 = %.1f MB per rank, %.1f MB gathered per rank\n"
+                             % (args.dist_backend, n_ranks_seen, dist.get_backend(), dev, HORIZON, HORIZON, n_log, HORIZON * n_log * 87 * 4 / 1e6,
+                                world * HORIZON * n_log * 87 * 4 / 1e6))
+            sys.stderr.flush()
 
     if args.workload == "rollout":
         return rollout_bench(args, dev, rank, world, local_dev)
@@ -364,7 +398,7 @@ def main():
 
     with torch.cuda.stream(stream):
         gen = torch.Generator(device=dev); gen.manual_seed(1234 + shard)
-        pool = 32
+        pool = HORIZON       # one 256-step horizon of i.i.d. N(0, 0.9^2) actions per (env, t), reused from horizon to horizon
         if full:
             actions = torch.randn((pool, n, A.NU), generator=gen, device=dev, dtype=torch.float64) * 0.9
         else:
@@ -472,7 +506,12 @@ def main():
                        "pipeline_sub_batches": max(1, min(args.pipeline, A.MAX_PIPELINE)),
                        "sim_steps_per_env_step": 1,
                        "mean_nefc": round(float(nefc.mean()), 2), "mean_pgs_sweeps": round(float(iters.mean()), 2),
-                       "overflow_envs": int((status & 1).sum())},
+                       "overflow_envs": int((status & 1).sum()),
+                       "actions": ("i.i.d. N(0, 0.9^2) per (env, step) within a %d-step horizon, pre-drawn on the device (%d x %d x 28 f64), the same "
+                                   "tensors reused by every horizon" % (pool, pool, n)) if full else "zeros (pure P-controller)",
+                       "timed_window": "%d dm_batch_step calls (state / obs / reward / done device-resident)%s" % (
+                           args.steps, ", %d horizon-end block packings + joins" % (args.steps // HORIZON) if args.steps >= HORIZON
+                           else "; shorter than the %d-step horizon: no block packing / join inside the window" % HORIZON)},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                          "kernel": "k_step_narrow", "kernel_ms": round(kernel_ms, 4),

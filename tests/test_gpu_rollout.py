@@ -162,6 +162,54 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_share_the_gpu_over_gloo():
+    """World size 8 — the driver's largest scaling point — on the ONE visible GPU: shard offsets 0 .. 7 N, eight-way gathered rollout
+    blocks (DoubleBufferedGather, host-staged over gloo), MAX-reduced timing, exactly one JSON line from rank 0.  BASELINE.json
+    configs[4]'s clip and reset mode at a reduced shard size (eight processes share one device)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29543",
+           os.path.join(root, "bench.py"), "--gpus", "8", "--dist-backend", "gloo", "--workload", "cfg5", "--envs", "256", "--steps", "300",
+           "--warmup", "8", "--prewarm-horizons", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["n_ranks_seen"] == 8 and j["config"]["dist_backend"] == "gloo"
+    assert j["config"]["global_envs"] == 8 * 256 and j["config"]["gathers_completed"] >= 1 and j["scaling"] == "weak"
+    assert j["config"]["clip"] == "dance_b" and j["value"] > 1e4 and "cpu_baseline" not in j
+    assert "rollout gather" in out.stderr, "the multi-rank start-up line (rank count, gather size) is missing"
+
+
+@pytest.mark.gpu
+def test_two_rank_training_keeps_replicas_bit_identical():
+    """tools/train_trpo.py on two ranks (gloo, sharing the GPU): after three TRPO updates — all-mean'd policy gradient, Fisher-vector
+    products, value gradients, all-reduced filter moments — both replicas hold bit-identical parameters, although their env
+    shards (and hence their rollouts) differ.  The reference's consistency check: src/mpi_adam.py:42-50."""
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    with tempfile.TemporaryDirectory() as td:
+        pre = os.path.join(td, "p")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29545",
+               os.path.join(root, "tools", "train_trpo.py"), "--dist-backend", "gloo", "--envs", "256", "--horizon", "32", "--iters", "3",
+               "--vf-batch", "1024", "--dump-params", pre]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+        assert out.returncode == 0, out.stderr[-3000:]
+        a = np.load(pre + ".rank0.npz"); b = np.load(pre + ".rank1.npz")
+        assert sorted(a.files) == sorted(b.files) and len(a.files) >= 14
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), "replicas diverged in %s" % k
+        fresh = MlpPolicy(device="cpu", seed=0).state_dict()
+        moved = [k for k in a.files if k in fresh and not np.array_equal(a[k], np.asarray(fresh[k]))]
+        assert len(moved) >= 10, "three updates must have changed the parameters (%s)" % moved
+
+
+@pytest.mark.gpu
 def test_pipelined_rollouts_equal_the_same_batches_stepped_one_after_the_other():
     """`pipelined_segment_generator`: two env batches whose policy -> env chains run concurrently on their own CUDA streams must
     produce exactly the segments the same two batches produce when their chains run back to back on one stream."""

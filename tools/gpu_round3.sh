@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-3 gpurun bundle (run from the repo root on the GPU box):  bash tools/gpu_round3.sh <tag> [tests|bench|all]
+# Outputs under gpurun_out/<tag>/ ; raw rocprofv3 exports (CSV, trimmed) under gpurun_out/<tag>/raw/ -> copy into profiles/raw/.
+set -u
+TAG=${1:-r03}; WHAT=${2:-all}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT/raw
+export TMPDIR=/tmp
+if [ "$WHAT" = tests ] || [ "$WHAT" = all ]; then
+  ( timeout 2400 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tail -60 ) > $OUT/pytest_gpu.log
+  tail -25 $OUT/pytest_gpu.log
+  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log
+fi
+if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
+  DM_PROFILE_KEEP=$OUT/raw timeout 900 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-400 $OUT/bench_cfg3.json
+  for rw in alive v3-config; do
+    timeout 300 python bench.py --reward $rw --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_$rw.json 2> $OUT/bench_cfg3_$rw.err; cut -c1-200 $OUT/bench_cfg3_$rw.json
+  done
+  for wl in cfg4 cfg5 cfg2; do
+    timeout 300 python bench.py --workload $wl --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; cut -c1-200 $OUT/bench_$wl.json
+  done
+  timeout 300 python bench.py --workload rollout --steps 2048 --warmup 256 > $OUT/bench_rollout_fused.json 2> $OUT/bench_rollout_fused.err; cut -c1-200 $OUT/bench_rollout_fused.json
+  # driver-sized window as the driver runs it
+  timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_driver_window.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg3_driver_window.json
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace -- python $OLDPWD/bench.py --steps 96 --warmup 16 --no-pmc --no-cpu-baseline --no-gym-loop > /dev/null 2>&1 )
+  ROWS=6 python tools/rocprof_summary.py $OUT/kstep_summary.md "step kernel — $TAG, MI355X (bench.py default workload: cfg3 + 5-term imitation reward, 4096 envs as 2 pipelined sub-batches)" \
+    $(find /tmp/p_trace -name "*.db" | head -1) > /dev/null; head -12 $OUT/kstep_summary.md
+  timeout 400 python tools/train_trpo.py --envs 4096 --horizon 128 --seconds 25 --out $OUT/trpo_train.json 2>&1 | tail -2 | tee $OUT/trpo_train.log
+fi

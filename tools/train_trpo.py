@@ -40,16 +40,25 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
     ap.add_argument("--log-dir", default=None, help="write progress.csv and monitor.csv in the reference's formats")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL, one GPU per rank; gloo = ranks may share a GPU (LOCAL_RANK modulo the visible devices)")
+    ap.add_argument("--dump-params", default=None, help="every rank writes its final parameters to <prefix>.rank<r>.npz (replica-consistency checks)")
     ap.add_argument("--save", default=None, help="write the trained policy: `x.npz` (reference variable names) or a checkpoint prefix -> "
                                                  "tf.train.Saver bundle (x.index + x.data-00000-of-00001) the reference's `--task evaluate --load_model_path x` restores")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); lr = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and world > ndev:
+        raise SystemExit("RCCL needs one GPU per rank: %d ranks, %d devices visible (use --dist-backend gloo to share a GPU)" % (world, ndev))
+    lr = lr % max(1, ndev)
     torch.cuda.set_device(lr)
     dev = torch.device("cuda", lr)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     fs = args.frame_skip if args.frame_skip in (None, "mocap") else int(args.frame_skip)
     if args.task == "evaluate":                     # src/trpo.py:480-487
         from deepmimic_mujoco_amd.trpo import runner
@@ -74,6 +83,9 @@ def main():
     hist = learn(env, pi, timesteps_per_batch=args.horizon, max_seconds=args.seconds if not args.iters else 0, max_iters=args.iters,
                  vf_batch_size=args.vf_batch, vf_stepsize=args.vf_stepsize, max_kl=args.max_kl, seed=args.seed, log_dir=args.log_dir,
                  fused=False if args.unfused else None)
+    if args.dump_params:
+        os.makedirs(os.path.dirname(os.path.abspath(args.dump_params)), exist_ok=True)
+        pi.save_npz("%s.rank%d.npz" % (args.dump_params, rank))
     if rank == 0:
         if args.out:
             os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
