@@ -196,26 +196,34 @@ def single_env_gym_loop(device, seconds=2.0):
 
 def _export_raw(cur, name, outdir, max_rows=4000):
     """DM_PROFILE_KEEP=<dir>: keep a trimmed raw export of a rocprofv3 pass (per-launch kernel rows; per-launch counter values) as CSV,
-    so that every figure the line derives from it can be re-derived from the repository (profiles/raw/)."""
+    so that every figure the line derives from it can be re-derived from the repository (profiles/raw/).  Never raises."""
     import csv
-    os.makedirs(outdir, exist_ok=True)
-    rows = cur.execute("select name, start, end, end - start, grid_size_x, workgroup_size_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
-                       "from kernels order by start limit ?", (max_rows,)).fetchall()
-    with open(os.path.join(outdir, "%s_kernels.csv" % name), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["kernel", "start_ns", "end_ns", "duration_ns", "grid_x", "workgroup_x", "vgpr_count(db)", "accum_vgpr_count(db)", "sgpr_count", "lds_bytes", "scratch_bytes"])
-        for r in rows:
-            w.writerow([str(r[0]).split("(")[0][:60]] + list(r[1:]))
-    if name != "trace":
-        try:
+    try:
+        os.makedirs(outdir, exist_ok=True)
+        cols = [d[0] for d in cur.execute("select * from kernels limit 1").description]
+        want = [c for c in ("name", "start", "end", "grid_size", "grid_size_x", "grid_x", "workgroup_size", "workgroup_size_x", "workgroup_x", "vgpr_count",
+                            "accum_vgpr_count", "sgpr_count", "lds_size", "scratch_size", "queue_id", "stream_id") if c in cols]
+        rows = cur.execute("select %s from kernels order by start limit ?" % ", ".join('"%s"' % c for c in want), (max_rows,)).fetchall()
+        with open(os.path.join(outdir, "%s_kernels.csv" % name), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(want + ["duration_ns"])
+            i0, i1 = want.index("start"), want.index("end")
+            for r in rows:
+                r = list(r); r[0] = str(r[0]).split("(")[0][:60]
+                w.writerow(r + [r[i1] - r[i0]])
+        open(os.path.join(outdir, "%s_kernels.columns.txt" % name), "w").write("all columns of the `kernels` view: " + ", ".join(cols) + "\n")
+        if name != "trace":
             rows = cur.execute("select kernel_name, counter_name, value from counters_collection where kernel_name like 'k_%' limit ?", (4 * max_rows,)).fetchall()
             with open(os.path.join(outdir, "%s_counters.csv" % name), "w", newline="") as f:
                 w = csv.writer(f)
                 w.writerow(["kernel", "counter", "value (one row per launch and counter)"])
                 for r in rows:
                     w.writerow([str(r[0]).split("(")[0][:60], r[1], r[2]])
-        except Exception as e:
-            open(os.path.join(outdir, "%s_counters.err" % name), "w").write(repr(e))
+    except Exception as e:
+        try:
+            open(os.path.join(outdir, "%s_export.err" % name), "w").write(repr(e))
+        except Exception:
+            pass
 
 
 def pmc_passes(argv_tail, kernel_prefix, timeout_s=150):

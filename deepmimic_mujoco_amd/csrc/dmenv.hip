@@ -16,6 +16,7 @@
 #include "dmenv.h"
 #include "policy_kernel.h"
 #include "vf_kernel.h"
+#include "pg_kernel.h"
 #include "env_step.h"
 #include "model_host.h"
 
@@ -676,6 +677,51 @@ extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, in
                        step_scale_host[i], (float)beta1, (float)beta2, (float)eps);
     HIPCHK(hipGetLastError());
   }
+  return DM_OK;
+}
+// ---- policy half of the TRPO update (csrc/pg_kernel.h) -------------------------------------------------------------------------
+static int pg_set_device(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) == hipSuccess) { if (hipSetDevice(at.device) != hipSuccess) return DM_EHIP; }
+  else (void)hipGetLastError();
+  return DM_OK;
+}
+extern "C" int dm_pg_param_count(void) { return dmg::NP; }
+extern "C" size_t dm_pg_scratch_bytes(void) { return (size_t)dmg::MAX_BLOCKS * dmg::NPAD * sizeof(float) + (size_t)dmg::MAX_BLOCKS * 2 * sizeof(double) + 256; }
+extern "C" int dm_pg_losses(const float* ob, int32_t n, const float* ac, const float* atarg, float* old_mean, const float* old_logstd, int32_t write_old,
+                            const float* theta, const float* rms_mean, const float* rms_std, double entcoeff, int32_t with_grad,
+                            float* out_grad, double* out_losses, void* scratch, void* hip_stream) {
+  if (!ob || !ac || !atarg || !old_mean || !old_logstd || !theta || !rms_mean || !rms_std || !out_losses || !scratch || n < 1 || (with_grad && !out_grad))
+    return fail(DM_EINVAL, "dm_pg_losses: bad argument");
+  if (pg_set_device(theta)) return fail(DM_EHIP, "dm_pg_losses: hipSetDevice failed");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int ntiles = (n + dmg::SB - 1) / dmg::SB, nblk = ntiles < dmg::MAX_BLOCKS ? ntiles : dmg::MAX_BLOCKS;
+  float* partial = (float*)scratch;
+  double* lpart = (double*)((char*)scratch + (((size_t)dmg::MAX_BLOCKS * dmg::NPAD * sizeof(float) + 255) / 256) * 256);
+  if (with_grad)
+    hipLaunchKernelGGL(dmg::k_pg<dmg::MODE_GRAD>, dim3(nblk), dim3(256), 0, st, ob, 1, (int)n, ac, atarg, old_mean, old_logstd, (int)write_old, theta,
+                       (const float*)nullptr, rms_mean, rms_std, 1.0f / (float)n, partial, lpart);
+  else
+    hipLaunchKernelGGL(dmg::k_pg<dmg::MODE_LOSS>, dim3(nblk), dim3(256), 0, st, ob, 1, (int)n, ac, atarg, old_mean, old_logstd, (int)write_old, theta,
+                       (const float*)nullptr, rms_mean, rms_std, 1.0f / (float)n, partial, lpart);
+  hipLaunchKernelGGL(dmg::k_pg_reduce, dim3((dmg::NP + 255) / 256), dim3(256), 0, st, (const float*)partial, (const double*)lpart, nblk,
+                     with_grad ? (int)dmg::MODE_GRAD : (int)dmg::MODE_LOSS, (float)entcoeff, (const float*)nullptr, 1.0 / (double)n, out_grad, out_losses);
+  HIPCHK(hipGetLastError());
+  return DM_OK;
+}
+extern "C" int dm_pg_fvp(const float* ob, int32_t stride, int32_t n, const float* theta, const float* v, const float* rms_mean, const float* rms_std,
+                         float* out_fv, void* scratch, void* hip_stream) {
+  if (!ob || !theta || !v || !rms_mean || !rms_std || !out_fv || !scratch || n < 1 || stride < 1) return fail(DM_EINVAL, "dm_pg_fvp: bad argument");
+  if (pg_set_device(theta)) return fail(DM_EHIP, "dm_pg_fvp: hipSetDevice failed");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int ntiles = (n + dmg::SB - 1) / dmg::SB, nblk = ntiles < dmg::MAX_BLOCKS ? ntiles : dmg::MAX_BLOCKS;
+  float* partial = (float*)scratch;
+  double* lpart = (double*)((char*)scratch + (((size_t)dmg::MAX_BLOCKS * dmg::NPAD * sizeof(float) + 255) / 256) * 256);
+  hipLaunchKernelGGL(dmg::k_pg<dmg::MODE_FVP>, dim3(nblk), dim3(256), 0, st, ob, (int)stride, (int)n, (const float*)nullptr, (const float*)nullptr,
+                     (float*)nullptr, (const float*)nullptr, 0, theta, v, rms_mean, rms_std, 1.0f / (float)n, partial, lpart);
+  hipLaunchKernelGGL(dmg::k_pg_reduce, dim3((dmg::NP + 255) / 256), dim3(256), 0, st, (const float*)partial, (const double*)lpart, nblk, (int)dmg::MODE_FVP,
+                     0.0f, v, 1.0 / (double)n, out_fv, (double*)nullptr);
+  HIPCHK(hipGetLastError());
   return DM_OK;
 }
 extern "C" int dm_batch_join(dm_batch* b) {

@@ -221,7 +221,7 @@ class TrpoLearner:
     """One policy/value update per segment; the reference's `learn()` body between `seg_gen.__next__()` and the logging."""
 
     def __init__(self, pi, *, max_kl=0.01, cg_iters=10, cg_damping=0.1, gamma=0.995, lam=0.97, entcoeff=0.0,
-                 vf_iters=3, vf_stepsize=1e-3, vf_batch_size=128, fvp_subsample=5, group=None, seed=0, vf_graph=None, vf_native=None):
+                 vf_iters=3, vf_stepsize=1e-3, vf_batch_size=128, fvp_subsample=5, group=None, seed=0, vf_graph=None, vf_native=None, pg_native=None):
         self.pi = pi
         self.max_kl, self.cg_iters, self.cg_damping = max_kl, cg_iters, cg_damping
         self.gamma, self.lam, self.entcoeff = gamma, lam, entcoeff
@@ -233,6 +233,10 @@ class TrpoLearner:
         # ... or as the hand-written kernels of csrc/vf_kernel.h (three launches per minibatch, one C call per epoch; None = when possible)
         self.vf_native = vf_native
         self._vf_scratch = None
+        # the policy half (losses + flat gradient, Fisher-vector products, line-search losses) as the kernels of csrc/pg_kernel.h
+        # (None = when possible: CUDA tensors, the reference's 56-100-100-28 policy; multi-rank runs all-mean the kernels' results)
+        self.pg_native = pg_native
+        self._pg_scratch = None
         self.group = group
         for k in POL_KEYS + VF_KEYS:
             pi.params[k].requires_grad_(True)
@@ -363,41 +367,126 @@ class TrpoLearner:
             return False
         return True
 
+    # ---- policy half as hand-written kernels (csrc/pg_kernel.h) -------------------------------------------------------------
+    def _pg_native_ready(self, ob, ac):
+        if self.pg_native is False or ob.device.type != "cuda":
+            return False
+        p = self.pi.params
+        ok = (ob.dtype == torch.float32 and ob.dim() == 2 and ob.shape[1] == 56 and ac.dtype == torch.float32 and ac.dim() == 2 and ac.shape[1] == 28
+              and getattr(self.pi, "native", False) and tuple(p["polfc1/w"].shape) == (56, 100) and tuple(p["polfc2/w"].shape) == (100, 100)
+              and tuple(p["polfinal/w"].shape) == (100, 28) and p["logstd"].numel() == 28 and all(p[k].dtype == torch.float32 for k in POL_KEYS)
+              and tuple(self.pi.ob_rms.shape) == (56,))
+        if not ok and self.pg_native is True:
+            raise ValueError("the native policy update needs float32 [n, 56] observations / [n, 28] actions and the 56-100-100-28 policy on a GPU")
+        return ok
+
+    def _pg_call(self, name, *args):
+        import ctypes as C
+        from . import _abi as A
+        L = A.load()
+        A.check(getattr(L, name)(*[C.c_void_p(a.data_ptr()) if torch.is_tensor(a) else a for a in args]), L)
+
+    def _pg_buffers(self, dev):
+        from . import _abi as A
+        L = A.load()
+        if self._pg_scratch is None or self._pg_scratch.device != dev:
+            assert L.dm_pg_param_count() == sum(p.numel() for p in self.pol)
+            self._pg_scratch = torch.empty(int(L.dm_pg_scratch_bytes()), dtype=torch.uint8, device=dev)
+        return self._pg_scratch
+
+    def _pg_losses(self, ob, ac, atarg, old_mean, old_logstd, theta, write_old, with_grad):
+        """-> (losses [5] float32 like `_losses`: optimgain, meankl, entbonus, surrgain, meanent; flat gradient or None)"""
+        import ctypes as C
+        dev = ob.device
+        sc = self._pg_buffers(dev)
+        rms = self.pi.ob_rms
+        out = torch.empty(2, dtype=torch.float64, device=dev)
+        g = torch.empty(theta.numel(), dtype=torch.float32, device=dev) if with_grad else None
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        self._pg_call("dm_pg_losses", ob, int(ob.shape[0]), ac, atarg, old_mean, old_logstd, 1 if write_old else 0, theta, rms.mean, rms.std,
+                      C.c_double(float(self.entcoeff)), 1 if with_grad else 0, g if with_grad else C.c_void_p(0), out, sc, st)
+        logstd = theta[-28:]
+        meanent = (logstd + 0.5 * math.log(2.0 * math.pi * math.e)).sum()
+        surr, kl = out[0].to(torch.float32), out[1].to(torch.float32)
+        entbonus = self.entcoeff * meanent
+        return torch.stack([surr + entbonus, kl, entbonus, surr, meanent]), g
+
+    def _pg_fvp(self, ob, theta, v):
+        import ctypes as C
+        dev = ob.device
+        sc = self._pg_buffers(dev)
+        rms = self.pi.ob_rms
+        k = int(self.fvp_subsample)
+        nf = (int(ob.shape[0]) + k - 1) // k                                # rows of ob[::k]
+        hv = torch.empty_like(v)
+        self._pg_call("dm_pg_fvp", ob, k, nf, theta, v.contiguous(), rms.mean, rms.std, hv, sc, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        return hv
+
     # ---- one update ----------------------------------------------------------------------------------------------------------
     def update(self, seg):
         pi = self.pi
+        import os
+        prof = {} if os.environ.get("DM_TRPO_PROFILE") else None             # phase times (ms, device-synchronised) in stats["profile_ms"]
+        t_last = [time.perf_counter()]
+
+        def tick(name):
+            if prof is None:
+                return
+            if seg["ob"].device.type == "cuda":
+                torch.cuda.synchronize(seg["ob"].device)
+            now = time.perf_counter()
+            prof[name] = prof.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
+        tick("_start")
         add_vtarg_and_adv(seg, self.gamma, self.lam)
         fl = flatten_segment(seg)
         ob, ac, atarg, tdlamret, vpredbefore = fl["ob"], fl["ac"], fl["adv"], fl["tdlamret"], fl["vpred"]
         atarg = (atarg - atarg.mean()) / atarg.std(unbiased=False)          # :240
         pi.ob_rms.update(ob, group=self.group)                              # :242
-        with torch.no_grad():                                               # :247 oldpi <- pi
-            old_mean = pi.forward_mean(ob)
-            old_logstd = pi.params["logstd"].detach().clone()
-        sub = slice(None, None, self.fvp_subsample)                         # :245 fvpargs = [arr[::5] ...]
-        ob_f, om_f = ob[sub], old_mean[sub]
-
-        losses = self._losses(ob, ac, atarg, old_mean, old_logstd)
-        g = flat(torch.autograd.grad(losses[0], self.pol))
-        lossbefore = allmean(torch.stack([l.detach() for l in losses]), self.group)
+        native_pg = self._pg_native_ready(ob, ac)
+        if native_pg:
+            ob = ob.contiguous(); ac = ac.contiguous(); atarg = atarg.to(torch.float32).contiguous()
+            theta0 = self.get_flat().contiguous()
+            old_logstd = pi.params["logstd"].detach().reshape(-1).clone()
+            old_mean = torch.empty((ob.shape[0], 28), dtype=torch.float32, device=ob.device)
+            # one launch: oldpi <- pi (:247: old_mean is written), the losses at pi == oldpi and the flat gradient of optimgain (:249)
+            lossbefore, g = self._pg_losses(ob, ac, atarg, old_mean, old_logstd, theta0, write_old=True, with_grad=True)
+            lossbefore = allmean(lossbefore, self.group)
+        else:
+            with torch.no_grad():                                           # :247 oldpi <- pi
+                old_mean = pi.forward_mean(ob)
+                old_logstd = pi.params["logstd"].detach().clone()
+            sub = slice(None, None, self.fvp_subsample)                     # :245 fvpargs = [arr[::5] ...]
+            ob_f, om_f = ob[sub], old_mean[sub]
+            losses = self._losses(ob, ac, atarg, old_mean, old_logstd)
+            g = flat(torch.autograd.grad(losses[0], self.pol))
+            lossbefore = allmean(torch.stack([l.detach() for l in losses]), self.group)
         g = allmean(g, self.group)
+        tick("gae_filter_losses_grad")
         stats = {}
         if bool(torch.allclose(g, torch.zeros_like(g))):
             stats["note"] = "zero gradient, not updating"
             meanlosses = lossbefore
         else:
-            # Fisher-vector products: gradient of (grad KL . v), the KL graph is built once and re-used by every product
-            mean_f, logstd_f = self._pd(ob_f)
-            kl_f = self._kl(om_f, old_logstd, mean_f, logstd_f).mean()
-            klgrads = flat(torch.autograd.grad(kl_f, self.pol, create_graph=True))
+            if native_pg:
+                # Fisher-vector products: forward-mode J v, then J^T (J v / sigma^2) / N — the exact Hessian of the mean KL at pi == oldpi
+                def fisher_vector_product(p):
+                    return allmean(self._pg_fvp(ob, theta0, p), self.group) + self.cg_damping * p        # :229
+                klgrads = None
+            else:
+                # Fisher-vector products: gradient of (grad KL . v), the KL graph is built once and re-used by every product
+                mean_f, logstd_f = self._pd(ob_f)
+                kl_f = self._kl(om_f, old_logstd, mean_f, logstd_f).mean()
+                klgrads = flat(torch.autograd.grad(kl_f, self.pol, create_graph=True))
 
-            def fisher_vector_product(p):
-                hv = flat(torch.autograd.grad(klgrads.dot(p), self.pol, retain_graph=True))
-                return allmean(hv, self.group) + self.cg_damping * p        # :229
+                def fisher_vector_product(p):
+                    hv = flat(torch.autograd.grad(klgrads.dot(p), self.pol, retain_graph=True))
+                    return allmean(hv, self.group) + self.cg_damping * p    # :229
 
             stepdir = cg(fisher_vector_product, g, cg_iters=self.cg_iters)
             assert bool(torch.isfinite(stepdir).all())
             shs = 0.5 * stepdir.dot(fisher_vector_product(stepdir))
+            tick("cg_fisher_products")
             lm = torch.sqrt(shs / self.max_kl)
             fullstep = stepdir / lm
             expectedimprove = float(g.dot(fullstep))
@@ -410,8 +499,11 @@ class TrpoLearner:
             ok = False
             for _ in range(10):                                             # :266-283
                 self.set_from_flat(thbefore + fullstep * stepsize)
-                with torch.no_grad():
-                    meanlosses = allmean(torch.stack(self._losses(ob, ac, atarg, old_mean, old_logstd)), self.group)
+                if native_pg:
+                    meanlosses = allmean(self._pg_losses(ob, ac, atarg, old_mean, old_logstd, self.get_flat().contiguous(), write_old=False, with_grad=False)[0], self.group)
+                else:
+                    with torch.no_grad():
+                        meanlosses = allmean(torch.stack(self._losses(ob, ac, atarg, old_mean, old_logstd)), self.group)
                 surr, kl = float(meanlosses[0]), float(meanlosses[1])
                 improve = surr - surrbefore
                 if not bool(torch.isfinite(meanlosses).all()):
@@ -427,6 +519,7 @@ class TrpoLearner:
             if not ok:
                 self.set_from_flat(thbefore)                                # "couldn't compute a good step"
             stats.update(expectedimprove=expectedimprove, improve=improve, stepsize=stepsize if ok else 0.0)
+            tick("line_search")
 
         # ---- value function (:288-296) ------------------------------------------------------------------------------------
         n = ob.shape[0]
@@ -445,6 +538,10 @@ class TrpoLearner:
                 mb = inds[o:o + bs]
                 self._vf_step(ob[mb], tdlamret[mb])
 
+        tick("value_fit")
+        if prof is not None:
+            prof.pop("_start", None)
+            stats["profile_ms"] = {k: round(v, 3) for k, v in prof.items()}
         pi.mark_dirty()                                                     # parameters / obs filter changed in place: the native act() repacks
         for name, val in zip(self.loss_names, meanlosses.tolist()):
             stats[name] = val

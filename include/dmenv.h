@@ -232,6 +232,24 @@ int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, int32_t bs, f
                     const float* step_scale_host, double beta1, double beta2, double eps, double* rms_sum, double* rms_sumsq,
                     double* rms_count, float* rms_mean, float* rms_std, void* scratch, void* hip_stream);
 
+/* Replaces: the policy half of one TRPO update (src/trpo.py:228-230, 245-283) for the 56-100-100-28 tanh Gaussian policy of
+ * src/mlp_policy_trpo.py:50-60.  theta: dm_pg_param_count() floats = polfc1/w, polfc1/b, polfc2/w, polfc2/b, polfinal/w, polfinal/b, logstd
+ * (weights row-major [in][out]: the learner's flat `var_list` order, :139); ob [n, 56] float32 raw observations, normalised inside with
+ * rms_mean / rms_std [56] and clipped to +-5; everything is a device pointer; `scratch`: dm_pg_scratch_bytes() bytes on the device.
+ *   dm_pg_losses  `compute_losses` / `compute_lossandgrad` (:224-226): out_losses[2] (float64) = {surrgain = mean(pnew / pold * atarg),
+ *                 meankl = mean KL(old || new)}; with_grad: out_grad = flat gradient of optimgain = surrgain + entcoeff * mean entropy.
+ *                 write_old != 0: old == new, and old_mean [n, 28] is WRITTEN (`assign_old_eq_new`, :247); else it is read, with old_logstd [28].
+ *   dm_pg_fvp     `compute_fvp` (:228-230) on the samples ob[i * stride], i < n (`fvpargs = arr[::5]`, :245): out_fv = Hessian of the mean KL
+ *                 at new == old times v — exactly J^T diag(1 / sigma^2) J v / n on the mean parameters and 2 v on logstd (pg_kernel.h); the
+ *                 caller adds cg_damping * v (:229).  One forward-mode and one reverse pass per sample, no second-order graph. */
+int dm_pg_param_count(void);
+size_t dm_pg_scratch_bytes(void);
+int dm_pg_losses(const float* ob, int32_t n, const float* ac, const float* atarg, float* old_mean, const float* old_logstd, int32_t write_old,
+                 const float* theta, const float* rms_mean, const float* rms_std, double entcoeff, int32_t with_grad,
+                 float* out_grad, double* out_losses, void* scratch, void* hip_stream);
+int dm_pg_fvp(const float* ob, int32_t stride, int32_t n, const float* theta, const float* v, const float* rms_mean, const float* rms_std,
+              float* out_fv, void* scratch, void* hip_stream);
+
 int dm_batch_sync(dm_batch* b);
 /* Make the batch's stream wait (device-side, no host wait) for every pipelined sub-batch launch in flight (DM_OPT_PIPELINE). */
 int dm_batch_join(dm_batch* b);

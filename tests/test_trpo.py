@@ -345,3 +345,93 @@ def test_value_fit_as_captured_graph_equals_the_eager_loop_on_gpu():
     assert float((ve - vg).abs().max()) < 1e-6 * max(1.0, float(ve.abs().max()))
     assert torch.allclose(pe.ob_rms.sum, pg.ob_rms.sum, rtol=1e-12, atol=1e-9) and float(pe.ob_rms.count) == float(pg.ob_rms.count)
     assert le.vfadam.t == lg.vfadam.t == 12 and float((le.vfadam.m - lg.vfadam.m).abs().max()) < 1e-7
+
+
+# ---- the policy half as hand-written kernels (csrc/pg_kernel.h) -------------------------------------------------------------------
+def _pg_case(n, seed=0):
+    """Random batch + policy for the native policy-gradient kernels, with the float64 numpy restatement's view of the same numbers."""
+    from deepmimic_mujoco_amd.trpo import TrpoLearner, POL_KEYS
+    from deepmimic_mujoco_amd.policy import MlpPolicy
+    from tests import trpo_numpy as TN
+    rng = np.random.RandomState(seed)
+    pi = MlpPolicy(device="cuda:0", seed=seed)
+    with torch.no_grad():
+        pi.params["logstd"].copy_(torch.as_tensor(rng.uniform(-0.7, 0.3, (1, 28)), dtype=torch.float32))
+        pi.params["polfinal/w"].mul_(20.0)                                  # (the initial 0.01 scale would make every mean ~0)
+        for k in ("polfc1/b", "polfc2/b", "polfinal/b"):
+            pi.params[k].copy_(torch.as_tensor(0.1 * rng.randn(*pi.params[k].shape), dtype=torch.float32))
+    ob = (rng.randn(n, 56) * np.linspace(0.5, 3.0, 56) + rng.randn(56)).astype(np.float32)
+    pi.ob_rms.update(torch.as_tensor(ob, device="cuda:0"))
+    ac = rng.randn(n, 28).astype(np.float32)
+    atarg = rng.randn(n).astype(np.float32)
+    p = {k: pi.params[k].detach().cpu().numpy().astype(np.float64) for k in POL_KEYS}
+    rms = TN.Rms(); rms.sum = pi.ob_rms.sum.cpu().numpy().copy(); rms.sumsq = pi.ob_rms.sumsq.cpu().numpy().copy(); rms.count = float(pi.ob_rms.count)
+    learner = TrpoLearner(pi, pg_native=True)
+    return learner, pi, p, rms, ob, ac, atarg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1000, 32 * 256 * 3 + 7])       # a ragged last tile; more tiles than blocks (every block loops) + a ragged tail
+def test_native_policy_gradient_and_fisher_product_match_the_analytic_float64_formulas_on_gpu(n):
+    """dm_pg_losses / dm_pg_fvp against tests/trpo_numpy.py (src/trpo.py:224-230 written out by hand in float64): surrogate gradient at
+    pi == oldpi, F v = J^T Sigma^-1 J v / N_f (+) 2 v on every 5th sample, and the losses at a moved policy — float32 tolerances."""
+    from deepmimic_mujoco_amd.trpo import POL_KEYS
+    from tests import trpo_numpy as TN
+    learner, pi, p, rms, ob, ac, atarg = _pg_case(n)
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(a, device=dev)
+    ob_t, ac_t, at_t = t(ob), t(ac), t(atarg)
+    theta0 = learner.get_flat().contiguous()
+    old_logstd = pi.params["logstd"].detach().reshape(-1).clone()
+    old_mean = torch.empty((n, 28), dtype=torch.float32, device=dev)
+    losses, g = learner._pg_losses(ob_t, ac_t, at_t, old_mean, old_logstd, theta0, write_old=True, with_grad=True)
+    # float64 side
+    x = TN.obz(ob.astype(np.float64), rms)
+    m0, cache = TN.pol_forward(p, x)
+    sig2 = np.exp(2 * p["logstd"])
+    a64, ac64 = atarg.astype(np.float64), ac.astype(np.float64)
+    dmean = a64[:, None] * (ac64 - m0) / sig2 / n
+    dls = (a64[:, None] * ((ac64 - m0) ** 2 / sig2 - 1.0)).sum(0) / n
+    g_ref = TN.pol_backward(p, cache, dmean, dls)
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / np.linalg.norm(b))
+    assert rel(old_mean.cpu().numpy(), m0) < 1e-5
+    assert rel(g.cpu().numpy(), g_ref) < 2e-4, rel(g.cpu().numpy(), g_ref)
+    L = losses.cpu().numpy()
+    assert abs(L[3] - a64.mean()) < 1e-5 and abs(L[1]) < 1e-6 and abs(L[0] - L[3] - L[2]) < 1e-6      # ratio == 1, KL == 0 at pi == oldpi
+    # Fisher-vector product on every 5th sample
+    rng = np.random.RandomState(3)
+    v = rng.randn(theta0.numel()) * np.abs(g_ref).mean()
+    xs = x[::5]; _, cache_f = TN.pol_forward(p, xs)
+    vd = TN.unflat(v, p, POL_KEYS)
+    fv_ref = TN.pol_backward(p, cache_f, TN.pol_jvp(p, cache_f, vd) / sig2 / xs.shape[0], 2.0 * vd["logstd"].reshape(-1))
+    fv = learner._pg_fvp(ob_t, theta0, t(v.astype(np.float32)))
+    assert rel(fv.cpu().numpy(), fv_ref) < 2e-4, rel(fv.cpu().numpy(), fv_ref)
+    v_t = t(v.astype(np.float32))
+    assert float(v_t.dot(fv)) > 0                                             # positive definite along v
+    # ... and against double back-propagation through torch's graph (the path it replaces)
+    learner2_fv = None
+    with torch.enable_grad():
+        mean_f, logstd_f = learner._pd(ob_t[::5])
+        kl_f = learner._kl(old_mean[::5], pi.params["logstd"].detach(), mean_f, logstd_f).mean()
+        klg = torch.cat([q.reshape(-1) for q in torch.autograd.grad(kl_f, learner.pol, create_graph=True)])
+        learner2_fv = torch.cat([q.reshape(-1) for q in torch.autograd.grad(klg.dot(v_t), learner.pol)])
+    assert rel(fv.cpu().numpy(), learner2_fv.double().cpu().numpy()) < 5e-4
+    # losses at a moved policy (the line search's evaluation, :262-283)
+    step = 0.05 * rng.randn(theta0.numel()) / np.sqrt(theta0.numel())
+    q = dict(p); q.update(TN.unflat(TN.flat(p, POL_KEYS) + step, p, POL_KEYS))
+    m1, _ = TN.pol_forward(q, x)
+    ratio = np.exp(TN.neglogp(ac64, m0, p["logstd"]) - TN.neglogp(ac64, m1, q["logstd"]))
+    surr_ref, kl_ref = float((ratio * a64).mean()), float(TN.kl(m0, p["logstd"], m1, q["logstd"]).mean())
+    theta1 = (theta0.double() + t(step)).float().contiguous()
+    l1, _ = learner._pg_losses(ob_t, ac_t, at_t, old_mean, old_logstd, theta1, write_old=False, with_grad=False)
+    l1 = l1.cpu().numpy()
+    assert abs(l1[3] - surr_ref) < 2e-4 * max(1.0, abs(surr_ref)) and abs(l1[1] - kl_ref) < 2e-4 * max(1e-2, kl_ref), (l1, surr_ref, kl_ref)
+    # deterministic: the same launch twice gives the same bits
+    _, g2 = learner._pg_losses(ob_t, ac_t, at_t, old_mean, old_logstd, theta0, write_old=False, with_grad=True)
+    assert torch.equal(g, g2) and torch.equal(fv, learner._pg_fvp(ob_t, theta0, v_t))
+
+
+@pytest.mark.gpu
+def test_learner_update_through_torch_autograd_matches_the_float64_restatement_on_gpu():
+    """The path the kernels replace stays covered on the device (multi-backend fallback of the learner: pg_native=False)."""
+    _check_against_golden(*_golden_update("cuda:0", pg_native=False))

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--log-dir", default=None, help="write progress.csv and monitor.csv in the reference's formats")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL, one GPU per rank; gloo = ranks may share a GPU (LOCAL_RANK modulo the visible devices)")
+    ap.add_argument("--no-pg-native", action="store_true", help="policy half of the update through torch autograd instead of csrc/pg_kernel.h")
     ap.add_argument("--dump-params", default=None, help="every rank writes its final parameters to <prefix>.rank<r>.npz (replica-consistency checks)")
     ap.add_argument("--save", default=None, help="write the trained policy: `x.npz` (reference variable names) or a checkpoint prefix -> "
                                                  "tf.train.Saver bundle (x.index + x.data-00000-of-00001) the reference's `--task evaluate --load_model_path x` restores")
@@ -82,7 +83,7 @@ def main():
     pi = MlpPolicy(device=dev, seed=args.seed); pi.seed(args.seed + 10000 * rank)
     hist = learn(env, pi, timesteps_per_batch=args.horizon, max_seconds=args.seconds if not args.iters else 0, max_iters=args.iters,
                  vf_batch_size=args.vf_batch, vf_stepsize=args.vf_stepsize, max_kl=args.max_kl, seed=args.seed, log_dir=args.log_dir,
-                 fused=False if args.unfused else None)
+                 fused=False if args.unfused else None, pg_native=False if args.no_pg_native else None)
     if args.dump_params:
         os.makedirs(os.path.dirname(os.path.abspath(args.dump_params)), exist_ok=True)
         pi.save_npz("%s.rank%d.npz" % (args.dump_params, rank))
