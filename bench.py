@@ -346,6 +346,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (N = 1 only; they add about a minute)")
     ap.add_argument("--no-gym-loop", action="store_true", help="skip the single-env Python DPEnv.step loop (N = 1 only; ~3 s)")
     ap.add_argument("--prewarm-horizons", type=int, default=6, help="untimed 256-step horizons before the warm-up steps (cold-box clock ramp, ~1 s)")
+    ap.add_argument("--packed", type=int, default=None, choices=[0, 1], help="DM option 105: four environments per wavefront (k_step_packed) where that kernel covers the workload (default: the library's)")
     ap.add_argument("--no-reorder", action="store_true", help="experiment: identity dispatch order instead of longest-first (DM option 104 = 0)")
     ap.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)   # profiled child of pmc_passes: GPU loop only, prints nothing
     args = ap.parse_args()
@@ -403,6 +404,8 @@ def main():
     env.batch.set_option(A.OPT_PIPELINE, max(1, min(args.pipeline, A.MAX_PIPELINE)))
     if args.no_reorder:
         env.batch.set_option(104, 0)
+    if args.packed is not None:
+        env.batch.set_option(105, args.packed)
 
     with torch.cuda.stream(stream):
         gen = torch.Generator(device=dev); gen.manual_seed(1234 + shard)

@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
-SOURCES = ["dmenv.hip", "env_kernel.h", "env_step.h", "model_host.h", "topology.h", "wave.h", "policy_kernel.h", "vf_kernel.h", "pg_kernel.h"]
+SOURCES = ["dmenv.hip", "env_kernel.h", "env_step.h", "model_host.h", "topology.h", "wave.h", "policy_kernel.h", "vf_kernel.h", "pg_kernel.h", "slot_kernel.h", "slot_step.h"]
 OUT = os.path.join(HERE, "libdmenv.so")
 
 

@@ -18,6 +18,7 @@
 #include "vf_kernel.h"
 #include "pg_kernel.h"
 #include "env_step.h"
+#include "slot_step.h"
 #include "model_host.h"
 
 using namespace dm;
@@ -83,6 +84,22 @@ __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ 
   const int env = blockIdx.x;
   if (env >= B.n_envs) return;
   env_step<Real, MAXEFC>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
+}
+
+// FOUR environments per wavefront (slot_kernel.h / slot_step.h): workgroup w steps the envs at dispatch positions first + 4 w .. + 3.
+__global__ __launch_bounds__(64) void k_step_packed(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
+                                                    Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
+                                                    int n_substeps, int first, int count) {
+  __shared__ SlotShared<Real> sh[SLOTS];
+  __shared__ SlotTables tb;
+  const int lane = dmw::lane(), slot = lane >> 4, sl = lane & 15;
+  stage_slot_tables(tb, lane);
+  const int last = first + count - 1;
+  int pos = first + SLOTS * (int)blockIdx.x + slot;
+  const bool live = pos <= last;
+  if (pos > last) pos = last;
+  const int env = B.order ? B.order[pos] : pos;
+  slot_env_step<Real>(*Mp, B, sh[slot], tb, env, sl, live, action, obs, reward, done, n_substeps);
 }
 
 // (Measured alternatives: having the launch's LAST workgroup sort the order before it exits — a device-scope counter, no ordering launch at
@@ -234,6 +251,7 @@ struct dm_batch {
   Ext *d_qpos_in = nullptr, *d_qvel_in = nullptr; int* d_fidx_in = nullptr;
   double* d_debug = nullptr;
   long long* d_prof = nullptr; bool prof = false;
+  bool packed = false;   // option 105: four environments per wavefront (k_step_packed) where that kernel covers the configuration
   bool two_tier = true, reorder = true, has_rows = true; int resident_waves = 2048;   // CUs x 8 single-wave workgroups (LDS-limited)
   bool timing = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f; bool ev_pending = false;
   // pipelined sub-batches (DM_OPT_PIPELINE): the env range is cut into `pipe` contiguous parts, each stepped on its own stream
@@ -399,6 +417,7 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
       b->B.order = nullptr;   /* the stored dispatch order belongs to the previous partition: identity for the next launch */
       break;
     }
+    case 105: b->packed = v != 0; break;        /* 1: four environments per wavefront (k_step_packed) where it covers the configuration */
     case 104: b->reorder = v != 0; if (!b->reorder) b->B.order = nullptr; break;   /* 1 (default): longest-first dispatch order (k_order) */
     case 100: b->B.env_offset = (int)v; break;  /* global id of env 0 (multi-GPU sharding) */
     case 102: b->two_tier = v != 0; break;       /* 1 (default): register tier of NARROW_ROWS columns + overflow strip; 0: all 64 columns in registers */
@@ -471,6 +490,8 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
   if (!piped && pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
   if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } if (!piped) HIPCHK(hipEventRecord(b->ev0, b->stream)); }
   const bool reorder = b->reorder && b->has_rows && b->n > b->resident_waves;   // more envs than resident waves: later rounds exist, their tail matters
+  // the packed kernel covers: models without constraint rows, reward modes alive / v3-config / v2-pose, no fused policy step
+  const bool use_packed = b->packed && !b->has_rows && b->B.reward_mode <= 2 && !pol && !b->prof && b->two_tier;
   if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, b->d_prof);
   else if (piped) {
     // Sub-batch h's launch of THIS call depends on its own launch of the previous call (stream order on ps[h]) and on the
@@ -484,6 +505,7 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
       HIPCHK(hipStreamWaitEvent(b->ps[h], b->ev_in, 0));
       if (b->timing && h == 0) HIPCHK(hipEventRecord(b->ev0, b->ps[0]));     // timing: sub-batch 0's kernel on ITS stream
       if (pol) hipLaunchKernelGGL(k_step_act, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, *pol);
+      else if (use_packed) hipLaunchKernelGGL(k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo);
       else hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo);
       if (b->timing && h == 0) { HIPCHK(hipEventRecord(b->ev1, b->ps[0])); b->ev_pending = true; }
       if (reorder) hipLaunchKernelGGL(k_order_wave, dim3(1), dim3(64), 0, b->ps[h], b->B, b->d_order, lo, hi - lo);
@@ -493,6 +515,7 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     b->pipe_pending = true;
   } else if (b->two_tier) {
     if (pol) hipLaunchKernelGGL(k_step_act, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, *pol);
+    else if (use_packed) hipLaunchKernelGGL(k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n);
     else hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0);
     if (reorder) {
       // (with a pipeline depth configured, every sub-batch's range is sorted on its own: a later pipelined launch reads order[lo..hi)

@@ -1,0 +1,209 @@
+// slot_step.h — DPEnv.step for the four-environments-per-wavefront layout of slot_kernel.h: RK4 driver with the accumulators in
+// registers (dof d lives in slot lane d % 16, register d / 16), the env epilogue (obs / reward / done, src/dp_env_v3.py:115-132)
+// and the auto-reset.  `sl` = lane inside the slot, `env` = the slot's environment, `live` = the slot holds a real environment (the
+// last wave of a launch may carry fewer than four: its spare slots recompute the last one and store nothing).
+#pragma once
+
+#include "env_step.h"
+#include "slot_kernel.h"
+
+namespace dm {
+
+// dof-distributed register vectors: element d of a 34- (35-) vector is r[d / 16] of slot lane d % 16
+template <class R> struct DofVec { R r[DOF_PASSES]; };
+
+// [MJ mj_integratePos] s.qpos <- x0q (+) h * dv with dv in s.tau.  Collective (row broadcasts): every lane calls it.
+template <class R>
+DM_DEV void slot_integrate_pos(SlotShared<R>& s, const DofVec<R>& x0q, int sl, R h) {
+  // the root quaternion's four components sit in lanes 3..6 of register 0
+  const R q0 = dmw::row_bcast<3>(x0q.r[0]), q1 = dmw::row_bcast<4>(x0q.r[0]), q2 = dmw::row_bcast<5>(x0q.r[0]), q3 = dmw::row_bcast<6>(x0q.r[0]);
+  if (sl < 3) s.qpos[sl] = x0q.r[0] + h * s.tau[sl];
+  else if (sl == 3) {
+    R ax[3] = {s.tau[3], s.tau[4], s.tau[5]}, q[4] = {q0, q1, q2, q3}, qr[4];
+    const R angle = h * normalize3(ax);
+    if (angle == R(0)) { qr[0] = 1; qr[1] = qr[2] = qr[3] = 0; } else axisangle2quat(qr, ax, angle);
+    normalize4(q);
+    quat_mul(q, q, qr);
+    s.qpos[3] = q[0]; s.qpos[4] = q[1]; s.qpos[5] = q[2]; s.qpos[6] = q[3];
+  } else if (sl >= 7) s.qpos[sl] = x0q.r[0] + h * s.tau[sl - 1];
+#pragma unroll
+  for (int c = 1; c < Q_PASSES; c++) { const int i = sl + SW * c; if (i < NQ) s.qpos[i] = x0q.r[c] + h * s.tau[i - 1]; }
+}
+
+// [MJ mj_step, integrator RK4] on the state in s.qpos / s.qvel / s.qws / s.act; xip = body COM positions of the 4th stage evaluation
+template <class R>
+DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, const LaneTopo& lt, R* xip) {
+  const R h = M.timestep;
+  const R A[3] = {R(0.5), R(0.5), R(1)};
+  const R Bw[4] = {R(1) / 6, R(1) / 3, R(1) / 3, R(1) / 6};
+  DofVec<R> x0q, x0v, vprev, aprev, sumv, suma;
+#pragma unroll
+  for (int c = 0; c < DOF_PASSES; c++) {
+    const int i = sl + SW * c;
+    x0q.r[c] = i < NQ ? s.qpos[i] : R(0);
+    const R v0 = i < NV ? s.qvel[i] : R(0);
+    x0v.r[c] = v0; vprev.r[c] = v0; aprev.r[c] = 0; sumv.r[c] = 0; suma.r[c] = 0;
+  }
+  dmw::sync();
+  for (int i = 0; i < 4; i++) {   // single call site of the forward evaluation
+    if (i > 0) {
+      const R cf = A[i - 1];
+#pragma unroll
+      for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) s.tau[d] = cf * vprev.r[c]; }
+      dmw::sync();
+      slot_integrate_pos(s, x0q, sl, h);
+#pragma unroll
+      for (int c = 0; c < DOF_PASSES; c++) {
+        const int d = sl + SW * c;
+        if (d < NV) { const R vi = x0v.r[c] + h * (cf * aprev.r[c]); vprev.r[c] = vi; s.qvel[d] = vi; }
+      }
+      dmw::sync();
+    }
+    slot_forward<R>(M, s, tb, sl, lt, xip, (const DebugOut*)0);
+#pragma unroll
+    for (int c = 0; c < DOF_PASSES; c++) {
+      const int d = sl + SW * c;
+      if (d < NV) { const R a = s.qacc[d]; aprev.r[c] = a; sumv.r[c] += Bw[i] * vprev.r[c]; suma.r[c] += Bw[i] * a; }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) s.tau[d] = sumv.r[c]; }
+  dmw::sync();
+  slot_integrate_pos(s, x0q, sl, h);
+#pragma unroll
+  for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) { s.qvel[d] = x0v.r[c] + h * suma.r[c]; s.qws[d] = aprev.r[c]; } }
+  dmw::sync();
+}
+
+// load the slot's env row (each slot reads 128-byte runs of its own row) and turn the action into actuator forces
+template <class R>
+DM_DEV void slot_load_env(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, int env, int sl, bool live, const double* action) {
+#pragma unroll
+  for (int c = 0; c < Q_PASSES; c++) {
+    const int i = sl + SW * c;
+    if (i < NQ) s.qpos[i] = B.qpos[(size_t)env * NQ + i];
+    if (i < NV) { s.qvel[i] = B.qvel[(size_t)env * NV + i]; s.qws[i] = B.qws[(size_t)env * NV + i]; s.act[i] = 0; }
+  }
+  if (sl == 0) { s.status = 0; s.nefc = 0; s.ncon = 0; s.solver_iter = 0; }
+  dmw::sync();
+  if (action) {
+#pragma unroll
+    for (int c = 0; c < HINGE_PASSES; c++) {
+      const int u = sl + SW * c;
+      if (u < NU) {
+        R a = (R)action[(size_t)env * NU + u];
+        if (B.action_mode == 1) {
+          const int idx = B.frame_idx[env];
+          a += R(0.8) * (B.mocap_cfg[(size_t)idx * NQ + 7 + u] - s.qpos[7 + u]);
+        } else if (B.action_mode == 2) {
+          const int idx = B.frame_idx[env];
+          a += M.kp[u + 6] * (B.mocap_cfg[(size_t)idx * NQ + 7 + u] - s.qpos[7 + u]) + M.kd[u + 6] * (B.mocap_vel[(size_t)idx * NV + 6 + u] - s.qvel[6 + u]);
+        }
+        if (live) B.ctrl[(size_t)env * NU + u] = a;
+        const int d = u + 6;
+        s.act[d] = M.gear[d] * clampr(a, M.ctrl_lo[d], M.ctrl_hi[d]);
+      }
+    }
+  }
+  dmw::sync_mem();
+}
+
+template <class R>
+DM_DEV void slot_store_state(const Batch<R>& B, SlotShared<R>& s, int env, int sl, bool live) {
+  if (!live) return;
+#pragma unroll
+  for (int c = 0; c < Q_PASSES; c++) {
+    const int i = sl + SW * c;
+    if (i < NQ) B.qpos[(size_t)env * NQ + i] = s.qpos[i];
+    if (i < NV) { B.qvel[(size_t)env * NV + i] = s.qvel[i]; B.qws[(size_t)env * NV + i] = s.qws[i]; }
+  }
+}
+
+// reset variants of env_step.h's reset_env for the slots whose `doit` is set (collective: every lane calls it; barriers are unconditional)
+template <class R>
+DM_DEV void slot_reset_env(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, int env, int sl, bool doit, int mode, int hard) {
+  const int ep = B.episode[env];
+  const int genv = B.env_offset + env;
+  int idx = (int)(rng_uniform(B.seed, genv, ep, 0) * (double)B.n_frames);
+  if (idx >= B.n_frames) idx = B.n_frames - 1;
+  if (doit) {
+#pragma unroll
+    for (int c = 0; c < Q_PASSES; c++) {
+      const int i = sl + SW * c;
+      if (mode == 0) {
+        if (i < NQ) s.qpos[i] = B.mocap_cfg[(size_t)idx * NQ + i];
+        if (i < NV) s.qvel[i] = B.mocap_vel[(size_t)idx * NV + i];
+      } else if (mode == 1) {
+        if (i < NQ) s.qpos[i] = M.qpos0[i] + (R)((rng_uniform(B.seed, genv, ep, 1 + i) * 2.0 - 1.0) * 0.01);
+        if (i < NV) s.qvel[i] = (R)((rng_uniform(B.seed, genv, ep, 64 + i) * 2.0 - 1.0) * 0.01);
+      } else {
+        if (i < NQ) s.qpos[i] = M.qpos0[i];
+        if (i < NV) s.qvel[i] = 0;
+      }
+      if (hard && i < NV) s.qws[i] = 0;
+    }
+    if (hard && sl == 0) B.time[env] = 0;
+  }
+  dmw::sync_mem();
+  if (doit && sl == 0) {
+    B.episode[env] = ep + 1;
+    if (mode == 0 || (mode == 1 && hard)) set_frame(B, env, idx); else B.cycle[env] = 0;
+  }
+}
+
+// DPEnv.step for the slot's environment (reward modes alive / v3-config / v2-pose; the imitation modes live in the one-env kernel until
+// their epilogue is ported).  Returns nothing: a slot that is not `live` computes and stores nothing outside LDS.
+template <class R>
+DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, SlotTables& tb, int env, int sl, bool live,
+                          const double* action, double* obs, double* reward, unsigned char* done, int n_substeps) {
+  const LaneTopo lt = lane_topo(sl);
+  slot_load_env(M, B, s, env, sl, live, action);
+  R xip[3];
+  for (int k = 0; k < n_substeps; k++) slot_rk4_step<R>(M, s, tb, sl, lt, xip);
+  // COM height of the 4th-stage body positions (src/dp_env_v3.py:134-139): mass-weighted sum over the body lanes
+  const R mz = sl < NB - 1 ? M.body_mass[sl + 1] * xip[2] : R(0);
+  const R z = dmw::sum16(mz) / M.total_mass;
+  bool dn = (z < R(0.7)) || (z > R(2.0));
+  if (live) {
+    if (B.diag != 0) {
+      if (sl < NB - 1) for (int k = 0; k < 3; k++) B.xipos[(size_t)env * NB * 3 + 3 * (sl + 1) + k] = xip[k];
+      if (sl < 3) B.xipos[(size_t)env * NB * 3 + sl] = 0;
+      for (int k = sl; k < MAXEFC * 2; k += SW) B.cong[(size_t)env * MAXEFC * 2 + k] = -1;
+    }
+    if (sl == 0) { B.comz[env] = z; B.ncon[env] = s.ncon; B.nefc[env] = s.nefc; B.status[env] = s.status; B.solver_iter[env] = s.solver_iter; }
+  }
+  R rew = 1;
+  if (B.reward_mode == REW_V3_CONFIG) {
+    const int idx = B.frame_idx[env];
+    R err = 0;
+    for (int i = 7; i < NQ; i++) err += fabs(s.qpos[i] - B.mocap_cfg[(size_t)idx * NQ + i]);
+    rew = exp_once(-err);
+    dmw::sync_mem();
+    if (live && sl == 0) B.frame_idx[env] = (idx + 1) % B.n_frames;
+  } else if (B.reward_mode == REW_V2_POSE) {
+    const int idx = B.frame_idx[env] + 1;
+    const int im = (idx + B.frame_init[env]) % B.n_frames;
+    R err = 0, acs = 0;
+    for (int i = 3; i < NQ; i++) err += fabs(s.qpos[i] - B.mocap_cfg[(size_t)im * NQ + i]);
+    for (int u = 0; u < NU; u++) { const R c = B.ctrl[(size_t)env * NU + u]; acs += c * c; }
+    rew = exp_once(R(-2) * err) - R(0.1) * acs;
+    dmw::sync_mem();
+    if (live && sl == 0) B.frame_idx[env] = idx;
+  }
+  if (live && sl == 0) { B.time[env] += M.timestep * n_substeps; reward[env] = rew; done[env] = dn ? 1 : 0; if (B.kin) B.kin_ok[env] = 0; }
+  if (B.autoreset) {                              // DummyVecEnv convention: obs of the fresh episode is returned
+    dmw::sync_mem();
+    slot_reset_env(M, B, s, env, sl, dn && live, B.autoreset == 1 ? 0 : 1, 1);
+  }
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < (NOBS + SW - 1) / SW; c++) {
+      const int o = sl + SW * c;
+      if (o < 28) obs[(size_t)env * NOBS + o] = s.qpos[7 + o];
+      else if (o < NOBS) obs[(size_t)env * NOBS + o] = s.qvel[6 + (o - 28)];
+    }
+  }
+  slot_store_state(B, s, env, sl, live);
+}
+
+}  // namespace dm

@@ -121,6 +121,24 @@ DM_DEV void reload_fence() { asm volatile("" ::: "memory"); }
 // Called by all lanes (the testbench implements it as a collective).
 DM_DEV void lds_sub(bool pred, double* p, double v) { if (pred) __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DM_DEV void lds_sub(bool pred, float* p, float v) { if (pred) __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// ---- 16-lane env slots (slot_kernel.h: four environments per wavefront, one DPP row each) -------------------------------------
+// row broadcast: every lane gets the value of lane I of ITS OWN 16-lane row — one v_mov_b64_dpp row_newbcast (gfx90a+), for all
+// four rows (= four environments) at once.  I is a compile-time lane number.
+template <int I> DM_DEV double row_bcast(double v) {
+  long long x = __double_as_longlong(v);
+  x = __builtin_amdgcn_update_dpp(0ll, x, 0x150 + I, 0xf, 0xf, true);
+  return __longlong_as_double(x);
+}
+template <int I> DM_DEV float row_bcast(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + I, 0xf, 0xf, true)); }
+template <int I> DM_DEV int row_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + I, 0xf, 0xf, true); }
+// acc += (lane I of the row's x) * y as ONE instruction: v_fmac_f64 with a DPP source (the only f64 arithmetic with a DPP form on
+// gfx950).  The leading s_nop covers the VALU-write -> DPP-read hazard, which the compiler cannot see through inline assembly.
+template <int I> DM_DEV void row_fmac(double& acc, double x, double y) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(I));
+}
+template <int I> DM_DEV void row_fmac(float& acc, float x, float y) { acc += row_bcast<I>(x) * y; }
+// this lane's 16 bits of a wave ballot (bit i = lane i of the own row)
+DM_DEV unsigned row_ballot(bool p, int lane_id) { return (unsigned)((__ballot(p) >> (lane_id & 48)) & 0xffffull); }
 }  // namespace dmw
 #endif
 

@@ -12,6 +12,7 @@
 #include "wave_testbench.h"
 // kernel source, unmodified
 #include "env_step.h"
+#include "slot_step.h"
 #include "model_host.h"
 
 namespace dmw {
@@ -57,7 +58,9 @@ struct EmuBatch {
   Batch<double> B;
   std::vector<double> qpos, qvel, qws, time, ctrl, xipos, comz, cfg, vel, aovf, imit, kin;
   std::vector<unsigned char> kin_ok;
-  bool two_tier = true;
+  bool two_tier = true, packed = false;
+  SlotShared<double> slots[SLOTS];
+  SlotTables slot_tabs;
   std::vector<int> fidx, finit, ncon, nefc, cong, status, siter, episode, cycle;
   Shared<double> sh;
   StepScratch<double> xs;
@@ -105,6 +108,7 @@ void emu_set_option(void* h, int opt, long long v) {
   else if (opt == DM_OPT_DIAGNOSTICS) e->B.diag = v != 0;
   else if (opt == 100) e->B.env_offset = (int)v;
   else if (opt == 102) e->two_tier = v != 0;
+  else if (opt == 105) e->packed = v != 0;
   else if (opt == 103) e->M.pgs_detect = v ? -1e300 : 1e-10;
 }
 void* emu_field(void* h, int field) {
@@ -121,6 +125,20 @@ void* emu_field(void* h, int field) {
 }
 void emu_step(void* h, const double* action, double* obs, double* reward, unsigned char* done, int nsub) {
   EmuBatch* e = (EmuBatch*)h;
+  const bool has_rows = e->M.enable_contact || e->M.enable_limit;
+  if (e->packed && !has_rows && e->B.reward_mode <= 2) {          // the device's routing (dmenv.hip step_impl): four envs per wave
+    const int n = e->B.n_envs;
+    for (int first = 0; first < n; first += SLOTS)
+      run_wave([&](int lane) {
+        const int slot = lane >> 4, sl = lane & 15;
+        stage_slot_tables(e->slot_tabs, lane);
+        int pos = first + slot;
+        const bool live = pos < n;
+        if (!live) pos = n - 1;
+        slot_env_step<double>(e->M, e->B, e->slots[slot], e->slot_tabs, pos, sl, live, action, obs, reward, done, nsub);
+      });
+    return;
+  }
   for (int env = 0; env < e->B.n_envs; env++)
   {
     // same scheme as the device: register tier (32 columns of A here, so that the overflow strip is exercised by every

@@ -112,6 +112,11 @@ template <class T> inline void lds_sub(bool pred, T* p, T v) {
   if (lane() == 0) for (int l = 0; l < 64; l++) if (bench().aptr[l]) *(T*)bench().aptr[l] -= (T)bench().aval[l];
   rendezvous();
 }
+// 16-lane env slots (wave.h): row-relative broadcast / fused multiply-add / ballot
+template <int I, class T> inline T row_bcast(T v) { return exchange(v, (lane() & 48) | I); }
+template <int I> inline int row_bcast_i(int v) { return exchange(v, (lane() & 48) | I); }
+template <int I, class T> inline void row_fmac(T& acc, T x, T y) { acc = std::fma(row_bcast<I>(x), y, acc); }
+inline unsigned row_ballot(bool p, int lane_id) { return (unsigned)((ballot(p) >> (lane_id & 48)) & 0xffffull); }
 inline int pin_zero() { return 0; }
 inline int launder(int v) { return v; }
 inline int launder_uniform(int v) { return v; }

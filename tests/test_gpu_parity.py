@@ -479,3 +479,30 @@ def test_float32_batch_full_size_rollout_and_shipped_policy_anchor():
         e.close()
     print("shipped policy, first-episode length: float64 %.1f, float32 %.1f" % (lens[64], lens[32]))
     assert abs(lens[32] / lens[64] - 1) < 0.15 and 200 < lens[32] < 360
+
+
+# ---- four environments per wavefront (csrc/slot_kernel.h, DM option 105) ------------------------------------------------------------
+@pytest.mark.parametrize("n", [13, 64])          # a last wave with spare slots; whole waves
+def test_packed_kernel_matches_oracle_on_the_rowless_model_config2(n):
+    """BASELINE.json configs[1] (contacts / limits off) through k_step_packed — four envs per wave, one 16-lane DPP row each — against
+    the oracle, all three frame-indexed reward modes it covers; and against the one-env-per-wave kernel to rounding."""
+    flags = A.FLAG_NO_CONTACT | A.FLAG_NO_LIMIT
+    om = H.oracle_model(enable_contact=0, enable_limit=0)
+    idx, q, v, _ws, _c = H.varied_states(n, seed=7)
+    for mode in (0, 1, 2):
+        b = make_batch(n, flags=flags)
+        b.set_option(105, 1); b.set_option(A.OPT_REWARD_MODE, mode)
+        worst, nd = H.compare_rollout(b, om, idx, q, v, steps=12, seed=2, reward_mode=mode, n_substeps=2 if mode == 1 else 1)
+        assert np.all(b.get(A.F_NEFC) == 0)
+        b.close()
+    outs = []
+    for packed in (1, 0):
+        b = make_batch(n, flags=flags)
+        b.set_option(105, packed); b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, 3); b.set_option(A.OPT_ACTION_MODE, 1)
+        b.reset(0, 1)
+        rng = np.random.RandomState(0)
+        o = [b.step(rng.randn(n, 28) * 0.3)[0].copy() for _ in range(8)]
+        outs.append((np.stack(o), b.get(A.F_QPOS), b.get(A.F_EPISODE), b.get(A.F_XIPOS), b.get(A.F_COM_Z)))
+        b.close()
+    for x, y in zip(outs[0], outs[1]):
+        assert H.rel_err(x, y) < 1e-11

@@ -185,3 +185,20 @@ def test_pgs_guarded_replay_path_gives_identical_results():
         outs.append((np.stack(o), b.get(A.F_SOLVER_ITER).copy(), b.get(A.F_QACC_WARMSTART).copy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
     assert outs[0][1].max() > 1
+
+
+def test_packed_slots_match_oracle_on_the_rowless_model():
+    """slot_kernel.h / slot_step.h (four environments per wavefront, one 16-lane row each) executed on the fibre testbench: rollouts of
+    the contact-free, limit-free model (BASELINE.json configs[1]) against the oracle in the three reward modes the packed epilogue
+    covers; 6 envs = one full wave + one wave with two spare slots."""
+    from tests.emu.emu import EmuBatch
+    mc = H.mocap()
+    n = 6
+    flags = A.FLAG_NO_CONTACT | A.FLAG_NO_LIMIT
+    idx, q, v, _ws, _c = H.varied_states(n, seed=7)
+    om = H.oracle_model(enable_contact=0, enable_limit=0)
+    for mode in (0, 1, 2):
+        b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, flags)
+        b.set_option(105, 1); b.set_option(A.OPT_REWARD_MODE, mode)
+        worst, _nd = H.compare_rollout(b, om, idx, q, v, steps=5, seed=2, reward_mode=mode, n_substeps=2 if mode == 1 else 1)
+        assert worst < 1e-12
