@@ -90,7 +90,7 @@ LIB_PATH = os.environ.get("DMENV_LIB") or os.path.join(_HERE, "csrc", "libdmenv.
 EXPORTS = ["dm_model_create", "dm_model_destroy", "dm_mocap_create", "dm_mocap_set_imitation", "dm_mocap_destroy", "dm_batch_create",
            "dm_batch_destroy", "dm_batch_set_stream", "dm_batch_set_option", "dm_batch_set_state", "dm_batch_reset",
            "dm_batch_step", "dm_batch_get_obs", "dm_batch_get", "dm_batch_set", "dm_batch_debug_forward",
-           "dm_batch_last_step_ms", "dm_batch_enable_timing", "dm_batch_read_profile", "dm_batch_sync", "dm_batch_join", "dm_policy_weight_count", "dm_policy_act", "dm_batch_step_act", "dm_vf_param_count", "dm_vf_scratch_bytes", "dm_vf_fit_epoch", "dm_pg_param_count", "dm_pg_scratch_bytes", "dm_pg_losses", "dm_pg_fvp", "dm_gae", "dm_last_error", "dm_abi_version", "dm_real_bits",
+           "dm_batch_last_step_ms", "dm_batch_enable_timing", "dm_batch_read_profile", "dm_batch_sync", "dm_batch_join", "dm_policy_weight_count", "dm_policy_act", "dm_batch_step_act", "dm_vf_param_count", "dm_vf_scratch_bytes", "dm_vf_fit_epoch", "dm_pg_param_count", "dm_pg_scratch_bytes", "dm_pg_losses", "dm_pg_fvp", "dm_batch_redo_total", "dm_gae", "dm_last_error", "dm_abi_version", "dm_real_bits",
            "dm_device_count"]
 _LIB = None
 
@@ -139,6 +139,7 @@ def load(dtype=64):
     L.dm_batch_join.argtypes = [vp]
     L.dm_policy_act.argtypes = [vp, vp, vp, vp, i32, i32, C.c_uint64, C.c_uint64, vp]
     L.dm_vf_scratch_bytes.argtypes = [i32]; L.dm_vf_scratch_bytes.restype = C.c_size_t
+    L.dm_batch_redo_total.argtypes = [vp, C.POINTER(C.c_int64)]
     L.dm_pg_scratch_bytes.argtypes = []; L.dm_pg_scratch_bytes.restype = C.c_size_t
     L.dm_pg_losses.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]
     L.dm_pg_fvp.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]

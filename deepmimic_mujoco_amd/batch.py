@@ -193,6 +193,12 @@ class Batch(object):
         A.check(self._L.dm_batch_read_profile(self._h, out.ctypes.data_as(C.POINTER(C.c_longlong))), self._L)
         return out
 
+    def redo_total(self):
+        """env-steps the four-envs-per-wave path (option 105) handed to the one-env kernel so far"""
+        v = C.c_int64(0)
+        A.check(self._L.dm_batch_redo_total(self._h, C.byref(v)), self._L)
+        return int(v.value)
+
     def sync(self):
         A.check(self._L.dm_batch_sync(self._h), self._L)
 

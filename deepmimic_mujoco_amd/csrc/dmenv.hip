@@ -87,9 +87,10 @@ __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ 
 }
 
 // FOUR environments per wavefront (slot_kernel.h / slot_step.h): workgroup w steps the envs at dispatch positions first + 4 w .. + 3.
+// Environments that exceed a capacity of that path are appended to the sub-batch's redo list instead of being stored ...
 __global__ __launch_bounds__(64) void k_step_packed(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                                     Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
-                                                    int n_substeps, int first, int count) {
+                                                    int n_substeps, int first, int count, int* __restrict__ redo_count) {
   __shared__ SlotShared<Real> sh[SLOTS];
   __shared__ SlotTables tb;
   const int lane = dmw::lane(), slot = lane >> 4, sl = lane & 15;
@@ -99,7 +100,21 @@ __global__ __launch_bounds__(64) void k_step_packed(const DevModel<Real>* __rest
   const bool live = pos <= last;
   if (pos > last) pos = last;
   const int env = B.order ? B.order[pos] : pos;
-  slot_env_step<Real>(*Mp, B, sh[slot], tb, env, sl, live, action, obs, reward, done, n_substeps);
+  slot_env_step<Real>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first);
+}
+// ... and stepped here, from their unchanged state, by the one-env code (a handful of persistent single-wave workgroups walk the list)
+__global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_redo(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
+                                                  Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
+                                                  int n_substeps, int first, const int* __restrict__ redo_count) {
+  __shared__ Shared<Real> s;
+  __shared__ StepScratch<Real> x;
+  const int n = dmw::uniform(*redo_count);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n > 0) atomicAdd(B.redo_why, n);       // running total (dm_batch_redo_total)
+  for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+    const int env = B.redo_list[first + i];
+    env_step<Real, NARROW_ROWS>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
+    dmw::sync_mem();
+  }
 }
 
 // (Measured alternatives: having the launch's LAST workgroup sort the order before it exits — a device-scope counter, no ordering launch at
@@ -311,7 +326,7 @@ extern "C" void dm_batch_destroy(dm_batch* b) {
   if (b->ev_in) hipEventDestroy(b->ev_in);
   void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
                   b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
-                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order, b->B.kin, b->B.kin_ok};
+                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order, b->B.kin, b->B.kin_ok, b->B.redo_list, b->B.redo_count, b->B.redo_why};
   for (void* p : ptrs) if (p) hipFree(p);
   if (b->h_out) hipHostFree(b->h_out);
   if (b->h_action) hipHostFree(b->h_action);
@@ -353,6 +368,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   ok = ok && hipHostMalloc((void**)&b->h_action, (size_t)n * NU * sizeof(Ext), hipHostMallocDefault) == hipSuccess;
   A(b->B.aovf, (size_t)n * AOVF_COLS * 64);
   A(b->B.kin, (size_t)n * KIN_DOUBLES); A(b->B.kin_ok, n);
+  A(b->B.redo_list, n); A(b->B.redo_count, DM_MAX_PIPELINE); A(b->B.redo_why, 8);
   A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
   if (sizeof(Real) != sizeof(Ext)) A(b->d_cvt, (size_t)n * NB * 3);   // largest Real field per env: xipos (42)
 #undef A
@@ -378,6 +394,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   if (!ok) { dm_batch_destroy(b); return fail(DM_EHIP, "dm_batch_create: upload failed"); }
   b->B.mocap_cfg = b->d_cfg; b->B.mocap_vel = b->d_vel; b->B.mocap_dt = mc->dt; b->B.n_frames = mc->n_frames; b->B.n_envs = n; b->B.env_offset = 0;
   b->B.reward_mode = 0; b->B.autoreset = 0; b->B.action_mode = 0; b->B.seed = 0; b->B.diag = 1;
+  { const char* ev = getenv("DMENV_PACKED"); if (ev) b->packed = atoi(ev) != 0; }     // default of option 105 (test / A-B hook)
   hipEventCreate(&b->ev0); hipEventCreate(&b->ev1);
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) == hipSuccess && cus > 0) b->resident_waves = cus * 4 * DM_STEP_WAVES; }
   *out = b;
@@ -491,7 +508,8 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
   if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } if (!piped) HIPCHK(hipEventRecord(b->ev0, b->stream)); }
   const bool reorder = b->reorder && b->has_rows && b->n > b->resident_waves;   // more envs than resident waves: later rounds exist, their tail matters
   // the packed kernel covers: models without constraint rows, reward modes alive / v3-config / v2-pose, no fused policy step
-  const bool use_packed = b->packed && !b->has_rows && b->B.reward_mode <= 2 && !pol && !b->prof && b->two_tier;
+  const bool use_packed = b->packed && b->B.reward_mode <= 2 && !pol && !b->prof && b->two_tier;
+  constexpr int REDO_BLOCKS = 64;
   if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, b->d_prof);
   else if (piped) {
     // Sub-batch h's launch of THIS call depends on its own launch of the previous call (stream order on ps[h]) and on the
@@ -505,7 +523,11 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
       HIPCHK(hipStreamWaitEvent(b->ps[h], b->ev_in, 0));
       if (b->timing && h == 0) HIPCHK(hipEventRecord(b->ev0, b->ps[0]));     // timing: sub-batch 0's kernel on ITS stream
       if (pol) hipLaunchKernelGGL(k_step_act, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, *pol);
-      else if (use_packed) hipLaunchKernelGGL(k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo);
+      else if (use_packed) {
+        HIPCHK(hipMemsetAsync(b->B.redo_count + h, 0, sizeof(int), b->ps[h]));
+        hipLaunchKernelGGL(k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, b->B.redo_count + h);
+        if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, (const int*)(b->B.redo_count + h));
+      }
       else hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo);
       if (b->timing && h == 0) { HIPCHK(hipEventRecord(b->ev1, b->ps[0])); b->ev_pending = true; }
       if (reorder) hipLaunchKernelGGL(k_order_wave, dim3(1), dim3(64), 0, b->ps[h], b->B, b->d_order, lo, hi - lo);
@@ -515,7 +537,11 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     b->pipe_pending = true;
   } else if (b->two_tier) {
     if (pol) hipLaunchKernelGGL(k_step_act, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, *pol);
-    else if (use_packed) hipLaunchKernelGGL(k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n);
+    else if (use_packed) {
+      HIPCHK(hipMemsetAsync(b->B.redo_count, 0, sizeof(int), b->stream));
+      hipLaunchKernelGGL(k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, b->B.redo_count);
+      if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)b->B.redo_count);
+    }
     else hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0);
     if (reorder) {
       // (with a pipeline depth configured, every sub-batch's range is sorted on its own: a later pipelined launch reads order[lo..hi)
@@ -745,6 +771,16 @@ extern "C" int dm_pg_fvp(const float* ob, int32_t stride, int32_t n, const float
   hipLaunchKernelGGL(dmg::k_pg_reduce, dim3((dmg::NP + 255) / 256), dim3(256), 0, st, (const float*)partial, (const double*)lpart, nblk, (int)dmg::MODE_FVP,
                      0.0f, v, 1.0 / (double)n, out_fv, (double*)nullptr);
   HIPCHK(hipGetLastError());
+  return DM_OK;
+}
+extern "C" int dm_batch_redo_total(dm_batch* b, int64_t* out) {
+  if (!b || !out) return fail(DM_EINVAL, "dm_batch_redo_total: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  int v = 0;
+  HIPCHK(hipMemcpyAsync(&v, b->B.redo_why, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  *out = v;
   return DM_OK;
 }
 extern "C" int dm_batch_join(dm_batch* b) {

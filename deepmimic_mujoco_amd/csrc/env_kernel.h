@@ -738,12 +738,21 @@ DM_DEV void sphere_sphere(PairContacts<R>& pc, const R* c1, R r1, const R* c2, R
 // contact (incident face clipped against the reference face, the 4 deepest clipped vertices within the margin) or one
 // edge-edge contact.  Own algorithm, identical to the oracle's box_box (MuJoCo's mjc_BoxBox is not restated).  Runs in a
 // single lane (the feet pair); the clipping polygons and the contacts are staged in LDS.
+// LDS scratch of the narrow phase, by pointer so that the one-env kernel (Shared) and the four-envs-per-wave kernel (slot_kernel.h)
+// share the routines: box axes [2][3][3] and clipping polygons [2][8][3] of box-box (dynamically indexed), and the staged contacts
+// (dist, pos) [slot][4][4] of the pair types that can yield more than two.
 template <class R>
-DM_DEV void box_box(Shared<R>& s, const R* p1, const R* m1, const R* s1, const R* p2, const R* m2, const R* s2, int slot, R margin,
+struct BoxScratch {
+  R (*axes)[3][3];
+  R (*poly)[8][3];
+  R (*boxc)[4][4];
+};
+template <class R>
+DM_DEV void box_box(const BoxScratch<R>& bx, const R* p1, const R* m1, const R* s1, const R* p2, const R* m2, const R* s2, int slot, R margin,
                     PairContacts<R>& pc) {
   // box axes live in LDS: they are indexed with run-time axis numbers below (register arrays would go to scratch)
-  R (*A)[3] = s.ub.g.axes[0];
-  R (*B)[3] = s.ub.g.axes[1];
+  R (*A)[3] = bx.axes[0];
+  R (*B)[3] = bx.axes[1];
   R aR[3][3];
   for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = m1[3 * k + i]; B[i][k] = m2[3 * k + i]; }
   const R d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
@@ -783,7 +792,7 @@ DM_DEV void box_box(Shared<R>& s, const R* p1, const R* m1, const R* s1, const R
     const R ab = dot3(A[ei], B[ej]), aw = dot3(A[ei], w), bw = dot3(B[ej], w), den = 1 - ab * ab;
     R ta = den > R(1e-12) ? (ab * bw - aw) / den : R(0), tb = den > R(1e-12) ? (bw - ab * aw) / den : R(0);
     ta = clampr(ta, -s1[ei], s1[ei]); tb = clampr(tb, -s2[ej], s2[ej]);
-    R* o = s.boxc[slot][0];
+    R* o = bx.boxc[slot][0];
     o[0] = ebest;
     for (int k = 0; k < 3; k++) o[1 + k] = R(0.5) * ((ca[k] + A[ei][k] * ta) + (cb[k] + B[ej][k] * tb));
     pc.nrm[0] = en[0]; pc.nrm[1] = en[1]; pc.nrm[2] = en[2];
@@ -807,20 +816,20 @@ DM_DEV void box_box(Shared<R>& s, const R* p1, const R* m1, const R* s1, const R
     const R a1 = (c == 0 || c == 3) ? R(1) : R(-1), a2 = (c < 2) ? R(1) : R(-1);
     R rel[3];
     for (int t = 0; t < 3; t++) rel[t] = pi[t] + fs * si[k] * Ri[k][t] + a1 * si[k1] * Ri[k1][t] + a2 * si[k2] * Ri[k2][t] - pr[t];
-    s.ub.g.poly[0][c][0] = dot3(rel, Rr[u]); s.ub.g.poly[0][c][1] = dot3(rel, Rr[v]); s.ub.g.poly[0][c][2] = sgn * dot3(rel, Rr[ax]);
+    bx.poly[0][c][0] = dot3(rel, Rr[u]); bx.poly[0][c][1] = dot3(rel, Rr[v]); bx.poly[0][c][2] = sgn * dot3(rel, Rr[ax]);
   }
   for (int e = 0; e < 4 && np > 0; e++) {
     const int cdim = e / 2;
     const R sg = (e % 2) ? R(-1) : R(1), lim = cdim == 0 ? sr[u] : sr[v];
     int nn = 0;
     for (int a = 0; a < np; a++) {
-      const R* P = s.ub.g.poly[cur][a]; const R* Q = s.ub.g.poly[cur][(a + 1) % np];
+      const R* P = bx.poly[cur][a]; const R* Q = bx.poly[cur][(a + 1) % np];
       const R P0 = P[0], P1 = P[1], P2 = P[2], Q0 = Q[0], Q1 = Q[1], Q2 = Q[2];
       const R dp = lim - sg * (cdim == 0 ? P0 : P1), dq = lim - sg * (cdim == 0 ? Q0 : Q1);
-      if (dp >= 0 && nn < 8) { R* o = s.ub.g.poly[1 - cur][nn]; o[0] = P0; o[1] = P1; o[2] = P2; nn++; }
+      if (dp >= 0 && nn < 8) { R* o = bx.poly[1 - cur][nn]; o[0] = P0; o[1] = P1; o[2] = P2; nn++; }
       if ((dp >= 0) != (dq >= 0) && nn < 8) {
         const R tt = dp / (dp - dq);
-        R* o = s.ub.g.poly[1 - cur][nn];
+        R* o = bx.poly[1 - cur][nn];
         o[0] = P0 + tt * (Q0 - P0); o[1] = P1 + tt * (Q1 - P1); o[2] = P2 + tt * (Q2 - P2); nn++;
       }
     }
@@ -829,18 +838,18 @@ DM_DEV void box_box(Shared<R>& s, const R* p1, const R* m1, const R* s1, const R
   // keep the (up to) 4 deepest candidates within the margin, in polygon order (bit mask instead of an array)
   unsigned keep = 0;
   int nk = 0;
-  for (int a = 0; a < np; a++) if (s.ub.g.poly[cur][a][2] - sr[ax] < margin) { keep |= 1u << a; nk++; }
+  for (int a = 0; a < np; a++) if (bx.poly[cur][a][2] - sr[ax] < margin) { keep |= 1u << a; nk++; }
   while (nk > 4) {
     int worst = -1;
     R wd = 0;
-    for (int a = 0; a < np; a++) if ((keep >> a) & 1u) { const R da = s.ub.g.poly[cur][a][2] - sr[ax]; if (worst < 0 || da > wd) { worst = a; wd = da; } }
+    for (int a = 0; a < np; a++) if ((keep >> a) & 1u) { const R da = bx.poly[cur][a][2] - sr[ax]; if (worst < 0 || da > wd) { worst = a; wd = da; } }
     keep &= ~(1u << worst); nk--;
   }
   int cnt = 0;
   for (int a = 0; a < np; a++) if ((keep >> a) & 1u) {
-    const R* P = s.ub.g.poly[cur][a];
+    const R* P = bx.poly[cur][a];
     const R da = P[2] - sr[ax];
-    R* o = s.boxc[slot][cnt];
+    R* o = bx.boxc[slot][cnt];
     o[0] = da;
     for (int t = 0; t < 3; t++) o[1 + t] = (pr[t] + P[0] * Rr[u][t] + P[1] * Rr[v][t] + sgn * P[2] * Rr[ax][t]) - n[t] * da / 2;
     cnt++;
@@ -849,16 +858,16 @@ DM_DEV void box_box(Shared<R>& s, const R* p1, const R* m1, const R* s1, const R
   pc.n = cnt;
 }
 
+// p1, m1 / p2, m2: world position and orientation (row-major 3x3) of the two geoms
 template <class R>
-DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s1, const R* s2, const R* gs1, const R* gs2, int stage_slot, R margin, PairContacts<R>& pc) {
+DM_DEV void narrowphase_at(const BoxScratch<R>& bx, const R* p1, const R* m1, const R* p2, const R* m2, int t1, int t2, const R* s1, const R* s2,
+                           const R* gs1, const R* gs2, int stage_slot, R margin, PairContacts<R>& pc) {
   // s1 / s2: the geom sizes in registers (requested with the rest of the pair record: no load inside the divergent type
   // branches); gs1 / gs2: the same in memory, for box-box, which indexes them with run-time axis numbers
   pc.n = 0; pc.boxslot = -1;
   pc.hint[0] = pc.hint[1] = pc.hint[2] = 0;
   pc.nrm[0] = pc.nrm[1] = 0; pc.nrm[2] = 1;
   pc.d0 = pc.d1 = 0; pc.p0[0] = pc.p0[1] = pc.p0[2] = 0; pc.p1[0] = pc.p1[1] = pc.p1[2] = 0;
-  const R* p1 = s.ub.g.gpos[g1]; const R* p2 = s.ub.g.gpos[g2];
-  const R* m1 = s.ub.g.gmat[g1]; const R* m2 = s.ub.g.gmat[g2];
   if (t1 == GEOM_PLANE) {
     const R n[3] = {m1[2], m1[5], m1[8]};
     pc.nrm[0] = n[0]; pc.nrm[1] = n[1]; pc.nrm[2] = n[2];
@@ -886,7 +895,7 @@ DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s
         if (dist + ld > margin || ld > 0) continue;
         const int k = pc.n++;
         const R dk = dist + ld, sc = -dk / 2;
-        R* o = s.boxc[slot][k];
+        R* o = bx.boxc[slot][k];
         o[0] = dk; o[1] = corner[0] + p2[0] + n[0] * sc; o[2] = corner[1] + p2[1] + n[1] * sc; o[3] = corner[2] + p2[2] + n[2] * sc;
       }
     }
@@ -1016,7 +1025,12 @@ DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s
     pc.p0[0] += p2[0]; pc.p0[1] += p2[1]; pc.p0[2] += p2[2];
     return;
   }
-  if (t1 == GEOM_BOX && t2 == GEOM_BOX) box_box(s, p1, m1, gs1, p2, m2, gs2, stage_slot, margin, pc);
+  if (t1 == GEOM_BOX && t2 == GEOM_BOX) box_box(bx, p1, m1, gs1, p2, m2, gs2, stage_slot, margin, pc);
+}
+template <class R>
+DM_DEV void narrowphase(Shared<R>& s, int g1, int g2, int t1, int t2, const R* s1, const R* s2, const R* gs1, const R* gs2, int stage_slot, R margin, PairContacts<R>& pc) {
+  const BoxScratch<R> bx{s.ub.g.axes, s.ub.g.poly, s.boxc};
+  narrowphase_at(bx, s.ub.g.gpos[g1], s.ub.g.gmat[g1], s.ub.g.gpos[g2], s.ub.g.gmat[g2], t1, t2, s1, s2, gs1, gs2, stage_slot, margin, pc);
 }
 
 // [MJ mju_makeFrame] rows of f: normal, tangent 1, tangent 2

@@ -30,6 +30,9 @@ struct Batch {
   int* cycle;       // [N] completed motion cycles since the episode started (imitation reward: root advance of the reference)
   R* kin;           // [N, KIN_DOUBLES] kinematics of the state an env was left in (see save_kin), valid where kin_ok[env] != 0
   unsigned char* kin_ok;   // [N]
+  int* redo_list;          // [N] envs the four-envs-per-wave kernel could not step (a capacity of slot_kernel.h exceeded): re-stepped by the one-env kernel
+  int* redo_count;         // [DM_MAX_PIPELINE] one counter per pipelined sub-batch (its list starts at redo_list[first env of the sub-batch])
+  int* redo_why;           // [8] diagnostic tallies of the reasons (see slot_step.h)
   const R* mocap_cfg;  // [F,35]
   const R* mocap_vel;  // [F,34]
   const R* imit_table; // [F,112] reference feature rows of the 5-term imitation reward (nullptr: not provided)

@@ -20,6 +20,8 @@
 namespace dm {
 
 constexpr int SLOTS = 4, SW = 16;            // environments per wavefront, lanes per environment
+constexpr int SLOT_MAXROWS = 32, SLOT_MAXCON = 8, SLOT_MAXCAND = 16, SLOT_BOXSLOTS = 3;   // per-environment capacities of the packed path; beyond: fix-up by the one-env kernel
+constexpr int PAIR_PASSES = MAXPAIR / SW;
 constexpr int DOF_PASSES = (NV + SW - 1) / SW, HINGE_PASSES = (NU + SW - 1) / SW, Q_PASSES = (NQ + SW - 1) / SW, ENT_PASSES = (310 + SW - 1) / SW;
 
 // per-slot LDS working set.  r1 / r2 are reused along one forward evaluation:
@@ -36,6 +38,18 @@ struct SlotShared {
     struct { R xquat[NB][4], sc[NU][2], off[NB][3]; } k;
     struct { R cvel[NB][6], cacc[NB][6], cfrc[NB][6]; } v;      // (the subtree sums of cfrc overwrite cvel)
     R fdof[NV][6];
+    struct {                                                    // collision .. constraint stage
+      R gpos[NG][3];                                            // geom world positions (orientations are re-formed per candidate pair)
+      R boxc[SLOT_BOXSLOTS][4][4];                              // contacts (dist, pos) of plane-box (slots 0, 1) and box-box (slot 2)
+      union {
+        struct { R axes[2][3][3], poly[2][8][3]; } bb;          // box-box scratch (narrow phase only)
+        R con[SLOT_MAXCON][10];                                 // staged contacts: pos[3], normal[3], tangent 1 [3], dist (emission .. row build)
+      } c;
+      R rowv[SLOT_MAXROWS];                                     // limit rows: distance
+      int rowi[SLOT_MAXROWS];                                   // row codes (see slot_rows)
+      int cand[SLOT_MAXCAND];                                   // candidate pair numbers past the broad phase, in pair-list order
+      int coni[SLOT_MAXCON];                                    // pair number of a staged contact
+    } rw;
   } r1;
   union {
     struct { R sin[NB][10], crb[NB][10]; } i;
@@ -43,6 +57,7 @@ struct SlotShared {
   } r2;
   int nefc, ncon, status, solver_iter;
 };
+static_assert(sizeof(SlotShared<double>) * SLOTS + 1576 <= 40 * 1024, "four waves of four environments must fit a CU's 160 KB of LDS");
 // index tables shared by the four slots of a workgroup (compile-time topology; see LaneTables)
 struct SlotTables {
   unsigned short tab_dst[NV][14];
@@ -367,27 +382,532 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
   dmw::sync();
 }
 
-// ---- unconstrained solve: qacc = qacc_smooth = L^-1 D^-1 L^-T tau.  Every lane of the slot carries the whole vector (factor entries
-// are slot-uniform LDS reads); lane 0 publishes the result. --------------------------------------------------------------------------
+// ---- small collectives over the four rows ------------------------------------------------------------------------------------------
+// maximum over the wave of a value that is uniform inside each row -> wave-uniform (SGPR)
+DM_DEV int rows_max(int v) {
+  const int a = dmw::bcast_i(v, 0), b = dmw::bcast_i(v, 16), c = dmw::bcast_i(v, 32), d = dmw::bcast_i(v, 48);
+  const int ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+// exclusive prefix sum over the lanes of the own row of a small non-negative int (< 32): one ballot + popcount per bit
+DM_DEV int row_exclusive_scan(int v, int sl, int lane, int* total) {
+  const unsigned below = (1u << sl) - 1u;
+  int pre = 0, tot = 0;
+#pragma unroll
+  for (int b = 0; b < 5; b++) {
+    const unsigned m = dmw::row_ballot(((v >> b) & 1) != 0, lane);
+    pre += __builtin_popcount(m & below) << b;
+    tot += __builtin_popcount(m) << b;
+  }
+  *total = tot;
+  return pre;
+}
+
+// ---- constraint rows of the slot's environment: joint limits first (joint order), then contacts (pair-list order)
+//      [MJ mj_collision, mj_makeConstraint]; env_kernel.h stage_rows re-mapped:
+//   * lane g forms the world POSITION of geom g; orientations are only formed for the pairs that pass the bounding spheres;
+//   * the 104 candidate pairs take 7 broad-phase passes of 16 lanes; survivors are compacted (in pair-list order) onto the lanes, so
+//     the divergent narrow phase and the row emission run ONCE for all four environments of the wave;
+//   * what a row's lane needs later is staged per CONTACT (position, normal, first tangent, distance) plus one code word per row;
+//     the row's Jacobian wrench is formed in registers by the constraint stage.
+// Row code: limit  ROW_LIMIT   | dof << 8 | (sign > 0) << 16;   contact  ROW_CONTACT | contact << 8 | pyramid edge q << 16 | condim << 20.
+// Capacities (SLOT_MAXCAND candidates, SLOT_MAXCON contacts, `cap` rows): an environment that exceeds one is flagged (`ovf`) and
+// re-stepped by the one-env kernel; nothing of it is stored by this wave.  Returns the slot's row count.
 template <class R>
-DM_DEV void slot_smooth_solve(SlotShared<R>& s, int sl, const DebugOut* dbg) {
-  R x[NV];
+DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, bool& ovf) {
+  const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
+  const unsigned below = (1u << sl) - 1u;
+  const int npair = dmw::uniform(M.npair);
+  int nrow = 0;
+  auto& W = s.r1.rw;
+  // broad-phase operands of this lane's pairs sl + 16 p, requested up front
+  int pk[PAIR_PASSES]; R pbound[PAIR_PASSES];
 #pragma unroll
-  for (int d = 0; d < NV; d++) x[d] = s.tau[d];
-  solve_LT(x, s.r2.qLD);
+  for (int p = 0; p < PAIR_PASSES; p++) {
+    const int pidx = sl + SW * p, pr = pidx < npair ? pidx : 0;
+    pk[p] = M.pair_rec[pr].g1 | (M.pair_rec[pr].g2 << 8) | ((M.pair_rec[pr].t1t2 & 0xff) << 16);
+    pbound[p] = M.pair_rec[pr].bound;
+  }
+  if (M.enable_contact) {
+    const int g = sl, gb = M.geom_body[g];                   // NG == SW: one geom per lane
+    R v[3];
+    mat_vec(v, s.xmat[gb], M.geom_pos[g]);
+    W.gpos[g][0] = s.xpos[gb][0] + v[0]; W.gpos[g][1] = s.xpos[gb][1] + v[1]; W.gpos[g][2] = s.xpos[gb][2] + v[2];
+  }
+  // ---- joint limits: hinge h = sl + 16 c, dof h + 6
+  if (M.enable_limit) {
 #pragma unroll
-  for (int d = 0; d < NV; d++) x[d] *= s.dinv[d];
-  solve_L(x, s.r2.qLD);
+    for (int c = 0; c < HINGE_PASSES; c++) {
+      const int h = sl + SW * c;
+      bool viol = false;
+      R dist = 0; int pos_sign = 0;
+      if (h < NU && M.jnt_limited[h + 1]) {
+        const R q = s.qpos[h + 7];
+        const R dlo = q - M.jnt_lo[h + 1], dhi = M.jnt_hi[h + 1] - q;
+        if (dlo < 0) { viol = true; dist = dlo; pos_sign = 1; }
+        else if (dhi < 0) { viol = true; dist = dhi; pos_sign = 0; }
+      }
+      const unsigned mask = dmw::row_ballot(viol, lane);
+      if (viol) {
+        const int r = nrow + __builtin_popcount(mask & below);
+        if (r < SLOT_MAXROWS) { W.rowi[r] = ROW_LIMIT | ((h + 6) << 8) | (pos_sign << 16); W.rowv[r] = dist; }
+      }
+      nrow += __builtin_popcount(mask);
+    }
+  }
+  dmw::sync();
+  int ncon = 0;
+  if (M.enable_contact) {
+    // ---- broad phase: bounding spheres (plane pairs: signed distance of the centre)
+    int ncand = 0;
+#pragma unroll
+    for (int p = 0; p < PAIR_PASSES; p++) {
+      if (p * SW < npair) {
+        const int pidx = sl + SW * p;
+        const int g1 = pk[p] & 0xff, g2 = (pk[p] >> 8) & 0xff, t1 = (pk[p] >> 16) & 0xff;
+        bool cand = false;
+        if (pidx < npair) {
+          const R d[3] = {W.gpos[g2][0] - W.gpos[g1][0], W.gpos[g2][1] - W.gpos[g1][1], W.gpos[g2][2] - W.gpos[g1][2]};
+          if (t1 == GEOM_PLANE) {
+            // plane normal = third column of its world orientation  xmat[body] * geom_mat
+            const int gb = M.geom_body[g1];
+            const R* a = s.xmat[gb]; const R* bm = M.geom_mat[g1];
+            const R nx = a[0] * bm[2] + a[1] * bm[5] + a[2] * bm[8], ny = a[3] * bm[2] + a[4] * bm[5] + a[5] * bm[8], nz = a[6] * bm[2] + a[7] * bm[5] + a[8] * bm[8];
+            cand = d[0] * nx + d[1] * ny + d[2] * nz <= pbound[p];
+          } else cand = dot3(d, d) <= pbound[p] * pbound[p];
+        }
+        const unsigned mask = dmw::row_ballot(cand, lane);
+        if (cand) { const int k = ncand + __builtin_popcount(mask & below); if (k < SLOT_MAXCAND) W.cand[k] = pidx; }
+        ncand += __builtin_popcount(mask);
+      }
+    }
+    if (ncand > SLOT_MAXCAND) { ovf = true; ncand = SLOT_MAXCAND; }
+    if (rows_max(ncand) > 0) {
+      dmw::sync();
+      // ---- narrow phase: candidate k of the environment on lane k
+      const bool has = sl < ncand;
+      const int pidx = has ? W.cand[sl] : 0;
+      const auto& rec = M.pair_rec[pidx];
+      const int g1 = rec.g1, g2 = rec.g2, tt = rec.t1t2, meta = rec.meta;
+      const R margin = rec.margin;
+      const R z1[3] = {rec.s1[0], rec.s1[1], rec.s1[2]}, z2[3] = {rec.s2[0], rec.s2[1], rec.s2[2]};
+      const int t1 = tt & 0xff, t2 = (tt >> 8) & 0xff, dim = (tt >> 16) & 0xff;
+      PairContacts<R> pc;
+      pc.n = 0; pc.boxslot = -1;
+      if (has) {
+        R p1[3], p2[3], m1[9], m2[9];
+        {
+          const R* a = s.xmat[meta & 0xff]; const R* bm = M.geom_mat[g1];
+          for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) m1[3 * i + jx] = a[3 * i] * bm[jx] + a[3 * i + 1] * bm[3 + jx] + a[3 * i + 2] * bm[6 + jx];
+          const R* c = s.xmat[(meta >> 8) & 0xff]; const R* dm2 = M.geom_mat[g2];
+          for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) m2[3 * i + jx] = c[3 * i] * dm2[jx] + c[3 * i + 1] * dm2[3 + jx] + c[3 * i + 2] * dm2[6 + jx];
+          for (int k = 0; k < 3; k++) { p1[k] = W.gpos[g1][k]; p2[k] = W.gpos[g2][k]; }
+        }
+        const int raw = ((meta >> 16) & 0xff) - 1;             // staging slot of the one-env kernel: plane-box 0..3, box-box 4..5
+        const int slotb = raw < 0 ? -1 : (raw < 4 ? raw : raw - 2);
+        if (slotb >= SLOT_BOXSLOTS || (raw >= 2 && raw < 4)) ovf = true;      // (a model with more boxes than the humanoid's two feet)
+        else {
+          const BoxScratch<R> bx{W.c.bb.axes, W.c.bb.poly, W.boxc};
+          narrowphase_at(bx, p1, m1, p2, m2, t1, t2, z1, z2, M.pair_rec[pidx].s1, M.pair_rec[pidx].s2, slotb, margin, pc);
+        }
+      }
+      if (rows_max((int)dmw::row_ballot(pc.n > 0, lane)) != 0) {
+        // ---- emission: contacts staged in list order, one code word per row
+        const int rows_per = dim == 1 ? 1 : 2 * (dim - 1);
+        int tot_rows, tot_con;
+        const int r0 = nrow + row_exclusive_scan(pc.n * rows_per, sl, lane, &tot_rows);
+        const int c0 = row_exclusive_scan(pc.n, sl, lane, &tot_con);
+        R fr[9];
+        if (pc.n > 0) make_frame(fr, pc.nrm, pc.hint);
+        dmw::sync();                                           // the box-box scratch (aliased by the staged contacts) is no longer in use
+        if (pc.n > 0) {
+          for (int k = 0; k < pc.n; k++) {
+            const int ci = c0 + k, rk = r0 + k * rows_per;
+            if (ci >= SLOT_MAXCON || rk + rows_per > SLOT_MAXROWS) { ovf = true; continue; }
+            R cdist, cpos[3];
+            if (pc.boxslot >= 0) { const R* o = W.boxc[pc.boxslot][k]; cdist = o[0]; cpos[0] = o[1]; cpos[1] = o[2]; cpos[2] = o[3]; }
+            else if (k == 0) { cdist = pc.d0; cpos[0] = pc.p0[0]; cpos[1] = pc.p0[1]; cpos[2] = pc.p0[2]; }
+            else { cdist = pc.d1; cpos[0] = pc.p1[0]; cpos[1] = pc.p1[1]; cpos[2] = pc.p1[2]; }
+            R* o = W.c.con[ci];
+            o[0] = cpos[0]; o[1] = cpos[1]; o[2] = cpos[2]; o[3] = fr[0]; o[4] = fr[1]; o[5] = fr[2]; o[6] = fr[3]; o[7] = fr[4]; o[8] = fr[5]; o[9] = cdist;
+            W.coni[ci] = pidx;
+            for (int q = 0; q < rows_per; q++) W.rowi[rk + q] = ROW_CONTACT | (ci << 8) | (q << 16) | (dim << 20);
+          }
+        }
+        nrow += tot_rows; ncon = tot_con;
+      }
+    }
+  }
+  // an overflow anywhere in the row -> the whole environment is flagged (ovf is per lane so far)
+  ovf = dmw::row_ballot(ovf, lane) != 0u;
+  if (nrow > SLOT_MAXROWS) ovf = true;
+  if (ovf) { nrow = 0; ncon = 0; }                             // nothing of this evaluation is used: no row may be read (some were never staged)
+  if (sl == 0) { s.nefc = nrow; s.ncon = ncon; }
+  dmw::sync();
+  return nrow;
+}
+
+// ---- half solves of several register vectors at once (the factor entries are loaded once per row): x_v <- L^-T x_v ---------------
+template <int I, int NVEC, class R>
+struct SlotSolveLTStep {
+  static DM_DEV void run(R (*x)[NV], const R* qLD, const R* cur) {
+    R nxt[14];
+    dmw::reload_fence();
+    load_factor_row<I - 1>(nxt, qLD);
+    dmw::sched_fence();
+#pragma unroll
+    for (int v = 0; v < NVEC; v++) {
+#pragma unroll
+      for (int a = 1; a < 14; a++) { const int j = TOPO.dof_anc[I][a]; if (j >= 0) x[v][j] -= cur[a] * x[v][I]; }
+      dmw::pin_value(x[v][TOPO.dof_anc[I][1]]);
+    }
+    SlotSolveLTStep<I - 1, NVEC, R>::run(x, qLD, nxt);
+  }
+};
+template <int NVEC, class R> struct SlotSolveLTStep<0, NVEC, R> { static DM_DEV void run(R (*)[NV], const R*, const R*) {} };
+template <int NVEC, class R> DM_DEV void slot_solve_LT(R (*x)[NV], const R* qLD) {
+  R cur[14];
+  dmw::reload_fence();
+  load_factor_row<NV - 1>(cur, qLD);
+  SlotSolveLTStep<NV - 1, NVEC, R>::run(x, qLD, cur);
+}
+
+// Jacobian rows of NS row sets at once (env_kernel.h RowStep; the dof's operands are loaded once for all sets)
+template <int D, class R>
+DM_DEV void slot_load_dof_operands(R* dst, const SlotShared<R>& s) {
+  if constexpr (D < NV) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) dst[r] = s.cdof[D][r];
+    dst[6] = s.qvel[D]; dst[7] = s.qws[D];
+  }
+}
+template <int D, int NS, class R>
+struct SlotRowStep {
+  static DM_DEV void run(R (*y)[NV], RowAcc<R>* ra, const SlotShared<R>& s, const R* cur) {
+    R nxt[8];
+    dmw::reload_fence();
+    slot_load_dof_operands<D + 1>(nxt, s);
+    dmw::sched_fence();
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      const int pb = (int)(D < 32 ? (ra[k].plus_lo >> D) & 1u : (ra[k].plus_hi >> (D - 32)) & 1u);
+      const int mb = (int)(D < 32 ? (ra[k].minus_lo >> D) & 1u : (ra[k].minus_hi >> (D - 32)) & 1u);
+      R j = ra[k].w[0] * cur[0] + ra[k].w[1] * cur[1] + ra[k].w[2] * cur[2] + ra[k].w[3] * cur[3] + ra[k].w[4] * cur[4] + ra[k].w[5] * cur[5];
+      j = (j + ra[k].w7) * (R)(pb - mb);
+      ra[k].vel += j * cur[6]; ra[k].jws += j * cur[7];
+      y[k][D] = j;
+      dmw::pin_value(ra[k].vel); dmw::pin_value(ra[k].jws);
+    }
+    SlotRowStep<D + 1, NS, R>::run(y, ra, s, nxt);
+  }
+};
+template <int NS, class R> struct SlotRowStep<NV, NS, R> { static DM_DEV void run(R (*)[NV], RowAcc<R>*, const SlotShared<R>&, const R*) {} };
+
+// ---- nested unrolling over the wave's largest row count (wave-uniform `nmax`): column / row group c is only reached through c - 4 ---
+// column CC of A = Y Y^T: AR[k][CC] = Y_(row of the lane, set k) . Y_CC, the partner row broadcast inside the DPP row
+template <int CC, int NS, class R>
+DM_DEV void slot_acol(R (*AR)[16 * NS], const R (*y)[NV]) {
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    R acc0 = 0, acc1 = 0;                 // two partial sums: halves the dependent chain of the 34 fused multiply-adds
+#pragma unroll
+    for (int d = 0; d < NV; d += 2) { dmw::row_fmac_old<CC % 16>(acc0, y[CC / 16][d], y[k][d]); dmw::row_fmac_old<CC % 16>(acc1, y[CC / 16][d + 1], y[k][d + 1]); }
+    AR[k][CC] = acc0 + acc1;
+  }
+}
+template <int C, int NS, class R>
+struct SlotACols {
+  static DM_DEV void run(R (*AR)[16 * NS], const R (*y)[NV], int nmax) {
+    if constexpr (C < 16 * NS) {
+      slot_acol<C, NS, R>(AR, y); slot_acol<C + 1, NS, R>(AR, y); slot_acol<C + 2, NS, R>(AR, y); slot_acol<C + 3, NS, R>(AR, y);
+      if (C + 4 < nmax) SlotACols<C + 4, NS, R>::run(AR, y, nmax);
+    }
+  }
+};
+// warm start: AR[k][c] scaled in place (row by -1 / A_rr);  t_k += A_scaled[k][c] f_c
+template <int CC, int NS, class R>
+DM_DEV void slot_warm_col(R (*AR)[16 * NS], R* t, const R* f, const R* ndinv) {
+#pragma unroll
+  for (int k = 0; k < NS; k++) { AR[k][CC] *= ndinv[k]; dmw::row_fmac_old<CC % 16>(t[k], f[CC / 16], AR[k][CC]); }
+}
+template <int C, int NS, class R>
+struct SlotWarm {
+  static DM_DEV void run(R (*AR)[16 * NS], R* t, const R* f, const R* ndinv, int nmax) {
+    if constexpr (C < 16 * NS) {
+      slot_warm_col<C, NS, R>(AR, t, f, ndinv); slot_warm_col<C + 1, NS, R>(AR, t, f, ndinv); slot_warm_col<C + 2, NS, R>(AR, t, f, ndinv); slot_warm_col<C + 3, NS, R>(AR, t, f, ndinv);
+      if (C + 4 < nmax) SlotWarm<C + 4, NS, R>::run(AR, t, f, ndinv, nmax);
+    }
+  }
+};
+// one PGS row (scaled-residual form of env_kernel.h): delta = max(-f, t) of the row's own lane, broadcast, t += A_s[:, row] delta
+template <int CC, int NS, class R>
+DM_DEV void slot_sweep_row(const R (*AR)[16 * NS], R* t, R* tsave, const R* nf0, int ln) {
+  const R delta = dmw::max_raw(nf0[CC / 16], t[CC / 16]);
+  if (ln == (CC % 16)) tsave[CC / 16] = t[CC / 16];
+  dmw::row_fmac<CC % 16>(t[0], delta, AR[0][CC]);              // (the fresh delta is the DPP source: hazard slot inside)
+#pragma unroll
+  for (int k = 1; k < NS; k++) dmw::row_fmac_old<CC % 16>(t[k], delta, AR[k][CC]);
+}
+template <int C, int NS, class R>
+struct SlotSweep {
+  static DM_DEV void run(const R (*AR)[16 * NS], R* t, R* tsave, const R* nf0, int ln, int nmax) {
+    if constexpr (C < 16 * NS) {
+      slot_sweep_row<C, NS, R>(AR, t, tsave, nf0, ln); slot_sweep_row<C + 1, NS, R>(AR, t, tsave, nf0, ln);
+      slot_sweep_row<C + 2, NS, R>(AR, t, tsave, nf0, ln); slot_sweep_row<C + 3, NS, R>(AR, t, tsave, nf0, ln);
+      if (C + 4 < nmax) SlotSweep<C + 4, NS, R>::run(AR, t, tsave, nf0, ln, nmax);
+    }
+  }
+};
+// sum over rows of f_r Y_r, row by row in order (the order of the one-env kernel's assembly): ws[d] += (f Y)_(row CC)[d]
+template <int CC, class R>
+DM_DEV void slot_assemble_row(R* ws, const R (*fy)[NV], R one) {
+#pragma unroll
+  for (int d = 0; d < NV; d++) dmw::row_fmac_old<CC % 16>(ws[d], fy[CC / 16][d], one);
+}
+template <int C, int NS, class R>
+struct SlotAssemble {
+  static DM_DEV void run(R* ws, const R (*fy)[NV], R one, int nmax) {
+    if constexpr (C < 16 * NS) {
+      slot_assemble_row<C, R>(ws, fy, one); slot_assemble_row<C + 1, R>(ws, fy, one); slot_assemble_row<C + 2, R>(ws, fy, one); slot_assemble_row<C + 3, R>(ws, fy, one);
+      if (C + 4 < nmax) SlotAssemble<C + 4, NS, R>::run(ws, fy, one, nmax);
+    }
+  }
+};
+
+// ---- constraint solve of the slot's environment; lane sl owns rows sl + 16 k, k < NS (limits first, then contacts in list order)
+//      [MJ mj_fwdAcceleration, mj_projectConstraint, mj_fwdConstraint (warmstart, mj_solPGS)] -----------------------------------------
+// Same mathematics as env_kernel.h stage_constraint (half-solved vectors Y = D^-1/2 L^-T J^T, A = Y Y^T + R, scaled-residual PGS,
+// qacc = L^-1 D^-1/2 (z + sum f Y)); what differs is the plumbing: rows of Y are exchanged by DPP row broadcasts instead of LDS, the
+// smooth force's half solve z is carried by EVERY lane beside its rows (same factor loads), and the final L^-1 pass runs on a
+// register vector that all 16 lanes of the slot hold.  `nefc` is the slot's row count, `nmax` the wave's largest (row loops run to it;
+// a slot's absent rows are exact zeros).  The sweeps of a converged environment are frozen, so its result does not depend on its partners.
+template <class R, int NS>
+DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int nefc, int nmax, bool& ovf, const DebugOut* dbg) {
+  const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
+  constexpr int NC = 16 * NS;
+  auto& W = s.r1.rw;
+  R y[NS + 1][NV];                     // rows' Jacobians -> Y;  y[NS] = tau -> z (identical in every lane of the slot)
+  RowAcc<R> ra[NS];
+  bool active[NS];
+  R pos[NS], margin[NS], dA[NS], rscale[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int r = sl + 16 * k;
+    active[k] = r < nefc;
+    const int code = active[k] ? W.rowi[r] : 0;
+    const int type = code & 0xff;
+    R w[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long mplus = 0, mminus = 0;
+    pos[k] = 0; margin[k] = 0; dA[k] = 0; rscale[k] = 1;
+    R w7 = 0;
+    if (type == ROW_LIMIT) {
+      const int d = (code >> 8) & 0xff;
+      w7 = ((code >> 16) & 1) ? R(1) : R(-1);
+      pos[k] = W.rowv[r]; dA[k] = M.dof_invw[d]; mplus = 1ull << d;
+    } else if (type == ROW_CONTACT) {
+      const int ci = (code >> 8) & 0xff, q = (code >> 16) & 0xf, cdim = (code >> 20) & 0xf;
+      const R* c = W.c.con[ci];
+      const auto& rec = M.pair_rec[W.coni[ci]];
+      const R cmu = rec.mu, ctran = rec.tran;
+      const int meta = rec.meta;
+      R dir[3] = {c[3], c[4], c[5]};
+      if (cdim != 1) {
+        const R n[3] = {c[3], c[4], c[5]}, t1[3] = {c[6], c[7], c[8]};
+        R t2[3];
+        cross3(t2, n, t1);
+        const R sg = (q & 1) ? -cmu : cmu;
+        const R* tg = (q >> 1) ? t2 : t1;
+        dir[0] += sg * tg[0]; dir[1] += sg * tg[1]; dir[2] += sg * tg[2];
+      }
+      cross3(w, c, dir);
+      w[3] = dir[0]; w[4] = dir[1]; w[5] = dir[2];
+      pos[k] = c[9]; margin[k] = rec.margin;
+      dA[k] = cdim == 1 ? ctran : ctran + cmu * cmu * ctran;
+      rscale[k] = cdim == 1 ? R(1) : 2 * cmu * cmu;
+      mminus = TOPO.chain[meta & 0xff]; mplus = TOPO.chain[(meta >> 8) & 0xff];
+    }
+    for (int r6 = 0; r6 < 6; r6++) ra[k].w[r6] = w[r6];
+    ra[k].w7 = w7; ra[k].w8 = 0; ra[k].vel = 0; ra[k].jws = 0;
+    ra[k].plus_lo = (unsigned)mplus; ra[k].plus_hi = (unsigned)(mplus >> 32); ra[k].minus_lo = (unsigned)mminus; ra[k].minus_hi = (unsigned)(mminus >> 32);
+  }
+  {
+    R cur[8];
+    dmw::reload_fence();
+    slot_load_dof_operands<0>(cur, s);
+    SlotRowStep<0, NS, R>::run(y, ra, s, cur);
+  }
+#pragma unroll
+  for (int d = 0; d < NV; d++) y[NS][d] = s.tau[d];
+  if (dbg) {
+#pragma unroll
+    for (int k = 0; k < NS; k++) if (active[k]) {
+      double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + (sl + 16 * k) * (34 + 6);
+#pragma unroll
+      for (int d = 0; d < NV; d++) o[d] = (double)y[k][d];
+    }
+  }
+  R Rr[NS], aref[NS], f[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const R imp = impedance(M, pos[k] - margin[k]);
+    Rr[k] = fmax(R(DM_MINVAL), (1 - imp) * dA[k] / imp);
+    if (rscale[k] != R(1)) Rr[k] = fmax(R(DM_MINVAL), rscale[k] * Rr[k]);
+    aref[k] = -M.B * ra[k].vel - M.K * imp * (pos[k] - margin[k]);
+    const R jar = ra[k].jws - aref[k];
+    f[k] = (active[k] && jar < 0) ? -jar / Rr[k] : R(0);
+  }
+  // half solves: rows J^T -> Y, tau -> z
+  slot_solve_LT<NS + 1>(y, s.r2.qLD);
+#pragma unroll
+  for (int d = 0; d < NV; d++) {
+    const R sc = s.dsq[d];
+#pragma unroll
+    for (int k = 0; k <= NS; k++) { y[k][d] *= sc; dmw::pin_value(y[k][d]); }
+  }
+  if (dbg) {      // debug dump only: qacc_smooth = L^-1 D^-1/2 z next to a constrained solve
+    R x[NV];
+#pragma unroll
+    for (int d = 0; d < NV; d++) x[d] = y[NS][d] * s.dsq[d];
+    solve_L(x, s.r2.qLD);
+    if (sl == 0) {
+#pragma unroll
+      for (int d = 0; d < NV; d++) dbg->out[34 * 34 + 34 + d] = (double)x[d];
+    }
+  }
+  R bb[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    R acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int d = 0; d < NV; d++) { if (d & 1) acc1 += y[k][d] * y[NS][d]; else acc0 += y[k][d] * y[NS][d]; }
+    bb[k] = active[k] ? (acc0 + acc1) - aref[k] : R(0);
+  }
+  // ---- A = Y Y^T + diag(R) --------------------------------------------------------------------------------------------------------
+  R AR[NS][NC];
+#pragma unroll
+  for (int k = 0; k < NS; k++)
+#pragma unroll
+    for (int c = 0; c < NC; c++) { AR[k][c] = 0; dmw::pin_value(AR[k][c]); }
+  dmw::dpp_settle();
+  SlotACols<0, NS, R>::run(AR, y, nmax);
+  R diag[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    R dg = 1;
+#pragma unroll
+    for (int c = 0; c < 16; c++) { if (sl == c) { AR[k][16 * k + c] += active[k] ? Rr[k] : R(0); dg = AR[k][16 * k + c]; } }
+    diag[k] = active[k] ? dg : R(1);
+  }
+  // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ---------------------------------------------------------
+  R ndinv[NS], tb[NS], t[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) { ndinv[k] = active[k] ? R(-1) / diag[k] : R(0); dmw::pin_value(ndinv[k]); tb[k] = bb[k] * ndinv[k]; t[k] = tb[k]; }
+  SlotWarm<0, NS, R>::run(AR, t, f, ndinv, nmax);
+  {
+    R c = 0;
+#pragma unroll
+    for (int k = 0; k < NS; k++) { const R res = -t[k] * diag[k]; c += active[k] ? f[k] * (R(0.5) * (res - bb[k]) + bb[k]) : R(0); }
+    const R cost = dmw::sum16(c);
+    if (cost > 0) {
+#pragma unroll
+      for (int k = 0; k < NS; k++) { f[k] = 0; t[k] = tb[k]; }
+    }
+  }
+  // ---- projected Gauss-Seidel: rows in order, every environment of the wave in step; a converged environment is frozen ----------------
+  const int maxiter = dmw::uniform(M.iterations);
+  R pgs_scale = M.pgs_scale, pgs_tol = M.tolerance, pgs_detect = M.pgs_detect;
+  dmw::pin_value(pgs_scale); dmw::pin_value(pgs_tol); dmw::pin_value(pgs_detect);
+  int iter = 0;
+  bool frozen = nefc == 0, anybad = false;
+  if (frozen) {
+#pragma unroll
+    for (int k = 0; k < NS; k++) t[k] = 0;
+  }
+  bool more = maxiter > 0 && rows_max(frozen ? 0 : 1) != 0;
+  while (more) {
+    const int nm = dmw::launder_uniform(nmax);
+    const int ln = dmw::launder(sl);
+    R nf0[NS], tsave[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) { nf0[k] = -f[k]; tsave[k] = t[k]; }
+    SlotSweep<0, NS, R>::run(AR, t, tsave, nf0, ln, nm);
+    R imp = 0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      const R delta = dmw::max_raw(nf0[k], tsave[k]);
+      const R change = (delta * diag[k]) * (R(0.5) * delta - tsave[k]);
+      f[k] += delta; imp -= change; bad = bad || (change > pgs_detect);
+    }
+    const R improvement = dmw::sum16(imp) * pgs_scale;
+    if (!frozen) { iter += 1; anybad = anybad || bad; }
+    const bool conv = !frozen && (improvement < pgs_tol || iter >= maxiter);
+    if (conv) {
+      // freeze: from now on every row's step is exactly zero (t = 0 where a force is held, t <= 0 where it is zero), forces stay
+      frozen = true;
+#pragma unroll
+      for (int k = 0; k < NS; k++) t[k] = f[k] > 0 ? R(0) : R(-1);
+    }
+    more = rows_max(frozen ? 0 : 1) != 0;
+  }
+  if (dmw::row_ballot(anybad, lane) != 0u) ovf = true;        // [MJ costChange] would have rejected a step: the one-env kernel's guarded replay decides
+  if (dbg) {
+#pragma unroll
+    for (int k = 0; k < NS; k++) if (active[k]) {
+      double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + (sl + 16 * k) * (34 + 6) + 34;
+      o[0] = (double)pos[k]; o[1] = (double)margin[k]; o[2] = (double)Rr[k]; o[3] = (double)aref[k]; o[4] = (double)bb[k]; o[5] = (double)f[k];
+    }
+  }
+  // ---- qacc = L^-1 D^-1/2 (z + sum_r f_r Y_r) -----------------------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const R fk = active[k] ? f[k] : R(0);
+#pragma unroll
+    for (int d = 0; d < NV; d++) { y[k][d] *= fk; dmw::pin_value(y[k][d]); }
+  }
+  R ws[NV];
+#pragma unroll
+  for (int d = 0; d < NV; d++) { ws[d] = 0; dmw::pin_value(ws[d]); }
+  R one = 1;
+  dmw::pin_value(one);
+  dmw::dpp_settle();
+  SlotAssemble<0, NS, R>::run(ws, y, one, nmax);
+#pragma unroll
+  for (int d = 0; d < NV; d++) ws[d] = (ws[d] + y[NS][d]) * s.dsq[d];
+  solve_L(ws, s.r2.qLD);
   if (sl == 0) {
 #pragma unroll
-    for (int d = 0; d < NV; d++) { s.qacc[d] = x[d]; if (dbg) dbg->out[34 * 34 + 34 + d] = (double)x[d]; }
+    for (int d = 0; d < NV; d++) s.qacc[d] = ws[d];
+    s.solver_iter = iter;
   }
   dmw::sync();
 }
 
-// one forward-dynamics evaluation of the slot's environment: s.qpos, s.qvel, s.act, s.qws -> s.qacc; xip = body COM positions (body lanes)
+// ---- no rows anywhere in the wave: qacc = L^-1 D^-1/2 (D^-1/2 L^-T tau), the constrained formula with an empty sum (so that an
+// environment's result does not depend on whether a partner has rows).  Every lane of the slot carries the whole vector. -----------
 template <class R>
-DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, const LaneTopo& lt, R* xip, const DebugOut* dbg) {
+DM_DEV void slot_smooth_solve(SlotShared<R>& s, int sl, const DebugOut* dbg) {
+  R x[1][NV];
+#pragma unroll
+  for (int d = 0; d < NV; d++) x[0][d] = s.tau[d];
+  slot_solve_LT<1>(x, s.r2.qLD);
+#pragma unroll
+  for (int d = 0; d < NV; d++) { x[0][d] *= s.dsq[d]; dmw::pin_value(x[0][d]); }
+#pragma unroll
+  for (int d = 0; d < NV; d++) x[0][d] = (R(0) + x[0][d]) * s.dsq[d];
+  solve_L(x[0], s.r2.qLD);
+  if (sl == 0) {
+#pragma unroll
+    for (int d = 0; d < NV; d++) { s.qacc[d] = x[0][d]; if (dbg) dbg->out[34 * 34 + 34 + d] = (double)x[0][d]; }
+    s.solver_iter = 0;
+  }
+  dmw::sync();
+}
+
+// one forward-dynamics evaluation of the slot's environment: s.qpos, s.qvel, s.act, s.qws -> s.qacc; xip = body COM positions (body
+// lanes); ovf: the environment exceeded a capacity of the packed path (sticky)
+template <class R>
+DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, int lane, const LaneTopo& lt, R* xip, bool& ovf, const DebugOut* dbg) {
   DM_MARK("slot_kinematics");
   slot_kinematics(M, s, sl, lt, xip);
   if (dbg) { for (int e = sl; e < NV * NV; e += SW) dbg->out[e] = 0; dmw::sync(); }
@@ -398,9 +918,15 @@ DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTable
   }
   DM_MARK("slot_mass_factor");
   slot_mass_matrix(M, s, tb, sl, lt, dbg);
+  DM_MARK("slot_rows");
+  int nefc = 0;
+  if (M.enable_contact || M.enable_limit) nefc = slot_rows(M, s, sl, lane, ovf);
+  else { if (sl == 0) { s.nefc = 0; s.ncon = 0; } dmw::sync(); }
   DM_MARK("slot_constraint");
-  if (sl == 0) { s.nefc = 0; s.ncon = 0; s.solver_iter = 0; }     // (models with contacts / limits: rows + constraint stages, below)
-  slot_smooth_solve(s, sl, dbg);
+  const int nmax = rows_max(nefc);
+  if (nmax == 0) slot_smooth_solve(s, sl, dbg);
+  else if (nmax <= 16) slot_constraint<R, 1>(M, s, sl, lane, nefc, nmax, ovf, dbg);
+  else slot_constraint<R, 2>(M, s, sl, lane, nefc, nmax, ovf, dbg);
   DM_MARK("slot_forward_end");
   if (dbg) {
     for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) dbg->out[34 * 34 + 68 + d] = (double)s.qacc[d]; }

@@ -32,7 +32,7 @@ DM_DEV void slot_integrate_pos(SlotShared<R>& s, const DofVec<R>& x0q, int sl, R
 
 // [MJ mj_step, integrator RK4] on the state in s.qpos / s.qvel / s.qws / s.act; xip = body COM positions of the 4th stage evaluation
 template <class R>
-DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, const LaneTopo& lt, R* xip) {
+DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, int lane, const LaneTopo& lt, R* xip, bool& ovf) {
   const R h = M.timestep;
   const R A[3] = {R(0.5), R(0.5), R(1)};
   const R Bw[4] = {R(1) / 6, R(1) / 3, R(1) / 3, R(1) / 6};
@@ -59,7 +59,7 @@ DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTabl
       }
       dmw::sync();
     }
-    slot_forward<R>(M, s, tb, sl, lt, xip, (const DebugOut*)0);
+    slot_forward<R>(M, s, tb, sl, lane, lt, xip, ovf, (const DebugOut*)0);
 #pragma unroll
     for (int c = 0; c < DOF_PASSES; c++) {
       const int d = sl + SW * c;
@@ -152,14 +152,20 @@ DM_DEV void slot_reset_env(const DevModel<R>& M, const Batch<R>& B, SlotShared<R
 }
 
 // DPEnv.step for the slot's environment (reward modes alive / v3-config / v2-pose; the imitation modes live in the one-env kernel until
-// their epilogue is ported).  Returns nothing: a slot that is not `live` computes and stores nothing outside LDS.
+// their epilogue is ported).  A slot that is not `live` computes and stores nothing outside LDS.  An environment that exceeded a
+// capacity of the packed path during the step (`ovf`) stores nothing either: it is appended to the launch's redo list
+// (redo[0] = counter, list = redo + 1 ...) and re-stepped from its unchanged state by the one-env kernel.
 template <class R>
-DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, SlotTables& tb, int env, int sl, bool live,
-                          const double* action, double* obs, double* reward, unsigned char* done, int n_substeps) {
+DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, SlotTables& tb, int env, int sl, int lane, bool live,
+                          const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int* redo_count, int* redo_list) {
   const LaneTopo lt = lane_topo(sl);
   slot_load_env(M, B, s, env, sl, live, action);
   R xip[3];
-  for (int k = 0; k < n_substeps; k++) slot_rk4_step<R>(M, s, tb, sl, lt, xip);
+  bool ovf = false;
+  for (int k = 0; k < n_substeps; k++) slot_rk4_step<R>(M, s, tb, sl, lane, lt, xip, ovf);
+  ovf = dmw::row_ballot(ovf, lane) != 0u;
+  if (ovf && live && sl == 0) { const int k = dmw::global_counter_next(redo_count); redo_list[k] = env; }
+  live = live && !ovf;
   // COM height of the 4th-stage body positions (src/dp_env_v3.py:134-139): mass-weighted sum over the body lanes
   const R mz = sl < NB - 1 ? M.body_mass[sl + 1] * xip[2] : R(0);
   const R z = dmw::sum16(mz) / M.total_mass;
@@ -168,7 +174,13 @@ DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
     if (B.diag != 0) {
       if (sl < NB - 1) for (int k = 0; k < 3; k++) B.xipos[(size_t)env * NB * 3 + 3 * (sl + 1) + k] = xip[k];
       if (sl < 3) B.xipos[(size_t)env * NB * 3 + sl] = 0;
-      for (int k = sl; k < MAXEFC * 2; k += SW) B.cong[(size_t)env * MAXEFC * 2 + k] = -1;
+      const int nc = s.ncon;
+      for (int k = sl; k < MAXEFC * 2; k += SW) {
+        const int c = k >> 1;
+        int gid = -1;
+        if (c < nc && c < SLOT_MAXCON) { const auto& rec = M.pair_rec[s.r1.rw.coni[c]]; gid = (k & 1) ? rec.g2 : rec.g1; }
+        B.cong[(size_t)env * MAXEFC * 2 + k] = gid;
+      }
     }
     if (sl == 0) { B.comz[env] = z; B.ncon[env] = s.ncon; B.nefc[env] = s.nefc; B.status[env] = s.status; B.solver_iter[env] = s.solver_iter; }
   }

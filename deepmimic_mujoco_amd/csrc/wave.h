@@ -134,9 +134,20 @@ template <int I> DM_DEV int row_bcast_i(int v) { return __builtin_amdgcn_update_
 // acc += (lane I of the row's x) * y as ONE instruction: v_fmac_f64 with a DPP source (the only f64 arithmetic with a DPP form on
 // gfx950).  The leading s_nop covers the VALU-write -> DPP-read hazard, which the compiler cannot see through inline assembly.
 template <int I> DM_DEV void row_fmac(double& acc, double x, double y) {
-  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(I));
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(I));
 }
 template <int I> DM_DEV void row_fmac(float& acc, float x, float y) { acc += row_bcast<I>(x) * y; }
+// the same without the hazard slot, for a DPP source x that was written long before: only between a dpp_settle() and the next write
+// of any such x.  volatile: these keep their order among themselves and after dpp_settle().
+template <int I> DM_DEV void row_fmac_old(double& acc, double x, double y) {
+  // (the hazard slot stays: a register that is "old" in the source may still have been refilled from an accumulation register or from
+  //  scratch by the instruction before — the compiler's hazard recogniser does not look inside inline assembly)
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(I));
+}
+template <int I> DM_DEV void row_fmac_old(float& acc, float x, float y) { acc += row_bcast<I>(x) * y; }
+DM_DEV void dpp_settle() { asm volatile("s_nop 4"); }
+// counter in global memory shared by all waves of a launch: returns the value before the increment
+DM_DEV int global_counter_next(int* p) { return atomicAdd(p, 1); }
 // this lane's 16 bits of a wave ballot (bit i = lane i of the own row)
 DM_DEV unsigned row_ballot(bool p, int lane_id) { return (unsigned)((__ballot(p) >> (lane_id & 48)) & 0xffffull); }
 }  // namespace dmw

@@ -28,6 +28,7 @@ def lib():
         L.emu_step.argtypes = [C.c_void_p, A._dp, A._dp, A._dp, C.POINTER(C.c_uint8), C.c_int]
         L.emu_set_state.argtypes = [C.c_void_p, A._dp, A._dp, A._ip, C.POINTER(C.c_uint8)]
         L.emu_reset.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+        L.emu_redo_total.argtypes = [C.c_void_p]; L.emu_redo_total.restype = C.c_long
         L.emu_debug_forward.argtypes = [C.c_void_p, C.c_int, A._dp]
         _LIB = L
     return _LIB
@@ -90,6 +91,10 @@ class EmuBatch(object):
     def reset(self, mode=0, hard=1, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         lib().emu_reset(self.h, mode, hard, None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)))
+
+    def redo_total(self):
+        """envs the packed path handed to the one-env kernel so far (a capacity of slot_kernel.h exceeded)"""
+        return int(lib().emu_redo_total(self.h))
 
     def get_obs(self, out=None):
         q = self.get(A.F_QPOS); v = self.get(A.F_QVEL)

@@ -61,7 +61,8 @@ struct EmuBatch {
   bool two_tier = true, packed = false;
   SlotShared<double> slots[SLOTS];
   SlotTables slot_tabs;
-  std::vector<int> fidx, finit, ncon, nefc, cong, status, siter, episode, cycle;
+  std::vector<int> fidx, finit, ncon, nefc, cong, status, siter, episode, cycle, redo;
+  long redo_total = 0;
   Shared<double> sh;
   StepScratch<double> xs;
 };
@@ -87,6 +88,7 @@ void* emu_create(const dm_model_desc* d, const double* cfg, const double* vel, i
   B.aovf = e->aovf.data(); B.cycle = e->cycle.data(); B.imit_table = nullptr; B.imit_pdev = nullptr; B.order = nullptr;
   B.solver_iter = e->siter.data(); B.episode = e->episode.data(); B.mocap_cfg = e->cfg.data(); B.mocap_vel = e->vel.data();
   e->kin.assign((size_t)n * KIN_DOUBLES, 0); e->kin_ok.assign(n, 0); B.kin = e->kin.data(); B.kin_ok = e->kin_ok.data();
+  e->redo.assign((size_t)n + 16, 0); B.redo_list = e->redo.data() + 16; B.redo_count = e->redo.data(); B.redo_why = e->redo.data() + 8;
   B.mocap_dt = mocap_dt; B.n_frames = F; B.n_envs = n; B.env_offset = 0; B.reward_mode = 0; B.autoreset = 0; B.action_mode = 0; B.seed = 0; B.diag = 1;
   return e;
 }
@@ -125,9 +127,9 @@ void* emu_field(void* h, int field) {
 }
 void emu_step(void* h, const double* action, double* obs, double* reward, unsigned char* done, int nsub) {
   EmuBatch* e = (EmuBatch*)h;
-  const bool has_rows = e->M.enable_contact || e->M.enable_limit;
-  if (e->packed && !has_rows && e->B.reward_mode <= 2) {          // the device's routing (dmenv.hip step_impl): four envs per wave
+  if (e->packed && e->B.reward_mode <= 2) {          // the device's routing (dmenv.hip step_impl): four envs per wave, overflowing envs re-stepped one per wave
     const int n = e->B.n_envs;
+    e->B.redo_count[0] = 0;
     for (int first = 0; first < n; first += SLOTS)
       run_wave([&](int lane) {
         const int slot = lane >> 4, sl = lane & 15;
@@ -135,8 +137,13 @@ void emu_step(void* h, const double* action, double* obs, double* reward, unsign
         int pos = first + slot;
         const bool live = pos < n;
         if (!live) pos = n - 1;
-        slot_env_step<double>(e->M, e->B, e->slots[slot], e->slot_tabs, pos, sl, live, action, obs, reward, done, nsub);
+        slot_env_step<double>(e->M, e->B, e->slots[slot], e->slot_tabs, pos, sl, lane, live, action, obs, reward, done, nsub, e->B.redo_count, e->B.redo_list);
       });
+    e->redo_total += e->B.redo_count[0];
+    for (int i = 0; i < e->B.redo_count[0]; i++) {
+      const int env = e->B.redo_list[i];
+      run_wave([&](int lane) { env_step<double, 32>(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); });
+    }
     return;
   }
   for (int env = 0; env < e->B.n_envs; env++)
@@ -147,6 +154,7 @@ void emu_step(void* h, const double* action, double* obs, double* reward, unsign
     else run_wave([&](int lane) { env_step<double, MAXEFC>(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); });
   }
 }
+long emu_redo_total(void* h) { return ((EmuBatch*)h)->redo_total; }
 void emu_set_state(void* h, const double* qpos, const double* qvel, const int* fidx, const unsigned char* mask) {
   EmuBatch* e = (EmuBatch*)h;
   std::fill(e->kin_ok.begin(), e->kin_ok.end(), 0);

@@ -116,6 +116,9 @@ template <class T> inline void lds_sub(bool pred, T* p, T v) {
 template <int I, class T> inline T row_bcast(T v) { return exchange(v, (lane() & 48) | I); }
 template <int I> inline int row_bcast_i(int v) { return exchange(v, (lane() & 48) | I); }
 template <int I, class T> inline void row_fmac(T& acc, T x, T y) { acc = std::fma(row_bcast<I>(x), y, acc); }
+template <int I, class T> inline void row_fmac_old(T& acc, T x, T y) { acc = std::fma(row_bcast<I>(x), y, acc); }
+inline void dpp_settle() {}
+inline int global_counter_next(int* p) { return (*p)++; }
 inline unsigned row_ballot(bool p, int lane_id) { return (unsigned)((ballot(p) >> (lane_id & 48)) & 0xffffull); }
 inline int pin_zero() { return 0; }
 inline int launder(int v) { return v; }
