@@ -195,9 +195,13 @@ class Batch(object):
 
     def redo_total(self):
         """env-steps the four-envs-per-wave path (option 105) handed to the one-env kernel so far"""
-        v = C.c_int64(0)
-        A.check(self._L.dm_batch_redo_total(self._h, C.byref(v)), self._L)
-        return int(v.value)
+        return self.redo_reasons()[0]
+
+    def redo_reasons(self):
+        """[total, > 16 candidate pairs, box slots, > 8 contacts, > 32 rows, PGS cost test] env-steps handed to the one-env kernel"""
+        v = (C.c_int64 * 8)()
+        A.check(self._L.dm_batch_redo_total(self._h, v), self._L)
+        return [int(x) for x in v[:6]]
 
     def sync(self):
         A.check(self._L.dm_batch_sync(self._h), self._L)

@@ -102,6 +102,21 @@ __global__ __launch_bounds__(64) void k_step_packed(const DevModel<Real>* __rest
   const int env = B.order ? B.order[pos] : pos;
   slot_env_step<Real>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first);
 }
+// the same with shader-clock stamps per stage, one record of 16 per wave (DM option 101 with option 105; diagnostic)
+__global__ __launch_bounds__(64) void k_step_packed_prof(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
+                                                         Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
+                                                         int n_substeps, int first, int count, int* __restrict__ redo_count, long long* __restrict__ prof) {
+  __shared__ SlotShared<Real> sh[SLOTS];
+  __shared__ SlotTables tb;
+  const int lane = dmw::lane(), slot = lane >> 4, sl = lane & 15;
+  stage_slot_tables(tb, lane);
+  const int last = first + count - 1;
+  int pos = first + SLOTS * (int)blockIdx.x + slot;
+  const bool live = pos <= last;
+  if (pos > last) pos = last;
+  const int env = B.order ? B.order[pos] : pos;
+  slot_env_step<Real, true>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first, prof + (size_t)blockIdx.x * 32);
+}
 // ... and stepped here, from their unchanged state, by the one-env code (a handful of persistent single-wave workgroups walk the list)
 __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_redo(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                                   Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
@@ -508,9 +523,14 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
   if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } if (!piped) HIPCHK(hipEventRecord(b->ev0, b->stream)); }
   const bool reorder = b->reorder && b->has_rows && b->n > b->resident_waves;   // more envs than resident waves: later rounds exist, their tail matters
   // the packed kernel covers: models without constraint rows, reward modes alive / v3-config / v2-pose, no fused policy step
-  const bool use_packed = b->packed && b->B.reward_mode <= 2 && !pol && !b->prof && b->two_tier;
+  const bool use_packed = b->packed && b->B.reward_mode <= 3 && !pol && !b->prof && b->two_tier;
   constexpr int REDO_BLOCKS = 64;
-  if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, b->d_prof);
+  if (b->prof && b->packed && b->B.reward_mode <= 3) {
+    HIPCHK(hipMemsetAsync(b->d_prof, 0, (size_t)b->n * dm::PROF_SLOTS * sizeof(long long), b->stream));
+    HIPCHK(hipMemsetAsync(b->B.redo_count, 0, sizeof(int), b->stream));
+    hipLaunchKernelGGL(k_step_packed_prof, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, b->B.redo_count, b->d_prof);
+    if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)b->B.redo_count);
+  } else if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, b->d_prof);
   else if (piped) {
     // Sub-batch h's launch of THIS call depends on its own launch of the previous call (stream order on ps[h]) and on the
     // caller's inputs (ev_in), not on the other sub-batches: while the last, cheap workgroups of one sub-batch drain, the
@@ -777,10 +797,10 @@ extern "C" int dm_batch_redo_total(dm_batch* b, int64_t* out) {
   if (!b || !out) return fail(DM_EINVAL, "dm_batch_redo_total: null argument");
   HIPCHK(hipSetDevice(b->device));
   if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
-  int v = 0;
-  HIPCHK(hipMemcpyAsync(&v, b->B.redo_why, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+  int v[8] = {0};
+  HIPCHK(hipMemcpyAsync(v, b->B.redo_why, sizeof v, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
-  *out = v;
+  for (int k = 0; k < 8; k++) out[k] = v[k];      /* [0] total; [1..5] by reason: candidates, box slots, contacts, rows, PGS cost test */
   return DM_OK;
 }
 extern "C" int dm_batch_join(dm_batch* b) {

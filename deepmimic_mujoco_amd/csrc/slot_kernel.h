@@ -20,7 +20,7 @@
 namespace dm {
 
 constexpr int SLOTS = 4, SW = 16;            // environments per wavefront, lanes per environment
-constexpr int SLOT_MAXROWS = 32, SLOT_MAXCON = 8, SLOT_MAXCAND = 16, SLOT_BOXSLOTS = 3;   // per-environment capacities of the packed path; beyond: fix-up by the one-env kernel
+constexpr int SLOT_MAXROWS = 32, SLOT_MAXLIMROWS = 16, SLOT_MAXCON = 10, SLOT_MAXCAND = 32, SLOT_BOXSLOTS = 3;   // per-environment capacities of the packed path; beyond: fix-up by the one-env kernel
 constexpr int PAIR_PASSES = MAXPAIR / SW;
 constexpr int DOF_PASSES = (NV + SW - 1) / SW, HINGE_PASSES = (NU + SW - 1) / SW, Q_PASSES = (NQ + SW - 1) / SW, ENT_PASSES = (310 + SW - 1) / SW;
 
@@ -31,9 +31,13 @@ template <class R>
 struct SlotShared {
   R qpos[36], qvel[NV];
   R xpos[NB][3], xmat[NB][9];
-  R tau[NV], qacc[NV];
+  R tau[NV];
+  union {
+    struct { R qacc[NV], dinv[NV]; } o;                         // result of the evaluation | 1 / D of the factorisation (M build only)
+    struct { R axes[2][3][3], poly[2][8][3]; } bb;              // box-box scratch of the narrow phase (both are dead then)
+  } qd;
   R cdof[NV][6];
-  R dinv[NV], dsq[NV], act[NV], qws[NV];
+  R dsq[NV], act[NV], qws[NV];
   union {
     struct { R xquat[NB][4], sc[NU][2], off[NB][3]; } k;
     struct { R cvel[NB][6], cacc[NB][6], cfrc[NB][6]; } v;      // (the subtree sums of cfrc overwrite cvel)
@@ -41,11 +45,8 @@ struct SlotShared {
     struct {                                                    // collision .. constraint stage
       R gpos[NG][3];                                            // geom world positions (orientations are re-formed per candidate pair)
       R boxc[SLOT_BOXSLOTS][4][4];                              // contacts (dist, pos) of plane-box (slots 0, 1) and box-box (slot 2)
-      union {
-        struct { R axes[2][3][3], poly[2][8][3]; } bb;          // box-box scratch (narrow phase only)
-        R con[SLOT_MAXCON][10];                                 // staged contacts: pos[3], normal[3], tangent 1 [3], dist (emission .. row build)
-      } c;
-      R rowv[SLOT_MAXROWS];                                     // limit rows: distance
+      R con[SLOT_MAXCON][10];                                   // staged contacts: pos[3], normal[3], tangent 1 [3], dist (emission .. row build)
+      R rowv[SLOT_MAXLIMROWS];                                  // limit rows (they come first): distance
       int rowi[SLOT_MAXROWS];                                   // row codes (see slot_rows)
       int cand[SLOT_MAXCAND];                                   // candidate pair numbers past the broad phase, in pair-list order
       int coni[SLOT_MAXCON];                                    // pair number of a staged contact
@@ -280,51 +281,65 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, int sl_in, const L
 // ---- mass matrix and its L^T D L factor (env_kernel.h stage_mass_matrix).  The elimination steps are those of ELIM_STEPS; the
 // columns of a step are taken one after the other by the slot's 16 lanes, in the order (pass, column, pair) in which the one-env
 // kernel's lane groups apply them, so that entries which several limbs update receive their contributions in the same order. ---------
-template <int S, int P, int CI, class R>
-DM_DEV void slot_eliminate_chunk(SlotShared<R>& s, const SlotTables& tb, int sl, const LaneTopo& lt) {
-  // chunk = 16 consecutive pair numbers [16 * q, 16 * q + 16) of column K = ELIM_STEPS[S].K[CI]; P is the one-env kernel's pass number
-  constexpr ElimStep st = ELIM_STEPS[S];
-  constexpr int K = st.K[CI], gs = elim_group_size(st.ncol, CI), np = elim_npairs(K), base = TOPO.madr[K];
-  constexpr int sub = gs / SW;                                  // 16-lane chunks per pass of the one-env lane group
-  const R inv = dmw::rcp_fast(s.r2.qLD[base]);
-#pragma unroll
-  for (int u = 0; u < sub; u++) {
-    constexpr int dummy = 0; (void)dummy;
-    const int t0 = gs * P + SW * u;
-    if (t0 < np) {
-      const int t = t0 + sl;
-      const bool on = t < np;
-      const int code = on ? (int)(lt.tri >> (8 * (t >> 4))) & 0xff : 0, e = code >> 4, a = code & 15;
-      const int dst = tb.tab_dst[K][a] + (e - a);
-      dmw::lds_sub(on, &s.r2.qLD[dst], s.r2.qLD[base + e] * (s.r2.qLD[base + a] * inv));
+// The chunks (16 consecutive pair numbers of one column) of a step, in the one-env kernel's order of application (pass, column, sub-chunk)
+struct SlotElimChunks { int n; int K[24]; int t0[24]; };
+constexpr SlotElimChunks make_slot_elim_chunks(int S) {
+  SlotElimChunks c{};
+  const ElimStep st = ELIM_STEPS[S];
+  for (int P = 0; P < elim_passes(S); P++)
+    for (int ci = 0; ci < st.ncol; ci++) {
+      const int gs = elim_group_size(st.ncol, ci), np = elim_npairs(st.K[ci]);
+      for (int u = 0; u < gs / SW; u++) {
+        const int t0 = gs * P + SW * u;
+        if (t0 < np) { c.K[c.n] = st.K[ci]; c.t0[c.n] = t0; c.n++; }
+      }
     }
-  }
+  return c;
 }
-template <int S, int P, int CI, class R>
-struct SlotElimCols {
-  static DM_DEV void run(SlotShared<R>& s, const SlotTables& tb, int sl, const LaneTopo& lt) {
-    if constexpr (CI < ELIM_STEPS[S].ncol) {
-      constexpr int gs = elim_group_size(ELIM_STEPS[S].ncol, CI), np = elim_npairs(ELIM_STEPS[S].K[CI]);
-      if constexpr (gs * P < np) slot_eliminate_chunk<S, P, CI, R>(s, tb, sl, lt);
-      SlotElimCols<S, P, CI + 1, R>::run(s, tb, sl, lt);
-    }
+constexpr bool slot_elim_chunks_fit() { for (int S = 0; S < N_ELIM_STEPS; S++) if (make_slot_elim_chunks(S).n > 24) return false; return true; }
+static_assert(slot_elim_chunks_fit(), "a step has at most 24 chunks");
+// One elimination step.  A column only READS its own row and only WRITES rows of its proper ancestors, and the columns of a step lie in
+// different branches: no update of the step touches anything the step reads.  So all operands are fetched first (one LDS round trip for
+// the whole step instead of one per chunk: a lone wave has nothing to hide them behind), the products formed, and the updates then
+// issued back to back as fire-and-forget LDS atomics in the one-env kernel's order.
+template <int S, class R>
+DM_DEV void slot_eliminate_step(SlotShared<R>& s, const SlotTables& tb, int sl, const LaneTopo& lt) {
+  constexpr SlotElimChunks CH = make_slot_elim_chunks(S);
+  constexpr ElimStep st = ELIM_STEPS[S];
+  R inv[4];
+#pragma unroll
+  for (int ci = 0; ci < st.ncol; ci++) inv[ci] = s.r2.qLD[TOPO.madr[st.K[ci]]];
+  R xe[CH.n], xa[CH.n];
+  int dst[CH.n];
+  bool on[CH.n];
+#pragma unroll
+  for (int c = 0; c < CH.n; c++) {
+    const int K = CH.K[c], np = elim_npairs(K), base = TOPO.madr[K];
+    const int t = CH.t0[c] + sl;
+    on[c] = t < np;
+    const int code = on[c] ? (int)(lt.tri >> (8 * (t >> 4))) & 0xff : 0, e = code >> 4, a = code & 15;
+    dst[c] = tb.tab_dst[K][a] + (e - a);
+    xe[c] = s.r2.qLD[base + e]; xa[c] = s.r2.qLD[base + a];
   }
-};
-template <int S, int P, class R>
-struct SlotElimPasses {
-  static DM_DEV void run(SlotShared<R>& s, const SlotTables& tb, int sl, const LaneTopo& lt) {
-    if constexpr (P < elim_passes(S)) {
-      SlotElimCols<S, P, 0, R>::run(s, tb, sl, lt);
-      SlotElimPasses<S, P + 1, R>::run(s, tb, sl, lt);
-    }
+#pragma unroll
+  for (int ci = 0; ci < st.ncol; ci++) inv[ci] = dmw::rcp_fast(inv[ci]);
+#pragma unroll
+  for (int c = 0; c < CH.n; c++) {
+    int ci = 0;
+#pragma unroll
+    for (int q = 0; q < st.ncol; q++) if (st.K[q] == CH.K[c]) ci = q;
+    xe[c] = xe[c] * (xa[c] * inv[ci]);
   }
-};
+  dmw::reload_fence();
+#pragma unroll
+  for (int c = 0; c < CH.n; c++) dmw::lds_sub(on[c], &s.r2.qLD[dst[c]], xe[c]);
+  dmw::sync();
+}
 template <int S, class R>
 struct SlotEliminateFrom {
   static DM_DEV void run(SlotShared<R>& s, const SlotTables& tb, int sl, const LaneTopo& lt) {
     if constexpr (S < N_ELIM_STEPS) {
-      SlotElimPasses<S, 0, R>::run(s, tb, dmw::launder(sl), lt);
-      dmw::sync();
+      slot_eliminate_step<S, R>(s, tb, dmw::launder(sl), lt);
       SlotEliminateFrom<S + 1, R>::run(s, tb, sl, lt);
     }
   }
@@ -347,17 +362,20 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
     const int d = sl + SW * c;
     if (d < NV) {
       for (int r = 0; r < 6; r++) s.r1.fdof[d][r] = f[c][r];
-      s.dinv[d] = M.dof_armature[d];
+      s.qd.o.dinv[d] = M.dof_armature[d];
     }
   }
+  int ijc[ENT_PASSES];                      // (i << 8) | j of this lane's entries, fetched ahead of the hand-off: the loop below then has no dependent look-up
+#pragma unroll
+  for (int c = 0; c < ENT_PASSES; c++) { const int e = sl + SW * c; ijc[c] = tb.tab_ent[e < 312 ? e : 0]; }
   dmw::sync();
 #pragma unroll
   for (int c = 0; c < ENT_PASSES; c++) {
     const int e = sl + SW * c;
     if ((c + 1) * SW <= TOPO.nM || e < TOPO.nM) {
-      const int ij = tb.tab_ent[e], i = ij >> 8, j = ij & 0xff;
+      const int ij = ijc[c], i = ij >> 8, j = ij & 0xff;
       R v = dot6(s.cdof[j], s.r1.fdof[i]);
-      if (i == j) v += s.dinv[i];
+      if (i == j) v += s.qd.o.dinv[i];
       s.r2.qLD[e] = v;
       if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
     }
@@ -367,15 +385,15 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
 #pragma unroll
   for (int c = 0; c < DOF_PASSES; c++) {
     const int d = sl + SW * c;
-    if (d < NV) { const R inv = R(1) / s.r2.qLD[TOPO.madr[d]]; s.dinv[d] = inv; s.dsq[d] = sqrt(inv); }
+    if (d < NV) { const R inv = R(1) / s.r2.qLD[TOPO.madr[d]]; s.qd.o.dinv[d] = inv; s.dsq[d] = sqrt(inv); }
   }
   dmw::sync();
 #pragma unroll
   for (int c = 0; c < ENT_PASSES; c++) {
     const int e = sl + SW * c;
     if ((c + 1) * SW <= TOPO.nM || e < TOPO.nM) {
-      const int ij = tb.tab_ent[e], i = ij >> 8, j = ij & 0xff;
-      const R sc = i != j ? s.dinv[i] : R(1);
+      const int ij = ijc[c], i = ij >> 8, j = ij & 0xff;
+      const R sc = i != j ? s.qd.o.dinv[i] : R(1);
       s.r2.qLD[e] *= sc;
     }
   }
@@ -411,10 +429,11 @@ DM_DEV int row_exclusive_scan(int v, int sl, int lane, int* total) {
 //   * what a row's lane needs later is staged per CONTACT (position, normal, first tangent, distance) plus one code word per row;
 //     the row's Jacobian wrench is formed in registers by the constraint stage.
 // Row code: limit  ROW_LIMIT   | dof << 8 | (sign > 0) << 16;   contact  ROW_CONTACT | contact << 8 | pyramid edge q << 16 | condim << 20.
-// Capacities (SLOT_MAXCAND candidates, SLOT_MAXCON contacts, `cap` rows): an environment that exceeds one is flagged (`ovf`) and
-// re-stepped by the one-env kernel; nothing of it is stored by this wave.  Returns the slot's row count.
+// Capacities (SLOT_MAXCAND candidates, SLOT_MAXCON contacts, SLOT_MAXROWS rows): an environment that exceeds one is flagged (`ovf`: bit 0
+// candidates, 1 box slots, 2 contacts, 3 rows, 4 a PGS step the cost test would reject, 6 any) and re-stepped by the one-env kernel;
+// nothing of it is stored by this wave.  Returns the slot's row count.
 template <class R>
-DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, bool& ovf) {
+DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int& ovf) {
   const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
   const unsigned below = (1u << sl) - 1u;
   const int npair = dmw::uniform(M.npair);
@@ -450,10 +469,11 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
       const unsigned mask = dmw::row_ballot(viol, lane);
       if (viol) {
         const int r = nrow + __builtin_popcount(mask & below);
-        if (r < SLOT_MAXROWS) { W.rowi[r] = ROW_LIMIT | ((h + 6) << 8) | (pos_sign << 16); W.rowv[r] = dist; }
+        if (r < SLOT_MAXLIMROWS) { W.rowi[r] = ROW_LIMIT | ((h + 6) << 8) | (pos_sign << 16); W.rowv[r] = dist; }
       }
       nrow += __builtin_popcount(mask);
     }
+    if (nrow > SLOT_MAXLIMROWS) ovf |= 8;
   }
   dmw::sync();
   int ncon = 0;
@@ -481,12 +501,14 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
         ncand += __builtin_popcount(mask);
       }
     }
-    if (ncand > SLOT_MAXCAND) { ovf = true; ncand = SLOT_MAXCAND; }
-    if (rows_max(ncand) > 0) {
-      dmw::sync();
-      // ---- narrow phase: candidate k of the environment on lane k
-      const bool has = sl < ncand;
-      const int pidx = has ? W.cand[sl] : 0;
+    if (ncand > SLOT_MAXCAND) { ovf |= 1; ncand = SLOT_MAXCAND; }
+    const int maxc = rows_max(ncand);
+    if (maxc > 0) dmw::sync();
+    for (int trip = 0; trip * SW < maxc; trip++) {            // (one trip unless an environment of the wave has more than 16 candidates)
+      // ---- narrow phase: candidate k of the environment on lane k % 16
+      const int kc = trip * SW + sl;
+      const bool has = kc < ncand;
+      const int pidx = has ? W.cand[kc] : 0;
       const auto& rec = M.pair_rec[pidx];
       const int g1 = rec.g1, g2 = rec.g2, tt = rec.t1t2, meta = rec.meta;
       const R margin = rec.margin;
@@ -505,9 +527,9 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
         }
         const int raw = ((meta >> 16) & 0xff) - 1;             // staging slot of the one-env kernel: plane-box 0..3, box-box 4..5
         const int slotb = raw < 0 ? -1 : (raw < 4 ? raw : raw - 2);
-        if (slotb >= SLOT_BOXSLOTS || (raw >= 2 && raw < 4)) ovf = true;      // (a model with more boxes than the humanoid's two feet)
+        if (slotb >= SLOT_BOXSLOTS || (raw >= 2 && raw < 4)) ovf |= 2;      // (a model with more boxes than the humanoid's two feet)
         else {
-          const BoxScratch<R> bx{W.c.bb.axes, W.c.bb.poly, W.boxc};
+          const BoxScratch<R> bx{s.qd.bb.axes, s.qd.bb.poly, W.boxc};
           narrowphase_at(bx, p1, m1, p2, m2, t1, t2, z1, z2, M.pair_rec[pidx].s1, M.pair_rec[pidx].s2, slotb, margin, pc);
         }
       }
@@ -516,32 +538,30 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
         const int rows_per = dim == 1 ? 1 : 2 * (dim - 1);
         int tot_rows, tot_con;
         const int r0 = nrow + row_exclusive_scan(pc.n * rows_per, sl, lane, &tot_rows);
-        const int c0 = row_exclusive_scan(pc.n, sl, lane, &tot_con);
+        const int c0 = ncon + row_exclusive_scan(pc.n, sl, lane, &tot_con);
         R fr[9];
         if (pc.n > 0) make_frame(fr, pc.nrm, pc.hint);
-        dmw::sync();                                           // the box-box scratch (aliased by the staged contacts) is no longer in use
         if (pc.n > 0) {
           for (int k = 0; k < pc.n; k++) {
             const int ci = c0 + k, rk = r0 + k * rows_per;
-            if (ci >= SLOT_MAXCON || rk + rows_per > SLOT_MAXROWS) { ovf = true; continue; }
+            if (ci >= SLOT_MAXCON || rk + rows_per > SLOT_MAXROWS) { ovf |= ci >= SLOT_MAXCON ? 4 : 8; continue; }
             R cdist, cpos[3];
             if (pc.boxslot >= 0) { const R* o = W.boxc[pc.boxslot][k]; cdist = o[0]; cpos[0] = o[1]; cpos[1] = o[2]; cpos[2] = o[3]; }
             else if (k == 0) { cdist = pc.d0; cpos[0] = pc.p0[0]; cpos[1] = pc.p0[1]; cpos[2] = pc.p0[2]; }
             else { cdist = pc.d1; cpos[0] = pc.p1[0]; cpos[1] = pc.p1[1]; cpos[2] = pc.p1[2]; }
-            R* o = W.c.con[ci];
+            R* o = W.con[ci];
             o[0] = cpos[0]; o[1] = cpos[1]; o[2] = cpos[2]; o[3] = fr[0]; o[4] = fr[1]; o[5] = fr[2]; o[6] = fr[3]; o[7] = fr[4]; o[8] = fr[5]; o[9] = cdist;
             W.coni[ci] = pidx;
             for (int q = 0; q < rows_per; q++) W.rowi[rk + q] = ROW_CONTACT | (ci << 8) | (q << 16) | (dim << 20);
           }
         }
-        nrow += tot_rows; ncon = tot_con;
+        nrow += tot_rows; ncon += tot_con;
       }
     }
   }
   // an overflow anywhere in the row -> the whole environment is flagged (ovf is per lane so far)
-  ovf = dmw::row_ballot(ovf, lane) != 0u;
-  if (nrow > SLOT_MAXROWS) ovf = true;
-  if (ovf) { nrow = 0; ncon = 0; }                             // nothing of this evaluation is used: no row may be read (some were never staged)
+  if (nrow > SLOT_MAXROWS) ovf |= 8;
+  if (dmw::row_ballot(ovf != 0, lane) != 0u) { ovf |= 64; nrow = 0; ncon = 0; }    // (bit 6: some lane of the row holds a reason)                             // nothing of this evaluation is used: no row may be read (some were never staged)
   if (sl == 0) { s.nefc = nrow; s.ncon = ncon; }
   dmw::sync();
   return nrow;
@@ -609,9 +629,11 @@ template <int CC, int NS, class R>
 DM_DEV void slot_acol(R (*AR)[16 * NS], const R (*y)[NV]) {
 #pragma unroll
   for (int k = 0; k < NS; k++) {
-    R acc0 = 0, acc1 = 0;                 // two partial sums: halves the dependent chain of the 34 fused multiply-adds
+    R acc0 = 0, acc1 = 0;                 // two partial sums (even / odd dofs): halves the dependent chain of the 34 fused multiply-adds
 #pragma unroll
-    for (int d = 0; d < NV; d += 2) { dmw::row_fmac_old<CC % 16>(acc0, y[CC / 16][d], y[k][d]); dmw::row_fmac_old<CC % 16>(acc1, y[CC / 16][d + 1], y[k][d + 1]); }
+    for (int d = 0; d + 8 <= NV; d += 8) dmw::row_fmac8<CC % 16>(acc0, acc1, &y[CC / 16][d], &y[k][d]);
+#pragma unroll
+    for (int d = NV / 8 * 8; d < NV; d += 2) { dmw::row_fmac_old<CC % 16>(acc0, y[CC / 16][d], y[k][d]); dmw::row_fmac_old<CC % 16>(acc1, y[CC / 16][d + 1], y[k][d + 1]); }
     AR[k][CC] = acc0 + acc1;
   }
 }
@@ -639,22 +661,20 @@ struct SlotWarm {
     }
   }
 };
-// one PGS row (scaled-residual form of env_kernel.h): delta = max(-f, t) of the row's own lane, broadcast, t += A_s[:, row] delta
+// one PGS row (scaled-residual form of env_kernel.h): delta = max(-f, t) of the row's own lane, broadcast, t += A_s[:, row] delta; the own
+// lane's residual at its row is kept through a one-hot multiply-add (oh[i] = 1 in slot lane i)
 template <int CC, int NS, class R>
-DM_DEV void slot_sweep_row(const R (*AR)[16 * NS], R* t, R* tsave, const R* nf0, int ln) {
-  const R delta = dmw::max_raw(nf0[CC / 16], t[CC / 16]);
-  if (ln == (CC % 16)) tsave[CC / 16] = t[CC / 16];
-  dmw::row_fmac<CC % 16>(t[0], delta, AR[0][CC]);              // (the fresh delta is the DPP source: hazard slot inside)
-#pragma unroll
-  for (int k = 1; k < NS; k++) dmw::row_fmac_old<CC % 16>(t[k], delta, AR[k][CC]);
+DM_DEV void slot_sweep_row(const R (*AR)[16 * NS], R* t, R* tsave, const R* nf0, const R* oh) {
+  if constexpr (NS == 1) dmw::pgs_row<CC % 16>(t[0], tsave[0], nf0[0], AR[0][CC], oh[CC % 16]);
+  else dmw::pgs_row2<CC % 16>(t[CC / 16], tsave[CC / 16], t[1 - CC / 16], nf0[CC / 16], AR[CC / 16][CC], AR[1 - CC / 16][CC], oh[CC % 16]);
 }
 template <int C, int NS, class R>
 struct SlotSweep {
-  static DM_DEV void run(const R (*AR)[16 * NS], R* t, R* tsave, const R* nf0, int ln, int nmax) {
+  static DM_DEV void run(const R (*AR)[16 * NS], R* t, R* tsave, const R* nf0, const R* oh, int nmax) {
     if constexpr (C < 16 * NS) {
-      slot_sweep_row<C, NS, R>(AR, t, tsave, nf0, ln); slot_sweep_row<C + 1, NS, R>(AR, t, tsave, nf0, ln);
-      slot_sweep_row<C + 2, NS, R>(AR, t, tsave, nf0, ln); slot_sweep_row<C + 3, NS, R>(AR, t, tsave, nf0, ln);
-      if (C + 4 < nmax) SlotSweep<C + 4, NS, R>::run(AR, t, tsave, nf0, ln, nmax);
+      slot_sweep_row<C, NS, R>(AR, t, tsave, nf0, oh); slot_sweep_row<C + 1, NS, R>(AR, t, tsave, nf0, oh);
+      slot_sweep_row<C + 2, NS, R>(AR, t, tsave, nf0, oh); slot_sweep_row<C + 3, NS, R>(AR, t, tsave, nf0, oh);
+      if (C + 4 < nmax) SlotSweep<C + 4, NS, R>::run(AR, t, tsave, nf0, oh, nmax);
     }
   }
 };
@@ -662,7 +682,9 @@ struct SlotSweep {
 template <int CC, class R>
 DM_DEV void slot_assemble_row(R* ws, const R (*fy)[NV], R one) {
 #pragma unroll
-  for (int d = 0; d < NV; d++) dmw::row_fmac_old<CC % 16>(ws[d], fy[CC / 16][d], one);
+  for (int d = 0; d + 8 <= NV; d += 8) dmw::row_add8<CC % 16>(&ws[d], &fy[CC / 16][d], one);
+#pragma unroll
+  for (int d = NV / 8 * 8; d < NV; d++) dmw::row_fmac_old<CC % 16>(ws[d], fy[CC / 16][d], one);
 }
 template <int C, int NS, class R>
 struct SlotAssemble {
@@ -681,9 +703,12 @@ struct SlotAssemble {
 // smooth force's half solve z is carried by EVERY lane beside its rows (same factor loads), and the final L^-1 pass runs on a
 // register vector that all 16 lanes of the slot hold.  `nefc` is the slot's row count, `nmax` the wave's largest (row loops run to it;
 // a slot's absent rows are exact zeros).  The sweeps of a converged environment are frozen, so its result does not depend on its partners.
-template <class R, int NS>
-DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int nefc, int nmax, bool& ovf, const DebugOut* dbg) {
+template <class R, int NS, bool PROF = false>
+DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int nefc, int nmax, int& ovf, const DebugOut* dbg, long long* prof = 0) {
   const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
+  long long pt0 = 0, pt1 = 0;
+  if (PROF) pt0 = dmw::clk();
+#define SLOT_STAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
   constexpr int NC = 16 * NS;
   auto& W = s.r1.rw;
   R y[NS + 1][NV];                     // rows' Jacobians -> Y;  y[NS] = tau -> z (identical in every lane of the slot)
@@ -706,7 +731,7 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
       pos[k] = W.rowv[r]; dA[k] = M.dof_invw[d]; mplus = 1ull << d;
     } else if (type == ROW_CONTACT) {
       const int ci = (code >> 8) & 0xff, q = (code >> 16) & 0xf, cdim = (code >> 20) & 0xf;
-      const R* c = W.c.con[ci];
+      const R* c = W.con[ci];
       const auto& rec = M.pair_rec[W.coni[ci]];
       const R cmu = rec.mu, ctran = rec.tran;
       const int meta = rec.meta;
@@ -746,6 +771,7 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
       for (int d = 0; d < NV; d++) o[d] = (double)y[k][d];
     }
   }
+  SLOT_STAMP(8)
   R Rr[NS], aref[NS], f[NS];
 #pragma unroll
   for (int k = 0; k < NS; k++) {
@@ -782,6 +808,7 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
     for (int d = 0; d < NV; d++) { if (d & 1) acc1 += y[k][d] * y[NS][d]; else acc0 += y[k][d] * y[NS][d]; }
     bb[k] = active[k] ? (acc0 + acc1) - aref[k] : R(0);
   }
+  SLOT_STAMP(9)
   // ---- A = Y Y^T + diag(R) --------------------------------------------------------------------------------------------------------
   R AR[NS][NC];
 #pragma unroll
@@ -798,6 +825,7 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
     for (int c = 0; c < 16; c++) { if (sl == c) { AR[k][16 * k + c] += active[k] ? Rr[k] : R(0); dg = AR[k][16 * k + c]; } }
     diag[k] = active[k] ? dg : R(1);
   }
+  SLOT_STAMP(10)
   // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ---------------------------------------------------------
   R ndinv[NS], tb[NS], t[NS];
 #pragma unroll
@@ -813,44 +841,65 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
       for (int k = 0; k < NS; k++) { f[k] = 0; t[k] = tb[k]; }
     }
   }
+  SLOT_STAMP(11)
   // ---- projected Gauss-Seidel: rows in order, every environment of the wave in step; a converged environment is frozen ----------------
   const int maxiter = dmw::uniform(M.iterations);
   R pgs_scale = M.pgs_scale, pgs_tol = M.tolerance, pgs_detect = M.pgs_detect;
   dmw::pin_value(pgs_scale); dmw::pin_value(pgs_tol); dmw::pin_value(pgs_detect);
   int iter = 0;
-  bool frozen = nefc == 0, anybad = false;
+  bool frozen = nefc == 0 || maxiter <= 0, anybad = false;
   if (frozen) {
 #pragma unroll
     for (int k = 0; k < NS; k++) t[k] = 0;
   }
-  bool more = maxiter > 0 && rows_max(frozen ? 0 : 1) != 0;
-  while (more) {
+  R oh[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { oh[i] = sl == i ? R(1) : R(0); dmw::pin_value(oh[i]); }
+  // one sweep: forces f, scaled residuals t; returns this lane's share of the cost improvement and whether [MJ costChange] would object
+  auto sweep = [&](R& imp, bool& bad) {
     const int nm = dmw::launder_uniform(nmax);
-    const int ln = dmw::launder(sl);
     R nf0[NS], tsave[NS];
 #pragma unroll
-    for (int k = 0; k < NS; k++) { nf0[k] = -f[k]; tsave[k] = t[k]; }
-    SlotSweep<0, NS, R>::run(AR, t, tsave, nf0, ln, nm);
-    R imp = 0;
-    bool bad = false;
+    for (int k = 0; k < NS; k++) { nf0[k] = -f[k]; tsave[k] = 0; }
+    SlotSweep<0, NS, R>::run(AR, t, tsave, nf0, oh, nm);
+    imp = 0; bad = false;
 #pragma unroll
     for (int k = 0; k < NS; k++) {
       const R delta = dmw::max_raw(nf0[k], tsave[k]);
       const R change = (delta * diag[k]) * (R(0.5) * delta - tsave[k]);
       f[k] += delta; imp -= change; bad = bad || (change > pgs_detect);
     }
-    const R improvement = dmw::sum16(imp) * pgs_scale;
-    if (!frozen) { iter += 1; anybad = anybad || bad; }
-    const bool conv = !frozen && (improvement < pgs_tol || iter >= maxiter);
-    if (conv) {
-      // freeze: from now on every row's step is exactly zero (t = 0 where a force is held, t <= 0 where it is zero), forces stay
-      frozen = true;
+  };
+  // The termination test of sweep k (a DPP reduction) is independent of the rows of sweep k + 1: sweep k + 1 is issued speculatively
+  // beside it and dropped — forces restored, rows frozen — for the environments that turn out to have converged at sweep k.
+  // Freezing: every row's step becomes exactly zero (t = 0 where a force is held, t < 0 where it is zero), so a finished environment's
+  // forces no longer move while its partners go on.
+  if (dmw::ballot(!frozen) != 0ull) {
+    R imp; bool bad;
+    sweep(imp, bad);
+    if (!frozen) { iter = 1; anybad = bad; }
+    bool more = true;
+    while (more) {
+      R fprev[NS];
 #pragma unroll
-      for (int k = 0; k < NS; k++) t[k] = f[k] > 0 ? R(0) : R(-1);
+      for (int k = 0; k < NS; k++) fprev[k] = f[k];
+      const R improvement = dmw::sum16(imp) * pgs_scale;          // of the last accepted sweep
+      R imp2; bool bad2;
+      sweep(imp2, bad2);                                          // speculative
+      const bool conv = !frozen && (improvement < pgs_tol || iter >= maxiter);
+      if (conv) {
+        frozen = true;
+#pragma unroll
+        for (int k = 0; k < NS; k++) { f[k] = fprev[k]; t[k] = fprev[k] > 0 ? R(0) : R(-1); }
+      } else if (!frozen) { iter += 1; anybad = anybad || bad2; }
+      imp = imp2;
+      more = dmw::ballot(!frozen) != 0ull;
+      if (PROF) prof[6] += 1;
     }
-    more = rows_max(frozen ? 0 : 1) != 0;
   }
-  if (dmw::row_ballot(anybad, lane) != 0u) ovf = true;        // [MJ costChange] would have rejected a step: the one-env kernel's guarded replay decides
+  SLOT_STAMP(12)
+  if (PROF) { prof[14] += nmax; prof[15] += 1; }
+  if (dmw::row_ballot(anybad, lane) != 0u) ovf |= 16 | 64;        // [MJ costChange] would have rejected a step: the one-env kernel's guarded replay decides
   if (dbg) {
 #pragma unroll
     for (int k = 0; k < NS; k++) if (active[k]) {
@@ -877,10 +926,12 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
   solve_L(ws, s.r2.qLD);
   if (sl == 0) {
 #pragma unroll
-    for (int d = 0; d < NV; d++) s.qacc[d] = ws[d];
+    for (int d = 0; d < NV; d++) s.qd.o.qacc[d] = ws[d];
     s.solver_iter = iter;
   }
   dmw::sync();
+  SLOT_STAMP(13)
+#undef SLOT_STAMP
 }
 
 // ---- no rows anywhere in the wave: qacc = L^-1 D^-1/2 (D^-1/2 L^-T tau), the constrained formula with an empty sum (so that an
@@ -898,7 +949,7 @@ DM_DEV void slot_smooth_solve(SlotShared<R>& s, int sl, const DebugOut* dbg) {
   solve_L(x[0], s.r2.qLD);
   if (sl == 0) {
 #pragma unroll
-    for (int d = 0; d < NV; d++) { s.qacc[d] = x[0][d]; if (dbg) dbg->out[34 * 34 + 34 + d] = (double)x[0][d]; }
+    for (int d = 0; d < NV; d++) { s.qd.o.qacc[d] = x[0][d]; if (dbg) dbg->out[34 * 34 + 34 + d] = (double)x[0][d]; }
     s.solver_iter = 0;
   }
   dmw::sync();
@@ -906,30 +957,39 @@ DM_DEV void slot_smooth_solve(SlotShared<R>& s, int sl, const DebugOut* dbg) {
 
 // one forward-dynamics evaluation of the slot's environment: s.qpos, s.qvel, s.act, s.qws -> s.qacc; xip = body COM positions (body
 // lanes); ovf: the environment exceeded a capacity of the packed path (sticky)
-template <class R>
-DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, int lane, const LaneTopo& lt, R* xip, bool& ovf, const DebugOut* dbg) {
+template <class R, bool PROF = false>
+DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, int lane, const LaneTopo& lt, R* xip, int& ovf, const DebugOut* dbg, long long* prof = 0) {
+  long long t0 = 0, t1 = 0;
+  if (PROF) t0 = dmw::clk();
+#define SLOT_FSTAMP(k) if (PROF) { t1 = dmw::clk(); prof[k] += t1 - t0; t0 = t1; }
   DM_MARK("slot_kinematics");
   slot_kinematics(M, s, sl, lt, xip);
+  SLOT_FSTAMP(0)
   if (dbg) { for (int e = sl; e < NV * NV; e += SW) dbg->out[e] = 0; dmw::sync(); }
   DM_MARK("slot_bias");
   slot_bias(M, s, sl, lt);
+  SLOT_FSTAMP(1)
   if (dbg) {
     for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) dbg->out[34 * 34 + d] = (double)(-M.dof_damping[d] * s.qvel[d] + s.act[d] - s.tau[d]); }
   }
   DM_MARK("slot_mass_factor");
   slot_mass_matrix(M, s, tb, sl, lt, dbg);
+  SLOT_FSTAMP(2)
   DM_MARK("slot_rows");
   int nefc = 0;
   if (M.enable_contact || M.enable_limit) nefc = slot_rows(M, s, sl, lane, ovf);
   else { if (sl == 0) { s.nefc = 0; s.ncon = 0; } dmw::sync(); }
+  SLOT_FSTAMP(3)
   DM_MARK("slot_constraint");
   const int nmax = rows_max(nefc);
   if (nmax == 0) slot_smooth_solve(s, sl, dbg);
-  else if (nmax <= 16) slot_constraint<R, 1>(M, s, sl, lane, nefc, nmax, ovf, dbg);
-  else slot_constraint<R, 2>(M, s, sl, lane, nefc, nmax, ovf, dbg);
+  else if (nmax <= 16) slot_constraint<R, 1, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof);
+  else { slot_constraint<R, 2, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof); if (PROF) prof[7] += 1; }
+  SLOT_FSTAMP(4)
   DM_MARK("slot_forward_end");
+#undef SLOT_FSTAMP
   if (dbg) {
-    for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) dbg->out[34 * 34 + 68 + d] = (double)s.qacc[d]; }
+    for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) dbg->out[34 * 34 + 68 + d] = (double)s.qd.o.qacc[d]; }
     if (sl < NB - 1) for (int k = 0; k < 3; k++) dbg->out[34 * 34 + 102 + 3 * (sl + 1) + k] = (double)xip[k];
     if (sl == 0) { dbg->out[34 * 34 + 144] = s.nefc; dbg->out[34 * 34 + 145] = s.ncon; dbg->out[34 * 34 + 146] = s.solver_iter; }
   }

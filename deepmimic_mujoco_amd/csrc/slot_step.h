@@ -31,8 +31,8 @@ DM_DEV void slot_integrate_pos(SlotShared<R>& s, const DofVec<R>& x0q, int sl, R
 }
 
 // [MJ mj_step, integrator RK4] on the state in s.qpos / s.qvel / s.qws / s.act; xip = body COM positions of the 4th stage evaluation
-template <class R>
-DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, int lane, const LaneTopo& lt, R* xip, bool& ovf) {
+template <class R, bool PROF = false>
+DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, int lane, const LaneTopo& lt, R* xip, int& ovf, long long* prof = 0) {
   const R h = M.timestep;
   const R A[3] = {R(0.5), R(0.5), R(1)};
   const R Bw[4] = {R(1) / 6, R(1) / 3, R(1) / 3, R(1) / 6};
@@ -59,11 +59,11 @@ DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTabl
       }
       dmw::sync();
     }
-    slot_forward<R>(M, s, tb, sl, lane, lt, xip, ovf, (const DebugOut*)0);
+    slot_forward<R, PROF>(M, s, tb, sl, lane, lt, xip, ovf, (const DebugOut*)0, prof);
 #pragma unroll
     for (int c = 0; c < DOF_PASSES; c++) {
       const int d = sl + SW * c;
-      if (d < NV) { const R a = s.qacc[d]; aprev.r[c] = a; sumv.r[c] += Bw[i] * vprev.r[c]; suma.r[c] += Bw[i] * a; }
+      if (d < NV) { const R a = s.qd.o.qacc[d]; aprev.r[c] = a; sumv.r[c] += Bw[i] * vprev.r[c]; suma.r[c] += Bw[i] * a; }
     }
   }
 #pragma unroll
@@ -151,20 +151,109 @@ DM_DEV void slot_reset_env(const DevModel<R>& M, const Batch<R>& B, SlotShared<R
   }
 }
 
-// DPEnv.step for the slot's environment (reward modes alive / v3-config / v2-pose; the imitation modes live in the one-env kernel until
-// their epilogue is ported).  A slot that is not `live` computes and stores nothing outside LDS.  An environment that exceeded a
+// ---- 5-term imitation reward (env_step.h imitation_reward; code.md:1017-1143) for the slot's environment: one extra kinematics pass on
+// the integrated state, whose by-products are the joint features.  Slot lane = body - 1 (lane 0 root, lanes 1..12 joint groups); the four
+// end effectors on lanes 0..3 beside them; linear momentum one dof per lane in three passes; row sums (sum16) instead of wave sums.
+template <class R>
+DM_DEV R slot_imitation_reward(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, int sl, const LaneTopo& lt, const R* ref, R shx, R shy) {
+  R qloc[4], aloc[3][3], xip[3];
+  slot_kinematics(M, s, sl, lt, xip, qloc, aloc);          // ends with a sync; s.r2.i.crb holds the composite inertias
+  const R* P = B.imit_pdev;
+  R rq[4] = {s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
+  normalize4(rq);
+  R pose = 0, vel = 0, eff = 0, root = 0, mx = 0, my = 0, mz = 0;
+  if (sl < 13) {
+    const int g = sl - 1;
+    const int da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum);
+    const bool isroot = sl == 0, ball = !isroot && nd == 3;
+    const R* rquat = ref + (isroot ? 3 : 13 + 4 * g);
+    const R ident[4] = {1, 0, 0, 0};
+    R q0[4], q1[4];
+    for (int k = 0; k < 4; k++) { q0[k] = isroot ? rq[k] : (ball ? qloc[k] : ident[k]); q1[k] = (isroot || ball) ? rquat[k] : ident[k]; }
+    const R th = quat_diff_theta(q0, q1);
+    R pe = th * th, ve = 0;
+    if (isroot) {
+      R wv[3];
+      const R wloc[3] = {s.qvel[3], s.qvel[4], s.qvel[5]};
+      quat_rot(wv, rq, wloc);
+      R dv2 = 0, dp2 = 0;
+      for (int k = 0; k < 3; k++) { const R a = ref[10 + k] - wv[k]; ve += a * a; const R c = ref[7 + k] - s.qvel[k]; dv2 += c * c; }
+      const R p1[3] = {ref[0] + shx, ref[1] + shy, ref[2]};
+      for (int k = 0; k < 3; k++) { const R a = s.qpos[k] - p1[k]; dp2 += a * a; }
+      root = dp2 + R(0.1) * pe + R(0.01) * dv2 + R(0.001) * ve;
+    } else if (ball) {
+      R wl[3] = {0, 0, 0};
+      for (int k = 0; k < 3; k++) { const R rate = s.qvel[da + k]; wl[0] += aloc[k][0] * rate; wl[1] += aloc[k][1] * rate; wl[2] += aloc[k][2] * rate; }
+      for (int k = 0; k < 3; k++) { const R w = ref[61 + 3 * g + k] - wl[k]; ve += w * w; }
+    } else {
+      const R a = ref[13 + 4 * g] - s.qpos[da + 1], w = ref[61 + 3 * g] - s.qvel[da];
+      pe = a * a; ve = w * w;
+    }
+    const R wj = P[isroot ? 12 : g];
+    pose = wj * pe; vel = wj * ve;
+  }
+  if (sl < 4) {
+    const int e = sl, b = (int)P[16 + e];
+    const R ex[3] = {1, 0, 0};
+    R fwd[3], p[3], rel[3];
+    quat_rot(fwd, rq, ex);
+    const R hn = sqrt(fwd[0] * fwd[0] + fwd[1] * fwd[1]);
+    const R c = hn > R(0) ? fwd[0] / hn : R(1), sn = hn > R(0) ? fwd[1] / hn : R(0);
+    mat_vec(p, s.xmat[b], P + 20 + 3 * e);
+    for (int k = 0; k < 3; k++) { p[k] += s.xpos[b][k]; rel[k] = p[k] - s.qpos[k]; }
+    rel[2] = p[2];
+    const R f0[3] = {c * rel[0] + sn * rel[1], -sn * rel[0] + c * rel[1], rel[2]};
+    for (int k = 0; k < 3; k++) { const R a = ref[97 + 3 * e + k] - f0[k]; eff += a * a; }
+  }
+#pragma unroll
+  for (int cpass = 0; cpass < DOF_PASSES; cpass++) {
+    const int d = sl + SW * cpass;
+    if (d < NV) {
+      const int b = TOPO.dof_body[d];
+      const R* cb = s.r2.i.crb[b];
+      const R* cd = s.cdof[d];
+      const R qd = s.qvel[d], ms = cb[9];
+      R axs[3];
+      cross3(axs, cd, cb + 6);
+      mx += qd * (ms * cd[3] + axs[0]); my += qd * (ms * cd[4] + axs[1]); mz += qd * (ms * cd[5] + axs[2]);
+    }
+  }
+  pose = dmw::sum16(pose); vel = dmw::sum16(vel); eff = dmw::sum16(eff) / 4; root = dmw::row_bcast<0>(root);
+  mx = dmw::sum16(mx) / M.total_mass; my = dmw::sum16(my) / M.total_mass; mz = dmw::sum16(mz) / M.total_mass;
+  const R dc[3] = {ref[109] - mx, ref[110] - my, ref[111] - mz};
+  const R com = R(0.1) * dot3(dc, dc);
+  const R arg = sl == 0 ? R(-2) * pose : sl == 1 ? R(-0.1) * vel : sl == 2 ? R(-40) * eff : sl == 3 ? R(-5) * root : R(-10) * com;
+  const R wgt = sl == 0 ? R(0.5) : sl == 1 ? R(0.05) : sl == 2 ? R(0.15) : sl == 3 ? R(0.2) : R(0.1);
+  R term = 0;
+  if (sl < 5) term = wgt * exp_once(arg);
+  return dmw::sum16(term);
+}
+
+// DPEnv.step for the slot's environment (reward modes alive / v3-config / v2-pose / the 5-term imitation reward; dp_env_v1's reward stays with the one-env kernel).  A slot that is not `live` computes and stores nothing outside LDS.  An environment that exceeded a
 // capacity of the packed path during the step (`ovf`) stores nothing either: it is appended to the launch's redo list
 // (redo[0] = counter, list = redo + 1 ...) and re-stepped from its unchanged state by the one-env kernel.
-template <class R>
+template <class R, bool PROF = false>
 DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, SlotTables& tb, int env, int sl, int lane, bool live,
-                          const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int* redo_count, int* redo_list) {
+                          const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int* redo_count, int* redo_list,
+                          long long* prof_out = 0) {
+  long long prof[16];
+  for (int k = 0; k < 16; k++) prof[k] = 0;
+  long long tstart = 0;
+  if (PROF) tstart = dmw::clk();
   const LaneTopo lt = lane_topo(sl);
   slot_load_env(M, B, s, env, sl, live, action);
   R xip[3];
-  bool ovf = false;
-  for (int k = 0; k < n_substeps; k++) slot_rk4_step<R>(M, s, tb, sl, lane, lt, xip, ovf);
-  ovf = dmw::row_ballot(ovf, lane) != 0u;
-  if (ovf && live && sl == 0) { const int k = dmw::global_counter_next(redo_count); redo_list[k] = env; }
+  int why = 0;
+  for (int k = 0; k < n_substeps; k++) slot_rk4_step<R, PROF>(M, s, tb, sl, lane, lt, xip, why, prof);
+  const bool ovf = dmw::row_ballot(why != 0, lane) != 0u;
+  if (dmw::ballot(ovf) != 0ull) {                     // rare: list the environment, tally the reasons (diagnostics)
+    unsigned bits = 0;
+    for (int r = 0; r < 5; r++) if (dmw::row_ballot(((why >> r) & 1) != 0, lane) != 0u) bits |= 1u << r;
+    if (ovf && live && sl == 0) {
+      const int k = dmw::global_counter_next(redo_count); redo_list[k] = env;
+      for (int r = 0; r < 5; r++) if ((bits >> r) & 1u) dmw::global_counter_next(B.redo_why + 1 + r);
+    }
+  }
   live = live && !ovf;
   // COM height of the 4th-stage body positions (src/dp_env_v3.py:134-139): mass-weighted sum over the body lanes
   const R mz = sl < NB - 1 ? M.body_mass[sl + 1] * xip[2] : R(0);
@@ -201,6 +290,14 @@ DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
     rew = exp_once(R(-2) * err) - R(0.1) * acs;
     dmw::sync_mem();
     if (live && sl == 0) B.frame_idx[env] = idx;
+  } else if (B.reward_mode == REW_IMITATION) {   // code.md:1017-1143: the state after the step against frame idx + 1 (env_step.h)
+    int k = B.frame_idx[env] + 1, cyc = B.cycle[env];
+    bool ended = false;
+    if (k >= B.n_frames) { if (B.imit_params[15] != R(0)) { k = 0; cyc += 1; } else { k = B.n_frames - 1; ended = true; } }
+    rew = slot_imitation_reward(M, B, s, sl, lt, B.imit_table + (size_t)k * IMIT_FEAT, cyc * B.imit_params[13], cyc * B.imit_params[14]);
+    dn = dn || ended;
+    dmw::sync_mem();
+    if (live && sl == 0) { B.frame_idx[env] = k; B.cycle[env] = cyc; }
   }
   if (live && sl == 0) { B.time[env] += M.timestep * n_substeps; reward[env] = rew; done[env] = dn ? 1 : 0; if (B.kin) B.kin_ok[env] = 0; }
   if (B.autoreset) {                              // DummyVecEnv convention: obs of the fresh episode is returned
@@ -216,6 +313,10 @@ DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
     }
   }
   slot_store_state(B, s, env, sl, live);
+  if (PROF && lane == 0) {                      // one record per WAVE: [0..4] kin, bias, mass, rows, constraint; [5] total; [6] PGS loop trips (speculative sweeps, wave-wide); [7] two-row-set evaluations;
+    prof[5] = dmw::clk() - tstart;              // [8..13] constraint parts: row build, imp + half solve, A, warm start, PGS, assembly + solve; [14] sum of nmax; [15] constrained evaluations
+    for (int k = 0; k < 16; k++) prof_out[k] = prof[k];
+  }
 }
 
 }  // namespace dm

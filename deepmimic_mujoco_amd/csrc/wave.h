@@ -145,6 +145,47 @@ template <int I> DM_DEV void row_fmac_old(double& acc, double x, double y) {
   asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(I));
 }
 template <int I> DM_DEV void row_fmac_old(float& acc, float x, float y) { acc += row_bcast<I>(x) * y; }
+// eight of them behind ONE hazard slot: the operands are in their registers before the block starts (whatever refills the compiler
+// inserted come first), so the single s_nop covers all eight.   acc0 += sum of the even k, acc1 += sum of the odd k of bcast_I(x[k]) * y[k]
+#define DM_FMAC_DPP(acc, x, y) "v_fmac_f64_dpp " acc ", " x ", " y " row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+template <int I> DM_DEV void row_fmac8(double& acc0, double& acc1, const double* x, const double* y) {
+  asm volatile("s_nop 1\n\t" DM_FMAC_DPP("%0", "%2", "%10") DM_FMAC_DPP("%1", "%3", "%11") DM_FMAC_DPP("%0", "%4", "%12") DM_FMAC_DPP("%1", "%5", "%13")
+               DM_FMAC_DPP("%0", "%6", "%14") DM_FMAC_DPP("%1", "%7", "%15") DM_FMAC_DPP("%0", "%8", "%16") DM_FMAC_DPP("%1", "%9", "%17")
+               : "+v"(acc0), "+v"(acc1)
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+                 "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "n"(I));
+}
+#undef DM_FMAC_DPP
+// a[k] += bcast_I(x[k]) * one for eight accumulators, one hazard slot
+#define DM_FMAC_DPP(acc, x) "v_fmac_f64_dpp " acc ", " x ", %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+template <int I> DM_DEV void row_add8(double* a, const double* x, double one) {
+  asm volatile("s_nop 1\n\t" DM_FMAC_DPP("%0", "%8") DM_FMAC_DPP("%1", "%9") DM_FMAC_DPP("%2", "%10") DM_FMAC_DPP("%3", "%11")
+               DM_FMAC_DPP("%4", "%12") DM_FMAC_DPP("%5", "%13") DM_FMAC_DPP("%6", "%14") DM_FMAC_DPP("%7", "%15")
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(one), "n"(I));
+}
+#undef DM_FMAC_DPP
+template <int I> DM_DEV void row_fmac8(float& acc0, float& acc1, const float* x, const float* y) { for (int k = 0; k < 8; k++) { if (k & 1) acc1 += row_bcast<I>(x[k]) * y[k]; else acc0 += row_bcast<I>(x[k]) * y[k]; } }
+template <int I> DM_DEV void row_add8(float* a, const float* x, float one) { for (int k = 0; k < 8; k++) a[k] += row_bcast<I>(x[k]) * one; }
+// One row of the packed Gauss-Seidel sweep as a single block (slot_kernel.h):  delta = max(nf0, t);  tsave += onehot * t  (lane I of the
+// row keeps the residual it saw at its own row: onehot is 1 there and 0 elsewhere);  t += bcast_I(delta) * a.  The fused multiply-add and a
+// one-cycle s_nop between the write of delta and its DPP read are exactly the two wait states that hazard needs.
+template <int I> DM_DEV void pgs_row(double& t, double& tsave, double nf0, double a, double onehot) {
+  double delta;
+  asm volatile("v_max_f64 %0, %3, %1\n\tv_fma_f64 %2, %5, %1, %2\n\ts_nop 0\n\tv_fmac_f64_dpp %1, %0, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+               : "=&v"(delta), "+v"(t), "+v"(tsave) : "v"(nf0), "v"(a), "v"(onehot), "n"(I));
+}
+// two row sets: the row belongs to set `own` (t_own, tsave_own); both sets' residuals are updated
+template <int I> DM_DEV void pgs_row2(double& t_own, double& tsave_own, double& t_other, double nf0, double a_own, double a_other, double onehot) {
+  double delta;
+  asm volatile("v_max_f64 %0, %4, %1\n\tv_fma_f64 %2, %7, %1, %2\n\ts_nop 0\n\tv_fmac_f64_dpp %1, %0, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f64_dpp %3, %0, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+               : "=&v"(delta), "+v"(t_own), "+v"(tsave_own), "+v"(t_other) : "v"(nf0), "v"(a_own), "v"(a_other), "v"(onehot), "n"(I));
+}
+template <int I> DM_DEV void pgs_row(float& t, float& tsave, float nf0, float a, float onehot) { const float d = max_raw(nf0, t); tsave += onehot * t; t += row_bcast<I>(d) * a; }
+template <int I> DM_DEV void pgs_row2(float& t_own, float& tsave_own, float& t_other, float nf0, float a_own, float a_other, float onehot) {
+  const float d = max_raw(nf0, t_own); tsave_own += onehot * t_own; const float b = row_bcast<I>(d); t_own += b * a_own; t_other += b * a_other;
+}
 DM_DEV void dpp_settle() { asm volatile("s_nop 4"); }
 // counter in global memory shared by all waves of a launch: returns the value before the increment
 DM_DEV int global_counter_next(int* p) { return atomicAdd(p, 1); }

@@ -253,7 +253,7 @@ int dm_pg_fvp(const float* ob, int32_t stride, int32_t n, const float* theta, co
 /* Diagnostics of DM option 105 (four environments per wavefront, csrc/slot_kernel.h): env-steps so far that exceeded a capacity of that
  * path (> 32 constraint rows, > 8 contacts, > 16 pairs past the bounding spheres, a PGS step the cost test would reject) and were
  * re-stepped by the one-env kernel. */
-int dm_batch_redo_total(dm_batch* b, int64_t* out);
+int dm_batch_redo_total(dm_batch* b, int64_t* out /* [8]: total, then by reason */);
 int dm_batch_sync(dm_batch* b);
 /* Make the batch's stream wait (device-side, no host wait) for every pipelined sub-batch launch in flight (DM_OPT_PIPELINE). */
 int dm_batch_join(dm_batch* b);

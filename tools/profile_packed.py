@@ -1,0 +1,38 @@
+"""Diagnostic: per-stage shader-clock profile of k_step_packed (four environments per wavefront; DM options 105 + 101), one record
+per WAVE, next to the one-env kernel's per-env profile of the same states."""
+import os
+import sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from deepmimic_mujoco_amd import DPVecEnv, _abi as A
+
+n = int(os.environ.get("DM_PROF_ENVS", "4096"))
+full = os.environ.get("DM_PROF_WL", "cfg3") == "cfg3"
+env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="rsi", seed=0, contacts=full, limits=full,
+               action_mode="raw" if full else "p-control", frame_skip=1)
+env.batch.set_option(105, 1)
+env.reset("rsi")
+rng = np.random.RandomState(0)
+for t in range(40):
+    env.step(rng.randn(n, 28) * (0.9 if full else 0.0))
+env.batch.set_option(101, 1)
+K = 5
+recs = []
+for t in range(K):
+    env.step(rng.randn(n, 28) * (0.9 if full else 0.0))
+    recs.append(env.batch.read_profile()[: (n + 3) // 4, :16].astype(np.float64))
+p = np.concatenate(recs)
+names = ["kinematics", "bias", "mass+factor", "rows", "constraint", "total"]
+tot = p[:, 5]
+print("k_step_packed, %d envs, cycles per WAVE-step (4 envs x 4 evaluations); mean total %.0f, median %.0f, p90 %.0f, max %.0f" % (n, tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max()))
+for k, nm in enumerate(names[:5]):
+    print("   %-14s %9.0f (%.1f%%)" % (nm, p[:, k].mean(), 100 * p[:, k].mean() / tot.mean()))
+print("   other          %9.0f" % (tot.mean() - p[:, :5].sum(1).mean()))
+sub = ["row build", "imp + half solve + b", "A build", "warm start", "PGS", "assembly + L solve"]
+for k, nm in enumerate(sub):
+    print("      constraint/%-22s %9.0f" % (nm, p[:, 8 + k].mean()))
+ev = np.maximum(p[:, 15], 1)
+print("   constrained evaluations per wave-step %.2f of 4; mean wave nmax %.1f; two-row-set evaluations per wave-step %.3f; PGS loop trips per constrained evaluation %.1f" % (
+    p[:, 15].mean(), (p[:, 14] / ev).mean(), p[:, 7].mean(), (p[:, 6] / ev).mean()))
+print("   redo env-steps so far [total, candidates, box slots, contacts, rows, PGS test]:", env.batch.redo_reasons())
+env.close()
