@@ -398,14 +398,14 @@ def main():
         warnings.simplefilter("ignore", UserWarning)        # frame_skip = 1 with the imitation reward is this benchmark's definition of a step
         env = DPVecEnv(n, motion=clip, device=local_dev, reward=args.reward if full else "alive",
                        autoreset="rsi", seed=0, contacts=full, limits=full,
-                       action_mode="raw" if full else "p-control", env_offset=shard * n, frame_skip=1, dtype=args.dtype)
+                       action_mode="raw" if full else "p-control", env_offset=shard * n, frame_skip=1, dtype=args.dtype,
+                       packed=None if args.packed is None else bool(args.packed))
+    step_kernel = "k_step_packed" if env.packed else "k_step_narrow"
     stream = torch.cuda.Stream(device=dev)
     env.batch.set_stream(stream.cuda_stream)
     env.batch.set_option(A.OPT_PIPELINE, max(1, min(args.pipeline, A.MAX_PIPELINE)))
     if args.no_reorder:
         env.batch.set_option(104, 0)
-    if args.packed is not None:
-        env.batch.set_option(105, args.packed)
 
     with torch.cuda.stream(stream):
         gen = torch.Generator(device=dev); gen.manual_seed(1234 + shard)
@@ -518,7 +518,7 @@ def main():
                        "sim_steps_per_env_step": 1,
                        "mean_nefc": round(float(nefc.mean()), 2), "mean_pgs_sweeps": round(float(iters.mean()), 2),
                        "overflow_envs": int((status & 1).sum()),
-                       "packed": args.packed, "packed_redo_env_steps": env.batch.redo_total(),
+                       "envs_per_wavefront": 4 if env.packed else 1, "packed_redo_env_steps": env.batch.redo_total() if env.packed else None,
                        "actions": ("i.i.d. N(0, 0.9^2) per (env, step) within a %d-step horizon, pre-drawn on the device (%d x %d x 28 f64), the same "
                                    "tensors reused by every horizon" % (pool, pool, n)) if full else "zeros (pure P-controller)",
                        "timed_window": "%d dm_batch_step calls (state / obs / reward / done device-resident)%s" % (
@@ -526,11 +526,11 @@ def main():
                            else "; shorter than the %d-step horizon: no block packing / join inside the window" % HORIZON)},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "k_step_narrow", "kernel_ms": round(kernel_ms, 4),
-                         "kernel_ms_covers": "HIP events around the timed region / steps: one dm_batch_step = k_step_narrow (all sub-batches) + k_order + 1/256 of a horizon's block packing; "
+                         "kernel": step_kernel, "kernel_ms": round(kernel_ms, 4),
+                         "kernel_ms_covers": "HIP events around the timed region / steps: one dm_batch_step = the step kernel (all sub-batches; the packed kernel is followed by k_step_redo) + k_order + 1/256 of a horizon's block packing; "
                                              "with --pipeline > 1 consecutive steps overlap, so this is the per-step issue interval, not a lone launch's latency",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
-                         "launch": {"kernel": "k_step_narrow", "envs_per_launch": n // P_sub, "launches_per_step": P_sub,
+                         "launch": {"kernel": step_kernel, "envs_per_launch": n // P_sub, "launches_per_step": P_sub,
                                     "algorithmic_bytes": ALGO_BYTES_PER_STEP * (n // P_sub),
                                     "avg_us": round(float(np.mean(launch_us)), 1) if launch_us else None,
                                     "measured": "HIP events on the launch's own stream, %d launches sampled after the timed region" % len(launch_us),
@@ -546,7 +546,7 @@ def main():
         if world == 1 and not args.no_pmc:
             tail = ["--workload", args.workload, "--reward", args.reward, "--steps", "48", "--warmup", "8", "--prewarm-horizons", "1",
                     "--envs", str(n), "--_child", "--no-pmc", "--no-cpu-baseline", "--no-gym-loop", "--pipeline", str(args.pipeline), "--dtype", str(args.dtype)] + (["--clip", args.clip] if args.clip else [])
-            pmc, err = pmc_passes(tail, "k_step_narrow")
+            pmc, err = pmc_passes(tail + (["--packed", "1" if env.packed else "0"]), step_kernel)
             r = out["roofline"]
             if pmc is None:
                 r["pmc"] = err

@@ -13,7 +13,7 @@ NBODY, NJNT, NQ, NV, NU, NGEOM, NOBS, MAXEFC = 14, 29, 35, 34, 28, 16, 56, 64
 DEBUG_DOUBLES = 34 * 34 + 34 * 3 + 42 + 3 + MAXEFC * (34 + 6)
 PTR_HOST, PTR_DEVICE = 0, 1
 FLAG_NO_CONTACT, FLAG_NO_LIMIT = 1, 2
-OPT_REWARD_MODE, OPT_AUTORESET, OPT_ACTION_MODE, OPT_SEED, OPT_DIAGNOSTICS, OPT_PIPELINE, OPT_ENV_OFFSET = 1, 2, 3, 4, 5, 6, 100
+OPT_REWARD_MODE, OPT_AUTORESET, OPT_ACTION_MODE, OPT_SEED, OPT_DIAGNOSTICS, OPT_PIPELINE, OPT_PACKED, OPT_ENV_OFFSET = 1, 2, 3, 4, 5, 6, 7, 100
 MAX_PIPELINE = 8
 (F_QPOS, F_QVEL, F_QACC_WARMSTART, F_TIME, F_FRAME_IDX, F_FRAME_INIT, F_XIPOS, F_COM_Z, F_NCON, F_NEFC,
  F_CONTACT_GEOMS, F_STATUS, F_SOLVER_ITER, F_CTRL, F_EPISODE, F_CYCLE) = range(1, 17)

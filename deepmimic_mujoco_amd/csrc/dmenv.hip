@@ -449,7 +449,7 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
       b->B.order = nullptr;   /* the stored dispatch order belongs to the previous partition: identity for the next launch */
       break;
     }
-    case 105: b->packed = v != 0; break;        /* 1: four environments per wavefront (k_step_packed) where it covers the configuration */
+    case DM_OPT_PACKED: case 105: b->packed = v != 0; break;        /* 1: four environments per wavefront (k_step_packed) where it covers the configuration */
     case 104: b->reorder = v != 0; if (!b->reorder) b->B.order = nullptr; break;   /* 1 (default): longest-first dispatch order (k_order) */
     case 100: b->B.env_offset = (int)v; break;  /* global id of env 0 (multi-GPU sharding) */
     case 102: b->two_tier = v != 0; break;       /* 1 (default): register tier of NARROW_ROWS columns + overflow strip; 0: all 64 columns in registers */

@@ -347,9 +347,12 @@ struct SlotEliminateFrom {
 static_assert(elim_group_size(4, 0) % SW == 0 && elim_group_size(3, 2) % SW == 0 && elim_group_size(1, 0) % SW == 0, "lane groups are whole slots");
 // (pair codes of a lane cover t = (lane & 15) + 16 j, j < 6, i.e. t < 96: elim_codes_ok)
 
-template <class R>
-DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl_in, const LaneTopo& lt, const DebugOut* dbg) {
+template <class R, bool PROF = false>
+DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl_in, const LaneTopo& lt, const DebugOut* dbg, long long* prof = 0) {
   const int sl = dmw::launder(sl_in);
+  long long pt0 = 0, pt1 = 0;
+  if (PROF) pt0 = dmw::clk();
+#define SLOT_MSTAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
   // f_d = (composite inertia of the dof's body) cdof_d: the inertias are read before the region they share with the factor is written
   R f[DOF_PASSES][6];
 #pragma unroll
@@ -381,7 +384,9 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
     }
   }
   dmw::sync();
+  SLOT_MSTAMP(16)
   SlotEliminateFrom<0, R>::run(s, tb, sl, lt);
+  SLOT_MSTAMP(17)
 #pragma unroll
   for (int c = 0; c < DOF_PASSES; c++) {
     const int d = sl + SW * c;
@@ -398,6 +403,8 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
     }
   }
   dmw::sync();
+  SLOT_MSTAMP(18)
+#undef SLOT_MSTAMP
 }
 
 // ---- small collectives over the four rows ------------------------------------------------------------------------------------------
@@ -432,9 +439,12 @@ DM_DEV int row_exclusive_scan(int v, int sl, int lane, int* total) {
 // Capacities (SLOT_MAXCAND candidates, SLOT_MAXCON contacts, SLOT_MAXROWS rows): an environment that exceeds one is flagged (`ovf`: bit 0
 // candidates, 1 box slots, 2 contacts, 3 rows, 4 a PGS step the cost test would reject, 6 any) and re-stepped by the one-env kernel;
 // nothing of it is stored by this wave.  Returns the slot's row count.
-template <class R>
-DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int& ovf) {
+template <class R, bool PROF = false>
+DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int& ovf, long long* prof = 0) {
   const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
+  long long pt0 = 0, pt1 = 0;
+  if (PROF) pt0 = dmw::clk();
+#define SLOT_RSTAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
   const unsigned below = (1u << sl) - 1u;
   const int npair = dmw::uniform(M.npair);
   int nrow = 0;
@@ -476,6 +486,7 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
     if (nrow > SLOT_MAXLIMROWS) ovf |= 8;
   }
   dmw::sync();
+  SLOT_RSTAMP(19)
   int ncon = 0;
   if (M.enable_contact) {
     // ---- broad phase: bounding spheres (plane pairs: signed distance of the centre)
@@ -504,6 +515,8 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
     if (ncand > SLOT_MAXCAND) { ovf |= 1; ncand = SLOT_MAXCAND; }
     const int maxc = rows_max(ncand);
     if (maxc > 0) dmw::sync();
+    SLOT_RSTAMP(20)
+    if (PROF) prof[23] += maxc;
     for (int trip = 0; trip * SW < maxc; trip++) {            // (one trip unless an environment of the wave has more than 16 candidates)
       // ---- narrow phase: candidate k of the environment on lane k % 16
       const int kc = trip * SW + sl;
@@ -564,6 +577,8 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
   if (dmw::row_ballot(ovf != 0, lane) != 0u) { ovf |= 64; nrow = 0; ncon = 0; }    // (bit 6: some lane of the row holds a reason)                             // nothing of this evaluation is used: no row may be read (some were never staged)
   if (sl == 0) { s.nefc = nrow; s.ncon = ncon; }
   dmw::sync();
+  SLOT_RSTAMP(21)
+#undef SLOT_RSTAMP
   return nrow;
 }
 
@@ -973,11 +988,11 @@ DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTable
     for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) dbg->out[34 * 34 + d] = (double)(-M.dof_damping[d] * s.qvel[d] + s.act[d] - s.tau[d]); }
   }
   DM_MARK("slot_mass_factor");
-  slot_mass_matrix(M, s, tb, sl, lt, dbg);
+  slot_mass_matrix<R, PROF>(M, s, tb, sl, lt, dbg, prof);
   SLOT_FSTAMP(2)
   DM_MARK("slot_rows");
   int nefc = 0;
-  if (M.enable_contact || M.enable_limit) nefc = slot_rows(M, s, sl, lane, ovf);
+  if (M.enable_contact || M.enable_limit) nefc = slot_rows<R, PROF>(M, s, sl, lane, ovf, prof);
   else { if (sl == 0) { s.nefc = 0; s.ncon = 0; } dmw::sync(); }
   SLOT_FSTAMP(3)
   DM_MARK("slot_constraint");

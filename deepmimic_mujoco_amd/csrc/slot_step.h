@@ -236,8 +236,8 @@ template <class R, bool PROF = false>
 DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, SlotTables& tb, int env, int sl, int lane, bool live,
                           const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int* redo_count, int* redo_list,
                           long long* prof_out = 0) {
-  long long prof[16];
-  for (int k = 0; k < 16; k++) prof[k] = 0;
+  long long prof[32];
+  for (int k = 0; k < 32; k++) prof[k] = 0;
   long long tstart = 0;
   if (PROF) tstart = dmw::clk();
   const LaneTopo lt = lane_topo(sl);
@@ -315,7 +315,7 @@ DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
   slot_store_state(B, s, env, sl, live);
   if (PROF && lane == 0) {                      // one record per WAVE: [0..4] kin, bias, mass, rows, constraint; [5] total; [6] PGS loop trips (speculative sweeps, wave-wide); [7] two-row-set evaluations;
     prof[5] = dmw::clk() - tstart;              // [8..13] constraint parts: row build, imp + half solve, A, warm start, PGS, assembly + solve; [14] sum of nmax; [15] constrained evaluations
-    for (int k = 0; k < 16; k++) prof_out[k] = prof[k];
+    for (int k = 0; k < 32; k++) prof_out[k] = prof[k];   // [16..18] mass: f + M entries, elimination, scaling; [19..21] rows: geoms + limits, broad phase, narrow phase + emission; [23] candidates
   }
 }
 

@@ -246,11 +246,14 @@ class DPEnv(object):
         return self._get_obs()
 
 
+PACKED_FROM_ENVS = 6144       # DPVecEnv(packed=None): batches of at least this many environments step four per wavefront
+
+
 class DPVecEnv(object):
     """N DeepMimic humanoids in lock step on one GPU (one wavefront per environment)."""
 
     def __init__(self, num_envs, motion="walk", xml_path=None, device=0, reward="alive", autoreset="rsi", seed=0,
-                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=None, diagnostics=False, dtype=64):
+                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=None, diagnostics=False, dtype=64, packed=None):
         """reward="imitation": the 5-term reward of code.md:1017-1143 (imitation.py) against the frame after the current one.
         frame_skip: sim steps per env step (src/dp_env_v3.py:108-112 hard-codes 1); "mocap" = floor(mocap_dt / timestep), the
         commented intent of :107-110, so that one env step spans one mocap frame.  Default (None): 1, except "mocap" for the
@@ -258,7 +261,10 @@ class DPVecEnv(object):
         other value plays the clip at the wrong speed (a warning says so when one is given).
         diagnostics: keep `sim.data.xipos` / the contact geom list up to date after every step (DM_OPT_DIAGNOSTICS; the batched
         training path does not read them, `DPEnv` and raw `Batch` objects default to on).
-        dtype: 64 (default) or 32 — arithmetic of the kernels; observations / actions stay float64 arrays."""
+        dtype: 64 (default) or 32 — arithmetic of the kernels; observations / actions stay float64 arrays.
+        packed: DM_OPT_PACKED — four environments per wavefront (k_step_packed) instead of one.  None (default) = by batch size: on from
+        PACKED_FROM_ENVS environments (two or more waves per SIMD on one MI355X, where it is 1.4-1.5x faster), float64, rewards other than
+        v1-quat; below that a launch is a single round of lone waves and the one-env kernel is faster."""
         self.num_envs = int(num_envs)
         self.mocap = MocapDM()
         self.mocap.load_mocap(motion)
@@ -295,6 +301,11 @@ class DPVecEnv(object):
         b.set_option(A.OPT_SEED, int(seed))
         b.set_option(A.OPT_ENV_OFFSET, int(env_offset))
         b.set_option(A.OPT_DIAGNOSTICS, 1 if diagnostics else 0)
+        if packed is None:
+            packed = batch_factory is None and self.num_envs >= PACKED_FROM_ENVS and dtype == 64 and reward != "v1-quat"
+        self.packed = bool(packed)
+        if self.packed:
+            b.set_option(A.OPT_PACKED, 1)
         cr = self._cm.actuator_ctrlrange
         self.action_space = Box(low=cr[:, 0], high=cr[:, 1], dtype=np.float32)
         self.observation_space = Box(low=-np.inf, high=np.inf, shape=(A.NOBS,), dtype=np.float32)

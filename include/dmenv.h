@@ -119,13 +119,21 @@ enum {
   DM_OPT_DIAGNOSTICS = 5, /* 1 (default): every step also stores sim.data.xipos and the contact (geom1, geom2) list (DM_F_XIPOS,
                              DM_F_CONTACT_GEOMS: 848 B per env-step); 0: state, obs, reward, done and the row / contact counts only —
                              those two fields then keep the values of the last set_state / reset (DPVecEnv's default) */
-  DM_OPT_PIPELINE = 6     /* 1 (default): a step is one launch on the batch's stream.  P = 2..DM_MAX_PIPELINE: the env range is cut
+  DM_OPT_PIPELINE = 6,    /* 1 (default): a step is one launch on the batch's stream.  P = 2..DM_MAX_PIPELINE: the env range is cut
                              into P contiguous sub-batches, each stepped on its own internal stream.  With DEVICE pointers a
                              sub-batch's launch of call k+1 waits only for its own launch of call k and for the caller's stream
                              at the time of the call (the inputs), so consecutive calls overlap: the next sub-batch's workgroups
                              take the wave slots freed while the previous one drains.  The outputs of such calls are complete
                              once the caller's stream has joined: dm_batch_join() (no host wait), dm_batch_sync(), or any other
                              entry point of the batch.  Results are identical for every P. */
+  DM_OPT_PACKED = 7       /* 0 (default): one environment per wavefront (k_step_narrow).  1: FOUR environments per wavefront, one 16-lane
+                             DPP row each (k_step_packed, csrc/slot_kernel.h) wherever that kernel covers the call — reward modes 0..3, no
+                             fused policy step; an environment that exceeds its per-env capacities in a step (32 constraint rows, 10
+                             contacts, 32 pairs past the bounding spheres) is re-stepped by the one-env code in the same call.  The
+                             throughput kernel for batches of two or more waves per SIMD (>= 8192 envs on one MI355X): 1.4-1.5x; at 4096
+                             envs a launch is one round of lone waves and the one-env kernel stays ahead.  Results agree with the oracle to
+                             the same 1e-9 bar and do not depend on which environments share a wave; they differ from the one-env kernel's
+                             in the last bits (other summation orders). */
 };
 #define DM_MAX_PIPELINE 8
 /* further option ids (diagnostics / tests; defaults are what the timed path uses):

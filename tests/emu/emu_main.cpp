@@ -110,7 +110,7 @@ void emu_set_option(void* h, int opt, long long v) {
   else if (opt == DM_OPT_DIAGNOSTICS) e->B.diag = v != 0;
   else if (opt == 100) e->B.env_offset = (int)v;
   else if (opt == 102) e->two_tier = v != 0;
-  else if (opt == 105) e->packed = v != 0;
+  else if (opt == 105 || opt == DM_OPT_PACKED) e->packed = v != 0;
   else if (opt == 103) e->M.pgs_detect = v ? -1e300 : 1e-10;
 }
 void* emu_field(void* h, int field) {

@@ -19,8 +19,8 @@ SEED = 11
 STEPS = 16
 
 
-@pytest.mark.parametrize("clip,n", [("walk", 4096), ("spinkick", 4096), ("dance_b", 8192)])
-def test_full_shard_matches_oracle_every_env_every_step(clip, n):
+@pytest.mark.parametrize("clip,n,packed", [("walk", 4096, 0), ("spinkick", 4096, 0), ("dance_b", 8192, 0), ("dance_b", 8192, 1), ("walk", 4096, 1)])
+def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     import torch
     from deepmimic_mujoco_amd import Batch
     from deepmimic_mujoco_amd.imitation import ImitationSpec
@@ -33,6 +33,7 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n):
     b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
     b.set_option(A.OPT_REWARD_MODE, 3); b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, SEED)
     b.set_option(A.OPT_ENV_OFFSET, off); b.set_option(A.OPT_DIAGNOSTICS, 1); b.set_option(A.OPT_PIPELINE, 2)
+    b.set_option(A.OPT_PACKED, packed)          # 0: one environment per wavefront; 1: four (what DPVecEnv picks from 6 144 envs up)
     b.reset(0, 1)                                                 # env.reset(): sim.reset() + RSI
     fidx = b.get(A.F_FRAME_IDX).copy()
     expect0 = np.array([H.device_rsi_frame(SEED, off + e, 0, F) for e in range(n)], dtype=np.int32)
@@ -93,6 +94,8 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n):
     assert np.abs(tm - ot).max() < 1e-12
     assert ndone > 0 and max_nefc > 16, "the run must contain early terminations and heavy contact (%d done, max nefc %d)" % (ndone, max_nefc)
     assert (b.get(A.F_STATUS) & 1).sum() == 0
+    if packed:
+        print("   packed: env-steps handed to the one-env code [total, candidates, box slots, contacts, rows, PGS test]:", b.redo_reasons())
     print("full shard %s x %d, %d steps: worst rel err %.2e, %d auto-resets, max nefc %d, oracle threads %d"
           % (clip, n, STEPS, worst, ndone, max_nefc, nthreads))
     b.close()

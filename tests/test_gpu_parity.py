@@ -329,9 +329,11 @@ def test_dispatch_order_does_not_change_results(n):
     assert outs[0][4].max() > 8                                        # contacts are present, so the order is not the identity
 
 
-@pytest.mark.parametrize("clip,n", [("spinkick", 4096), ("dance_b", 8192)])     # one GPU's shard of BASELINE.json configs[3] / [4]
-def test_full_size_shard_properties_cfg4_cfg5(clip, n):
-    """Full per-GPU shard sizes of the 8-GPU configurations, size-independent properties: RSI + early termination + auto-reset
+@pytest.mark.parametrize("clip,n,packed", [("spinkick", 4096, False), ("dance_b", 8192, False), ("dance_b", 8192, True)])     # one GPU's shard of BASELINE.json configs[3] / [4]; [4] also on the kernel DPVecEnv picks at that size
+def test_full_size_shard_properties_cfg4_cfg5(clip, n, packed):
+    """(`packed`: one or four environments per wavefront — the shard-cut invariance holds within either kernel; DPVecEnv's default picks by
+    batch size, so a caller who compares differently sized batches bit for bit pins the choice.)
+    Full per-GPU shard sizes of the 8-GPU configurations, size-independent properties: RSI + early termination + auto-reset
     from an interior shard's global env ids (shard 3: env_offset = 3 n); the step is bit-reproducible; results do not depend on
     how the shard is cut (two half batches with their own offsets reproduce the full batch bit for bit: per-env RNG streams
     are keyed by the GLOBAL env id); RSI resets land exactly on mocap frames; state stays finite; no capacity overflow."""
@@ -344,7 +346,7 @@ def test_full_size_shard_properties_cfg4_cfg5(clip, n):
 
     def run(lo, hi):
         m = hi - lo
-        env = DPVecEnv(m, motion=clip, device=0, reward="imitation", autoreset="rsi", seed=11, env_offset=3 * n + lo, frame_skip=1)
+        env = DPVecEnv(m, motion=clip, device=0, reward="imitation", autoreset="rsi", seed=11, env_offset=3 * n + lo, frame_skip=1, packed=packed)
         env.reset("rsi")
         fi0 = env.batch.get(A.F_FRAME_IDX).copy()
         dones = np.zeros(m, dtype=np.int64); rews = []
@@ -491,14 +493,14 @@ def test_packed_kernel_matches_oracle_on_the_rowless_model_config2(n):
     idx, q, v, _ws, _c = H.varied_states(n, seed=7)
     for mode in (0, 1, 2):
         b = make_batch(n, flags=flags)
-        b.set_option(105, 1); b.set_option(A.OPT_REWARD_MODE, mode)
+        b.set_option(A.OPT_PACKED, 1); b.set_option(A.OPT_REWARD_MODE, mode)
         worst, nd = H.compare_rollout(b, om, idx, q, v, steps=12, seed=2, reward_mode=mode, n_substeps=2 if mode == 1 else 1)
         assert np.all(b.get(A.F_NEFC) == 0)
         b.close()
     outs = []
     for packed in (1, 0):
         b = make_batch(n, flags=flags)
-        b.set_option(105, packed); b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, 3); b.set_option(A.OPT_ACTION_MODE, 1)
+        b.set_option(A.OPT_PACKED, packed); b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, 3); b.set_option(A.OPT_ACTION_MODE, 1)
         b.reset(0, 1)
         rng = np.random.RandomState(0)
         o = [b.step(rng.randn(n, 28) * 0.3)[0].copy() for _ in range(8)]
@@ -506,3 +508,43 @@ def test_packed_kernel_matches_oracle_on_the_rowless_model_config2(n):
         b.close()
     for x, y in zip(outs[0], outs[1]):
         assert H.rel_err(x, y) < 1e-11
+
+
+@pytest.mark.parametrize("clip", CLIPS)
+def test_packed_kernel_matches_oracle_full_contact(clip):
+    """Contacts, joint limits, PGS on the four-envs-per-wave path against the oracle: 64 varied states (several exceed the packed path's
+    capacities and come back through the one-env code), 30 steps, all frame-indexed reward modes; sweep counts, row counts and contact
+    lists of the last evaluation identical."""
+    from oracle import oracle as O
+    n = 64
+    om = H.oracle_model()
+    idx, q, v, _ws, _c = H.varied_states(n, seed=5, clip=clip)
+    for mode in (0, 1, 2):
+        b = make_batch(n, clip=clip)
+        b.set_option(A.OPT_PACKED, 1); b.set_option(A.OPT_REWARD_MODE, mode)
+        worst, nd = H.compare_rollout(b, om, idx, q, v, steps=30 if mode == 0 else 8, seed=1, reward_mode=mode, clip=clip)
+        if mode == 0:
+            print("packed rollout (%s): worst rel err %.2e, %d done, redo %s" % (clip, worst, nd, b.redo_reasons()))
+            assert b.redo_total() > 0
+        b.close()
+    # diagnostics of a packed step: PGS sweep counts, row / contact counts, contact geom lists
+    b = make_batch(n, clip=clip); b.set_option(A.OPT_PACKED, 1)
+    b.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); b.set_state(q, v, frame_idx=idx)
+    ods = [O.Data(om) for _ in range(n)]
+    for e in range(n):
+        ods[e].reset(); ods[e].set_state(q[e], v[e])
+    rng = np.random.RandomState(0)
+    for t in range(4):
+        a = rng.randn(n, 28) * 0.9
+        b.step(a)
+        for e in range(n):
+            ods[e].env_step(a[e])
+        assert np.array_equal(b.get(A.F_SOLVER_ITER), np.array([int(d.get("solver_iter")[0]) for d in ods]))
+        assert np.array_equal(b.get(A.F_NEFC), np.array([int(d.get("nefc")[0]) for d in ods]))
+        onc = np.array([int(d.get("ncon")[0]) for d in ods])
+        assert np.array_equal(b.get(A.F_NCON), onc)
+        cg = b.get(A.F_CONTACT_GEOMS)
+        for e in range(n):
+            k = min(int(onc[e]), A.MAXEFC)
+            assert np.array_equal(cg[e][:k], ods[e].get("contact_geom").reshape(-1, 2).astype(np.int32)[:k]) and np.all(cg[e][k:] == -1)
+    b.close()

@@ -199,7 +199,7 @@ def test_packed_slots_match_oracle_on_the_rowless_model():
     om = H.oracle_model(enable_contact=0, enable_limit=0)
     for mode in (0, 1, 2):
         b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, flags)
-        b.set_option(105, 1); b.set_option(A.OPT_REWARD_MODE, mode)
+        b.set_option(A.OPT_PACKED, 1); b.set_option(A.OPT_REWARD_MODE, mode)
         worst, _nd = H.compare_rollout(b, om, idx, q, v, steps=5, seed=2, reward_mode=mode, n_substeps=2 if mode == 1 else 1)
         assert worst < 1e-12
 
@@ -213,7 +213,7 @@ def test_packed_slots_match_oracle_with_contacts_and_limits():
     n = 8
     idx, q, v, _ws, _c = H.varied_states(n, seed=5)
     b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0)
-    b.set_option(105, 1)
+    b.set_option(A.OPT_PACKED, 1)
     worst, _nd = H.compare_rollout(b, H.oracle_model(), idx, q, v, steps=4, seed=1)
     assert worst < 1e-11
     assert 0 < b.redo_total() < 4 * n and b.get(A.F_NEFC).max() > 16        # both row-set instantiations and the redo path ran

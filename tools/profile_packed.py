@@ -20,7 +20,7 @@ K = 5
 recs = []
 for t in range(K):
     env.step(rng.randn(n, 28) * (0.9 if full else 0.0))
-    recs.append(env.batch.read_profile()[: (n + 3) // 4, :16].astype(np.float64))
+    recs.append(env.batch.read_profile()[: (n + 3) // 4, :32].astype(np.float64))
 p = np.concatenate(recs)
 names = ["kinematics", "bias", "mass+factor", "rows", "constraint", "total"]
 tot = p[:, 5]
@@ -31,6 +31,9 @@ print("   other          %9.0f" % (tot.mean() - p[:, :5].sum(1).mean()))
 sub = ["row build", "imp + half solve + b", "A build", "warm start", "PGS", "assembly + L solve"]
 for k, nm in enumerate(sub):
     print("      constraint/%-22s %9.0f" % (nm, p[:, 8 + k].mean()))
+for k, nm in enumerate(["mass/f + M entries", "mass/elimination", "mass/D, scaling", "rows/geoms + limits", "rows/broad phase", "rows/narrow phase + emission"]):
+    print("      %-32s %9.0f" % (nm, p[:, 16 + k].mean()))
+print("      rows/largest candidate count of the wave per evaluation %.1f" % (p[:, 23].mean() / 4))
 ev = np.maximum(p[:, 15], 1)
 print("   constrained evaluations per wave-step %.2f of 4; mean wave nmax %.1f; two-row-set evaluations per wave-step %.3f; PGS loop trips per constrained evaluation %.1f" % (
     p[:, 15].mean(), (p[:, 14] / ev).mean(), p[:, 7].mean(), (p[:, 6] / ev).mean()))
