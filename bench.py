@@ -518,7 +518,7 @@ def main():
                        "sim_steps_per_env_step": 1,
                        "mean_nefc": round(float(nefc.mean()), 2), "mean_pgs_sweeps": round(float(iters.mean()), 2),
                        "overflow_envs": int((status & 1).sum()),
-                       "envs_per_wavefront": 4 if env.packed else 1, "packed_redo_env_steps": env.batch.redo_total() if env.packed else None,
+                       "envs_per_wavefront": 4 if env.packed else 1, "kernel_switches_by_row_statistics": getattr(env.batch, "auto_switches", None), "packed_redo_env_steps": env.batch.redo_total() if env.packed else None,
                        "actions": ("i.i.d. N(0, 0.9^2) per (env, step) within a %d-step horizon, pre-drawn on the device (%d x %d x 28 f64), the same "
                                    "tensors reused by every horizon" % (pool, pool, n)) if full else "zeros (pure P-controller)",
                        "timed_window": "%d dm_batch_step calls (state / obs / reward / done device-resident)%s" % (

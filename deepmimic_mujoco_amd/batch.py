@@ -93,8 +93,40 @@ class Batch(object):
         A.check(self._L.dm_batch_set_stream(self._h, C.c_void_p(int(stream_handle))), self._L)
         self._stream_handle = int(stream_handle)
 
+    # ---- kernel choice by workload (DPVecEnv(packed=None)) ---------------------------------------------------------------
+    ADAPT_EVERY = 256            # steps between looks at the batch's row statistics (one small D2H + stream sync each)
+    REDO_RATE_MAX = 3e-4         # packed -> one-env: env-steps per env-step that overflowed the packed path's capacities
+    HEAVY_ROWS = 30              # one-env -> packed: no environment of the batch holds more constraint rows than this
+
+    def enable_auto_packed(self, on=True):
+        """Let the batch choose between one and four environments per wavefront (DM_OPT_PACKED) from what it is simulating: the packed
+        kernel is 1.4-1.5x faster while environments stay within its per-env capacities (32 rows, 10 contacts), but every environment
+        beyond them is re-stepped one per wave AFTER the packed launch — with a policy that stands on both feet (32+ rows most of the
+        time) that tail costs more than the packing saves.  Every ADAPT_EVERY steps the redo rate (packed) or the largest row count
+        (one-env) of the batch decides; the choice is a deterministic function of the trajectory."""
+        self._auto = bool(on)
+        self._auto_ctr = 0
+        self._redo_last = self.redo_total() if on else 0
+        self.auto_switches = 0
+
+    def _adapt(self):
+        self._auto_ctr += 1
+        if self._auto_ctr % self.ADAPT_EVERY:
+            return
+        if self.__dict__.get("options", {}).get(A.OPT_PACKED, 0):
+            redo = self.redo_total()
+            rate = (redo - self._redo_last) / float(self.ADAPT_EVERY * self.n)
+            self._redo_last = redo
+            if rate > self.REDO_RATE_MAX:
+                self.set_option(A.OPT_PACKED, 0); self.auto_switches += 1
+        elif int(self.get(A.F_NEFC).max()) <= self.HEAVY_ROWS:
+            self.set_option(A.OPT_PACKED, 1); self.auto_switches += 1
+            self._redo_last = self.redo_total()
+
     # ---- the hot path -------------------------------------------------------------------------------
     def step(self, action, n_substeps=1, out=None):
+        if self.__dict__.get("_auto"):
+            self._adapt()
         n = self.n
         ap, kind, _ka = self._ptr(action, np.float64, (n, A.NU))
         if out is None:
@@ -118,6 +150,8 @@ class Batch(object):
         """`step` followed, inside the step kernel, by the policy's step on the new observations (dm_batch_step_act): device tensors
         only.  action [n, 28] f64 -> out = (obs [n, 56] f64, rew [n] f64, done [n] u8); next_action [n, 28] f64 and next_vpred [n] f32
         receive the action / value for those observations; `weights` is MlpPolicy.pack()'s float32 block."""
+        if self.__dict__.get("_auto"):
+            self._adapt()
         n = self.n
         ap, kind, _ka = self._ptr(action, np.float64, (n, A.NU))
         obs, rew, done = out

@@ -102,6 +102,31 @@ __global__ __launch_bounds__(64) void k_step_packed(const DevModel<Real>* __rest
   const int env = B.order ? B.order[pos] : pos;
   slot_env_step<Real>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first);
 }
+// ... followed, in the same wave, by the policy's step on the four observations it produced (dm_batch_step_act on the packed path): one
+// weight stream per wave serves four environments
+__global__ __launch_bounds__(64) void k_step_packed_act(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
+                                                        Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
+                                                        int n_substeps, int first, int count, int* __restrict__ redo_count, dmp::PolicyArgs pa) {
+  __shared__ SlotShared<Real> sh[SLOTS];
+  __shared__ SlotTables tb;
+  const int lane = dmw::lane(), slot = lane >> 4, sl = lane & 15;
+  stage_slot_tables(tb, lane);
+  const int last = first + count - 1;
+  int pos = first + SLOTS * (int)blockIdx.x + slot;
+  const bool live = pos <= last;
+  if (pos > last) pos = last;
+  const int env = B.order ? B.order[pos] : pos;
+  const bool stored = slot_env_step<Real>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first);
+  // s.qpos / s.qvel of every slot hold the state its observation was written from (the fresh episode's after an auto-reset); r1 is free
+  // the r1 + r2 regions (adjacent) are free
+  static_assert(offsetof(SlotShared<Real>, r2) == offsetof(SlotShared<Real>, r1) + sizeof(sh[0].r1) && sizeof(sh[0].r1) + sizeof(sh[0].r2) >= 464 * sizeof(float), "policy scratch");
+  dmw::sync();
+  const int envs[4] = {dmw::bcast_i(env, 0), dmw::bcast_i(env, 16), dmw::bcast_i(env, 32), dmw::bcast_i(env, 48)};
+  const int st = stored ? 1 : 0;
+  const bool wr[4] = {dmw::bcast_i(st, 0) != 0, dmw::bcast_i(st, 16) != 0, dmw::bcast_i(st, 32) != 0, dmw::bcast_i(st, 48) != 0};
+  dmp::policy_wave4<Real>(pa, envs, wr, lane, reinterpret_cast<char*>(&sh[0]), (unsigned)sizeof(SlotShared<Real>), (unsigned)(offsetof(SlotShared<Real>, qpos) + 7 * sizeof(Real)),
+                          (unsigned)(offsetof(SlotShared<Real>, qvel) + 6 * sizeof(Real)), (unsigned)offsetof(SlotShared<Real>, r1));
+}
 // the same with shader-clock stamps per stage, one record of 16 per wave (DM option 101 with option 105; diagnostic)
 __global__ __launch_bounds__(64) void k_step_packed_prof(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                                          Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
@@ -120,7 +145,7 @@ __global__ __launch_bounds__(64) void k_step_packed_prof(const DevModel<Real>* _
 // ... and stepped here, from their unchanged state, by the one-env code (a handful of persistent single-wave workgroups walk the list)
 __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_redo(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                                   Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
-                                                  int n_substeps, int first, const int* __restrict__ redo_count) {
+                                                  int n_substeps, int first, const int* __restrict__ redo_count, dmp::PolicyArgs pa) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
   const int n = dmw::uniform(*redo_count);
@@ -128,6 +153,7 @@ __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_redo(const DevModel<
   for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
     const int env = B.redo_list[first + i];
     env_step<Real, NARROW_ROWS>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
+    if (pa.P) { dmw::sync(); dmp::policy_wave(pa, env, dmw::lane(), &s.qpos[7], &s.qvel[6], reinterpret_cast<float*>(&s.u)); }
     dmw::sync_mem();
   }
 }
@@ -139,6 +165,10 @@ __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_redo(const DevModel<
 // shader ticks from 0 to 32 rows) first.  4096 envs are two rounds of resident waves, so the launch ends when the last wave
 // of round two does; longest-first list scheduling trims that tail (measured -9 % kernel time).  Counting sort by
 // min(nefc, 63), descending; the order inside a bucket is arbitrary — results never depend on the dispatch order.
+// cost key of an environment for the dispatch order: constraint rows + a quarter of the PGS sweeps of its last evaluation
+#ifndef DM_ORDER_KEY
+#define DM_ORDER_KEY(nefc, iter) ((nefc) + ((iter) >> 2))
+#endif
 __global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__ order, int first, int count) {
   __shared__ int hist[64], start[64];
   const int tid = threadIdx.x, n = count;                // envs first .. first + count - 1 are sorted into order[first ..]
@@ -150,15 +180,15 @@ __global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__
   for (int j = 0; j < PER; j++) {
     const int e = tid + j * 1024;
     key[j] = -1;
-    if (e < n) { const int k = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); key[j] = k < 0 ? 0 : (k > 63 ? 63 : k); atomicAdd(&hist[key[j]], 1); }
+    if (e < n) { const int k = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]); key[j] = k < 0 ? 0 : (k > 63 ? 63 : k); atomicAdd(&hist[key[j]], 1); }
   }
-  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
+  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
   __syncthreads();
   if (tid == 0) { int acc = 0; for (int k = 63; k >= 0; k--) { start[k] = acc; acc += hist[k]; } }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < PER; j++) if (key[j] >= 0) order[first + atomicAdd(&start[key[j]], 1)] = first + tid + j * 1024;
-  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k0 = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[first + atomicAdd(&start[k], 1)] = first + e; }
+  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k0 = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[first + atomicAdd(&start[k], 1)] = first + e; }
 }
 
 // The same ordering for the pipelined path, where the step kernel of ANOTHER sub-batch is resident while it runs: ONE wave, so that
@@ -176,17 +206,17 @@ __global__ __launch_bounds__(64) void k_order_wave(Batch<Real> B, int* __restric
   for (int j = 0; j < PER; j++) {
     const int e = lane + j * 64;
     key[j] = -1;
-    if (e < count) key[j] = B.nefc[first + e] + (B.solver_iter[first + e] >> 2);
+    if (e < count) key[j] = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]);
   }
 #pragma unroll
   for (int j = 0; j < PER; j++) if (key[j] >= 0 || (lane + j * 64) < count) { key[j] = key[j] < 0 ? 0 : (key[j] > 63 ? 63 : key[j]); atomicAdd(&hist[key[j]], 1); }
-  for (int e = lane + PER * 64; e < count; e += 64) { const int k = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
+  for (int e = lane + PER * 64; e < count; e += 64) { const int k = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
   __syncthreads();
   if (lane == 0) { int acc = 0; for (int k = 63; k >= 0; k--) { start[k] = acc; acc += hist[k]; } }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < PER; j++) if ((lane + j * 64) < count) order[first + atomicAdd(&start[key[j]], 1)] = first + lane + j * 64;
-  for (int e = lane + PER * 64; e < count; e += 64) { const int k0 = B.nefc[first + e] + (B.solver_iter[first + e] >> 2); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[first + atomicAdd(&start[k], 1)] = first + e; }
+  for (int e = lane + PER * 64; e < count; e += 64) { const int k0 = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[first + atomicAdd(&start[k], 1)] = first + e; }
 }
 
 // same step with per-stage shader-clock accounting (DM_OPT 101); not used on the timed path
@@ -523,13 +553,14 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
   if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } if (!piped) HIPCHK(hipEventRecord(b->ev0, b->stream)); }
   const bool reorder = b->reorder && b->has_rows && b->n > b->resident_waves;   // more envs than resident waves: later rounds exist, their tail matters
   // the packed kernel covers: models without constraint rows, reward modes alive / v3-config / v2-pose, no fused policy step
-  const bool use_packed = b->packed && b->B.reward_mode <= 3 && !pol && !b->prof && b->two_tier;
+  const bool use_packed = b->packed && b->B.reward_mode <= 3 && !b->prof && b->two_tier;
+  const dmp::PolicyArgs nopol{nullptr, nullptr, nullptr, 0, 0ull, 0ull};
   constexpr int REDO_BLOCKS = 64;
   if (b->prof && b->packed && b->B.reward_mode <= 3) {
     HIPCHK(hipMemsetAsync(b->d_prof, 0, (size_t)b->n * dm::PROF_SLOTS * sizeof(long long), b->stream));
     HIPCHK(hipMemsetAsync(b->B.redo_count, 0, sizeof(int), b->stream));
     hipLaunchKernelGGL(k_step_packed_prof, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, b->B.redo_count, b->d_prof);
-    if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)b->B.redo_count);
+    if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)b->B.redo_count, nopol);
   } else if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, b->d_prof);
   else if (piped) {
     // Sub-batch h's launch of THIS call depends on its own launch of the previous call (stream order on ps[h]) and on the
@@ -542,12 +573,13 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
       if (hi <= lo) continue;
       HIPCHK(hipStreamWaitEvent(b->ps[h], b->ev_in, 0));
       if (b->timing && h == 0) HIPCHK(hipEventRecord(b->ev0, b->ps[0]));     // timing: sub-batch 0's kernel on ITS stream
-      if (pol) hipLaunchKernelGGL(k_step_act, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, *pol);
-      else if (use_packed) {
+      if (use_packed) {
         HIPCHK(hipMemsetAsync(b->B.redo_count + h, 0, sizeof(int), b->ps[h]));
-        hipLaunchKernelGGL(k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, b->B.redo_count + h);
-        if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, (const int*)(b->B.redo_count + h));
+        if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, b->B.redo_count + h, *pol);
+        else hipLaunchKernelGGL(k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, b->B.redo_count + h);
+        if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, (const int*)(b->B.redo_count + h), pol ? *pol : nopol);
       }
+      else if (pol) hipLaunchKernelGGL(k_step_act, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, *pol);
       else hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo);
       if (b->timing && h == 0) { HIPCHK(hipEventRecord(b->ev1, b->ps[0])); b->ev_pending = true; }
       if (reorder) hipLaunchKernelGGL(k_order_wave, dim3(1), dim3(64), 0, b->ps[h], b->B, b->d_order, lo, hi - lo);
@@ -556,12 +588,13 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     if (reorder) b->B.order = b->d_order;  // valid from the next launch on (same streams: ordered after each part's k_order)
     b->pipe_pending = true;
   } else if (b->two_tier) {
-    if (pol) hipLaunchKernelGGL(k_step_act, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, *pol);
-    else if (use_packed) {
+    if (use_packed) {
       HIPCHK(hipMemsetAsync(b->B.redo_count, 0, sizeof(int), b->stream));
-      hipLaunchKernelGGL(k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, b->B.redo_count);
-      if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)b->B.redo_count);
+      if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, b->B.redo_count, *pol);
+      else hipLaunchKernelGGL(k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, b->B.redo_count);
+      if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)b->B.redo_count, pol ? *pol : nopol);
     }
+    else if (pol) hipLaunchKernelGGL(k_step_act, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, *pol);
     else hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0);
     if (reorder) {
       // (with a pipeline depth configured, every sub-batch's range is sorted on its own: a later pipelined launch reads order[lo..hi)

@@ -176,6 +176,106 @@ __device__ inline void policy_wave(const PolicyArgs& pa, int env, int lane, cons
   }
 }
 
+// ... and for the FOUR environments of a packed wave (slot_kernel.h) at once: the same lane -> hidden-unit map, every 16-byte weight load
+// now feeds 16 multiply-adds (four environments x four units), so the weight stream that dominated the one-env epilogue is paid once
+// per four environments.  in0..in3 / scratch: one block of >= 464 floats per environment (z[64] | h1[200] | h2[200]).
+template <int K, int UNROLL>
+__device__ inline void dense4_wave4(const float* __restrict__ W, const float* __restrict__ bias, const float* (&in)[4], float4 (&acc)[4]) {
+  const float4 b = *reinterpret_cast<const float4*>(bias);
+#pragma unroll
+  for (int e = 0; e < 4; e++) acc[e] = b;
+#pragma unroll 1
+  for (int k0 = 0; k0 < K; k0 += UNROLL) {
+    float4 w[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) if (k0 + u < K) w[u] = *reinterpret_cast<const float4*>(W + (size_t)(k0 + u) * HID);
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) if (k0 + u < K) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float x = in[e][k0 + u];
+        acc[e].x += x * w[u].x; acc[e].y += x * w[u].y; acc[e].z += x * w[u].z; acc[e].w += x * w[u].w;
+      }
+    }
+  }
+}
+// env[e] / write[e]: the environment of slot e and whether its outputs are stored.  The four slots' blocks lie `stride` bytes apart from
+// `slot0` (LDS); inside a block: observation halves at off_q (qpos + 7: 28 T) and off_v (qvel + 6: 28 T), scratch at off_scr.
+template <class T>
+__device__ inline void policy_wave4(const PolicyArgs& pa, const int (&env)[4], const bool (&write)[4], int lane, char* slot0, unsigned stride, unsigned off_q, unsigned off_v, unsigned off_scr) {
+  const float* __restrict__ P = pa.P;
+  const T* ob_q[4]; const T* ob_v[4]; float* scr[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    ob_q[e] = reinterpret_cast<const T*>(slot0 + e * stride + off_q); ob_v[e] = reinterpret_cast<const T*>(slot0 + e * stride + off_v);
+    scr[e] = reinterpret_cast<float*>(slot0 + e * stride + off_scr);
+  }
+  {   // every slot normalises its own observation: slot lane sl takes inputs sl, sl + 16, ...
+    const int slot = lane >> 4, sl = lane & 15;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = sl + 16 * c;
+      if (i < OB) {
+        const float o = i < 28 ? (float)ob_q[slot][i] : (float)ob_v[slot][i - 28];
+        scr[slot][i] = fminf(fmaxf((o - P[O_MEAN + i]) / P[O_STD + i], -5.0f), 5.0f);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+  const bool hid = lane < 2 * (HID / 4);
+  const int net = lane >= HID / 4 ? 1 : 0, j4 = 4 * (lane - net * (HID / 4));
+  const int jj = hid ? j4 : 0;
+  {
+    const float* in[4] = {scr[0], scr[1], scr[2], scr[3]};
+    float4 a[4];
+    dense4_wave4<OB, 14>(P + (net ? O_VW1 : O_PW1) + jj, P + (net ? O_VB1 : O_PB1) + jj, in, a);
+    if (hid) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) *reinterpret_cast<float4*>(scr[e] + 64 + net * HID + j4) = make_float4(tanhf(a[e].x), tanhf(a[e].y), tanhf(a[e].z), tanhf(a[e].w));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+  {
+    const float* in[4] = {scr[0] + 64 + net * HID, scr[1] + 64 + net * HID, scr[2] + 64 + net * HID, scr[3] + 64 + net * HID};
+    float4 a[4];
+    dense4_wave4<HID, 20>(P + (net ? O_VW2 : O_PW2) + jj, P + (net ? O_VB2 : O_PB2) + jj, in, a);
+    if (hid) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) *reinterpret_cast<float4*>(scr[e] + 264 + net * HID + j4) = make_float4(tanhf(a[e].x), tanhf(a[e].y), tanhf(a[e].z), tanhf(a[e].w));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+  {
+    const bool isv = lane == AC, on = lane <= AC;
+    const float* W = P + (isv ? O_VW3 : O_PW3);
+    const int ws = isv ? 1 : AC, wo = (isv || !on) ? 0 : lane;
+    const int ho = 264 + (isv ? HID : 0);
+    const float b = isv ? P[O_VB3] : P[O_PB3 + wo];
+    float sacc[4] = {b, b, b, b};
+#pragma unroll 1
+    for (int k0 = 0; k0 < HID; k0 += 20) {
+      float w[20];
+#pragma unroll
+      for (int u = 0; u < 20; u++) w[u] = W[(k0 + u) * ws + wo];
+#pragma unroll
+      for (int u = 0; u < 20; u++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) sacc[e] += scr[e][ho + k0 + u] * w[u];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (!write[e]) continue;
+      if (isv) pa.vpred[env[e]] = sacc[e];
+      else if (on) {
+        float a = sacc[e];
+        if (pa.stochastic) a += expf(P[O_LOGSTD + lane]) * normal_from(pa.seed, pa.counter, (unsigned)(env[e] * AC + lane));
+        pa.action[(size_t)env[e] * AC + lane] = (double)a;
+      }
+    }
+  }
+}
+
 // GAE(lambda) of src/trpo.py:83-94 for N environments: thread = env, a backward loop over the T rows of the [T, N] segment
 // (coalesced across envs), instead of T small launches.
 __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, const float* __restrict__ vpred, const int* __restrict__ isnew,

@@ -721,8 +721,8 @@ struct SlotAssemble {
 template <class R, int NS, bool PROF = false>
 DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int nefc, int nmax, int& ovf, const DebugOut* dbg, long long* prof = 0) {
   const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
-  long long pt0 = 0, pt1 = 0;
-  if (PROF) pt0 = dmw::clk();
+  long long pt0 = 0, pt1 = 0, pt_enter = 0;
+  if (PROF) { pt0 = dmw::clk(); pt_enter = pt0; }
 #define SLOT_STAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
   constexpr int NC = 16 * NS;
   auto& W = s.r1.rw;
@@ -912,6 +912,7 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
       if (PROF) prof[6] += 1;
     }
   }
+  if (PROF && NS == 2) { prof[22] += dmw::clk() - pt0; }
   SLOT_STAMP(12)
   if (PROF) { prof[14] += nmax; prof[15] += 1; }
   if (dmw::row_ballot(anybad, lane) != 0u) ovf |= 16 | 64;        // [MJ costChange] would have rejected a step: the one-env kernel's guarded replay decides
@@ -946,6 +947,7 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
   }
   dmw::sync();
   SLOT_STAMP(13)
+  if (PROF && NS == 2) prof[24] += dmw::clk() - pt_enter;
 #undef SLOT_STAMP
 }
 

@@ -233,7 +233,7 @@ DM_DEV R slot_imitation_reward(const DevModel<R>& M, const Batch<R>& B, SlotShar
 // capacity of the packed path during the step (`ovf`) stores nothing either: it is appended to the launch's redo list
 // (redo[0] = counter, list = redo + 1 ...) and re-stepped from its unchanged state by the one-env kernel.
 template <class R, bool PROF = false>
-DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, SlotTables& tb, int env, int sl, int lane, bool live,
+DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, SlotTables& tb, int env, int sl, int lane, bool live,
                           const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int* redo_count, int* redo_list,
                           long long* prof_out = 0) {
   long long prof[32];
@@ -317,6 +317,7 @@ DM_DEV void slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
     prof[5] = dmw::clk() - tstart;              // [8..13] constraint parts: row build, imp + half solve, A, warm start, PGS, assembly + solve; [14] sum of nmax; [15] constrained evaluations
     for (int k = 0; k < 32; k++) prof_out[k] = prof[k];   // [16..18] mass: f + M entries, elimination, scaling; [19..21] rows: geoms + limits, broad phase, narrow phase + emission; [23] candidates
   }
+  return live;                                  // the slot's environment was stepped and stored by this wave
 }
 
 }  // namespace dm

@@ -262,9 +262,11 @@ class DPVecEnv(object):
         diagnostics: keep `sim.data.xipos` / the contact geom list up to date after every step (DM_OPT_DIAGNOSTICS; the batched
         training path does not read them, `DPEnv` and raw `Batch` objects default to on).
         dtype: 64 (default) or 32 — arithmetic of the kernels; observations / actions stay float64 arrays.
-        packed: DM_OPT_PACKED — four environments per wavefront (k_step_packed) instead of one.  None (default) = by batch size: on from
-        PACKED_FROM_ENVS environments (two or more waves per SIMD on one MI355X, where it is 1.4-1.5x faster), float64, rewards other than
-        v1-quat; below that a launch is a single round of lone waves and the one-env kernel is faster."""
+        packed: DM_OPT_PACKED — four environments per wavefront (k_step_packed) instead of one.  True / False pin the kernel.  None
+        (default): batches of PACKED_FROM_ENVS environments or more (two or more waves per SIMD on one MI355X; float64; rewards other than
+        v1-quat) start on the packed kernel and re-decide every 256 steps from their own row statistics (Batch.enable_auto_packed): it is
+        1.4-1.5x faster while environments stay within its per-env capacities (the RSI / early-termination regimes), and hands over to
+        the one-env kernel when a competent policy keeps most environments on both feet (32+ rows).  Smaller batches: one env per wave."""
         self.num_envs = int(num_envs)
         self.mocap = MocapDM()
         self.mocap.load_mocap(motion)
@@ -301,11 +303,11 @@ class DPVecEnv(object):
         b.set_option(A.OPT_SEED, int(seed))
         b.set_option(A.OPT_ENV_OFFSET, int(env_offset))
         b.set_option(A.OPT_DIAGNOSTICS, 1 if diagnostics else 0)
-        if packed is None:
-            packed = batch_factory is None and self.num_envs >= PACKED_FROM_ENVS and dtype == 64 and reward != "v1-quat"
-        self.packed = bool(packed)
-        if self.packed:
+        auto = packed is None and batch_factory is None and self.num_envs >= PACKED_FROM_ENVS and dtype == 64 and reward != "v1-quat"
+        if packed or auto:
             b.set_option(A.OPT_PACKED, 1)
+        if auto:
+            b.enable_auto_packed(True)
         cr = self._cm.actuator_ctrlrange
         self.action_space = Box(low=cr[:, 0], high=cr[:, 1], dtype=np.float32)
         self.observation_space = Box(low=-np.inf, high=np.inf, shape=(A.NOBS,), dtype=np.float32)
@@ -314,6 +316,11 @@ class DPVecEnv(object):
     @property
     def batch(self):
         return self._batch
+
+    @property
+    def packed(self):
+        """True while the batch steps four environments per wavefront (DM_OPT_PACKED; may change over a run with packed=None)"""
+        return bool(getattr(self._batch, "options", {}).get(A.OPT_PACKED, 0))
 
     def seed(self, seed):
         self._batch.set_option(A.OPT_SEED, int(seed))

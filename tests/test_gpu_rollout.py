@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from deepmimic_mujoco_amd import _abi as A
+
 from deepmimic_mujoco_amd import DPVecEnv, MlpPolicy, traj_segment_generator, add_vtarg_and_adv
 from tests.test_policy import CKPT, GOLD, _gae_reference_loop
 
@@ -266,18 +268,19 @@ def test_bench_other_workloads_print_the_contract_line(extra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipeline", [1, 2])
-def test_fused_policy_step_equals_step_then_act(pipeline):
+@pytest.mark.parametrize("pipeline,packed", [(1, False), (2, False), (1, True), (2, True)])
+def test_fused_policy_step_equals_step_then_act(pipeline, packed):
     """dm_batch_step_act == dm_batch_step followed by dm_policy_act on the observations it produced: same obs / reward / done
     (bit-exact: the same env kernel code), same actions and values (the per-wave MLP sums in a different order: 1e-5), over
     closed-loop steps with auto-resets (an untrained policy: episodes of ~34 steps), at one launch per step and with pipelined
-    sub-batches."""
+    sub-batches; `packed`: the same on the four-environments-per-wavefront kernel (k_step_packed_act: one weight stream per wave
+    serves four environments; 642 envs = a last wave with spare slots)."""
     from deepmimic_mujoco_amd import _abi as A
-    n, steps = 640, 48
+    n, steps = (642 if packed else 640), 48
     pol = MlpPolicy(device=DEV, seed=2); pol.seed(5)
     outs = []
     for fused in (False, True):
-        env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=3)
+        env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=3, packed=packed)
         env.batch.set_option(A.OPT_PIPELINE, pipeline)
         ob = torch.zeros((steps + 1, n, 56), dtype=torch.float64, device=DEV)
         ac = torch.zeros((steps + 1, n, 28), dtype=torch.float64, device=DEV)
@@ -378,3 +381,32 @@ def test_fused_policy_step_on_tiny_and_odd_batches(n, pipeline):
         env.close()
     assert torch.equal(res[0][0], res[1][0])
     assert float((res[0][1] - res[1][1]).abs().max()) < 1e-5 and float((res[0][2] - res[1][2]).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_auto_packed_follows_the_workload():
+    """DPVecEnv(packed=None) at 8192 envs starts four-per-wave and re-decides from the batch's own row statistics: RSI + random actions
+    (the benchmark regime: envs fall, few rows) stays packed; a population standing on both feet (the init pose under zero actions:
+    8 foot corners x 4 pyramid rows = 32 rows, more with any limit or self-contact) overflows the packed path's 32-row capacity and is
+    handed to the one-env kernel; once the rows are gone (RSI + random actions again) the batch returns to the packed kernel."""
+    n = 8192
+    env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="rsi", seed=1)
+    assert env.packed and env.batch._auto
+    env.batch.ADAPT_EVERY = 32
+    env.reset("rsi")
+    g = torch.Generator(device=DEV); g.manual_seed(0)
+    for t in range(96):
+        env.step(torch.randn((n, 28), generator=g, device=DEV, dtype=torch.float64) * 0.9)
+    assert env.packed and env.batch.auto_switches == 0, "the benchmark regime must stay on the packed kernel"
+    env.reset("qpos0")                                               # everybody upright on both feet
+    zero = torch.zeros((n, 28), device=DEV, dtype=torch.float64)
+    env.batch.set_option(A.OPT_AUTORESET, 2)                         # fallen envs restart upright
+    for t in range(96):
+        env.step(zero)
+    assert not env.packed and env.batch.auto_switches == 1, "a standing population must be handed to the one-env kernel (redo %s)" % (env.batch.redo_reasons(),)
+    env.batch.set_option(A.OPT_AUTORESET, 1)
+    env.reset("rsi")
+    for t in range(128):
+        env.step(torch.randn((n, 28), generator=g, device=DEV, dtype=torch.float64) * 0.9)
+    assert env.packed and env.batch.auto_switches == 2
+    env.close()

@@ -1,0 +1,10 @@
+#!/bin/bash
+# build_ab/<name>.so = libdmenv.so of the working tree with extra defines; run with DMENV_LIB=build_ab/<name>.so (A/B inside one gpurun call)
+#   tools/build_variant.sh keyiter '-DDM_ORDER_KEY(n,i)=((i)+((n)>>2))'
+set -eu
+cd "$(dirname "$0")/.."
+mkdir -p build_ab
+name=$1; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-shift-count-negative -Wno-implicit-const-int-float-conversion \
+  "$@" -Iinclude -Ideepmimic_mujoco_amd/csrc deepmimic_mujoco_amd/csrc/dmenv.hip -o build_ab/$name.so
+ls -la build_ab/$name.so

@@ -34,6 +34,10 @@ for k, nm in enumerate(sub):
 for k, nm in enumerate(["mass/f + M entries", "mass/elimination", "mass/D, scaling", "rows/geoms + limits", "rows/broad phase", "rows/narrow phase + emission"]):
     print("      %-32s %9.0f" % (nm, p[:, 16 + k].mean()))
 print("      rows/largest candidate count of the wave per evaluation %.1f" % (p[:, 23].mean() / 4))
+n2 = p[:, 7].sum()
+if n2:
+    print("      two-row-set evaluations: %.0f cycles each (PGS %.0f); one-row-set: %.0f each (PGS %.0f)" % (
+        p[:, 24].sum() / n2, p[:, 22].sum() / n2, (p[:, 8:14].sum() - p[:, 24].sum()) / max(1, p[:, 15].sum() - n2), (p[:, 12].sum() - p[:, 22].sum()) / max(1, p[:, 15].sum() - n2)))
 ev = np.maximum(p[:, 15], 1)
 print("   constrained evaluations per wave-step %.2f of 4; mean wave nmax %.1f; two-row-set evaluations per wave-step %.3f; PGS loop trips per constrained evaluation %.1f" % (
     p[:, 15].mean(), (p[:, 14] / ev).mean(), p[:, 7].mean(), (p[:, 6] / ev).mean()))
