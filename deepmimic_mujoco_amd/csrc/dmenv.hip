@@ -145,10 +145,13 @@ __global__ __launch_bounds__(64) void k_step_packed_prof(const DevModel<Real>* _
 // ... and stepped here, from their unchanged state, by the one-env code (a handful of persistent single-wave workgroups walk the list)
 __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_redo(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                                   Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
-                                                  int n_substeps, int first, const int* __restrict__ redo_count, dmp::PolicyArgs pa) {
+                                                  int n_substeps, int first, const int* __restrict__ redo_count, int* __restrict__ redo_count_next, dmp::PolicyArgs pa) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
   const int n = dmw::uniform(*redo_count);
+  // the two counters of a sub-batch alternate from step to step: this launch clears the one the NEXT packed launch will count into (its last
+  // reader, the redo launch of the step before, finished before this step's packed launch began: stream order) — no memset between launches
+  if (blockIdx.x == 0 && threadIdx.x == 0) *redo_count_next = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0 && n > 0) atomicAdd(B.redo_why, n);       // running total (dm_batch_redo_total)
   for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
     const int env = B.redo_list[first + i];
@@ -311,6 +314,8 @@ struct dm_batch {
   Ext *d_qpos_in = nullptr, *d_qvel_in = nullptr; int* d_fidx_in = nullptr;
   double* d_debug = nullptr;
   long long* d_prof = nullptr; bool prof = false;
+  int redo_phase = 0;    // which of a sub-batch's two redo counters the next packed launch counts into
+  int redo_mode = -1;    // 1 / 0: the last packed step was / was not pipelined (the counter pairs are re-zeroed when that changes)
   bool packed = false;   // option 105: four environments per wavefront (k_step_packed) where that kernel covers the configuration
   bool two_tier = true, reorder = true, has_rows = true; int resident_waves = 2048;   // CUs x 8 single-wave workgroups (LDS-limited)
   bool timing = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f; bool ev_pending = false;
@@ -413,7 +418,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   ok = ok && hipHostMalloc((void**)&b->h_action, (size_t)n * NU * sizeof(Ext), hipHostMallocDefault) == hipSuccess;
   A(b->B.aovf, (size_t)n * AOVF_COLS * 64);
   A(b->B.kin, (size_t)n * KIN_DOUBLES); A(b->B.kin_ok, n);
-  A(b->B.redo_list, n); A(b->B.redo_count, DM_MAX_PIPELINE); A(b->B.redo_why, 8);
+  A(b->B.redo_list, n); A(b->B.redo_count, 2 * DM_MAX_PIPELINE); A(b->B.redo_why, 8);
   A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
   if (sizeof(Real) != sizeof(Ext)) A(b->d_cvt, (size_t)n * NB * 3);   // largest Real field per env: xipos (42)
 #undef A
@@ -555,12 +560,20 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
   // the packed kernel covers: models without constraint rows, reward modes alive / v3-config / v2-pose, no fused policy step
   const bool use_packed = b->packed && b->B.reward_mode <= 3 && !b->prof && b->two_tier;
   const dmp::PolicyArgs nopol{nullptr, nullptr, nullptr, 0, 0ull, 0ull};
+  if (use_packed || (b->prof && b->packed)) {
+    const int mode = piped ? 1 : 0;
+    if (mode != b->redo_mode) {      // (rare: the first packed step, or a host-pointer step between pipelined ones; every earlier launch is ordered before this stream here)
+      if (piped && pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+      HIPCHK(hipMemsetAsync(b->B.redo_count, 0, 2 * DM_MAX_PIPELINE * sizeof(int), b->stream));
+      b->redo_mode = mode; b->redo_phase = 0;
+    }
+  }
   constexpr int REDO_BLOCKS = 64;
   if (b->prof && b->packed && b->B.reward_mode <= 3) {
     HIPCHK(hipMemsetAsync(b->d_prof, 0, (size_t)b->n * dm::PROF_SLOTS * sizeof(long long), b->stream));
-    HIPCHK(hipMemsetAsync(b->B.redo_count, 0, sizeof(int), b->stream));
-    hipLaunchKernelGGL(k_step_packed_prof, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, b->B.redo_count, b->d_prof);
-    if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)b->B.redo_count, nopol);
+    int* rc = b->B.redo_count + b->redo_phase; int* rn = b->B.redo_count + (1 - b->redo_phase);
+    hipLaunchKernelGGL(k_step_packed_prof, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc, b->d_prof);
+    if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)rc, rn, nopol);
   } else if (b->prof) hipLaunchKernelGGL(k_step_prof, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, b->d_prof);
   else if (piped) {
     // Sub-batch h's launch of THIS call depends on its own launch of the previous call (stream order on ps[h]) and on the
@@ -574,10 +587,10 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
       HIPCHK(hipStreamWaitEvent(b->ps[h], b->ev_in, 0));
       if (b->timing && h == 0) HIPCHK(hipEventRecord(b->ev0, b->ps[0]));     // timing: sub-batch 0's kernel on ITS stream
       if (use_packed) {
-        HIPCHK(hipMemsetAsync(b->B.redo_count + h, 0, sizeof(int), b->ps[h]));
-        if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, b->B.redo_count + h, *pol);
-        else hipLaunchKernelGGL(k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, b->B.redo_count + h);
-        if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, (const int*)(b->B.redo_count + h), pol ? *pol : nopol);
+        int* rc = b->B.redo_count + 2 * h + b->redo_phase; int* rn = b->B.redo_count + 2 * h + (1 - b->redo_phase);
+        if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, rc, *pol);
+        else hipLaunchKernelGGL(k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, rc);
+        if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, (const int*)rc, rn, pol ? *pol : nopol);
       }
       else if (pol) hipLaunchKernelGGL(k_step_act, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, *pol);
       else hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo);
@@ -589,10 +602,12 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     b->pipe_pending = true;
   } else if (b->two_tier) {
     if (use_packed) {
-      HIPCHK(hipMemsetAsync(b->B.redo_count, 0, sizeof(int), b->stream));
-      if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, b->B.redo_count, *pol);
-      else hipLaunchKernelGGL(k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, b->B.redo_count);
-      if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)b->B.redo_count, pol ? *pol : nopol);
+      // (a step that is not pipelined has joined every sub-batch stream: all of them are idle, so ONE pair of counters is clean — pair 0's
+      //  two are cleared here once if a pipelined step used them before)
+      int* rc = b->B.redo_count + b->redo_phase; int* rn = b->B.redo_count + (1 - b->redo_phase);
+      if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc, *pol);
+      else hipLaunchKernelGGL(k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc);
+      if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)rc, rn, pol ? *pol : nopol);
     }
     else if (pol) hipLaunchKernelGGL(k_step_act, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, *pol);
     else hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0);
@@ -608,6 +623,7 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     }
   } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub);
   HIPCHK(hipGetLastError());
+  if (b->packed && b->B.reward_mode <= 3 && b->two_tier) b->redo_phase ^= 1;
   if (b->timing && !piped) { HIPCHK(hipEventRecord(b->ev1, b->stream)); b->ev_pending = true; }
   if (kind == DM_PTR_HOST) {
     HIPCHK(hipMemcpyAsync(b->h_out, b->d_obs, b->out_bytes, hipMemcpyDeviceToHost, b->stream));

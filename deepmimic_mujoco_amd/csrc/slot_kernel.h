@@ -20,7 +20,7 @@
 namespace dm {
 
 constexpr int SLOTS = 4, SW = 16;            // environments per wavefront, lanes per environment
-constexpr int SLOT_MAXROWS = 32, SLOT_MAXLIMROWS = 16, SLOT_MAXCON = 10, SLOT_MAXCAND = 32, SLOT_BOXSLOTS = 3;   // per-environment capacities of the packed path; beyond: fix-up by the one-env kernel
+constexpr int SLOT_MAXROWS = 32, SLOT_MAXLIMROWS = 16, SLOT_MAXCON = 13, SLOT_MAXFRAME = 8, SLOT_MAXCAND = 32, SLOT_BOXSLOTS = 3;   // per-environment capacities of the packed path; beyond: fix-up by the one-env kernel
 constexpr int PAIR_PASSES = MAXPAIR / SW;
 constexpr int DOF_PASSES = (NV + SW - 1) / SW, HINGE_PASSES = (NU + SW - 1) / SW, Q_PASSES = (NQ + SW - 1) / SW, ENT_PASSES = (310 + SW - 1) / SW;
 
@@ -45,11 +45,12 @@ struct SlotShared {
     struct {                                                    // collision .. constraint stage
       R gpos[NG][3];                                            // geom world positions (orientations are re-formed per candidate pair)
       R boxc[SLOT_BOXSLOTS][4][4];                              // contacts (dist, pos) of plane-box (slots 0, 1) and box-box (slot 2)
-      R con[SLOT_MAXCON][10];                                   // staged contacts: pos[3], normal[3], tangent 1 [3], dist (emission .. row build)
+      R con[SLOT_MAXCON][4];                                    // staged contacts: pos[3], dist (emission .. row build)
+      R frm[SLOT_MAXFRAME][6];                                  // contact frames, one per pair with contacts: normal[3], tangent 1 [3]
       R rowv[SLOT_MAXLIMROWS];                                  // limit rows (they come first): distance
       int rowi[SLOT_MAXROWS];                                   // row codes (see slot_rows)
       int cand[SLOT_MAXCAND];                                   // candidate pair numbers past the broad phase, in pair-list order
-      int coni[SLOT_MAXCON];                                    // pair number of a staged contact
+      int coni[SLOT_MAXCON + 1];                                // pair number | frame << 8 of a staged contact
     } rw;
   } r1;
   union {
@@ -487,7 +488,7 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
   }
   dmw::sync();
   SLOT_RSTAMP(19)
-  int ncon = 0;
+  int ncon = 0, nfr = 0;
   if (M.enable_contact) {
     // ---- broad phase: bounding spheres (plane pairs: signed distance of the centre)
     int ncand = 0;
@@ -552,19 +553,23 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
         int tot_rows, tot_con;
         const int r0 = nrow + row_exclusive_scan(pc.n * rows_per, sl, lane, &tot_rows);
         const int c0 = ncon + row_exclusive_scan(pc.n, sl, lane, &tot_con);
-        R fr[9];
-        if (pc.n > 0) make_frame(fr, pc.nrm, pc.hint);
+        const unsigned fmask = dmw::row_ballot(pc.n > 0, lane);
+        const int fi = nfr + __builtin_popcount(fmask & below);          // this pair's frame
+        nfr += __builtin_popcount(fmask);
         if (pc.n > 0) {
+          R fr[9];
+          make_frame(fr, pc.nrm, pc.hint);
+          if (fi < SLOT_MAXFRAME) { R* o = W.frm[fi]; for (int t = 0; t < 6; t++) o[t] = fr[t]; }
           for (int k = 0; k < pc.n; k++) {
             const int ci = c0 + k, rk = r0 + k * rows_per;
-            if (ci >= SLOT_MAXCON || rk + rows_per > SLOT_MAXROWS) { ovf |= ci >= SLOT_MAXCON ? 4 : 8; continue; }
+            if (ci >= SLOT_MAXCON || fi >= SLOT_MAXFRAME || rk + rows_per > SLOT_MAXROWS) { ovf |= (ci >= SLOT_MAXCON || fi >= SLOT_MAXFRAME) ? 4 : 8; continue; }
             R cdist, cpos[3];
             if (pc.boxslot >= 0) { const R* o = W.boxc[pc.boxslot][k]; cdist = o[0]; cpos[0] = o[1]; cpos[1] = o[2]; cpos[2] = o[3]; }
             else if (k == 0) { cdist = pc.d0; cpos[0] = pc.p0[0]; cpos[1] = pc.p0[1]; cpos[2] = pc.p0[2]; }
             else { cdist = pc.d1; cpos[0] = pc.p1[0]; cpos[1] = pc.p1[1]; cpos[2] = pc.p1[2]; }
             R* o = W.con[ci];
-            o[0] = cpos[0]; o[1] = cpos[1]; o[2] = cpos[2]; o[3] = fr[0]; o[4] = fr[1]; o[5] = fr[2]; o[6] = fr[3]; o[7] = fr[4]; o[8] = fr[5]; o[9] = cdist;
-            W.coni[ci] = pidx;
+            o[0] = cpos[0]; o[1] = cpos[1]; o[2] = cpos[2]; o[3] = cdist;
+            W.coni[ci] = pidx | (fi << 8);
             for (int q = 0; q < rows_per; q++) W.rowi[rk + q] = ROW_CONTACT | (ci << 8) | (q << 16) | (dim << 20);
           }
         }
@@ -747,12 +752,14 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
     } else if (type == ROW_CONTACT) {
       const int ci = (code >> 8) & 0xff, q = (code >> 16) & 0xf, cdim = (code >> 20) & 0xf;
       const R* c = W.con[ci];
-      const auto& rec = M.pair_rec[W.coni[ci]];
+      const int cw = W.coni[ci];
+      const R* fm = W.frm[(cw >> 8) & 0xff];
+      const auto& rec = M.pair_rec[cw & 0xff];
       const R cmu = rec.mu, ctran = rec.tran;
       const int meta = rec.meta;
-      R dir[3] = {c[3], c[4], c[5]};
+      R dir[3] = {fm[0], fm[1], fm[2]};
       if (cdim != 1) {
-        const R n[3] = {c[3], c[4], c[5]}, t1[3] = {c[6], c[7], c[8]};
+        const R n[3] = {fm[0], fm[1], fm[2]}, t1[3] = {fm[3], fm[4], fm[5]};
         R t2[3];
         cross3(t2, n, t1);
         const R sg = (q & 1) ? -cmu : cmu;
@@ -761,7 +768,7 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
       }
       cross3(w, c, dir);
       w[3] = dir[0]; w[4] = dir[1]; w[5] = dir[2];
-      pos[k] = c[9]; margin[k] = rec.margin;
+      pos[k] = c[3]; margin[k] = rec.margin;
       dA[k] = cdim == 1 ? ctran : ctran + cmu * cmu * ctran;
       rscale[k] = cdim == 1 ? R(1) : 2 * cmu * cmu;
       mminus = TOPO.chain[meta & 0xff]; mplus = TOPO.chain[(meta >> 8) & 0xff];

@@ -267,7 +267,7 @@ DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
       for (int k = sl; k < MAXEFC * 2; k += SW) {
         const int c = k >> 1;
         int gid = -1;
-        if (c < nc && c < SLOT_MAXCON) { const auto& rec = M.pair_rec[s.r1.rw.coni[c]]; gid = (k & 1) ? rec.g2 : rec.g1; }
+        if (c < nc && c < SLOT_MAXCON) { const auto& rec = M.pair_rec[s.r1.rw.coni[c] & 0xff]; gid = (k & 1) ? rec.g2 : rec.g1; }
         B.cong[(size_t)env * MAXEFC * 2 + k] = gid;
       }
     }

@@ -16,9 +16,19 @@ if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   for rw in alive v3-config; do
     timeout 300 python bench.py --reward $rw --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_$rw.json 2> $OUT/bench_cfg3_$rw.err; cut -c1-200 $OUT/bench_cfg3_$rw.json
   done
-  for wl in cfg4 cfg5 cfg2; do
+  for wl in cfg4 cfg2; do
     timeout 300 python bench.py --workload $wl --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; cut -c1-200 $OUT/bench_$wl.json
   done
+  # configs[4] shard (8192 envs): DPVecEnv picks four environments per wavefront; with the live PMC passes of that kernel; and pinned to the one-env kernel
+  mkdir -p $OUT/raw_packed
+  DM_PROFILE_KEEP=$OUT/raw_packed timeout 600 python bench.py --workload cfg5 --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; cut -c1-200 $OUT/bench_cfg5.json
+  timeout 300 python bench.py --workload cfg5 --packed 0 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg5_one_env_per_wave.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg5_one_env_per_wave.json
+  for n in 4096 16384 32768; do timeout 300 python bench.py --envs $n --packed 1 --pipeline $([ $n = 4096 ] && echo 1 || echo 2) --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_packed_$n.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg3_packed_$n.json; done
+  timeout 300 python bench.py --envs 16384 --packed 0 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_one_env_16384.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg3_one_env_16384.json
+  timeout 300 python tools/profile_packed.py > $OUT/packed_stage_cycles.txt 2>&1; head -30 $OUT/packed_stage_cycles.txt
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace5 -- python $OLDPWD/bench.py --workload cfg5 --steps 96 --warmup 16 --no-pmc --no-cpu-baseline --no-gym-loop > /dev/null 2>&1 )
+  ROWS=6 python tools/rocprof_summary.py $OUT/kstep_packed_summary.md "step kernels — $TAG, MI355X (bench.py --workload cfg5: dance_b, 8192 envs, four environments per wavefront, 2 pipelined sub-batches)" \
+    $(find /tmp/p_trace5 -name "*.db" | head -1) > /dev/null; head -12 $OUT/kstep_packed_summary.md
   timeout 300 python bench.py --workload rollout --steps 2048 --warmup 256 > $OUT/bench_rollout_fused.json 2> $OUT/bench_rollout_fused.err; cut -c1-200 $OUT/bench_rollout_fused.json
   # driver-sized window as the driver runs it
   timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_driver_window.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg3_driver_window.json
