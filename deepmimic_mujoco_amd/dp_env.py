@@ -266,7 +266,9 @@ class DPVecEnv(object):
         (default): batches of PACKED_FROM_ENVS environments or more (two or more waves per SIMD on one MI355X; float64; rewards other than
         v1-quat) start on the packed kernel and re-decide every 256 steps from their own row statistics (Batch.enable_auto_packed): it is
         1.4-1.5x faster while environments stay within its per-env capacities (the RSI / early-termination regimes), and hands over to
-        the one-env kernel when a competent policy keeps most environments on both feet (32+ rows).  Smaller batches: one env per wave."""
+        the one-env kernel when a competent policy keeps most environments on both feet (32+ rows).  Smaller batches: one env per wave —
+        except for models without contacts and limits (BASELINE configs[1]): all waves cost the same there and four per wave is 1.5x
+        faster at any size."""
         self.num_envs = int(num_envs)
         self.mocap = MocapDM()
         self.mocap.load_mocap(motion)
@@ -303,7 +305,8 @@ class DPVecEnv(object):
         b.set_option(A.OPT_SEED, int(seed))
         b.set_option(A.OPT_ENV_OFFSET, int(env_offset))
         b.set_option(A.OPT_DIAGNOSTICS, 1 if diagnostics else 0)
-        auto = packed is None and batch_factory is None and self.num_envs >= PACKED_FROM_ENVS and dtype == 64 and reward != "v1-quat"
+        rowless = not (contacts or limits)          # no constraint rows: every wave costs the same, the packed kernel wins at any batch size
+        auto = packed is None and batch_factory is None and (self.num_envs >= PACKED_FROM_ENVS or (rowless and self.num_envs >= 256)) and dtype == 64 and reward != "v1-quat"
         if packed or auto:
             b.set_option(A.OPT_PACKED, 1)
         if auto:

@@ -25,7 +25,10 @@ if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   timeout 300 python bench.py --workload cfg5 --packed 0 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg5_one_env_per_wave.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg5_one_env_per_wave.json
   for n in 4096 16384 32768; do timeout 300 python bench.py --envs $n --packed 1 --pipeline $([ $n = 4096 ] && echo 1 || echo 2) --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_packed_$n.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg3_packed_$n.json; done
   timeout 300 python bench.py --envs 16384 --packed 0 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_one_env_16384.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg3_one_env_16384.json
+  timeout 300 python bench.py --workload cfg5 --no-reorder --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg5_no_reorder.json 2>/dev/null; cut -c1-120 $OUT/bench_cfg5_no_reorder.json
   timeout 300 python tools/profile_packed.py > $OUT/packed_stage_cycles.txt 2>&1; head -30 $OUT/packed_stage_cycles.txt
+  timeout 300 python tools/profile_stages.py > $OUT/stage_cycles.txt 2>&1; head -12 $OUT/stage_cycles.txt
+  [ -x tools/ubench/lone ] && tools/ubench/lone > $OUT/ubench_lone.txt 2>&1; cat $OUT/ubench_lone.txt
   ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace5 -- python $OLDPWD/bench.py --workload cfg5 --steps 96 --warmup 16 --no-pmc --no-cpu-baseline --no-gym-loop > /dev/null 2>&1 )
   ROWS=6 python tools/rocprof_summary.py $OUT/kstep_packed_summary.md "step kernels — $TAG, MI355X (bench.py --workload cfg5: dance_b, 8192 envs, four environments per wavefront, 2 pipelined sub-batches)" \
     $(find /tmp/p_trace5 -name "*.db" | head -1) > /dev/null; head -12 $OUT/kstep_packed_summary.md
