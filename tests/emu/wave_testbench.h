@@ -115,18 +115,19 @@ template <class T> inline void lds_sub(bool pred, T* p, T v) {
 // 16-lane env slots (wave.h): row-relative broadcast / fused multiply-add / ballot
 template <int I, class T> inline T row_bcast(T v) { return exchange(v, (lane() & 48) | I); }
 template <int I> inline int row_bcast_i(int v) { return exchange(v, (lane() & 48) | I); }
-template <int I, class T> inline void row_fmac(T& acc, T x, T y) { acc = std::fma(row_bcast<I>(x), y, acc); }
-template <int I, class T> inline void row_fmac_old(T& acc, T x, T y) { acc = std::fma(row_bcast<I>(x), y, acc); }
+// (unfused like every other multiply-add of the testbench build, -ffp-contract=off: paths that must agree bit for bit then do so here as on the device)
+template <int I, class T> inline void row_fmac(T& acc, T x, T y) { acc = acc + row_bcast<I>(x) * y; }
+template <int I, class T> inline void row_fmac_old(T& acc, T x, T y) { acc = acc + row_bcast<I>(x) * y; }
 template <int I, class T> inline void row_fmac8(T& acc0, T& acc1, const T* x, const T* y) {
-  for (int k = 0; k < 8; k++) { if (k & 1) acc1 = std::fma(row_bcast<I>(x[k]), y[k], acc1); else acc0 = std::fma(row_bcast<I>(x[k]), y[k], acc0); }
+  for (int k = 0; k < 8; k++) { if (k & 1) acc1 = acc1 + row_bcast<I>(x[k]) * y[k]; else acc0 = acc0 + row_bcast<I>(x[k]) * y[k]; }
 }
-template <int I, class T> inline void row_add8(T* a, const T* x, T one) { for (int k = 0; k < 8; k++) a[k] = std::fma(row_bcast<I>(x[k]), one, a[k]); }
+template <int I, class T> inline void row_add8(T* a, const T* x, T one) { for (int k = 0; k < 8; k++) a[k] = a[k] + row_bcast<I>(x[k]) * one; }
 template <int I, class T> inline void pgs_row(T& t, T& tsave, T nf0, T a, T onehot) {
-  const T d = std::fmax(nf0, t); tsave = std::fma(onehot, t, tsave); t = std::fma(row_bcast<I>(d), a, t);
+  const T d = std::fmax(nf0, t); tsave = tsave + onehot * t; t = t + row_bcast<I>(d) * a;
 }
 template <int I, class T> inline void pgs_row2(T& t_own, T& tsave_own, T& t_other, T nf0, T a_own, T a_other, T onehot) {
-  const T d = std::fmax(nf0, t_own); tsave_own = std::fma(onehot, t_own, tsave_own); const T b = row_bcast<I>(d);
-  t_own = std::fma(b, a_own, t_own); t_other = std::fma(b, a_other, t_other);
+  const T d = std::fmax(nf0, t_own); tsave_own = tsave_own + onehot * t_own; const T b = row_bcast<I>(d);
+  t_own = t_own + b * a_own; t_other = t_other + b * a_other;
 }
 inline void dpp_settle() {}
 inline int global_counter_next(int* p) { return (*p)++; }
