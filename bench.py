@@ -291,7 +291,8 @@ def rollout_bench(args, dev, rank, world, local_dev):
     pol = MlpPolicy(device=dev, seed=0); pol.seed(rank)
     if not args.unfused:        # one batch, P pipelined sub-batches, the policy step inside the env step kernel: one launch per step
         from deepmimic_mujoco_amd import _abi as A
-        env = DPVecEnv(n, motion=clip, device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n)
+        env = DPVecEnv(n, motion=clip, device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n,
+                       packed=None if args.packed is None else bool(args.packed))
         env.batch.set_option(A.OPT_PIPELINE, min(P, A.MAX_PIPELINE))
         gen = traj_segment_generator(pol, env, HORIZON, stochastic=True, fused=True)
     elif P > 1:
@@ -316,10 +317,12 @@ def rollout_bench(args, dev, rank, world, local_dev):
     if rank == 0:
         print(json.dumps({"metric": "rollout env-steps/sec (policy in the loop + GAE)", "value": round(world * n * segs * HORIZON / el, 1),
                           "unit": "env-steps/s", "n_gpus": world, "steps": segs * HORIZON, "ms_per_step": round(el / (segs * HORIZON) * 1e3, 4),
-                          "episodes": eps, "config": {"workload": "rollout: %d envs/GPU, %s, untrained 2x100 tanh policy, alive reward, "
+                          "episodes": eps, "horizon_launch": (not args.unfused) and bool(env.packed), "packed_redo_env_steps": env.batch.redo_total() if not args.unfused else None,
+                          "config": {"workload": "rollout: %d envs/GPU, %s, untrained 2x100 tanh policy, alive reward, "
                                                                   "noisy-init autoreset, %d-step segments + GAE(0.995, 0.97)"
                                                                   % (n, ("%d concurrently stepped batch(es), one policy launch + one env launch per step" % P) if args.unfused
-                                                                     else ("policy step fused into the env step kernel (one launch per step), %d pipelined sub-batch(es)" % P), HORIZON)}}))
+                                                                     else (("policy step inside the horizon launch: four environments per wavefront, each wave runs its %d steps at its own pace (dm_batch_rollout, k_rollout_packed)" % HORIZON)
+                                                                           if env.packed else ("policy step fused into the env step kernel (one launch per step), %d pipelined sub-batch(es)" % P)), HORIZON)}}))
 
 
 def main():
@@ -346,6 +349,10 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (N = 1 only; they add about a minute)")
     ap.add_argument("--no-gym-loop", action="store_true", help="skip the single-env Python DPEnv.step loop (N = 1 only; ~3 s)")
     ap.add_argument("--prewarm-horizons", type=int, default=6, help="untimed 256-step horizons before the warm-up steps (cold-box clock ramp, ~1 s)")
+    ap.add_argument("--horizon-launch", action="store_true",
+                    help="step through dm_batch_rollout: up to one %d-step horizon of pre-drawn actions per call (on the packed path ONE launch in which every "
+                         "wavefront runs its four environments through all steps at its own pace) instead of one dm_batch_step call per step; implies --packed 1 unless given" % HORIZON)
+    ap.add_argument("--horizon-chunk", type=int, default=HORIZON, help="--horizon-launch: steps per dm_batch_rollout call (the dispatch order — which environments share a wavefront — is renewed between calls)")
     ap.add_argument("--packed", type=int, default=None, choices=[0, 1], help="DM option 105: four environments per wavefront (k_step_packed) where that kernel covers the workload (default: the library's)")
     ap.add_argument("--no-reorder", action="store_true", help="experiment: identity dispatch order instead of longest-first (DM option 104 = 0)")
     ap.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)   # profiled child of pmc_passes: GPU loop only, prints nothing
@@ -399,8 +406,8 @@ def main():
         env = DPVecEnv(n, motion=clip, device=local_dev, reward=args.reward if full else "alive",
                        autoreset="rsi", seed=0, contacts=full, limits=full,
                        action_mode="raw" if full else "p-control", env_offset=shard * n, frame_skip=1, dtype=args.dtype,
-                       packed=None if args.packed is None else bool(args.packed))
-    step_kernel = "k_step_packed" if env.packed else "k_step_narrow"
+                       packed=(True if args.horizon_launch else None) if args.packed is None else bool(args.packed))
+    step_kernel = ("k_rollout_packed" if args.horizon_launch else "k_step_packed") if env.packed else "k_step_narrow"
     stream = torch.cuda.Stream(device=dev)
     env.batch.set_stream(stream.cuda_stream)
     env.batch.set_option(A.OPT_PIPELINE, max(1, min(args.pipeline, A.MAX_PIPELINE)))
@@ -411,9 +418,9 @@ def main():
         gen = torch.Generator(device=dev); gen.manual_seed(1234 + shard)
         pool = HORIZON       # one 256-step horizon of i.i.d. N(0, 0.9^2) actions per (env, t), reused from horizon to horizon
         if full:
-            actions = torch.randn((pool, n, A.NU), generator=gen, device=dev, dtype=torch.float64) * 0.9
+            actions = torch.randn((pool + 1, n, A.NU), generator=gen, device=dev, dtype=torch.float64) * 0.9     # (row `pool`: never read, dm_batch_rollout's T + 1 shape)
         else:
-            actions = torch.zeros((pool, n, A.NU), device=dev, dtype=torch.float64)   # cfg2: pure P-controller
+            actions = torch.zeros((pool + 1, n, A.NU), device=dev, dtype=torch.float64)   # cfg2: pure P-controller
         # the kernel writes obs / reward / done of step t straight into row t of [T, n, .] staging buffers (no per-step copy
         # kernels); at the end of each 256-step horizon they are packed into the f32 rollout block (obs 56 + act 28 + rew + done
         # + vpred) in one go.  Blocks are double-buffered: while one is all-gathered (async, on the collective's own stream) the
@@ -439,14 +446,31 @@ def main():
 
         drain = dbg.drain
 
+        def run_steps(t_from, t_to):
+            """steps t_from .. t_to - 1: one dm_batch_step call each, or (--horizon-launch) one dm_batch_rollout call per stretch inside a horizon"""
+            if not args.horizon_launch:
+                for t in range(t_from, t_to):
+                    one_step(t)
+                return
+            t = t_from
+            while t < t_to:
+                k = t % HORIZON
+                m = min(HORIZON - k, t_to - t, max(1, args.horizon_chunk))
+                env.batch.rollout(actions[k:k + m + 1], (obs_T[k:k + m], rew_T[k:k + m], done_T[k:k + m]), 1)
+                t += m
+                if t % HORIZON == 0:
+                    env.batch.join()
+                    blk = dbg.block(t - 1)
+                    blk[:, :, :56] = obs_T; blk[:, :, 56:84] = actions[:pool]
+                    blk[:, :, 84] = rew_T; blk[:, :, 85] = done_T
+                    dbg.commit(t - 1)
+
         # untimed: bring a cold box (first process after boot: idle clocks, unmapped VRAM) to its steady state, then the W warm-up steps
         # (a fixed number of horizons, so that every rank issues the same sequence of collectives)
         for _ in range(args.prewarm_horizons):
-            for t in range(HORIZON):
-                one_step(t)
+            run_steps(0, HORIZON)
             drain(); env.batch.sync()
-        for t in range(args.warmup):
-            one_step(t)
+        run_steps(0, args.warmup)
         drain()
         env.batch.sync()
         if world > 1:
@@ -455,8 +479,7 @@ def main():
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
-        for t in range(args.steps):
-            one_step(t)
+        run_steps(0, args.steps)
         env.batch.join()                                                   # every sub-batch launch is inside the events
         drain()                                                            # outstanding gathers finish inside the timed region
         ev1.record(stream)
@@ -468,7 +491,7 @@ def main():
         # per-launch duration of the step kernel by HIP events on the stream it is launched on (pipelined: sub-batch 0's launch on
         # its own stream, while the other sub-batches keep the machine busy): untimed, sampled after the clock stopped
         launch_us = []
-        if not args._child:
+        if not args._child and not args.horizon_launch:
             env.batch.enable_timing(True)
             for t in range(args.steps, args.steps + 48):
                 one_step(t)
@@ -521,8 +544,8 @@ def main():
                        "envs_per_wavefront": 4 if env.packed else 1, "kernel_switches_by_row_statistics": getattr(env.batch, "auto_switches", None), "packed_redo_env_steps": env.batch.redo_total() if env.packed else None,
                        "actions": ("i.i.d. N(0, 0.9^2) per (env, step) within a %d-step horizon, pre-drawn on the device (%d x %d x 28 f64), the same "
                                    "tensors reused by every horizon" % (pool, pool, n)) if full else "zeros (pure P-controller)",
-                       "timed_window": "%d dm_batch_step calls (state / obs / reward / done device-resident)%s" % (
-                           args.steps, ", %d horizon-end block packings + joins" % (args.steps // HORIZON) if args.steps >= HORIZON
+                       "timed_window": "%s (state / obs / reward / done device-resident)%s" % (
+                           ("%d steps through dm_batch_rollout, %d steps per call" % (args.steps, min(HORIZON, max(1, args.horizon_chunk)))) if args.horizon_launch else "%d dm_batch_step calls" % args.steps, ", %d horizon-end block packings + joins" % (args.steps // HORIZON) if args.steps >= HORIZON
                            else "; shorter than the %d-step horizon: no block packing / join inside the window" % HORIZON)},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,

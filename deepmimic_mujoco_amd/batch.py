@@ -170,6 +170,29 @@ class Batch(object):
                                           C.c_void_p(next_vpred.data_ptr()), 1 if stochastic else 0, int(seed) & (2 ** 64 - 1), int(counter)), self._L)
         return obs, rew, done
 
+    def rollout(self, action, out, n_substeps=1, weights=None, vpred=None, stochastic=True, seed=0, counter=0):
+        """T steps in one call (dm_batch_rollout), device tensors only: action [T + 1, n, 28] f64 (row t feeds step t; with `weights` — the
+        packed policy block — rows 1..T are written by the policy), out = (obs [T, n, 56] f64, rew [T, n] f64, done [T, n] u8), vpred [T, n]
+        f32 (with weights).  Same results as T `step` / `step_act` calls; on the packed path (option 105) one launch for the horizon."""
+        import torch
+        obs, rew, done = out
+        T, n = int(obs.shape[0]), self.n
+        ap, k0, _ = self._ptr(action, np.float64, (T + 1, n, A.NU), out=True)
+        op, k1, _ = self._ptr(obs, np.float64, (T, n, A.NOBS), out=True)
+        rp, k2, _ = self._ptr(rew, np.float64, (T, n), out=True)
+        dp, k3, _ = self._ptr(done, np.uint8, (T, n), out=True)
+        if not (k0 == k1 == k2 == k3 == A.PTR_DEVICE):
+            raise ValueError("rollout works on device tensors")
+        wp = vp = None
+        if weights is not None:
+            if not (weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous() and weights.numel() == self._L.dm_policy_weight_count()):
+                raise ValueError("weights: the packed float32 policy block (MlpPolicy.pack()) on the device")
+            if vpred is None or not (vpred.is_cuda and vpred.dtype == torch.float32 and vpred.is_contiguous() and tuple(vpred.shape) == (T, n)):
+                raise ValueError("vpred: float32 [T, n] on the device")
+            wp, vp = C.c_void_p(weights.data_ptr()), C.c_void_p(vpred.data_ptr())
+        A.check(self._L.dm_batch_rollout(self._h, ap, op, rp, dp, T, int(n_substeps), wp, vp, 1 if stochastic else 0, int(seed) & (2 ** 64 - 1), int(counter)), self._L)
+        return obs, rew, done
+
     def get_obs(self, out=None):
         if out is None:
             out = np.empty((self.n, A.NOBS))

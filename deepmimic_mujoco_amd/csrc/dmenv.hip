@@ -127,6 +127,40 @@ __global__ __launch_bounds__(64) void k_step_packed_act(const DevModel<Real>* __
   dmp::policy_wave4<Real>(pa, envs, wr, lane, reinterpret_cast<char*>(&sh[0]), (unsigned)sizeof(SlotShared<Real>), (unsigned)(offsetof(SlotShared<Real>, qpos) + 7 * sizeof(Real)),
                           (unsigned)(offsetof(SlotShared<Real>, qvel) + 6 * sizeof(Real)), (unsigned)offsetof(SlotShared<Real>, r1));
 }
+// A whole horizon of T steps in ONE launch (dm_batch_rollout; slot_step.h slot_rollout): every wave steps its four environments T times
+// without waiting for any other wave — optionally with the policy's step in between (pa.P; pa.action = the [T + 1, N, 28] action rows,
+// pa.vpred = the [T, N] value rows, pa.counter = the first step's draw counter) — and re-steps an environment that exceeds a capacity of
+// the packed path itself, with the one-env code, in the LDS the slots leave free between two steps.
+__global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __restrict__ Mp, const Batch<Real>* __restrict__ Bp, const Ext* action,
+                                                       Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
+                                                       int n_substeps, int first, int count, int T, dmp::PolicyArgs pa, long long* __restrict__ wave_clk) {
+  __shared__ SlotOrOne<Real> u;
+  __shared__ SlotTables tb;
+  static_assert(sizeof(SlotOrOne<Real>) == sizeof(SlotShared<Real>) * SLOTS, "the one-env code's LDS fits into the four slots'");
+  const Batch<Real>& B = *Bp;       // (in device memory, not a by-value argument: the called step functions are handed its address)
+  const int lane = dmw::lane(), slot = lane >> 4;
+  stage_slot_tables(tb, lane);
+  const int last = first + count - 1;
+  int pos = first + SLOTS * (int)blockIdx.x + slot;
+  const bool live = pos <= last;
+  if (pos > last) pos = last;
+  const int env = B.order ? B.order[pos] : pos;
+  const int envs[4] = {dmw::bcast_i(env, 0), dmw::bcast_i(env, 16), dmw::bcast_i(env, 32), dmw::bcast_i(env, 48)};
+  const int lv = live ? 1 : 0;
+  const bool wr[4] = {dmw::bcast_i(lv, 0) != 0, dmw::bcast_i(lv, 16) != 0, dmw::bcast_i(lv, 32) != 0, dmw::bcast_i(lv, 48) != 0};
+  const size_t n = (size_t)B.n_envs;
+  const long long t_enter = wave_clk ? dmw::clk() : 0;
+  slot_rollout<Real, NARROW_ROWS>(*Mp, B, u.sh, tb, u.one.s, u.one.x, env, lane, live, action, obs, reward, done, n_substeps, T, [&](int t) {
+    if (!pa.P) return;
+    dmp::PolicyArgs p = pa;
+    p.action = pa.action + (size_t)(t + 1) * n * NU; p.vpred = pa.vpred + (size_t)t * n; p.counter = pa.counter + (unsigned long long)t;
+    dmw::sync();
+    dmp::policy_wave4<Real>(p, envs, wr, lane, reinterpret_cast<char*>(&u.sh[0]), (unsigned)sizeof(SlotShared<Real>), (unsigned)(offsetof(SlotShared<Real>, qpos) + 7 * sizeof(Real)),
+                            (unsigned)(offsetof(SlotShared<Real>, qvel) + 6 * sizeof(Real)), (unsigned)offsetof(SlotShared<Real>, r1));
+  });
+  // diagnostic (DM option 101): shader-clock cycles this wave spent on its horizon, slot 5 ("total") of workgroup w's profile record
+  if (wave_clk && lane == 0) wave_clk[(size_t)blockIdx.x * dm::PROF_SLOTS + 5] = dmw::clk() - t_enter;
+}
 // the same with shader-clock stamps per stage, one record of 16 per wave (DM option 101 with option 105; diagnostic)
 __global__ __launch_bounds__(64) void k_step_packed_prof(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                                          Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
@@ -304,6 +338,7 @@ struct dm_batch {
   hipStream_t stream = nullptr; bool own_stream = false;
   DevModel<Real>* d_model = nullptr;
   Batch<Real> B{};
+  Batch<Real>* d_B = nullptr;   // a copy of B in device memory for the horizon launch (refreshed before each: its code is reached through calls, which take a pointer)
   Real *d_cfg = nullptr, *d_vel = nullptr, *d_imit = nullptr; int* d_order = nullptr;
   // staging for DM_PTR_HOST callers
   Ext *d_action = nullptr, *d_obs = nullptr, *d_reward = nullptr; unsigned char *d_done = nullptr, *d_mask = nullptr;
@@ -376,7 +411,7 @@ extern "C" void dm_batch_destroy(dm_batch* b) {
   if (b->ev_in) hipEventDestroy(b->ev_in);
   void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
                   b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
-                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order, b->B.kin, b->B.kin_ok, b->B.redo_list, b->B.redo_count, b->B.redo_why};
+                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order, b->B.kin, b->B.kin_ok, b->B.redo_list, b->B.redo_count, b->B.redo_why, b->d_B};
   for (void* p : ptrs) if (p) hipFree(p);
   if (b->h_out) hipHostFree(b->h_out);
   if (b->h_action) hipHostFree(b->h_action);
@@ -404,7 +439,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   b->has_rows = hm.enable_contact || hm.enable_limit;     // without rows every env costs the same: no reordering
   bool ok = true;
 #define A(p, cnt) ok = ok && (dalloc(&(p), (size_t)(cnt)) == hipSuccess)
-  A(b->d_model, 1);
+  A(b->d_model, 1); A(b->d_B, 1);
   A(b->B.qpos, (size_t)n * NQ); A(b->B.qvel, (size_t)n * NV); A(b->B.qws, (size_t)n * NV); A(b->B.time, n); A(b->B.ctrl, (size_t)n * NU);
   A(b->B.xipos, (size_t)n * NB * 3); A(b->B.comz, n); A(b->B.frame_idx, n); A(b->B.frame_init, n); A(b->B.ncon, n); A(b->B.nefc, n);
   A(b->B.cong, (size_t)n * MAXEFC * 2); A(b->B.status, n); A(b->B.solver_iter, n); A(b->B.episode, n); A(b->B.cycle, n); A(b->d_order, n);
@@ -642,6 +677,39 @@ extern "C" int dm_batch_step_act(dm_batch* b, const double* action, double* obs,
   if (!weights || !next_action || !next_vpred) return fail(DM_EINVAL, "dm_batch_step_act: null policy argument");
   dmp::PolicyArgs pa{weights, next_action, next_vpred, (int)stochastic, (unsigned long long)seed, (unsigned long long)counter};
   return step_impl(b, action, obs, reward, done, nsub, DM_PTR_DEVICE, &pa);
+}
+
+/* T steps per call (device pointers).  On the packed path ONE launch runs the whole horizon (k_rollout_packed); elsewhere T step launches. */
+extern "C" int dm_batch_rollout(dm_batch* b, double* action, double* obs, double* reward, uint8_t* done, int32_t T, int32_t nsub,
+                                const float* weights, float* vpred, int32_t stochastic, uint64_t seed, uint64_t counter) {
+  if (!b || !action || !obs || !reward || !done || T < 1 || nsub < 1) return fail(DM_EINVAL, "dm_batch_rollout: bad argument");
+  if (weights && !vpred) return fail(DM_EINVAL, "dm_batch_rollout: a policy needs the value rows");
+  const size_t n = (size_t)b->n;
+  const bool use_packed = b->packed && b->B.reward_mode <= 3 && b->two_tier;     // (with option 101 the horizon launch records every wave's cycles)
+  if (!use_packed) {
+    for (int t = 0; t < T; t++) {
+      dmp::PolicyArgs pa{weights, action + (size_t)(t + 1) * n * NU, weights ? vpred + (size_t)t * n : nullptr, (int)stochastic, (unsigned long long)seed, (unsigned long long)counter + t};
+      const int rc = step_impl(b, action + (size_t)t * n * NU, obs + (size_t)t * n * NOBS, reward + (size_t)t * n, done + (size_t)t * n, nsub, DM_PTR_DEVICE, weights ? &pa : nullptr);
+      if (rc != DM_OK) return rc;
+    }
+    return DM_OK;
+  }
+  HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  dmp::PolicyArgs pa{weights, action, vpred, (int)stochastic, (unsigned long long)seed, (unsigned long long)counter};
+  HIPCHK(hipMemcpyAsync(b->d_B, &b->B, sizeof(Batch<Real>), hipMemcpyHostToDevice, b->stream));
+  hipLaunchKernelGGL(k_rollout_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, (const Batch<Real>*)b->d_B, (const Ext*)action, obs, reward, done, (int)nsub, 0, b->n, (int)T, pa, b->prof ? b->d_prof : (long long*)nullptr);
+  // dispatch order for the next launch: environments with similar row counts share a wave (and, for per-step launches, longest first)
+  if (b->reorder && b->has_rows) {
+    const int parts = b->pipe > 1 ? b->pipe : 1;
+    for (int h = 0; h < parts; h++) {
+      const int lo = (int)((long long)b->n * h / parts), hi = (int)((long long)b->n * (h + 1) / parts);
+      if (hi > lo) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order, lo, hi - lo);
+    }
+    b->B.order = b->d_order;
+  }
+  HIPCHK(hipGetLastError());
+  return DM_OK;
 }
 
 extern "C" int dm_batch_get_obs(dm_batch* b, double* obs, int32_t kind) {

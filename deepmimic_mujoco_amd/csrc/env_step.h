@@ -47,6 +47,20 @@ struct Batch {
   unsigned long long seed;
 };
 
+// the same batch for code behind a real call (slot_step.h): there the struct arrives through a generic pointer and so would its members
+template <class R>
+DM_DEV Batch<R> global_members(Batch<R> b) {
+  using dmw::in_global;          // (the members are wave-uniform: loaded through a uniform pointer)
+  b.qpos = in_global(b.qpos); b.qvel = in_global(b.qvel); b.qws = in_global(b.qws); b.time = in_global(b.time); b.ctrl = in_global(b.ctrl);
+  b.xipos = in_global(b.xipos); b.comz = in_global(b.comz); b.frame_idx = in_global(b.frame_idx); b.frame_init = in_global(b.frame_init);
+  b.ncon = in_global(b.ncon); b.nefc = in_global(b.nefc); b.cong = in_global(b.cong); b.aovf = in_global(b.aovf); b.status = in_global(b.status);
+  b.solver_iter = in_global(b.solver_iter); b.episode = in_global(b.episode); b.order = in_global(b.order); b.cycle = in_global(b.cycle);
+  b.kin = in_global(b.kin); b.kin_ok = in_global(b.kin_ok); b.redo_list = in_global(b.redo_list); b.redo_count = in_global(b.redo_count);
+  b.redo_why = in_global(b.redo_why); b.mocap_cfg = in_global(b.mocap_cfg); b.mocap_vel = in_global(b.mocap_vel);
+  b.imit_table = in_global(b.imit_table); b.imit_pdev = in_global(b.imit_pdev);
+  return b;
+}
+
 // counter-based RNG: splitmix64 finaliser over (seed, global env, episode, k) -> U[0,1)
 DM_DEV unsigned long long mix64(unsigned long long z) {
   z += 0x9E3779B97F4A7C15ull;

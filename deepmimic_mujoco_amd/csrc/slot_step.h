@@ -250,7 +250,7 @@ DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
     unsigned bits = 0;
     for (int r = 0; r < 5; r++) if (dmw::row_ballot(((why >> r) & 1) != 0, lane) != 0u) bits |= 1u << r;
     if (ovf && live && sl == 0) {
-      const int k = dmw::global_counter_next(redo_count); redo_list[k] = env;
+      if (redo_count) { const int k = dmw::global_counter_next(redo_count); redo_list[k] = env; }     // (no list: the caller re-steps it itself, slot_rollout)
       for (int r = 0; r < 5; r++) if ((bits >> r) & 1u) dmw::global_counter_next(B.redo_why + 1 + r);
     }
   }
@@ -318,6 +318,79 @@ DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
     for (int k = 0; k < 32; k++) prof_out[k] = prof[k];   // [16..18] mass: f + M entries, elimination, scaling; [19..21] rows: geoms + limits, broad phase, narrow phase + emission; [23] candidates
   }
   return live;                                  // the slot's environment was stepped and stored by this wave
+}
+
+// ---- a whole horizon without leaving the wave (dm_batch_rollout) ---------------------------------------------------------------------
+// T consecutive DPEnv.steps (src/dp_env_v3.py:106-132) of the wave's four environments; between two steps an optional policy step on the
+// four observations just produced (src/trpo.py:49 `ac, vpred = pi.act(stochastic, ob)`), i.e. the loop body of traj_segment_generator
+// (src/trpo.py:47-80) for T iterations.  Rows: action[t] is consumed by step t ([T (+1), N, 28]; the policy writes row t + 1),
+// obs / reward / done row t is what step t returns ([T, N, ...]).
+// Why: with one launch per step a step lasts as long as its SLOWEST wave (4 096 environments are exactly one wave per SIMD: nothing to
+// balance against), and a wave is slow only while one of its environments is in heavy contact.  Here every wave runs ahead at its own
+// pace and the horizon lasts as long as the slowest wave's SUM over T steps.
+// An environment that exceeds a capacity of the packed path in some step is re-stepped right here by the one-env code (env_step, all 64
+// lanes, from its unchanged state in memory) before the wave goes on: `one_s` / `one_x` may alias the slots' LDS (nothing in it outlives
+// a step; the observations the policy reads are fetched again from the rows just written).  NR = the one-env code's register tier.
+template <class R> union SlotOrOne {
+  SlotShared<R> sh[SLOTS];
+  struct { Shared<R> s; StepScratch<R> x; } one;
+};
+// (a real call: the one-env step keeps its own register allocation and spill slots, the hot loop around it is compiled as if it were not there)
+template <class R, int NR>
+DM_DEV_CALL64 void restep_one_env(const DevModel<R>* M, const Batch<R>* B, Shared<R>* s, StepScratch<R>* x, int env, int lane, const double* action, double* obs,
+                                    double* reward, unsigned char* done, int n_substeps) {
+  using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global;
+  const Batch<R> Bv = *in_global(uniform_ptr(B));       // (the struct's pointers are generic too: a copy whose members are told to be global)
+  env_step<R, NR>(*in_global(uniform_ptr(M)), global_members(Bv), *in_lds(uniform_ptr(s)), *in_lds(uniform_ptr(x)), dmw::uniform(env), lane, in_global(uniform_ptr(action)),
+                  in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps));
+}
+// (the packed step as a call too: its body is then compiled exactly as in k_step_packed — inlined into the horizon loop the register
+//  allocator produced four times the spills and a 27 % slower step)
+template <class R>
+DM_DEV_CALL64 bool slot_env_step_call(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
+                                      const double* action, double* obs, double* reward, unsigned char* done, int n_substeps) {
+  using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global;
+  const Batch<R> Bv = *in_global(uniform_ptr(B));
+  return slot_env_step<R>(*in_global(uniform_ptr(M)), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
+                          in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0);
+}
+template <class R, int NR, class POLICY>
+DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<R>* sh, SlotTables& tb, Shared<R>& one_s, StepScratch<R>& one_x,
+                         int env, int lane, bool live, const double* action, double* obs, double* reward, unsigned char* done,
+                         int n_substeps, int T, POLICY&& policy) {
+  const int slot = lane >> 4, sl = lane & 15;
+  const size_t n = (size_t)B.n_envs;
+  for (int t = 0; t < T; t++) {
+    // (every step reads the model afresh: hoisting those loads out of the loop would keep hundreds of registers alive across it)
+    const DevModel<R>& M = *dmw::launder_uniform_ptr(&M_in);
+    const double* a_t = action + (size_t)t * n * NU;
+    double* o_t = obs + (size_t)t * n * NOBS;
+    double* r_t = reward + (size_t)t * n;
+    unsigned char* d_t = done + (size_t)t * n;
+    const bool stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps);
+    const int need = (live && !stored) ? 1 : 0;
+    bool any = false;
+    for (int k = 0; k < SLOTS; k++) {
+      if (dmw::bcast_i(need, SW * k) == 0) continue;             // wave-uniform
+      any = true;
+      const int e = dmw::bcast_i(env, SW * k);
+      dmw::sync_mem();
+      restep_one_env<R, NR>(&M, &B, &one_s, &one_x, e, lane, a_t, o_t, r_t, d_t, n_substeps);
+      if (lane == 0) dmw::global_counter_next(B.redo_why);       // running total (dm_batch_redo_total)
+      dmw::sync_mem();
+    }
+    if (any) {                                                   // the slots' LDS may have been overwritten: the policy's inputs again
+#pragma unroll
+      for (int c = 0; c < (NOBS + SW - 1) / SW; c++) {
+        const int o = sl + SW * c;
+        if (o < 28) sh[slot].qpos[7 + o] = (R)o_t[(size_t)env * NOBS + o];
+        else if (o < NOBS) sh[slot].qvel[6 + (o - 28)] = (R)o_t[(size_t)env * NOBS + o];
+      }
+      dmw::sync_mem();
+    }
+    policy(t);
+    dmw::sync_mem();                                             // state / action rows written by other lanes of this wave are read next step
+  }
 }
 
 }  // namespace dm

@@ -16,6 +16,8 @@
 
 #define DM_DEV __device__ __forceinline__
 #define DM_DEV_NOINLINE __device__ __noinline__
+// a real call from a one-wave workgroup (the callee inherits its callers' register budget: the backend propagates the kernel's work-group size)
+#define DM_DEV_CALL64 __device__ __noinline__
 #define DM_CONSTANT __device__ constexpr
 
 namespace dmw {
@@ -115,6 +117,26 @@ DM_DEV void pin_value(float& v) { asm volatile("" : "+v"(v)); }
 // live across the whole step: hundreds of VGPRs)
 DM_DEV int launder(int v) { asm volatile("" : "+v"(v)); return v; }
 DM_DEV int launder_uniform(int v) { asm volatile("" : "+s"(v)); return v; }   // same for a wave-uniform (SGPR) value
+// a pointer that is the same in every lane, told to the compiler (arguments of a called function arrive in vector registers and count as
+// divergent: loads through them would be vector loads and their addresses would occupy vector registers)
+template <class T> DM_DEV T* uniform_ptr(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+// ... and whose address space is told to it as well (a called function sees generic pointers: every access, LDS included, would be a flat one)
+template <class T> DM_DEV T* in_lds(T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_assume(__builtin_amdgcn_is_shared((const void*)p));
+#endif
+  return p;
+}
+template <class T> DM_DEV T* in_global(T* p) {      // wave-uniform pointers into global memory (through an opaque copy: a plain cast pair would be folded away before the address spaces are inferred)
+  __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)uniform_ptr(p);
+  asm volatile("" : "+s"(g));
+  return (T*)g;
+}
+template <class T> DM_DEV T* launder_uniform_ptr(T* p) { asm volatile("" : "+s"(p)); return p; }   // loads through the result cannot be hoisted above this point
 DM_DEV void reload_fence() { asm volatile("" ::: "memory"); }
 // if (pred) *p -= v in LDS as one fire-and-forget ds_add_f64: lanes of one instruction may hit the same address (the
 // LDS applies them one after the other), and nothing comes back, so the issuing lane does not wait for the old value.

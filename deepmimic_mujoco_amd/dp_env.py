@@ -307,6 +307,9 @@ class DPVecEnv(object):
         b.set_option(A.OPT_DIAGNOSTICS, 1 if diagnostics else 0)
         rowless = not (contacts or limits)          # no constraint rows: every wave costs the same, the packed kernel wins at any batch size
         auto = packed is None and batch_factory is None and (self.num_envs >= PACKED_FROM_ENVS or (rowless and self.num_envs >= 256)) and dtype == 64 and reward != "v1-quat"
+        # a horizon launch (Batch.rollout, rollout.SegmentCollector) may use the packed kernel at ANY batch size: there a wave does not wait
+        # for the slowest wave of every step
+        self.horizon_packed_ok = packed is None and batch_factory is None and self.num_envs >= 256 and dtype == 64 and reward != "v1-quat"
         if packed or auto:
             b.set_option(A.OPT_PACKED, 1)
         if auto:

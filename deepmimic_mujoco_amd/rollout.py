@@ -127,6 +127,8 @@ class SegmentCollector(object):
             raise ValueError("fused rollout steps need the native policy kernel (56-100-100-28) and a device-resident env batch")
         self.fused = bool(fused)
         self.have_ac0 = False
+        self._redo_seen = None
+        self.kernel_switches = 0
         with self._on_stream():
             env.reset(first_reset, out=self.as_buf(self.ob64[0]))                  # trpo.py:32 `ob = env.reset()` (RSI); later episodes: noisy init
 
@@ -152,6 +154,14 @@ class SegmentCollector(object):
                     pi.act(self.stochastic, ob64[0], out=ac64[0], vpred_out=vpreds[0])                   # very first step: :49
                 else:
                     vpreds[0] = pi.forward_value(ob64[0])                                                 # :56, the updated policy's value
+                if hasattr(env.batch, "rollout"):
+                    # the whole horizon in one call (dm_batch_rollout): on the packed path ONE launch in which every wavefront runs its four
+                    # environments through all T steps at its own pace; on the one-env path T step launches issued without returning here
+                    self._choose_kernel()
+                    env.batch.rollout(ac64, (ob64[1:], rew64, done8), fs, pi._packed, vpreds[1:], self.stochastic, pi._seed, pi._counter + 1)
+                    pi._counter += T
+                    env.batch.join()
+                    return
                 for t in range(T):                                                                       # :49 + :66, one launch
                     pi._counter += 1
                     env.batch.step_act(ac64[t], fs, (ob64[t + 1], rew64[t], done8[t]), pi._packed, ac64[t + 1], vpreds[t + 1],
@@ -163,6 +173,35 @@ class SegmentCollector(object):
                 env.batch.step(as_buf(ac64[t]), fs, (as_buf(ob64[t + 1]), as_buf(rew64[t]), as_buf(done8[t])))   # :66, one launch
             vpreds[T] = pi.forward(ob64[T])[1]                                      # value of the observation after the segment (:49-52);
         # the action for it is sampled at the top of the next segment, i.e. from the policy as updated in between
+
+    # horizon launch -> one-env steps: an in-wave re-step holds a wave (four environments) for about one lone one-env step, so a
+    # rate r of overflowing env-steps costs about 4 r of the horizon (2 % here: 8 %) — far more tolerant than the per-step redo list
+    HORIZON_REDO_RATE_MAX = 2e-2
+
+    def _choose_kernel(self):
+        """Four environments per wavefront or one, for the next horizon (envs that leave the choice open: DPVecEnv.horizon_packed_ok).
+        The horizon launch re-steps an environment beyond the packed path's capacities inside its wave, which holds up its three
+        partners: fine at the 1e-4 rates of a falling / walking population, not for one that stands on both feet (32+ rows) most of the
+        time.  Decided from the last horizon's own statistics (redo rate on the packed path, largest row count on the one-env path):
+        a deterministic function of the trajectory."""
+        from . import _abi as A
+        env, b = self.env, self.env.batch
+        if not getattr(env, "horizon_packed_ok", False):
+            return
+        if b.__dict__.get("_auto"):
+            b.enable_auto_packed(False)                                     # the per-step chooser would fight this one
+        on = bool(b.__dict__.get("options", {}).get(A.OPT_PACKED, 0))
+        if self._redo_seen is None:                                         # first horizon: start packed
+            want = True
+        elif on:
+            redo = b.redo_total()
+            want = (redo - self._redo_seen) / float(self.T * self.n) <= self.HORIZON_REDO_RATE_MAX
+        else:
+            want = int(b.get(A.F_NEFC).max()) <= b.HEAVY_ROWS
+        if want != on:
+            b.set_option(A.OPT_PACKED, 1 if want else 0)
+            self.kernel_switches += 1
+        self._redo_seen = b.redo_total()
 
     def collect(self):
         import torch

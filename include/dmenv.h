@@ -222,6 +222,18 @@ int dm_policy_act(const float* weights, const double* obs, double* action, float
 int dm_batch_step_act(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t n_substeps,
                       const float* weights, double* next_action, float* next_vpred, int32_t stochastic, uint64_t seed, uint64_t counter);
 
+/* T steps per call — the loop body of traj_segment_generator (src/trpo.py:47-80: `ac, vpred = pi.act(stochastic, ob)`;
+ * `ob, rew, new, _ = env.step(ac)`; on `new` the reset of :77-79 through DM_OPT_AUTORESET) for a whole horizon.  Device pointers only.
+ *   action [T + 1, N, 28] f64: row t is consumed by step t; with `weights` rows 1..T are WRITTEN (the policy's action for the observation
+ *                              of step t - 1: row 0 is the caller's, row T belongs to the next horizon); without, rows 0..T-1 are read only
+ *   obs [T, N, 56] f64, reward [T, N] f64, done [T, N] u8: row t = what dm_batch_step returns for step t
+ *   vpred [T, N] f32 (with `weights`): row t = the value of obs row t;  counter: the draw counter of step 0 (step t uses counter + t)
+ * Results are those of T dm_batch_step / dm_batch_step_act calls.  With DM_OPT_PACKED (and a reward mode that kernel covers) the horizon
+ * is ONE launch: every wavefront steps its four environments T times at its own pace, so the horizon lasts as long as the slowest wave's
+ * sum over T steps instead of the sum of every step's slowest wave; otherwise T step launches are issued. */
+int dm_batch_rollout(dm_batch* b, double* action, double* obs, double* reward, uint8_t* done, int32_t T, int32_t n_substeps,
+                     const float* weights, float* vpred, int32_t stochastic, uint64_t seed, uint64_t counter);
+
 /* Replaces: add_vtarg_and_adv (src/trpo.py:83-94) for N environments at once: rew, vpred, adv, tdlamret [T, N] float32,
  * isnew [T, N] int32 (isnew[t] = the observation of step t starts an episode), nextvpred [N]; device pointers. */
 int dm_gae(const float* rew, const float* vpred, const int32_t* isnew, const float* nextvpred, float* adv, float* tdlamret,

@@ -29,6 +29,7 @@ def lib():
         L.emu_set_state.argtypes = [C.c_void_p, A._dp, A._dp, A._ip, C.POINTER(C.c_uint8)]
         L.emu_reset.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
         L.emu_redo_total.argtypes = [C.c_void_p]; L.emu_redo_total.restype = C.c_long
+        L.emu_rollout.argtypes = [C.c_void_p, A._dp, A._dp, A._dp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
         L.emu_debug_forward.argtypes = [C.c_void_p, C.c_int, A._dp]
         _LIB = L
     return _LIB
@@ -77,6 +78,16 @@ class EmuBatch(object):
             assert obs.flags.c_contiguous and obs.shape == (self.n, A.NOBS)
         lib().emu_step(self.h, a.ctypes.data_as(A._dp), obs.ctypes.data_as(A._dp), rew.ctypes.data_as(A._dp),
                        done.ctypes.data_as(C.POINTER(C.c_uint8)), n_substeps)
+        return obs, rew, done
+
+    def rollout(self, actions, n_substeps=1):
+        """dm_batch_rollout on the packed path, open loop: actions [T, n, 28] -> (obs [T, n, 56], rew [T, n], done [T, n])"""
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        T = a.shape[0]
+        assert a.shape == (T, self.n, A.NU)
+        obs = np.zeros((T, self.n, A.NOBS)); rew = np.zeros((T, self.n)); done = np.zeros((T, self.n), dtype=np.uint8)
+        lib().emu_rollout(self.h, a.ctypes.data_as(A._dp), obs.ctypes.data_as(A._dp), rew.ctypes.data_as(A._dp),
+                          done.ctypes.data_as(C.POINTER(C.c_uint8)), n_substeps, T)
         return obs, rew, done
 
     def set_state(self, qpos, qvel, frame_idx=None, mask=None):

@@ -60,6 +60,7 @@ struct EmuBatch {
   std::vector<unsigned char> kin_ok;
   bool two_tier = true, packed = false;
   SlotShared<double> slots[SLOTS];
+  SlotOrOne<double> roll;          // emu_rollout: the one-env code's LDS ALIASES the four slots', as in k_rollout_packed
   SlotTables slot_tabs;
   std::vector<int> fidx, finit, ncon, nefc, cong, status, siter, episode, cycle, redo;
   long redo_total = 0;
@@ -153,6 +154,22 @@ void emu_step(void* h, const double* action, double* obs, double* reward, unsign
     if (e->two_tier) run_wave([&](int lane) { env_step<double, 32>(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); });
     else run_wave([&](int lane) { env_step<double, MAXEFC>(e->M, e->B, e->sh, e->xs, env, lane, action, obs, reward, done, nsub); });
   }
+}
+// dm_batch_rollout on the packed path, open loop (k_rollout_packed without a policy): action [T, n, 28], obs [T, n, 56], reward / done [T, n]
+void emu_rollout(void* h, const double* action, double* obs, double* reward, unsigned char* done, int nsub, int T) {
+  EmuBatch* e = (EmuBatch*)h;
+  const int n = e->B.n_envs;
+  const int before = e->B.redo_why[0];
+  for (int first = 0; first < n; first += SLOTS)
+    run_wave([&](int lane) {
+      const int slot = lane >> 4;
+      stage_slot_tables(e->slot_tabs, lane);
+      int pos = first + slot;
+      const bool live = pos < n;
+      if (!live) pos = n - 1;
+      slot_rollout<double, 32>(e->M, e->B, e->roll.sh, e->slot_tabs, e->roll.one.s, e->roll.one.x, pos, lane, live, action, obs, reward, done, nsub, T, [](int) {});
+    });
+  e->redo_total += e->B.redo_why[0] - before;
 }
 long emu_redo_total(void* h) { return ((EmuBatch*)h)->redo_total; }
 void emu_set_state(void* h, const double* qpos, const double* qvel, const int* fidx, const unsigned char* mask) {

@@ -11,6 +11,7 @@
 
 #define DM_DEV inline
 #define DM_DEV_NOINLINE inline
+#define DM_DEV_CALL64 inline
 #define DM_CONSTANT constexpr
 
 namespace dmw {
@@ -135,6 +136,10 @@ inline unsigned row_ballot(bool p, int lane_id) { return (unsigned)((ballot(p) >
 inline int pin_zero() { return 0; }
 inline int launder(int v) { return v; }
 inline int launder_uniform(int v) { return v; }
+template <class T> inline T* launder_uniform_ptr(T* p) { return p; }
+template <class T> inline T* uniform_ptr(T* p) { return p; }
+template <class T> inline T* in_lds(T* p) { return p; }
+template <class T> inline T* in_global(T* p) { return p; }
 inline void pin_value(double&) {}
 inline void pin_value(float&) {}
 

@@ -1,5 +1,6 @@
 """Full-size oracle parity (run with -m gpu): the REAL per-GPU shard of BASELINE.json configs[2], [3], [4] — 4 096 'walk', 4 096
-'spinkick', 8 192 'dance_b' environments — stepped exactly as bench.py steps it (5-term imitation reward, RSI auto-reset from the
+'spinkick', 8 192 'dance_b' environments — stepped exactly as bench.py steps it (one dm_batch_step per step on either kernel, or the whole
+run as ONE dm_batch_rollout launch) (5-term imitation reward, RSI auto-reset from the
 device's counter-based RNG, two pipelined sub-batches, longest-first dispatch order, an interior shard's global env ids) against the
 CPU oracle's OpenMP batch step, EVERY env, every step: observations and rewards to 1e-9, done flags, frame cursors, cycle counters,
 constraint-row counts, contact counts and contact (geom1, geom2) lists identical.  The oracle side mirrors the device's auto-reset
@@ -19,7 +20,7 @@ SEED = 11
 STEPS = 16
 
 
-@pytest.mark.parametrize("clip,n,packed", [("walk", 4096, 0), ("spinkick", 4096, 0), ("dance_b", 8192, 0), ("dance_b", 8192, 1), ("walk", 4096, 1)])
+@pytest.mark.parametrize("clip,n,packed", [("walk", 4096, 0), ("spinkick", 4096, 0), ("dance_b", 8192, 0), ("dance_b", 8192, 1), ("walk", 4096, 1), ("walk", 4096, 2), ("spinkick", 4096, 2)])
 def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     import torch
     from deepmimic_mujoco_amd import Batch
@@ -33,7 +34,8 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
     b.set_option(A.OPT_REWARD_MODE, 3); b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, SEED)
     b.set_option(A.OPT_ENV_OFFSET, off); b.set_option(A.OPT_DIAGNOSTICS, 1); b.set_option(A.OPT_PIPELINE, 2)
-    b.set_option(A.OPT_PACKED, packed)          # 0: one environment per wavefront; 1: four (what DPVecEnv picks from 6 144 envs up)
+    b.set_option(A.OPT_PACKED, 1 if packed else 0)   # 0: one environment per wavefront; 1: four (what DPVecEnv picks from 6 144 envs up);
+    horizon = packed == 2                            # 2: four, and all 16 steps in ONE launch (dm_batch_rollout: every wave at its own pace)
     b.reset(0, 1)                                                 # env.reset(): sim.reset() + RSI
     fidx = b.get(A.F_FRAME_IDX).copy()
     expect0 = np.array([H.device_rsi_frame(SEED, off + e, 0, F) for e in range(n)], dtype=np.int32)
@@ -47,29 +49,37 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     nthreads = max(1, len(os.sched_getaffinity(0)))
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     dev = torch.device("cuda:0")
-    obs_t = torch.empty((n, 56), dtype=torch.float64, device=dev); rew_t = torch.empty(n, dtype=torch.float64, device=dev)
-    done_t = torch.empty(n, dtype=torch.uint8, device=dev)
-    worst = 0.0; ndone = 0; max_nefc = 0; reordered = False
+    acts = torch.empty((STEPS + 1, n, 28), dtype=torch.float64, device=dev)
     for t in range(STEPS):
-        a_t = torch.randn((n, 28), generator=g, device=dev, dtype=torch.float64) * 0.9
-        b.step(a_t, 1, (obs_t, rew_t, done_t))                   # pipelined: two sub-batch launches on their own streams
+        acts[t] = torch.randn((n, 28), generator=g, device=dev, dtype=torch.float64) * 0.9
+    obs_T = torch.empty((STEPS, n, 56), dtype=torch.float64, device=dev); rew_T = torch.empty((STEPS, n), dtype=torch.float64, device=dev)
+    done_T = torch.empty((STEPS, n), dtype=torch.uint8, device=dev)
+    worst = 0.0; ndone = 0; max_nefc = 0; reordered = False
+    if horizon:
+        b.rollout(acts, (obs_T, rew_T, done_T), 1)
         b.join(); torch.cuda.current_stream().synchronize()
-        a = a_t.cpu().numpy(); obs = obs_t.cpu().numpy(); rew = rew_t.cpu().numpy(); done = done_t.cpu().numpy()
+    for t in range(STEPS):
+        if not horizon:
+            b.step(acts[t], 1, (obs_T[t], rew_T[t], done_T[t]))  # pipelined: two sub-batch launches on their own streams
+            b.join(); torch.cuda.current_stream().synchronize()
+        a = acts[t].cpu().numpy(); obs = obs_T[t].cpu().numpy(); rew = rew_T[t].cpu().numpy(); done = done_T[t].cpu().numpy()
         o_obs, o_rew, o_done = O.batch_step_imitation(om, ods, a, 1, T, P, fidx, cyc, nthreads=nthreads)
         assert np.array_equal(done, o_done), "done flags differ at step %d: envs %s" % (t, np.nonzero(done != o_done)[0][:8])
+        state_now = (not horizon) or t == STEPS - 1              # the batch's fields are those of step t (horizon launch: of the last step only)
         # sim.data.* as they stand after sim.step(): row / contact counts and the contact list of the 4th RK stage, every env
-        nefc = b.get(A.F_NEFC); ncon = b.get(A.F_NCON); cg = b.get(A.F_CONTACT_GEOMS)
         o_nefc = np.array([int(d.get("nefc")[0]) for d in ods], dtype=np.int32)
-        o_ncon = np.array([int(d.get("ncon")[0]) for d in ods], dtype=np.int32)
-        assert np.array_equal(nefc, o_nefc), "nefc differs at step %d: envs %s" % (t, np.nonzero(nefc != o_nefc)[0][:8])
-        assert np.array_equal(ncon, o_ncon), "ncon differs at step %d" % t
-        for e in range(n):
-            k = min(int(o_ncon[e]), A.MAXEFC)
-            if k:
-                ocg = ods[e].get("contact_geom").reshape(-1, 2).astype(np.int32)
-                assert np.array_equal(cg[e][:k], ocg[:k]), "contact (geom1, geom2) list differs: step %d env %d" % (t, e)
-            assert np.all(cg[e][k:] == -1)
-        max_nefc = max(max_nefc, int(nefc.max()))
+        if state_now:
+            nefc = b.get(A.F_NEFC); ncon = b.get(A.F_NCON); cg = b.get(A.F_CONTACT_GEOMS)
+            o_ncon = np.array([int(d.get("ncon")[0]) for d in ods], dtype=np.int32)
+            assert np.array_equal(nefc, o_nefc), "nefc differs at step %d: envs %s" % (t, np.nonzero(nefc != o_nefc)[0][:8])
+            assert np.array_equal(ncon, o_ncon), "ncon differs at step %d" % t
+            for e in range(n):
+                k = min(int(o_ncon[e]), A.MAXEFC)
+                if k:
+                    ocg = ods[e].get("contact_geom").reshape(-1, 2).astype(np.int32)
+                    assert np.array_equal(cg[e][:k], ocg[:k]), "contact (geom1, geom2) list differs: step %d env %d" % (t, e)
+                assert np.all(cg[e][k:] == -1)
+        max_nefc = max(max_nefc, int(o_nefc.max()))
         # mirror of the device's auto-reset: hard reset onto the frame its RNG draws for (seed, global id, episode)
         dn = np.nonzero(done)[0]
         for e in dn:
@@ -84,9 +94,10 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
         worst = max(worst, float(err_o.max()), float(err_r.max()))
         assert err_o.max() < 1e-9, "obs differ at step %d: env %d rel err %.3e" % (t, int(err_o.argmax()), err_o.max())
         assert err_r.max() < 1e-9, "reward differs at step %d: env %d" % (t, int(err_r.argmax()))
-        assert np.array_equal(b.get(A.F_FRAME_IDX), fidx), "frame cursors differ at step %d" % t
-        assert np.array_equal(b.get(A.F_CYCLE), cyc), "cycle counters differ at step %d" % t
-        assert np.array_equal(b.get(A.F_EPISODE), episode.astype(np.int32))
+        if state_now:
+            assert np.array_equal(b.get(A.F_FRAME_IDX), fidx), "frame cursors differ at step %d" % t
+            assert np.array_equal(b.get(A.F_CYCLE), cyc), "cycle counters differ at step %d" % t
+            assert np.array_equal(b.get(A.F_EPISODE), episode.astype(np.int32))
     q = b.get(A.F_QPOS); w = b.get(A.F_QACC_WARMSTART); tm = b.get(A.F_TIME)
     oq = np.stack([d.get("qpos") for d in ods]); ow = np.stack([d.get("qacc_warmstart") for d in ods]); ot = np.array([d.get("time")[0] for d in ods])
     assert np.abs(q - oq).max() / max(1.0, np.abs(oq).max()) < 1e-9
