@@ -352,6 +352,7 @@ def main():
     ap.add_argument("--horizon-launch", action="store_true",
                     help="step through dm_batch_rollout: up to one %d-step horizon of pre-drawn actions per call (on the packed path ONE launch in which every "
                          "wavefront runs its four environments through all steps at its own pace) instead of one dm_batch_step call per step; implies --packed 1 unless given" % HORIZON)
+    ap.add_argument("--no-horizon-leg", action="store_true", help="skip the second timed leg (the same steps through dm_batch_rollout, reported as `horizon_launch`)")
     ap.add_argument("--horizon-chunk", type=int, default=HORIZON, help="--horizon-launch: steps per dm_batch_rollout call (the dispatch order — which environments share a wavefront — is renewed between calls)")
     ap.add_argument("--packed", type=int, default=None, choices=[0, 1], help="DM option 105: four environments per wavefront (k_step_packed) where that kernel covers the workload (default: the library's)")
     ap.add_argument("--no-reorder", action="store_true", help="experiment: identity dispatch order instead of longest-first (DM option 104 = 0)")
@@ -446,9 +447,9 @@ def main():
 
         drain = dbg.drain
 
-        def run_steps(t_from, t_to):
+        def run_steps(t_from, t_to, horizon=None):
             """steps t_from .. t_to - 1: one dm_batch_step call each, or (--horizon-launch) one dm_batch_rollout call per stretch inside a horizon"""
-            if not args.horizon_launch:
+            if not (args.horizon_launch if horizon is None else horizon):
                 for t in range(t_from, t_to):
                     one_step(t)
                 return
@@ -506,11 +507,38 @@ def main():
                 env.batch.sync()
                 stat_nefc.append(env.batch.get(A.F_NEFC)); stat_iter.append(env.batch.get(A.F_SOLVER_ITER))
             drain()
+        # second leg, reported beside the judged value: the SAME steps (same state stream, same pre-drawn actions, bit-identical results:
+        # tests/test_gpu_rollout.py, tests/test_gpu_fullsize.py) through dm_batch_rollout — one launch per horizon in which every wavefront
+        # runs its four environments through all steps at its own pace instead of waiting for the slowest wave of every step
+        hl_elapsed = None; hl_redo = None
+        if not args._child and args.dtype == 64 and not args.horizon_launch and not args.no_horizon_leg:
+            bt = env.batch
+            was_packed = env.packed; was_auto = bool(bt.__dict__.get("_auto", False))
+            if was_auto:
+                bt.enable_auto_packed(False)
+            bt.set_option(A.OPT_PACKED, 1)
+            r0 = bt.redo_total()
+            run_steps(0, HORIZON, horizon=True); drain(); bt.sync()            # untimed: first use of the kernel
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            run_steps(0, args.steps, horizon=True)
+            bt.join(); drain(); stream.synchronize(); torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            hl_elapsed = time.perf_counter() - h0
+            hl_redo = bt.redo_total() - r0
+            bt.set_option(A.OPT_PACKED, 1 if was_packed else 0)
+            if was_auto:
+                bt.enable_auto_packed(True)
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed, hl_elapsed or 0.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = float(tt[0].item())
+        if hl_elapsed is not None:
+            hl_elapsed = float(tt[1].item())
     if args._child:
         return
     gpu_ms = ev0.elapsed_time(ev1)
@@ -547,6 +575,14 @@ def main():
                        "timed_window": "%s (state / obs / reward / done device-resident)%s" % (
                            ("%d steps through dm_batch_rollout, %d steps per call" % (args.steps, min(HORIZON, max(1, args.horizon_chunk)))) if args.horizon_launch else "%d dm_batch_step calls" % args.steps, ", %d horizon-end block packings + joins" % (args.steps // HORIZON) if args.steps >= HORIZON
                            else "; shorter than the %d-step horizon: no block packing / join inside the window" % HORIZON)},
+            "horizon_launch": None if hl_elapsed is None else {
+                "value": round(total_steps / hl_elapsed, 1), "unit": "env-steps/s", "ms_per_step": round(hl_elapsed / args.steps * 1e3, 4), "steps": args.steps,
+                "steps_per_call": min(HORIZON, max(1, args.horizon_chunk), args.steps), "kernel": "k_rollout_packed", "envs_per_wavefront": 4,
+                "env_steps_re_stepped_in_wave": hl_redo,
+                "what": "the same %d steps of the same workload through dm_batch_rollout (max over ranks, same barriers): ONE launch per horizon of pre-drawn actions, every wavefront "
+                        "steps its four environments through the whole horizon at its own pace; results bit-identical to the dm_batch_step calls of `value` on the packed "
+                        "kernel (tests/test_gpu_rollout.py::test_horizon_launch_equals_step_by_step) and oracle-checked at full shard size "
+                        "(tests/test_gpu_fullsize.py [*-2]).  `value` stays the one-call-per-step figure: the drop-in for VecEnv.step" % args.steps},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                          "kernel": step_kernel, "kernel_ms": round(kernel_ms, 4),

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NBODY, NJNT, NQ, NV, NU, NGEOM, NOBS, MAXEFC = 14, 29, 35, 34, 28, 16, 56, 64
 DEBUG_DOUBLES = 34 * 34 + 34 * 3 + 42 + 3 + MAXEFC * (34 + 6)
 PTR_HOST, PTR_DEVICE = 0, 1
@@ -138,12 +138,12 @@ def load(dtype=64):
     L.dm_batch_sync.argtypes = [vp]
     L.dm_batch_join.argtypes = [vp]
     L.dm_policy_act.argtypes = [vp, vp, vp, vp, i32, i32, C.c_uint64, C.c_uint64, vp]
-    L.dm_vf_scratch_bytes.argtypes = [i32]; L.dm_vf_scratch_bytes.restype = C.c_size_t
+    L.dm_vf_scratch_bytes.argtypes = [i32, i32]; L.dm_vf_scratch_bytes.restype = C.c_size_t
     L.dm_batch_redo_total.argtypes = [vp, C.POINTER(C.c_int64)]
     L.dm_pg_scratch_bytes.argtypes = []; L.dm_pg_scratch_bytes.restype = C.c_size_t
     L.dm_pg_losses.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]
     L.dm_pg_fvp.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
-    L.dm_vf_fit_epoch.argtypes = [vp, vp, i32, i32, vp, vp, vp, C.POINTER(C.c_float), C.c_double, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp]
+    L.dm_vf_fit_epoch.argtypes = [vp, vp, i32, i32, vp, vp, vp, C.POINTER(C.c_float), C.c_double, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp, i32]
     L.dm_batch_step_act.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_uint64, C.c_uint64]
     L.dm_batch_rollout.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, C.c_uint64, C.c_uint64]
     L.dm_gae.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, C.c_double, C.c_double, vp]

@@ -832,13 +832,24 @@ extern "C" int dm_gae(const float* rew, const float* vpred, const int32_t* isnew
   return DM_OK;
 }
 extern "C" int dm_vf_param_count(void) { return dmv::NP; }
-extern "C" size_t dm_vf_scratch_bytes(int32_t bs) {
-  const size_t nblk = (size_t)((bs + dmv::SB - 1) / dmv::SB);
-  return nblk * dmv::NPAD * sizeof(float) + (size_t)dmv::RMS_BLOCKS * 2 * dmv::OB * sizeof(double) + 256;
+static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+struct VfScratch { size_t partial, rpart, part_all, means, stds, total; };
+static VfScratch vf_scratch_layout(int nb, int bs) {
+  const size_t ntile = (size_t)((bs + dmv::SB - 1) / dmv::SB);
+  VfScratch L;
+  size_t o = 0;
+  L.partial = o; o += up256(ntile * dmv::NPAD * sizeof(float));
+  L.rpart = o; o += up256((size_t)dmv::RMS_BLOCKS * 2 * dmv::OB * sizeof(double) + 64);          // + the ticket of the three-launch form
+  L.part_all = o; o += up256((size_t)nb * dmv::RMS_BLOCKS * 2 * dmv::OB * sizeof(double));
+  L.means = o; o += up256((size_t)nb * dmv::OB * sizeof(float));
+  L.stds = o; o += up256((size_t)nb * dmv::OB * sizeof(float));
+  L.total = o;
+  return L;
 }
+extern "C" size_t dm_vf_scratch_bytes(int32_t nb, int32_t bs) { return vf_scratch_layout(nb < 1 ? 1 : nb, bs < 1 ? 1 : bs).total; }
 extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, int32_t bs, float* theta, float* adam_m, float* adam_v,
                                const float* step_scale_host, double beta1, double beta2, double eps, double* rms_sum, double* rms_sumsq,
-                               double* rms_count, float* rms_mean, float* rms_std, void* scratch, void* hip_stream) {
+                               double* rms_count, float* rms_mean, float* rms_std, void* scratch, void* hip_stream, int32_t epoch_filter) {
   if (!ob || !ret || !theta || !adam_m || !adam_v || !step_scale_host || !rms_sum || !rms_sumsq || !rms_count || !rms_mean || !rms_std || !scratch ||
       nb < 1 || bs < 1)
     return fail(DM_EINVAL, "dm_vf_fit_epoch: bad argument");
@@ -848,9 +859,26 @@ extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, in
     if (hipPointerGetAttributes(&at, theta) == hipSuccess) HIPCHK(hipSetDevice(at.device));
     else (void)hipGetLastError();
   }
+  const VfScratch L = vf_scratch_layout(nb, bs);
   const int nblk = (bs + dmv::SB - 1) / dmv::SB;
-  float* partial = (float*)scratch;
-  double* rpart = (double*)((char*)scratch + (((size_t)nblk * dmv::NPAD * sizeof(float) + 255) / 256) * 256);
+  char* base = (char*)scratch;
+  float* partial = (float*)(base + L.partial);
+  if (epoch_filter) {
+    // the obs filter's sums of every minibatch up front and their scan (csrc/vf_kernel.h); per minibatch: gradient partials, reduction + Adam
+    double* part_all = (double*)(base + L.part_all);
+    float* means = (float*)(base + L.means); float* stds = (float*)(base + L.stds);
+    hipLaunchKernelGGL(dmv::k_vf_rms_part, dim3(dmv::RMS_BLOCKS, nb), dim3(256), 0, st, ob, (int)bs, part_all);
+    hipLaunchKernelGGL(dmv::k_vf_rms_scan, dim3(1), dim3(128), 0, st, (const double*)part_all, (int)nb, (int)bs, rms_sum, rms_sumsq, rms_count, rms_mean, rms_std, means, stds);
+    for (int i = 0; i < nb; i++) {
+      hipLaunchKernelGGL(dmv::k_vf_grad, dim3(nblk), dim3(256), 0, st, ob + (size_t)i * bs * dmv::OB, ret + (size_t)i * bs, (int)bs, (const float*)theta,
+                         (const float*)(means + (size_t)i * dmv::OB), (const float*)(stds + (size_t)i * dmv::OB), partial);
+      hipLaunchKernelGGL(dmv::k_vf_adam, dim3((dmv::NP + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk, theta, adam_m, adam_v,
+                         step_scale_host[i], (float)beta1, (float)beta2, (float)eps);
+    }
+    HIPCHK(hipGetLastError());
+    return DM_OK;
+  }
+  double* rpart = (double*)(base + L.rpart);
   unsigned* ticket = (unsigned*)(rpart + dmv::RMS_BLOCKS * 2 * dmv::OB);
   HIPCHK(hipMemsetAsync(ticket, 0, sizeof(unsigned), st));
   for (int i = 0; i < nb; i++) {

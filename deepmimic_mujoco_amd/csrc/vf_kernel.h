@@ -9,7 +9,8 @@
 //              writes its partial gradient of the 15 901 parameters,
 //   k_vf_adam  one thread per parameter: partial gradients summed in block order, Adam moments, step.
 // fp32 like the reference's TF graph (sums of the filter in float64 like its numpy arrays).  A whole epoch of minibatches is
-// enqueued by one C call (dm_vf_fit_epoch); nothing comes back to the host.
+// enqueued by one C call (dm_vf_fit_epoch); nothing comes back to the host.  There the filter sums of all minibatches are taken up front
+// (k_vf_rms_part / k_vf_rms_scan below): two launches per minibatch remain.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -114,11 +115,8 @@ __device__ inline float row_sum(const float* r) {            // sum over the SB 
   return a;
 }
 
-__global__ __launch_bounds__(256) void k_vf_grad(const float* __restrict__ ob, const float* __restrict__ ret, int bs, const float* __restrict__ theta,
-                                                 const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ partial) {
-  __shared__ VfShared S;                                      // 123 KB: one block per CU (a gfx950 workgroup may hold up to 160 KB)
-  const int tid = threadIdx.x, s0 = blockIdx.x * SB;
-  float* out = partial + (size_t)blockIdx.x * NPAD;
+// the value net's weights into LDS (once per block and minibatch)
+__device__ inline void vf_stage_weights(VfShared& S, const float* __restrict__ theta, int tid) {
   {   // weights: 16-byte loads, several in flight (both blocks start 16-byte aligned in the packed layout)
     const float4* g1 = reinterpret_cast<const float4*>(theta + O_W1); float4* l1 = reinterpret_cast<float4*>(S.W1);
     const float4* g2 = reinterpret_cast<const float4*>(theta + O_W2); float4* l2 = reinterpret_cast<float4*>(S.W2);
@@ -128,6 +126,10 @@ __global__ __launch_bounds__(256) void k_vf_grad(const float* __restrict__ ob, c
     for (int i = tid; i < H * H / 4; i += 256) l2[i] = g2[i];
   }
   if (tid < H) { S.w3[tid] = theta[O_W3 + tid]; S.b1[tid] = theta[O_B1 + tid]; S.b2[tid] = theta[O_B2 + tid]; }
+}
+// forward + backward of samples s0 .. s0 + SB - 1 of the minibatch; the tile's partial gradient goes to `out` (NPAD floats)
+__device__ inline void vf_grad_tile(VfShared& S, const float* __restrict__ ob, const float* __restrict__ ret, int bs, const float* __restrict__ theta,
+                                    const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ out, int s0, int tid) {
 #pragma unroll 7
   for (int i = tid; i < SB * OB; i += 256) {                  // coalesced read of [sample][input], transposed store
     const int sm = i / OB, k = i % OB, r = s0 + sm;
@@ -203,6 +205,13 @@ __global__ __launch_bounds__(256) void k_vf_grad(const float* __restrict__ ob, c
   if (tid < 140) tile_4x10(S.z, S.d1, (tid / 10) * 4, (tid % 10) * 10, out + O_W1);
   else if (tid >= 156) out[O_B1 + tid - 156] = row_sum(S.d1[tid - 156]);
 }
+__global__ __launch_bounds__(256) void k_vf_grad(const float* __restrict__ ob, const float* __restrict__ ret, int bs, const float* __restrict__ theta,
+                                                 const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ partial) {
+  __shared__ VfShared S;                                      // 123 KB: one block per CU (a gfx950 workgroup may hold up to 160 KB)
+  const int tid = threadIdx.x;
+  vf_stage_weights(S, theta, tid);
+  vf_grad_tile(S, ob, ret, bs, theta, mean, stdv, partial + (size_t)blockIdx.x * NPAD, blockIdx.x * SB, tid);
+}
 
 // ---- gradient reduction + MpiAdam step (src/mpi_adam.py:21-35) -----------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_vf_adam(const float* __restrict__ partial, int nblk, float* __restrict__ theta, float* __restrict__ m,
@@ -225,4 +234,70 @@ __global__ __launch_bounds__(256) void k_vf_adam(const float* __restrict__ parti
   theta[p] += (-a) * mm / (sqrtf(vv) + eps);
 }
 
+// ---- the obs filter's statistics for a whole epoch up front -------------------------------------------------------------------
+// k_vf_rms is a third of a minibatch's time (rocprofv3: 12.9 of 57 us at 4 096 samples) and does not depend on the parameters:
+//   k_vf_rms_part   the column sums / sums of squares of EVERY minibatch of the epoch at once (grid RMS_BLOCKS x nb; the same partial sums,
+//                   in the same order, as k_vf_rms computes for one),
+//   k_vf_rms_scan   one block: minibatch after minibatch it adds the partials (block order) to the filter's state and records the
+//                   float32 mean / std the filter holds AFTER that minibatch — what that minibatch's gradient step normalises with.
+// Same arithmetic in the same order as a k_vf_rms per minibatch: bit-identical filter state and parameters (tests/test_trpo.py).
+// (Measured dead end, round 3: the whole epoch as ONE launch — resident blocks walking the minibatches with a grid barrier between the
+//  gradient and the Adam step, exchanged data through device-scope accesses — 67 us per minibatch against 44 us for the two launches: a
+//  barrier across 128 CUs on eight XCDs costs more than a kernel boundary here.)
+__global__ __launch_bounds__(256) void k_vf_rms_part(const float* __restrict__ ob_all, int bs, double* __restrict__ part_all /*[nb][RMS_BLOCKS][2*OB]*/) {
+  __shared__ double red[4][2 * OB];
+  const float* ob = ob_all + (size_t)blockIdx.y * bs * OB;
+  double* part = part_all + (size_t)blockIdx.y * RMS_BLOCKS * 2 * OB;
+  const int tid = threadIdx.x, col = tid % OB, rg = tid / OB;
+  const int rows = (bs + RMS_BLOCKS - 1) / RMS_BLOCKS, r0 = blockIdx.x * rows, r1 = min(bs, r0 + rows);
+  if (rg < 4) {
+    double s = 0.0, q = 0.0;
+    int r = r0 + rg;
+    for (; r + 12 < r1; r += 16) {
+      const float x0 = ob[(size_t)r * OB + col], x1 = ob[(size_t)(r + 4) * OB + col], x2 = ob[(size_t)(r + 8) * OB + col], x3 = ob[(size_t)(r + 12) * OB + col];
+      s += (double)x0; q += (double)x0 * (double)x0; s += (double)x1; q += (double)x1 * (double)x1;
+      s += (double)x2; q += (double)x2 * (double)x2; s += (double)x3; q += (double)x3 * (double)x3;
+    }
+    for (; r < r1; r += 4) { const double x = (double)ob[(size_t)r * OB + col]; s += x; q += x * x; }
+    red[rg][col] = s; red[rg][OB + col] = q;
+  }
+  __syncthreads();
+  if (tid < 2 * OB) part[blockIdx.x * 2 * OB + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+__global__ __launch_bounds__(128) void k_vf_rms_scan(const double* __restrict__ part_all, int nb, int bs, double* __restrict__ sum, double* __restrict__ sumsq,
+                                                     double* __restrict__ count, float* __restrict__ mean, float* __restrict__ stdv,
+                                                     float* __restrict__ means /*[nb][OB]*/, float* __restrict__ stds /*[nb][OB]*/) {
+  __shared__ double st[2 * OB];
+  const int tid = threadIdx.x;
+  if (tid < 2 * OB) st[tid] = tid < OB ? sum[tid] : sumsq[tid - OB];
+  double c = *count;
+  float m = 0.0f, sd = 1.0f;
+  __syncthreads();
+  for (int i = 0; i < nb; i++) {
+    const double* part = part_all + (size_t)i * RMS_BLOCKS * 2 * OB;
+    if (tid < 2 * OB) {
+      double a = 0.0;
+      for (int b = 0; b < RMS_BLOCKS; b += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = part[(b + u) * 2 * OB + tid];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a += x[u];
+      }
+      st[tid] += a;
+    }
+    c += (double)bs;
+    __syncthreads();
+    if (tid < OB) {                                                             // RunningMeanStd._refresh (policy.py)
+      m = (float)(st[tid] / c);
+      const float var = (float)(st[OB + tid] / c) - m * m;
+      sd = sqrtf(fmaxf(var, 1e-2f));
+      means[(size_t)i * OB + tid] = m; stds[(size_t)i * OB + tid] = sd;
+    }
+    __syncthreads();
+  }
+  if (tid < OB) { sum[tid] = st[tid]; mean[tid] = m; stdv[tid] = sd; }
+  else if (tid < 2 * OB) sumsq[tid - OB] = st[tid];
+  if (tid == 0) *count = c;
+}
 }  // namespace dmv

@@ -229,6 +229,8 @@ class TrpoLearner:
         self.fvp_subsample = fvp_subsample
         # value-fit minibatch steps as one captured hipGraph each (single-process GPU runs; None = when possible)
         self.vf_graph = vf_graph
+        import os
+        self.vf_epoch_filter = os.environ.get("DM_VF_EPOCH_FILTER", "1") != "0"   # obs-filter sums of an epoch's minibatches up front (False: per minibatch)
         self._vfg = None
         # ... or as the hand-written kernels of csrc/vf_kernel.h (three launches per minibatch, one C call per epoch; None = when possible)
         self.vf_native = vf_native
@@ -331,14 +333,14 @@ class TrpoLearner:
         ob_s = ob[used].contiguous(); ret_s = ret[used].contiguous()
         theta = ad.getflat().to(torch.float32).contiguous()
         assert theta.numel() == L.dm_vf_param_count()
-        need = int(L.dm_vf_scratch_bytes(int(bs)))
+        need = int(L.dm_vf_scratch_bytes(int(nb), int(bs)))
         if self._vf_scratch is None or self._vf_scratch.numel() < need or self._vf_scratch.device != ob.device:
             self._vf_scratch = torch.empty(need, dtype=torch.uint8, device=ob.device)
         scale = (C.c_float * nb)(*[self.vf_stepsize * math.sqrt(1 - ad.beta2 ** (ad.t + 1 + k)) / (1 - ad.beta1 ** (ad.t + 1 + k)) for k in range(nb)])
         pp = lambda t: C.c_void_p(t.data_ptr())
         A.check(L.dm_vf_fit_epoch(pp(ob_s), pp(ret_s), nb, int(bs), pp(theta), pp(ad.m), pp(ad.v), scale, float(ad.beta1), float(ad.beta2), float(ad.epsilon),
                                   pp(rms.sum), pp(rms.sumsq), pp(rms.count), pp(rms.mean), pp(rms.std), pp(self._vf_scratch),
-                                  C.c_void_p(torch.cuda.current_stream(ob.device).cuda_stream)), L)
+                                  C.c_void_p(torch.cuda.current_stream(ob.device).cuda_stream), 1 if self.vf_epoch_filter else 0), L)
         ad.setfromflat(theta)
         ad.t += nb
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 2
+#define DM_ABI_VERSION 3
 
 /* fixed sizes of the DeepMimic humanoid (dp_env_v3.xml:21-156): the kernels are specialised to this tree */
 #define DM_NBODY 14
@@ -244,13 +244,15 @@ int dm_gae(const float* rew, const float* vpred, const int32_t* isnew, const flo
  * rms_count float64, rms_mean / rms_std [56] float32 refreshed), the gradient of mean((vpred - ret)^2) w.r.t. the 56-100-100-1 tanh
  * value net (theta: dm_vf_param_count() floats = vffc1/w, vffc1/b, vffc2/w, vffc2/b, vffinal/w, vffinal/b, weights row-major
  * [in][out]) and the MpiAdam step (src/mpi_adam.py:21-35) with the caller's per-step scale a_i = stepsize sqrt(1 - b2^t) / (1 - b1^t)
- * (step_scale_host: HOST array [nb]).  Three launches per minibatch, all enqueued by this one call; device pointers otherwise;
- * `scratch`: dm_vf_scratch_bytes(bs) bytes on the device. */
+ * (step_scale_host: HOST array [nb]).  All of it enqueued by this one call; device pointers otherwise; `scratch`:
+ * dm_vf_scratch_bytes(nb, bs) bytes on the device.  epoch_filter = 1: the filter's sums of all nb minibatches are taken up front (two
+ * launches) and two launches per minibatch remain (gradient partials; reduction + Adam); 0: three launches per minibatch.  Same arithmetic
+ * in the same order either way: bit-identical results. */
 int dm_vf_param_count(void);
-size_t dm_vf_scratch_bytes(int32_t bs);
+size_t dm_vf_scratch_bytes(int32_t nb, int32_t bs);
 int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, int32_t bs, float* theta, float* adam_m, float* adam_v,
                     const float* step_scale_host, double beta1, double beta2, double eps, double* rms_sum, double* rms_sumsq,
-                    double* rms_count, float* rms_mean, float* rms_std, void* scratch, void* hip_stream);
+                    double* rms_count, float* rms_mean, float* rms_std, void* scratch, void* hip_stream, int32_t epoch_filter);
 
 /* Replaces: the policy half of one TRPO update (src/trpo.py:228-230, 245-283) for the 56-100-100-28 tanh Gaussian policy of
  * src/mlp_policy_trpo.py:50-60.  theta: dm_pg_param_count() floats = polfc1/w, polfc1/b, polfc2/w, polfc2/b, polfinal/w, polfinal/b, logstd

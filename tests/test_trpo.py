@@ -435,3 +435,32 @@ def test_native_policy_gradient_and_fisher_product_match_the_analytic_float64_fo
 def test_learner_update_through_torch_autograd_matches_the_float64_restatement_on_gpu():
     """The path the kernels replace stays covered on the device (multi-backend fallback of the learner: pg_native=False)."""
     _check_against_golden(*_golden_update("cuda:0", pg_native=False))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bs,nb", [(4096, 6), (37, 5), (9000, 2)])
+def test_value_fit_with_the_epochs_filter_sums_up_front_equals_three_launches_per_minibatch(bs, nb):
+    """dm_vf_fit_epoch(epoch_filter=1) — every minibatch's filter sums at once and their scan, then gradient + Adam per minibatch — against
+    the three-launches-per-minibatch form: value parameters, Adam moments and the obs filter's state BIT for bit after two epochs
+    (ragged minibatches; 9 000 samples: 282 blocks of partial gradients)."""
+    from deepmimic_mujoco_amd.trpo import VF_KEYS, flat, TrpoLearner
+    from deepmimic_mujoco_amd.policy import MlpPolicy
+    torch.manual_seed(2)
+    n = nb * bs + 3
+    ob = torch.randn(n, 56, device="cuda:0") * 1.5 + 0.3; ret = torch.randn(n, device="cuda:0") * 2.0
+    outs = []
+    for one in (False, True):
+        pi = MlpPolicy(device="cuda:0", seed=5)
+        L = TrpoLearner(pi, vf_batch_size=bs, vf_iters=2, vf_graph=False, vf_native=True)
+        L.vf_epoch_filter = one
+        for k in (7, 8):
+            inds = torch.randperm(n, generator=torch.Generator().manual_seed(k)).to("cuda:0")
+            L._vf_native_epoch(ob, ret, inds, bs)
+        torch.cuda.synchronize()
+        r = pi.ob_rms
+        outs.append((flat([pi.params[k].detach() for k in VF_KEYS]).clone(), L.vfadam.m.clone(), L.vfadam.v.clone(), r.sum.clone(), r.sumsq.clone(),
+                     r.count.clone() if torch.is_tensor(r.count) else torch.tensor(float(r.count)), r.mean.clone(), r.std.clone()))
+        assert L.vfadam.t == 2 * nb
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert bool(torch.isfinite(outs[1][0]).all()) and float((outs[1][1]).abs().max()) > 0
