@@ -589,7 +589,11 @@ def main():
                          "kernel_ms_covers": "HIP events around the timed region / steps: one dm_batch_step = the step kernel (all sub-batches; the packed kernel is followed by k_step_redo) + k_order + 1/256 of a horizon's block packing; "
                                              "with --pipeline > 1 consecutive steps overlap, so this is the per-step issue interval, not a lone launch's latency",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
-                         "launch": {"kernel": step_kernel, "envs_per_launch": n // P_sub, "launches_per_step": P_sub,
+                         "launch": ({"kernel": step_kernel, "envs_per_launch": n, "steps_per_launch": min(HORIZON, max(1, args.horizon_chunk), args.steps),
+                                     "algorithmic_bytes": ALGO_BYTES_PER_STEP * n * min(HORIZON, max(1, args.horizon_chunk), args.steps),
+                                     "avg_us": round(kernel_ms * 1e3 * min(HORIZON, max(1, args.horizon_chunk), args.steps), 1),
+                                     "measured": "HIP events around the timed region / launches (one launch = one horizon of all envs; launches do not overlap)"}
+                                    if args.horizon_launch else None) or {"kernel": step_kernel, "envs_per_launch": n // P_sub, "launches_per_step": P_sub,
                                     "algorithmic_bytes": ALGO_BYTES_PER_STEP * (n // P_sub),
                                     "avg_us": round(float(np.mean(launch_us)), 1) if launch_us else None,
                                     "measured": "HIP events on the launch's own stream, %d launches sampled after the timed region" % len(launch_us),
@@ -603,34 +607,39 @@ def main():
                          "fp64_frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5)},
         }
         if world == 1 and not args.no_pmc:
-            tail = ["--workload", args.workload, "--reward", args.reward, "--steps", "48", "--warmup", "8", "--prewarm-horizons", "1",
+            hz = args.horizon_launch
+            tail = ["--workload", args.workload, "--reward", args.reward] + (["--steps", str(HORIZON), "--warmup", "0", "--prewarm-horizons", "0", "--horizon-launch"] if hz
+                                                                              else ["--steps", "48", "--warmup", "8", "--prewarm-horizons", "1"]) + [
                     "--envs", str(n), "--_child", "--no-pmc", "--no-cpu-baseline", "--no-gym-loop", "--pipeline", str(args.pipeline), "--dtype", str(args.dtype)] + (["--clip", args.clip] if args.clip else [])
             pmc, err = pmc_passes(tail + (["--packed", "1" if env.packed else "0"]), step_kernel)
             r = out["roofline"]
+            # counters are averages per LAUNCH: one step is P_sub launches of n / P_sub envs (one call per step), or 1 / HORIZON of a launch of all n envs
+            # (--horizon-launch: the profiled child runs exactly one HORIZON-step launch)
+            launches_per_step = (1.0 / HORIZON) if hz else float(P_sub)
+            envsteps_per_launch = float(n * HORIZON) if hz else float(n // P_sub)
             if pmc is None:
                 r["pmc"] = err
             else:
                 r["pmc"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in pmc.items()}
-                # counters are averages per k_step_narrow LAUNCH; a step is P_sub launches of n / P_sub envs each
                 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                     # FETCH_SIZE / WRITE_SIZE are KiB.  The guide's x2 gfx950 correction of FETCH_SIZE was calibrated on 16 B/lane
                     # streaming reads; this kernel reads 8 B/lane rows, an uncalibrated width: both readings are reported
-                    r["traffic"] = round((pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * P_sub)
-                    r["traffic_fetch_doubled"] = round((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * P_sub)
+                    r["traffic"] = round((pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * launches_per_step)
+                    r["traffic_fetch_doubled"] = round((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * launches_per_step)
                     r["traffic_over_algorithmic"] = round(r["traffic"] / (ALGO_BYTES_PER_STEP * n), 3)
-                    r["traffic_source"] = "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, HBM bytes per step (= %d launches)" % P_sub
+                    r["traffic_source"] = "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, HBM bytes per step (= %.4g launches)" % launches_per_step
                     if full and args.reward == "imitation":
                         r["traffic_note"] = ("includes the parked kinematics of the imitation modes: 694 doubles written by a step's reward pass and read back by the "
                                              "next step instead of recomputing one kinematics pass in five (5 552 B each way per env-step = %.1f MB per step; +2 %% "
                                              "env-steps/s for 0.6 %% of the HBM peak)" % (2 * 694 * 8 * n / 1e6))
                 if pmc.get("SQ_ACTIVE_INST_VALU"):
                     # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; the denominator is the un-profiled step interval
-                    r["valu_issue_frac"] = round(P_sub * pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * kernel_ms * 1e-3 * MAX_CLOCK_HZ), 4)
+                    r["valu_issue_frac"] = round(launches_per_step * pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * kernel_ms * 1e-3 * MAX_CLOCK_HZ), 4)
                     r["valu_issue_frac_note"] = "launches/step x SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x step interval x 2.4 GHz)"
                 if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("trace", {}).get("avg_us"):
                     r["effective_clock_ghz"] = round(pmc["GRBM_GUI_ACTIVE"] / 8.0 / (pmc["trace"]["avg_us"] * 1e-6) / 1e9, 3)   # summed over the 8 XCDs
                 if pmc.get("SQ_INSTS_VALU"):
-                    per_env = pmc["SQ_INSTS_VALU"] / (n / P_sub)
+                    per_env = pmc["SQ_INSTS_VALU"] / envsteps_per_launch
                     r["valu_wave_instr_per_env_step"] = round(per_env, 1)
                     # useful fp64 lane-operations (an FMA lane does 2 flops) over the lane slots of all VALU instructions issued
                     r["lane_efficiency"] = round((flops / 2.0) / (per_env * 64.0), 4)

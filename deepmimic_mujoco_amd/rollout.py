@@ -209,6 +209,11 @@ class SegmentCollector(object):
         f32 = torch.float32
         if self.stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        import os
+        import time
+        prof = os.environ.get("DM_TRPO_PROFILE") and device.type == "cuda"
+        if prof:
+            torch.cuda.synchronize(device); t_c = time.perf_counter()
         ob64, ac64, rew64, done8, vpreds = self.ob64, self.ac64, self.rew64, self.done8, self.vpreds
         done = done8.to(torch.bool)
         new = torch.cat([self.first[None], done8[:-1].to(torch.int32)], 0)
@@ -249,6 +254,9 @@ class SegmentCollector(object):
             ac64[0].copy_(ac64[T]); self.have_ac0 = True
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))   # the copies above are ordered before the next launch
+        if prof:
+            torch.cuda.synchronize(device); self.collect_ms = (time.perf_counter() - t_c) * 1e3
+            seg["collect_ms"] = self.collect_ms
         return seg
 
 

@@ -22,6 +22,7 @@ that are logged).  The value-function minibatch size is a parameter: the referen
 use a few thousand (a 1M-sample segment at 128 would be 8 000 sequential Adam steps per epoch).
 """
 import math
+import os
 import time
 from collections import deque
 
@@ -230,6 +231,9 @@ class TrpoLearner:
         # value-fit minibatch steps as one captured hipGraph each (single-process GPU runs; None = when possible)
         self.vf_graph = vf_graph
         import os
+        self.vf_overlap = os.environ.get("DM_VF_OVERLAP", "1") != "0"     # value fit on a second stream beside the policy step (both on kernels)
+        self._vf_stream = None
+        self._rms_pol = None
         self.vf_epoch_filter = os.environ.get("DM_VF_EPOCH_FILTER", "1") != "0"   # obs-filter sums of an epoch's minibatches up front (False: per minibatch)
         self._vfg = None
         # ... or as the hand-written kernels of csrc/vf_kernel.h (three launches per minibatch, one C call per epoch; None = when possible)
@@ -401,11 +405,11 @@ class TrpoLearner:
         import ctypes as C
         dev = ob.device
         sc = self._pg_buffers(dev)
-        rms = self.pi.ob_rms
+        rms_mean, rms_std = self._rms_pol or (self.pi.ob_rms.mean, self.pi.ob_rms.std)
         out = torch.empty(2, dtype=torch.float64, device=dev)
         g = torch.empty(theta.numel(), dtype=torch.float32, device=dev) if with_grad else None
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        self._pg_call("dm_pg_losses", ob, int(ob.shape[0]), ac, atarg, old_mean, old_logstd, 1 if write_old else 0, theta, rms.mean, rms.std,
+        self._pg_call("dm_pg_losses", ob, int(ob.shape[0]), ac, atarg, old_mean, old_logstd, 1 if write_old else 0, theta, rms_mean, rms_std,
                       C.c_double(float(self.entcoeff)), 1 if with_grad else 0, g if with_grad else C.c_void_p(0), out, sc, st)
         logstd = theta[-28:]
         meanent = (logstd + 0.5 * math.log(2.0 * math.pi * math.e)).sum()
@@ -417,11 +421,11 @@ class TrpoLearner:
         import ctypes as C
         dev = ob.device
         sc = self._pg_buffers(dev)
-        rms = self.pi.ob_rms
+        rms_mean, rms_std = self._rms_pol or (self.pi.ob_rms.mean, self.pi.ob_rms.std)
         k = int(self.fvp_subsample)
         nf = (int(ob.shape[0]) + k - 1) // k                                # rows of ob[::k]
         hv = torch.empty_like(v)
-        self._pg_call("dm_pg_fvp", ob, k, nf, theta, v.contiguous(), rms.mean, rms.std, hv, sc, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        self._pg_call("dm_pg_fvp", ob, k, nf, theta, v.contiguous(), rms_mean, rms_std, hv, sc, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         return hv
 
     # ---- one update ----------------------------------------------------------------------------------------------------------
@@ -435,7 +439,7 @@ class TrpoLearner:
             if prof is None:
                 return
             if seg["ob"].device.type == "cuda":
-                torch.cuda.synchronize(seg["ob"].device)
+                torch.cuda.current_stream(seg["ob"].device).synchronize()   # (this stream only: the value fit may be running beside it; its own entry is then what is left to wait for)
             now = time.perf_counter()
             prof[name] = prof.get(name, 0.0) + (now - t_last[0]) * 1e3
             t_last[0] = now
@@ -446,6 +450,38 @@ class TrpoLearner:
         atarg = (atarg - atarg.mean()) / atarg.std(unbiased=False)          # :240
         pi.ob_rms.update(ob, group=self.group)                              # :242
         native_pg = self._pg_native_ready(ob, ac)
+        # ---- value function (:288-296).  It shares nothing with the policy step but the obs filter, which it moves on minibatch by minibatch:
+        # with both halves on kernels the fit is enqueued NOW on a second stream and runs beside the policy step (its gradient kernel holds one
+        # block per CU on half the CUs); the policy step reads a copy of the filter as :242 left it — the reference's order of effects.
+        n = ob.shape[0]
+        bs = min(self.vf_batch_size, n)
+        vf_native = self._vf_native_ready(ob, tdlamret)
+        graphed = (not vf_native) and self._vf_graph_ready(ob, tdlamret, bs)
+
+        def fit_value():
+            for _ in range(self.vf_iters):
+                inds = self.perm_source(n).to(ob.device) if self.perm_source is not None else torch.randperm(n, device=ob.device, generator=self._perm_gen)
+                if vf_native:
+                    self._vf_native_epoch(ob, tdlamret, inds, bs)
+                    continue
+                if graphed:
+                    self._vfg.run_epoch(ob, tdlamret, inds)
+                    continue
+                for o in range(0, n - bs + 1, bs):                          # include_final_partial_batch=False
+                    mb = inds[o:o + bs]
+                    self._vf_step(ob[mb], tdlamret[mb])
+
+        overlap = bool(native_pg and vf_native and self.vf_overlap)
+        rms_pol = (pi.ob_rms.mean, pi.ob_rms.std)
+        if overlap:
+            rms_pol = (pi.ob_rms.mean.clone(), pi.ob_rms.std.clone())
+            if self._vf_stream is None or self._vf_stream.device != ob.device:
+                self._vf_stream = torch.cuda.Stream(device=ob.device)
+            main = torch.cuda.current_stream(ob.device)
+            self._vf_stream.wait_stream(main)
+            with torch.cuda.stream(self._vf_stream):
+                fit_value()
+        self._rms_pol = rms_pol
         if native_pg:
             ob = ob.contiguous(); ac = ac.contiguous(); atarg = atarg.to(torch.float32).contiguous()
             theta0 = self.get_flat().contiguous()
@@ -523,27 +559,15 @@ class TrpoLearner:
             stats.update(expectedimprove=expectedimprove, improve=improve, stepsize=stepsize if ok else 0.0)
             tick("line_search")
 
-        # ---- value function (:288-296) ------------------------------------------------------------------------------------
-        n = ob.shape[0]
-        bs = min(self.vf_batch_size, n)
-        native = self._vf_native_ready(ob, tdlamret)
-        graphed = (not native) and self._vf_graph_ready(ob, tdlamret, bs)
-        for _ in range(self.vf_iters):
-            inds = self.perm_source(n).to(ob.device) if self.perm_source is not None else torch.randperm(n, device=ob.device, generator=self._perm_gen)
-            if native:
-                self._vf_native_epoch(ob, tdlamret, inds, bs)
-                continue
-            if graphed:
-                self._vfg.run_epoch(ob, tdlamret, inds)
-                continue
-            for o in range(0, n - bs + 1, bs):                              # include_final_partial_batch=False
-                mb = inds[o:o + bs]
-                self._vf_step(ob[mb], tdlamret[mb])
-
+        if overlap:
+            torch.cuda.current_stream(ob.device).wait_stream(self._vf_stream)   # the fit's parameters / filter state before anything after this update
+        else:
+            fit_value()
         tick("value_fit")
         if prof is not None:
             prof.pop("_start", None)
             stats["profile_ms"] = {k: round(v, 3) for k, v in prof.items()}
+        self._rms_pol = None
         pi.mark_dirty()                                                     # parameters / obs filter changed in place: the native act() repacks
         for name, val in zip(self.loss_names, meanlosses.tolist()):
             stats[name] = val
@@ -579,7 +603,6 @@ def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max
     history = []
     progress = monitor = None
     if log_dir and rank == 0:
-        import os
         from .logio import ProgressCsv, MonitorWriter
         os.makedirs(log_dir, exist_ok=True)
         progress = ProgressCsv(os.path.join(log_dir, "progress.csv"))
@@ -601,8 +624,17 @@ def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max
                 stop = bool(flag.item() > 0)
             if stop:
                 break
-        seg = next(seg_gen)
+        if os.environ.get("DM_TRPO_PROFILE") and pi.device.type == "cuda":
+            torch.cuda.synchronize(pi.device); t_seg = time.perf_counter()
+            seg = next(seg_gen)
+            torch.cuda.synchronize(pi.device); t_seg = (time.perf_counter() - t_seg) * 1e3
+        else:
+            seg = next(seg_gen); t_seg = None
         stats = learner.update(seg)
+        if t_seg is not None and "profile_ms" in stats:
+            stats["profile_ms"]["rollout_segment"] = round(t_seg, 3)
+            if "collect_ms" in seg:
+                stats["profile_ms"]["of_which_segment_bookkeeping"] = round(float(seg["collect_ms"]), 3)
         lens, rets = seg["ep_lens"], seg["ep_rets"]
         n_eps = torch.tensor([len(lens), sum(lens), sum(rets)], dtype=torch.float64, device=pi.device)
         if world > 1:                                            # :300-302 allgather of (ep_lens, ep_rets): the sums suffice here

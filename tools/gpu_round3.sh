@@ -33,10 +33,22 @@ if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   ROWS=6 python tools/rocprof_summary.py $OUT/kstep_packed_summary.md "step kernels — $TAG, MI355X (bench.py --workload cfg5: dance_b, 8192 envs, four environments per wavefront, 2 pipelined sub-batches)" \
     $(find /tmp/p_trace5 -name "*.db" | head -1) > /dev/null; head -12 $OUT/kstep_packed_summary.md
   timeout 300 python bench.py --workload rollout --steps 2048 --warmup 256 > $OUT/bench_rollout_fused.json 2> $OUT/bench_rollout_fused.err; cut -c1-200 $OUT/bench_rollout_fused.json
+  # the horizon launch (dm_batch_rollout, k_rollout_packed): its own line with live PMC passes, the per-wave cycle spread, a kernel trace
+  mkdir -p $OUT/raw_horizon
+  DM_PROFILE_KEEP=$OUT/raw_horizon timeout 600 python bench.py --horizon-launch --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_horizon_launch.json 2> $OUT/bench_cfg3_horizon_launch.err; cut -c1-200 $OUT/bench_cfg3_horizon_launch.json
+  for rw in alive v3-config; do timeout 300 python bench.py --horizon-launch --reward $rw --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_horizon_launch_$rw.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg3_horizon_launch_$rw.json; done
+  timeout 300 python bench.py --horizon-launch --workload cfg4 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg4_horizon_launch.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg4_horizon_launch.json
+  timeout 300 python bench.py --horizon-launch --workload cfg5 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg5_horizon_launch.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg5_horizon_launch.json
+  ( for a in "256 4096 imitation" "128 4096 imitation" "256 4096 alive" "128 4096 alive policy"; do timeout 120 python tools/horizon_wave_times.py $a | tail -1; done ) > $OUT/horizon_wave_times.txt 2>&1; cat $OUT/horizon_wave_times.txt
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_traceh -- python $OLDPWD/bench.py --horizon-launch --steps 512 --warmup 0 --prewarm-horizons 1 --no-pmc --no-cpu-baseline --no-gym-loop > /dev/null 2>&1 )
+  ROWS=6 python tools/rocprof_summary.py $OUT/krollout_summary.md "horizon launch — $TAG, MI355X (bench.py --horizon-launch: cfg3 + 5-term imitation reward, 4096 envs, 256 steps per launch)" \
+    $(find /tmp/p_traceh -name "*.db" | head -1) > /dev/null; head -12 $OUT/krollout_summary.md
   # driver-sized window as the driver runs it
   timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-pmc --no-cpu-baseline --no-gym-loop > $OUT/bench_cfg3_driver_window.json 2>/dev/null; cut -c1-160 $OUT/bench_cfg3_driver_window.json
   ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace -- python $OLDPWD/bench.py --steps 96 --warmup 16 --no-pmc --no-cpu-baseline --no-gym-loop > /dev/null 2>&1 )
   ROWS=6 python tools/rocprof_summary.py $OUT/kstep_summary.md "step kernel — $TAG, MI355X (bench.py default workload: cfg3 + 5-term imitation reward, 4096 envs as 2 pipelined sub-batches)" \
     $(find /tmp/p_trace -name "*.db" | head -1) > /dev/null; head -12 $OUT/kstep_summary.md
   timeout 400 python tools/train_trpo.py --envs 4096 --horizon 128 --seconds 25 --out $OUT/trpo_train.json 2>&1 | tail -2 | tee $OUT/trpo_train.log
+  DM_TRPO_PROFILE=1 timeout 300 python tools/train_trpo.py --envs 4096 --horizon 128 --iters 40 --out $OUT/trpo_update_profile.json 2>&1 | tail -1
+  timeout 120 python tools/vf_bench.py > $OUT/vf_bench.txt 2>&1; cat $OUT/vf_bench.txt
 fi

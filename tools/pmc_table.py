@@ -23,7 +23,7 @@ if cut:
 lines += ["## PMC (`rocprofv3 --kernel-trace --pmc ...`, one counter group per pass; averages per launch; raw per-launch values: `%s_*_counters.csv`)" % prefix, "",
           "| kernel | counter | avg per launch | launches |", "|---|---|---|---|"]
 for (k, c), (s, n) in acc.items():
-    if k.startswith("k_step") or k.startswith("k_order"):
+    if k.startswith("k_step") or k.startswith("k_order") or k.startswith("k_rollout"):
         lines.append("| %s | %s | %.1f | %d |" % (k, c, s / n, n))
 if note:
     lines += ["", note]

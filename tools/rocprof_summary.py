@@ -19,7 +19,7 @@ def main():
     lines += ["", "## PMC (one counter group per pass; averages per launch)", "", "| kernel | counter | avg per launch | launches |", "|---|---|---|---|"]
     for db in pmcs:
         cur = sqlite3.connect(db).cursor()
-        for r in cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like 'k_step%' "
+        for r in cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where (kernel_name like 'k_step%' or kernel_name like 'k_rollout%') "
                              "group by kernel_name, counter_name").fetchall():
             lines.append("| %s | %s | %.1f | %d |" % (r[0].split("(")[0], r[1], r[2], r[3]))
     open(out, "w").write("\n".join(lines) + "\n")
