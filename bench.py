@@ -408,7 +408,7 @@ def main():
                        autoreset="rsi", seed=0, contacts=full, limits=full,
                        action_mode="raw" if full else "p-control", env_offset=shard * n, frame_skip=1, dtype=args.dtype,
                        packed=(True if args.horizon_launch else None) if args.packed is None else bool(args.packed))
-    step_kernel = ("k_rollout_packed" if args.horizon_launch else "k_step_packed") if env.packed else "k_step_narrow"
+    step_kernel = ("k_rollout_packed" if (args.horizon_launch and full and n <= 8192) else "k_step_packed") if env.packed else "k_step_narrow"
     stream = torch.cuda.Stream(device=dev)
     env.batch.set_stream(stream.cuda_stream)
     env.batch.set_option(A.OPT_PIPELINE, max(1, min(args.pipeline, A.MAX_PIPELINE)))
@@ -577,7 +577,9 @@ def main():
                            else "; shorter than the %d-step horizon: no block packing / join inside the window" % HORIZON)},
             "horizon_launch": None if hl_elapsed is None else {
                 "value": round(total_steps / hl_elapsed, 1), "unit": "env-steps/s", "ms_per_step": round(hl_elapsed / args.steps * 1e3, 4), "steps": args.steps,
-                "steps_per_call": min(HORIZON, max(1, args.horizon_chunk), args.steps), "kernel": "k_rollout_packed", "envs_per_wavefront": 4,
+                "steps_per_call": min(HORIZON, max(1, args.horizon_chunk), args.steps),
+                "kernel": "k_rollout_packed" if (full and n <= 8192) else "k_step_packed: the library issues the step launches itself (no constraint rows, or more than two packed waves per SIMD: one launch per horizon does not pay there)",
+                "envs_per_wavefront": 4,
                 "env_steps_re_stepped_in_wave": hl_redo,
                 "what": "the same %d steps of the same workload through dm_batch_rollout (max over ranks, same barriers): ONE launch per horizon of pre-drawn actions, every wavefront "
                         "steps its four environments through the whole horizon at its own pace; results bit-identical to the dm_batch_step calls of `value` on the packed "

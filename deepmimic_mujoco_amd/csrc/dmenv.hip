@@ -351,6 +351,7 @@ struct dm_batch {
   long long* d_prof = nullptr; bool prof = false;
   int redo_phase = 0;    // which of a sub-batch's two redo counters the next packed launch counts into
   int redo_mode = -1;    // 1 / 0: the last packed step was / was not pipelined (the counter pairs are re-zeroed when that changes)
+  int horizon_mode = -1; // option 106: dm_batch_rollout on the packed path as ONE launch per horizon (1), as step launches (0), by batch size (-1, default)
   bool packed = false;   // option 105: four environments per wavefront (k_step_packed) where that kernel covers the configuration
   bool two_tier = true, reorder = true, has_rows = true; int resident_waves = 2048;   // CUs x 8 single-wave workgroups (LDS-limited)
   bool timing = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f; bool ev_pending = false;
@@ -519,6 +520,7 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
       b->B.order = nullptr;   /* the stored dispatch order belongs to the previous partition: identity for the next launch */
       break;
     }
+    case 106: b->horizon_mode = v < 0 ? -1 : (v != 0 ? 1 : 0); break;   /* dm_batch_rollout on the packed path: 1 one launch per horizon, 0 step launches, -1 (default) by batch size */
     case DM_OPT_PACKED: case 105: b->packed = v != 0; break;        /* 1: four environments per wavefront (k_step_packed) where it covers the configuration */
     case 104: b->reorder = v != 0; if (!b->reorder) b->B.order = nullptr; break;   /* 1 (default): longest-first dispatch order (k_order) */
     case 100: b->B.env_offset = (int)v; break;  /* global id of env 0 (multi-GPU sharding) */
@@ -685,7 +687,13 @@ extern "C" int dm_batch_rollout(dm_batch* b, double* action, double* obs, double
   if (!b || !action || !obs || !reward || !done || T < 1 || nsub < 1) return fail(DM_EINVAL, "dm_batch_rollout: bad argument");
   if (weights && !vpred) return fail(DM_EINVAL, "dm_batch_rollout: a policy needs the value rows");
   const size_t n = (size_t)b->n;
-  const bool use_packed = b->packed && b->B.reward_mode <= 3 && b->two_tier;     // (with option 101 the horizon launch records every wave's cycles)
+  // ONE launch for the horizon where that wins (measured, profiles/r03_bench_*): batches with constraint rows of up to two packed waves per
+  // SIMD (8 192 envs on an MI355X; at 4 096 envs 16.6 M env-steps/s against 12.2 M for the one-env steps and 11.2 M for the packed ones).
+  // Larger batches keep several rounds of waves busy anyway and gain more from the per-step dispatch order, which puts environments with
+  // similar row counts into one wave (16 384 envs: 18.8 M per step, 16.9 M per horizon); without rows there is no slow wave to wait for.
+  const int simds = b->resident_waves / DM_STEP_WAVES;
+  const bool use_packed = b->packed && b->B.reward_mode <= 3 && b->two_tier &&     // (with option 101 the horizon launch records every wave's cycles)
+                          (b->horizon_mode == 1 || (b->horizon_mode < 0 && b->has_rows && b->n <= 2 * SLOTS * simds));
   if (!use_packed) {
     for (int t = 0; t < T; t++) {
       dmp::PolicyArgs pa{weights, action + (size_t)(t + 1) * n * NU, weights ? vpred + (size_t)t * n : nullptr, (int)stochastic, (unsigned long long)seed, (unsigned long long)counter + t};
