@@ -511,6 +511,7 @@ def main():
         # tests/test_gpu_rollout.py, tests/test_gpu_fullsize.py) through dm_batch_rollout — one launch per horizon in which every wavefront
         # runs its four environments through all steps at its own pace instead of waiting for the slowest wave of every step
         hl_elapsed = None; hl_redo = None
+        hl_steps = (args.steps + HORIZON - 1) // HORIZON * HORIZON          # whole horizons: a horizon launch shorter than a horizon has not averaged its waves yet
         if not args._child and args.dtype == 64 and not args.horizon_launch and not args.no_horizon_leg:
             bt = env.batch
             was_packed = env.packed; was_auto = bool(bt.__dict__.get("_auto", False))
@@ -523,7 +524,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             h0 = time.perf_counter()
-            run_steps(0, args.steps, horizon=True)
+            run_steps(0, hl_steps, horizon=True)
             bt.join(); drain(); stream.synchronize(); torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -576,15 +577,15 @@ def main():
                            ("%d steps through dm_batch_rollout, %d steps per call" % (args.steps, min(HORIZON, max(1, args.horizon_chunk)))) if args.horizon_launch else "%d dm_batch_step calls" % args.steps, ", %d horizon-end block packings + joins" % (args.steps // HORIZON) if args.steps >= HORIZON
                            else "; shorter than the %d-step horizon: no block packing / join inside the window" % HORIZON)},
             "horizon_launch": None if hl_elapsed is None else {
-                "value": round(total_steps / hl_elapsed, 1), "unit": "env-steps/s", "ms_per_step": round(hl_elapsed / args.steps * 1e3, 4), "steps": args.steps,
-                "steps_per_call": min(HORIZON, max(1, args.horizon_chunk), args.steps),
+                "value": round(world * n * hl_steps / hl_elapsed, 1), "unit": "env-steps/s", "ms_per_step": round(hl_elapsed / hl_steps * 1e3, 4), "steps": hl_steps,
+                "steps_per_call": min(HORIZON, max(1, args.horizon_chunk)),
                 "kernel": "k_rollout_packed" if (full and n <= 8192) else "k_step_packed: the library issues the step launches itself (no constraint rows, or more than two packed waves per SIMD: one launch per horizon does not pay there)",
                 "envs_per_wavefront": 4,
                 "env_steps_re_stepped_in_wave": hl_redo,
-                "what": "the same %d steps of the same workload through dm_batch_rollout (max over ranks, same barriers): ONE launch per horizon of pre-drawn actions, every wavefront "
+                "what": "%d steps (the timed window rounded up to whole 256-step horizons) of the same workload and state stream through dm_batch_rollout (max over ranks, same barriers): ONE launch per horizon of pre-drawn actions, every wavefront "
                         "steps its four environments through the whole horizon at its own pace; results bit-identical to the dm_batch_step calls of `value` on the packed "
                         "kernel (tests/test_gpu_rollout.py::test_horizon_launch_equals_step_by_step) and oracle-checked at full shard size "
-                        "(tests/test_gpu_fullsize.py [*-2]).  `value` stays the one-call-per-step figure: the drop-in for VecEnv.step" % args.steps},
+                        "(tests/test_gpu_fullsize.py [*-2]).  `value` stays the one-call-per-step figure: the drop-in for VecEnv.step" % hl_steps},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                          "kernel": step_kernel, "kernel_ms": round(kernel_ms, 4),

@@ -127,6 +127,8 @@ __global__ __launch_bounds__(64) void k_step_packed_act(const DevModel<Real>* __
   dmp::policy_wave4<Real>(pa, envs, wr, lane, reinterpret_cast<char*>(&sh[0]), (unsigned)sizeof(SlotShared<Real>), (unsigned)(offsetof(SlotShared<Real>, qpos) + 7 * sizeof(Real)),
                           (unsigned)(offsetof(SlotShared<Real>, qvel) + 6 * sizeof(Real)), (unsigned)offsetof(SlotShared<Real>, r1));
 }
+// the batch descriptor into device memory, stream-ordered before the horizon launch that reads it there
+__global__ void k_put_batch(Batch<Real> B, Batch<Real>* __restrict__ dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = B; }
 // A whole horizon of T steps in ONE launch (dm_batch_rollout; slot_step.h slot_rollout): every wave steps its four environments T times
 // without waiting for any other wave — optionally with the policy's step in between (pa.P; pa.action = the [T + 1, N, 28] action rows,
 // pa.vpred = the [T, N] value rows, pa.counter = the first step's draw counter) — and re-steps an environment that exceeds a capacity of
@@ -705,7 +707,7 @@ extern "C" int dm_batch_rollout(dm_batch* b, double* action, double* obs, double
   HIPCHK(hipSetDevice(b->device));
   if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
   dmp::PolicyArgs pa{weights, action, vpred, (int)stochastic, (unsigned long long)seed, (unsigned long long)counter};
-  HIPCHK(hipMemcpyAsync(b->d_B, &b->B, sizeof(Batch<Real>), hipMemcpyHostToDevice, b->stream));
+  hipLaunchKernelGGL(k_put_batch, dim3(1), dim3(64), 0, b->stream, b->B, b->d_B);
   hipLaunchKernelGGL(k_rollout_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, (const Batch<Real>*)b->d_B, (const Ext*)action, obs, reward, done, (int)nsub, 0, b->n, (int)T, pa, b->prof ? b->d_prof : (long long*)nullptr);
   // dispatch order for the next launch: environments with similar row counts share a wave (and, for per-step launches, longest first)
   if (b->reorder && b->has_rows) {

@@ -471,3 +471,60 @@ def test_horizon_launch_equals_step_by_step(packed, policy):
         assert np.array_equal(x[i], y[i]), "final state differs (%d)" % i
     if packed and not policy:
         assert x[11] == y[11] > 0, "capacity overflows: %d per-step, %d in the horizon launch" % (x[11], y[11])
+
+
+@pytest.mark.gpu
+def test_horizon_launch_forms_agree_with_substeps_and_odd_sizes():
+    """dm_batch_rollout's two forms on the packed path (DM option 106: 1 = one launch per horizon, 0 = the library issues the step launches)
+    with n_substeps = 2 and an env count that leaves spare slots in the last wave: identical rows and final state; with the option left at
+    its default the library picks the one-launch form for this batch (constraint rows, at most two packed waves per SIMD)."""
+    n, T = 301, 12
+    outs = []
+    for mode in (0, 1, -1):
+        env = DPVecEnv(n, motion="spinkick", device=0, reward="alive", autoreset="rsi", seed=4, packed=True)
+        b = env.batch
+        b.set_option(106, mode)
+        g = torch.Generator(device=DEV); g.manual_seed(3)
+        ac = torch.randn((T + 1, n, 28), generator=g, dtype=torch.float64, device=DEV) * 0.9
+        ob = torch.zeros((T, n, 56), dtype=torch.float64, device=DEV); rew = torch.zeros((T, n), dtype=torch.float64, device=DEV)
+        dn = torch.zeros((T, n), dtype=torch.uint8, device=DEV)
+        env.reset("rsi")
+        b.rollout(ac, (ob, rew, dn), 2)
+        b.join(); b.sync()
+        outs.append((ob.clone(), rew.clone(), dn.clone(), torch.as_tensor(b.get(A.F_QPOS)), torch.as_tensor(b.get(A.F_TIME)), torch.as_tensor(b.get(A.F_EPISODE))))
+        env.close()
+    for k in (1, 2):
+        for x, y in zip(outs[0], outs[k]):
+            assert torch.equal(x, y)
+    assert bool(torch.isfinite(outs[0][0]).all()) and float(outs[0][4].max()) > 0
+
+
+@pytest.mark.gpu
+def test_segment_collector_chooses_the_kernel_from_its_own_horizons():
+    """`SegmentCollector` (fused) steps a horizon through dm_batch_rollout and decides, horizon by horizon, between four environments per
+    wavefront (one launch per horizon) and one (step launches) from the last horizon's own statistics.  Both an untrained policy's falling
+    population and the reference's shipped policy (standing on both feet: 0.4 % of env-steps beyond a slot's capacity, re-stepped inside
+    their waves — still 12.2 M against 9.2 M env-steps/s, tools/rollout_policy_bench.py) stay on the packed horizon launch; with the
+    tolerated overflow rate set below what the shipped policy produces, the batch is handed to the one-env steps after its first horizon.
+    Either way the segments follow the generator's protocol."""
+    from deepmimic_mujoco_amd.rollout import SegmentCollector
+    n, T = 512, 64
+    for shipped, tolerate in ((False, None), (True, None), (True, 1e-4)):
+        pol = MlpPolicy.from_tf_checkpoint(CKPT, device=DEV) if shipped else MlpPolicy(device=DEV, seed=1)
+        pol.seed(2)
+        env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=0)
+        assert env.horizon_packed_ok
+        c = SegmentCollector(pol, env, T, stochastic=True, first_reset="init", fused=True)
+        if tolerate is not None:
+            c.HORIZON_REDO_RATE_MAX = tolerate
+        segs = []
+        for _ in range(5):
+            c.launch(); segs.append(c.collect())
+        for a, bseg in zip(segs[:-1], segs[1:]):
+            assert torch.equal(bseg["prevac"][0], a["ac"][-1])
+        assert all(bool(torch.isfinite(sg["ob"]).all()) and bool((sg["rew"] == 1).all()) for sg in segs)
+        if tolerate is None:
+            assert env.packed and c.kernel_switches == 1, "stays on the packed horizon launch (switched on once, at the first horizon)"
+        else:
+            assert c.kernel_switches >= 2, "handed to the one-env steps after the first horizon (and back only when no env holds more than 30 rows)"
+        env.close()
