@@ -353,6 +353,8 @@ def main():
                     help="step through dm_batch_rollout: up to one %d-step horizon of pre-drawn actions per call (on the packed path ONE launch in which every "
                          "wavefront runs its four environments through all steps at its own pace) instead of one dm_batch_step call per step; implies --packed 1 unless given" % HORIZON)
     ap.add_argument("--no-horizon-leg", action="store_true", help="skip the second timed leg (the same steps through dm_batch_rollout, reported as `horizon_launch`)")
+    ap.add_argument("--rollout-form", default="auto", choices=["auto", "launch", "steps"],
+                    help="dm_batch_rollout on the packed path (DM option 106): one launch per call, the library's step launches, or chosen by batch size (default)")
     ap.add_argument("--horizon-chunk", type=int, default=HORIZON, help="--horizon-launch: steps per dm_batch_rollout call (the dispatch order — which environments share a wavefront — is renewed between calls)")
     ap.add_argument("--packed", type=int, default=None, choices=[0, 1], help="DM option 105: four environments per wavefront (k_step_packed) where that kernel covers the workload (default: the library's)")
     ap.add_argument("--no-reorder", action="store_true", help="experiment: identity dispatch order instead of longest-first (DM option 104 = 0)")
@@ -414,6 +416,8 @@ def main():
     env.batch.set_option(A.OPT_PIPELINE, max(1, min(args.pipeline, A.MAX_PIPELINE)))
     if args.no_reorder:
         env.batch.set_option(104, 0)
+    if args.rollout_form != "auto":
+        env.batch.set_option(106, 1 if args.rollout_form == "launch" else 0)
 
     with torch.cuda.stream(stream):
         gen = torch.Generator(device=dev); gen.manual_seed(1234 + shard)
