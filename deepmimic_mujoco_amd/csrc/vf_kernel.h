@@ -5,7 +5,7 @@
 // MpiAdam rule of src/mpi_adam.py:21-35.  Here:
 //   k_vf_rms   column sums / sums of squares of the minibatch in float64 (fixed reduction order), the LAST block to finish adds
 //              them to the filter's state and refreshes its float32 mean / std,
-//   k_vf_grad  a block takes 32 samples: normalise + clip, forward, backward, all in LDS (weights staged once per block), and
+//   k_vf_grad  a block takes 16 samples: normalise + clip, forward, backward, all in LDS (weights staged once per block), and
 //              writes its partial gradient of the 15 901 parameters,
 //   k_vf_adam  one thread per parameter: partial gradients summed in block order, Adam moments, step.
 // fp32 like the reference's TF graph (sums of the filter in float64 like its numpy arrays).  A whole epoch of minibatches is
@@ -17,7 +17,7 @@
 
 namespace dmv {
 
-constexpr int OB = 56, H = 100, SB = 32;            // SB: samples per block of k_vf_grad
+constexpr int OB = 56, H = 100, SB = 16;            // SB: samples per block of k_vf_grad (16: a 4 096-sample minibatch is 256 blocks, one per CU of an MI355X)
 constexpr int O_W1 = 0, O_B1 = O_W1 + OB * H, O_W2 = O_B1 + H, O_B2 = O_W2 + H * H, O_W3 = O_B2 + H, O_B3 = O_W3 + H, NP = O_B3 + 1;
 constexpr int NPAD = (NP + 63) / 64 * 64;
 constexpr int RMS_BLOCKS = 64;
@@ -72,8 +72,9 @@ __global__ __launch_bounds__(256) void k_vf_rms(const float* __restrict__ ob, in
 }
 
 // ---- forward + backward of 32 samples ------------------------------------------------------------------------------------------
-// Activations are kept TRANSPOSED in LDS ([unit][sample]): a thread of the dense layers owns a 4 units x 4 samples register tile and
-// feeds 16 FMAs from two 16-byte LDS reads (four weights of one input, four samples of that input); the weight-gradient products run
+// Activations are kept TRANSPOSED in LDS ([unit][sample]): a thread of the dense layers owns a 2 units x 4 samples register tile (round 3;
+// 4 x 4 on 32-sample blocks before: half the blocks, half the CUs, twice the serial work per thread — 36 us per 4 096-sample minibatch) and
+// feeds 8 FMAs from a 16-byte and an 8-byte LDS read (four samples of one input, two weights of that input); the weight-gradient products run
 // over the sample axis with 16-byte reads as well (4 x 10 tiles).
 struct alignas(16) VfShared {
   float W1[OB * H], W2[H * H];
@@ -130,7 +131,7 @@ __device__ inline void vf_stage_weights(VfShared& S, const float* __restrict__ t
 // forward + backward of samples s0 .. s0 + SB - 1 of the minibatch; the tile's partial gradient goes to `out` (NPAD floats)
 __device__ inline void vf_grad_tile(VfShared& S, const float* __restrict__ ob, const float* __restrict__ ret, int bs, const float* __restrict__ theta,
                                     const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ out, int s0, int tid) {
-#pragma unroll 7
+#pragma unroll 4
   for (int i = tid; i < SB * OB; i += 256) {                  // coalesced read of [sample][input], transposed store
     const int sm = i / OB, k = i % OB, r = s0 + sm;
     float v = 0.0f;
@@ -138,33 +139,34 @@ __device__ inline void vf_grad_tile(VfShared& S, const float* __restrict__ ob, c
     S.z[k][sm] = v;
   }
   __syncthreads();
-  const int sq = (tid % 8) * 4, uq = (tid / 8) * 4;           // this thread's 4 samples x 4 units (threads 0..199)
+  static_assert(SB == 16, "thread tiles below: 4 sample quads x 50 unit pairs");
+  const int sq = (tid % 4) * 4, uq = (tid / 4) * 2;           // this thread's 4 samples x 2 units (threads 0..199)
   const bool dense = tid < 200;
   // layer 1, layer 2
   if (dense) {
-    float4 acc[4];
+    float4 acc[2];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const float b = S.b1[uq + u]; acc[u] = make_float4(b, b, b, b); }
-#pragma unroll 4
+    for (int u = 0; u < 2; u++) { const float b = S.b1[uq + u]; acc[u] = make_float4(b, b, b, b); }
+#pragma unroll 8
     for (int k = 0; k < OB; k++) {
-      const float4 x = f4(&S.z[k][sq]), w = f4(&S.W1[k * H + uq]);
-      fma4(acc[0], w.x, x); fma4(acc[1], w.y, x); fma4(acc[2], w.z, x); fma4(acc[3], w.w, x);
+      const float4 x = f4(&S.z[k][sq]); const float2 w = *reinterpret_cast<const float2*>(&S.W1[k * H + uq]);
+      fma4(acc[0], w.x, x); fma4(acc[1], w.y, x);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) *reinterpret_cast<float4*>(&S.h1[uq + u][sq]) = make_float4(tanhf(acc[u].x), tanhf(acc[u].y), tanhf(acc[u].z), tanhf(acc[u].w));
+    for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(&S.h1[uq + u][sq]) = make_float4(tanhf(acc[u].x), tanhf(acc[u].y), tanhf(acc[u].z), tanhf(acc[u].w));
   }
   __syncthreads();
   if (dense) {
-    float4 acc[4];
+    float4 acc[2];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const float b = S.b2[uq + u]; acc[u] = make_float4(b, b, b, b); }
-#pragma unroll 4
+    for (int u = 0; u < 2; u++) { const float b = S.b2[uq + u]; acc[u] = make_float4(b, b, b, b); }
+#pragma unroll 10
     for (int k = 0; k < H; k++) {
-      const float4 x = f4(&S.h1[k][sq]), w = f4(&S.W2[k * H + uq]);
-      fma4(acc[0], w.x, x); fma4(acc[1], w.y, x); fma4(acc[2], w.z, x); fma4(acc[3], w.w, x);
+      const float4 x = f4(&S.h1[k][sq]); const float2 w = *reinterpret_cast<const float2*>(&S.W2[k * H + uq]);
+      fma4(acc[0], w.x, x); fma4(acc[1], w.y, x);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) *reinterpret_cast<float4*>(&S.h2[uq + u][sq]) = make_float4(tanhf(acc[u].x), tanhf(acc[u].y), tanhf(acc[u].z), tanhf(acc[u].w));
+    for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(&S.h2[uq + u][sq]) = make_float4(tanhf(acc[u].x), tanhf(acc[u].y), tanhf(acc[u].z), tanhf(acc[u].w));
   }
   __syncthreads();
   // output, error, d loss / d vpred  (loss = mean over the minibatch of (vpred - ret)^2)
@@ -182,20 +184,20 @@ __device__ inline void vf_grad_tile(VfShared& S, const float* __restrict__ ob, c
   // dW2 = h1^T d2 (250 tiles), db2
   if (tid < 250) tile_4x10(S.h1, S.d2, (tid / 10) * 4, (tid % 10) * 10, out + O_W2);
   if (tid < H) out[O_B2 + tid] = row_sum(S.d2[tid]);
-  // d h1 = d2 W2^T, d a1 = d h1 (1 - h1^2): 4 samples x 4 units per thread, four j at a time
+  // d h1 = d2 W2^T, d a1 = d h1 (1 - h1^2): 4 samples x 2 units per thread, four j at a time
   if (dense) {
-    float4 acc[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-#pragma unroll 2
+    float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+#pragma unroll 5
     for (int j = 0; j < H; j += 4) {
       const float4 d0 = f4(&S.d2[j][sq]), d1 = f4(&S.d2[j + 1][sq]), d2 = f4(&S.d2[j + 2][sq]), d3 = f4(&S.d2[j + 3][sq]);
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < 2; u++) {
         const float4 w = f4(&S.W2[(uq + u) * H + j]);
         fma4(acc[u], w.x, d0); fma4(acc[u], w.y, d1); fma4(acc[u], w.z, d2); fma4(acc[u], w.w, d3);
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < 2; u++) {
       const float4 h = f4(&S.h1[uq + u][sq]);
       *reinterpret_cast<float4*>(&S.d1[uq + u][sq]) = make_float4(acc[u].x * (1.0f - h.x * h.x), acc[u].y * (1.0f - h.y * h.y), acc[u].z * (1.0f - h.z * h.z), acc[u].w * (1.0f - h.w * h.w));
     }
@@ -207,7 +209,7 @@ __device__ inline void vf_grad_tile(VfShared& S, const float* __restrict__ ob, c
 }
 __global__ __launch_bounds__(256) void k_vf_grad(const float* __restrict__ ob, const float* __restrict__ ret, int bs, const float* __restrict__ theta,
                                                  const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ partial) {
-  __shared__ VfShared S;                                      // 123 KB: one block per CU (a gfx950 workgroup may hold up to 160 KB)
+  __shared__ VfShared S;                                      // 93 KB: one block per CU (a gfx950 workgroup may hold up to 160 KB)
   const int tid = threadIdx.x;
   vf_stage_weights(S, theta, tid);
   vf_grad_tile(S, ob, ret, bs, theta, mean, stdv, partial + (size_t)blockIdx.x * NPAD, blockIdx.x * SB, tid);
@@ -220,12 +222,12 @@ __global__ __launch_bounds__(256) void k_vf_adam(const float* __restrict__ parti
   if (p >= NP) return;
   float g = 0.0f;
   int b = 0;
-  for (; b + 8 <= nblk; b += 8) {                    // eight loads in flight; the additions stay in block order
-    float x[8];
+  for (; b + 16 <= nblk; b += 16) {                  // sixteen loads in flight; the additions stay in block order
+    float x[16];
 #pragma unroll
-    for (int u = 0; u < 8; u++) x[u] = partial[(size_t)(b + u) * NPAD + p];
+    for (int u = 0; u < 16; u++) x[u] = partial[(size_t)(b + u) * NPAD + p];
 #pragma unroll
-    for (int u = 0; u < 8; u++) g += x[u];
+    for (int u = 0; u < 16; u++) g += x[u];
   }
   for (; b < nblk; b++) g += partial[(size_t)b * NPAD + p];
   const float mm = beta1 * m[p] + (1.0f - beta1) * g;
