@@ -339,9 +339,9 @@ template <class R> union SlotOrOne {
 template <class R, int NR>
 DM_DEV_CALL64 void restep_one_env(const DevModel<R>* M, const Batch<R>* B, Shared<R>* s, StepScratch<R>* x, int env, int lane, const double* action, double* obs,
                                     double* reward, unsigned char* done, int n_substeps) {
-  using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global;
-  const Batch<R> Bv = *in_global(uniform_ptr(B));       // (the struct's pointers are generic too: a copy whose members are told to be global)
-  env_step<R, NR>(*in_global(uniform_ptr(M)), global_members(Bv), *in_lds(uniform_ptr(s)), *in_lds(uniform_ptr(x)), dmw::uniform(env), lane, in_global(uniform_ptr(action)),
+  using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global; using dmw::in_constant;
+  const Batch<R> Bv = *in_constant(B);                  // (the struct's pointers are generic too: a copy whose members are told to be global)
+  env_step<R, NR>(*in_constant(M), global_members(Bv), *in_lds(uniform_ptr(s)), *in_lds(uniform_ptr(x)), dmw::uniform(env), lane, in_global(uniform_ptr(action)),
                   in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps));
 }
 // (the packed step as a call too: its body is then compiled exactly as in k_step_packed — inlined into the horizon loop the register
@@ -349,9 +349,9 @@ DM_DEV_CALL64 void restep_one_env(const DevModel<R>* M, const Batch<R>* B, Share
 template <class R>
 DM_DEV_CALL64 bool slot_env_step_call(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
                                       const double* action, double* obs, double* reward, unsigned char* done, int n_substeps) {
-  using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global;
-  const Batch<R> Bv = *in_global(uniform_ptr(B));
-  return slot_env_step<R>(*in_global(uniform_ptr(M)), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
+  using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global; using dmw::in_constant;
+  const Batch<R> Bv = *in_constant(B);
+  return slot_env_step<R>(*in_constant(M), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
                           in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0);
 }
 template <class R, int NR, class POLICY>

@@ -136,6 +136,14 @@ template <class T> DM_DEV T* in_global(T* p) {      // wave-uniform pointers int
   asm volatile("" : "+s"(g));
   return (T*)g;
 }
+// ... into global memory that NOTHING writes while the kernel runs (model, batch descriptor): the constant address space makes every
+// wave-uniform load through it a scalar load again (inside a called function a plain global pointer may alias the function's own stores, so
+// the compiler turns them into vector loads: 58 of them in the packed step, each a ~600-cycle stall of a lone wave)
+template <class T> DM_DEV const T* in_constant(const T* p) {
+  __attribute__((address_space(4))) const T* g = (__attribute__((address_space(4))) const T*)uniform_ptr(p);
+  asm volatile("" : "+s"(g));
+  return (const T*)g;
+}
 template <class T> DM_DEV T* launder_uniform_ptr(T* p) { asm volatile("" : "+s"(p)); return p; }   // loads through the result cannot be hoisted above this point
 DM_DEV void reload_fence() { asm volatile("" ::: "memory"); }
 // if (pred) *p -= v in LDS as one fire-and-forget ds_add_f64: lanes of one instruction may hit the same address (the

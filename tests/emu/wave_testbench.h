@@ -140,6 +140,7 @@ template <class T> inline T* launder_uniform_ptr(T* p) { return p; }
 template <class T> inline T* uniform_ptr(T* p) { return p; }
 template <class T> inline T* in_lds(T* p) { return p; }
 template <class T> inline T* in_global(T* p) { return p; }
+template <class T> inline const T* in_constant(const T* p) { return p; }
 inline void pin_value(double&) {}
 inline void pin_value(float&) {}
 
