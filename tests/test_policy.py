@@ -333,3 +333,57 @@ def test_fused_rollout_step_is_refused_without_the_native_path():
     assert not can_fuse(pi, Env())
     with pytest.raises(ValueError):
         SegmentCollector(pi, Env(), 4, fused=True)
+
+
+def test_collector_kernel_choice_is_a_function_of_the_last_horizons_statistics():
+    """`SegmentCollector._choose_kernel` (host logic, no device): starts packed, hands a batch to the one-env steps when more than
+    HORIZON_REDO_RATE_MAX of the last horizon's env-steps overflowed the packed path, hands it back when no environment holds more than
+    HEAVY_ROWS constraint rows, and leaves batches alone whose configuration pins the kernel."""
+    import numpy as np
+    from deepmimic_mujoco_amd import _abi as A
+    from deepmimic_mujoco_amd.rollout import SegmentCollector
+
+    class FakeBatch:
+        REDO_RATE_MAX, HEAVY_ROWS = 3e-4, 30
+
+        def __init__(self):
+            self.options, self.redo, self.nefc, self._auto = {}, 0, np.zeros(8, dtype=np.int32), True
+
+        def set_option(self, o, v):
+            self.options[int(o)] = int(v)
+
+        def enable_auto_packed(self, on):
+            self._auto = bool(on)
+
+        def redo_total(self):
+            return self.redo
+
+        def get(self, f):
+            assert f == A.F_NEFC
+            return self.nefc
+
+    class FakeEnv:
+        def __init__(self, ok):
+            self.batch, self.horizon_packed_ok = FakeBatch(), ok
+
+    c = SegmentCollector.__new__(SegmentCollector)
+    c.env, c.T, c.n, c._redo_seen, c.kernel_switches = FakeEnv(True), 100, 8, None, 0
+    b = c.env.batch
+    c._choose_kernel()                                                   # first horizon: packed, the per-step chooser switched off
+    assert b.options[A.OPT_PACKED] == 1 and b._auto is False and c.kernel_switches == 1
+    b.redo += 10                                                         # 10 / 800 = 1.25 % of env-steps: tolerated (2 %)
+    c._choose_kernel()
+    assert b.options[A.OPT_PACKED] == 1 and c.kernel_switches == 1
+    b.redo += 40                                                         # 5 %: to the one-env steps
+    c._choose_kernel()
+    assert b.options[A.OPT_PACKED] == 0 and c.kernel_switches == 2
+    b.nefc[3] = 36                                                       # an environment beyond a slot's rows: stays
+    c._choose_kernel()
+    assert b.options[A.OPT_PACKED] == 0 and c.kernel_switches == 2
+    b.nefc[3] = 22                                                       # nobody above 30 rows: back
+    c._choose_kernel()
+    assert b.options[A.OPT_PACKED] == 1 and c.kernel_switches == 3
+    c2 = SegmentCollector.__new__(SegmentCollector)
+    c2.env, c2.T, c2.n, c2._redo_seen, c2.kernel_switches = FakeEnv(False), 100, 8, None, 0
+    c2._choose_kernel()                                                  # DPVecEnv(packed=False / True), float32, v1-quat reward: not touched
+    assert c2.env.batch.options == {} and c2.kernel_switches == 0 and c2.env.batch._auto is True
