@@ -35,6 +35,54 @@ def test_every_clip_imitation_rollout_matches_oracle(clip):
     b.close()
 
 
+@pytest.mark.parametrize("clip", ALL_CLIPS)
+def test_every_clip_through_one_horizon_launch_matches_oracle(clip):
+    """The same rollouts — 5-term imitation reward, `frame_skip="mocap"`, wrapping and `Loop: none` clips — as ONE dm_batch_rollout launch on the
+    packed path (four environments per wavefront, every wave through all steps at its own pace; 10 envs = two full waves + two spare
+    slots): every row of obs / reward / done against the oracle stepped env by env, frame cursors and cycle counters at the end."""
+    import torch
+    from deepmimic_mujoco_amd import Batch
+    from oracle import oracle as O
+    sp, mc, T, P = _imit_inputs(clip)
+    n, steps = 10, 8
+    nsub = max(1, int(float(mc.dt) / 0.0166))
+    F = len(T)
+    b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
+    b.set_option(A.OPT_REWARD_MODE, 3); b.set_option(A.OPT_PACKED, 1); b.set_option(106, 1)
+    rng = np.random.RandomState(7)
+    idx = np.concatenate([[F - 3, F - 2], rng.randint(0, F, size=n - 2)]).astype(np.int32)
+    q = mc.data_config[idx].copy(); v = mc.data_vel[idx].copy()
+    q[n // 2:, 7:] += 0.05 * rng.randn(n - n // 2, 28)
+    b.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); b.set(A.F_TIME, np.zeros(n))
+    b.set_state(q, v, frame_idx=idx)
+    acts = rng.randn(steps + 1, n, 28) * 0.3
+    dev = "cuda:0"
+    ac = torch.as_tensor(acts, dtype=torch.float64, device=dev).contiguous()
+    ob = torch.zeros((steps, n, 56), dtype=torch.float64, device=dev); rew = torch.zeros((steps, n), dtype=torch.float64, device=dev)
+    dn = torch.zeros((steps, n), dtype=torch.uint8, device=dev)
+    b.rollout(ac, (ob, rew, dn), nsub)
+    b.join(); b.sync()
+    ob, rew, dn = ob.cpu().numpy(), rew.cpu().numpy(), dn.cpu().numpy()
+    om = H.oracle_model()
+    ods = [O.Data(om) for _ in range(n)]
+    for e in range(n):
+        ods[e].reset(); ods[e].set_state(q[e], v[e])
+    fidx = idx.astype(int).copy(); cyc = np.zeros(n, int)
+    worst = 0.0
+    for t in range(steps):
+        for e in range(n):
+            o, r, d, fidx[e], cyc[e] = O.env_step_imitation(om, ods[e], acts[t, e], nsub, T, P, fidx[e], cyc[e])
+            worst = max(worst, abs(rew[t, e] - r), H.rel_err(ob[t, e], o))
+            assert bool(dn[t, e]) == d, (clip, t, e)
+    assert worst < 1e-9, "%s: %.3e" % (clip, worst)
+    assert np.array_equal(b.get(A.F_FRAME_IDX), fidx.astype(np.int32)) and np.array_equal(b.get(A.F_CYCLE), cyc.astype(np.int32))
+    if mc.loop == "none":
+        assert fidx[0] == F - 1 and fidx[1] == F - 1
+    else:
+        assert cyc[0] == 1 and cyc[1] == 1
+    b.close()
+
+
 def test_at_least_one_clip_of_each_loop_kind_is_bundled():
     kinds = {H.mocap(c).loop for c in ALL_CLIPS}
     assert kinds == {"wrap", "none"}, kinds
