@@ -882,7 +882,7 @@ extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, in
     for (int i = 0; i < nb; i++) {
       hipLaunchKernelGGL(dmv::k_vf_grad, dim3(nblk), dim3(256), 0, st, ob + (size_t)i * bs * dmv::OB, ret + (size_t)i * bs, (int)bs, (const float*)theta,
                          (const float*)(means + (size_t)i * dmv::OB), (const float*)(stds + (size_t)i * dmv::OB), partial);
-      hipLaunchKernelGGL(dmv::k_vf_adam, dim3((dmv::NP + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk, theta, adam_m, adam_v,
+      hipLaunchKernelGGL(dmv::k_vf_adam, dim3((dmv::NP + dmv::ADAM_PARAMS - 1) / dmv::ADAM_PARAMS), dim3(256), 0, st, (const float*)partial, nblk, theta, adam_m, adam_v,
                          step_scale_host[i], (float)beta1, (float)beta2, (float)eps);
     }
     HIPCHK(hipGetLastError());
@@ -897,7 +897,7 @@ extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, in
     hipLaunchKernelGGL(dmv::k_vf_rms, dim3(dmv::RMS_BLOCKS), dim3(256), 0, st, mbob, (int)bs, rpart, ticket, rms_sum, rms_sumsq, rms_count, rms_mean, rms_std);
     hipLaunchKernelGGL(dmv::k_vf_grad, dim3(nblk), dim3(256), 0, st, mbob, mbret, (int)bs, (const float*)theta, (const float*)rms_mean,
                        (const float*)rms_std, partial);
-    hipLaunchKernelGGL(dmv::k_vf_adam, dim3((dmv::NP + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk, theta, adam_m, adam_v,
+    hipLaunchKernelGGL(dmv::k_vf_adam, dim3((dmv::NP + dmv::ADAM_PARAMS - 1) / dmv::ADAM_PARAMS), dim3(256), 0, st, (const float*)partial, nblk, theta, adam_m, adam_v,
                        step_scale_host[i], (float)beta1, (float)beta2, (float)eps);
     HIPCHK(hipGetLastError());
   }

@@ -7,7 +7,7 @@
 //              them to the filter's state and refreshes its float32 mean / std,
 //   k_vf_grad  a block takes 16 samples: normalise + clip, forward, backward, all in LDS (weights staged once per block), and
 //              writes its partial gradient of the 15 901 parameters,
-//   k_vf_adam  one thread per parameter: partial gradients summed in block order, Adam moments, step.
+//   k_vf_adam  partial gradients summed in a fixed order (four quarters of the blocks, each in block order), Adam moments, step.
 // fp32 like the reference's TF graph (sums of the filter in float64 like its numpy arrays).  A whole epoch of minibatches is
 // enqueued by one C call (dm_vf_fit_epoch); nothing comes back to the host.  There the filter sums of all minibatches are taken up front
 // (k_vf_rms_part / k_vf_rms_scan below): two launches per minibatch remain.
@@ -216,20 +216,30 @@ __global__ __launch_bounds__(256) void k_vf_grad(const float* __restrict__ ob, c
 }
 
 // ---- gradient reduction + MpiAdam step (src/mpi_adam.py:21-35) -----------------------------------------------------------------
+// A block takes 64 parameters; its four waves each sum a quarter of the blocks' partials (in block order, sixteen loads in flight), the
+// quarters are added in order: a fixed summation tree — results do not depend on timing.
+constexpr int ADAM_PARAMS = 64;
 __global__ __launch_bounds__(256) void k_vf_adam(const float* __restrict__ partial, int nblk, float* __restrict__ theta, float* __restrict__ m,
                                                  float* __restrict__ v, float a, float beta1, float beta2, float eps) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= NP) return;
+  __shared__ float quarter[4][ADAM_PARAMS];
+  const int w = threadIdx.x / ADAM_PARAMS, p = blockIdx.x * ADAM_PARAMS + threadIdx.x % ADAM_PARAMS;
+  const int per = (nblk + 3) / 4, b0 = w * per, b1 = min(nblk, b0 + per);
   float g = 0.0f;
-  int b = 0;
-  for (; b + 16 <= nblk; b += 16) {                  // sixteen loads in flight; the additions stay in block order
-    float x[16];
+  if (p < NP) {
+    int b = b0;
+    for (; b + 16 <= b1; b += 16) {
+      float x[16];
 #pragma unroll
-    for (int u = 0; u < 16; u++) x[u] = partial[(size_t)(b + u) * NPAD + p];
+      for (int u = 0; u < 16; u++) x[u] = partial[(size_t)(b + u) * NPAD + p];
 #pragma unroll
-    for (int u = 0; u < 16; u++) g += x[u];
+      for (int u = 0; u < 16; u++) g += x[u];
+    }
+    for (; b < b1; b++) g += partial[(size_t)b * NPAD + p];
   }
-  for (; b < nblk; b++) g += partial[(size_t)b * NPAD + p];
+  quarter[w][threadIdx.x % ADAM_PARAMS] = g;
+  __syncthreads();
+  if (w != 0 || p >= NP) return;
+  g = ((quarter[0][threadIdx.x] + quarter[1][threadIdx.x]) + quarter[2][threadIdx.x]) + quarter[3][threadIdx.x];
   const float mm = beta1 * m[p] + (1.0f - beta1) * g;
   const float vv = beta2 * v[p] + (1.0f - beta2) * g * g;
   m[p] = mm; v[p] = vv;
