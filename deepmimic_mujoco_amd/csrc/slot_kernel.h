@@ -908,12 +908,19 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
       const R improvement = dmw::sum16(imp) * pgs_scale;          // of the last accepted sweep
       R imp2; bool bad2;
       sweep(imp2, bad2);                                          // speculative
-      const bool conv = !frozen && (improvement < pgs_tol || iter >= maxiter);
-      if (conv) {
-        frozen = true;
+      // (selects, not branches: `frozen` differs from slot to slot, and a divergent region costs more than the handful of moves it guards)
+      const bool act = !frozen;
+      const bool conv = act && (improvement < pgs_tol || iter >= maxiter);
 #pragma unroll
-        for (int k = 0; k < NS; k++) { f[k] = fprev[k]; t[k] = fprev[k] > 0 ? R(0) : R(-1); }
-      } else if (!frozen) { iter += 1; anybad = anybad || bad2; }
+      for (int k = 0; k < NS; k++) {
+        const R tf = fprev[k] > 0 ? R(0) : R(-1);
+        f[k] = conv ? fprev[k] : f[k];
+        t[k] = conv ? tf : t[k];
+      }
+      const bool go = act && !conv;
+      iter += go ? 1 : 0;
+      anybad = anybad || (go && bad2);
+      frozen = frozen || conv;
       imp = imp2;
       more = dmw::ballot(!frozen) != 0ull;
       if (PROF) prof[6] += 1;
