@@ -910,17 +910,17 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
       sweep(imp2, bad2);                                          // speculative
       // (selects, not branches: `frozen` differs from slot to slot, and a divergent region costs more than the handful of moves it guards)
       const bool act = !frozen;
-      const bool conv = act && (improvement < pgs_tol || iter >= maxiter);
+      const bool conv = (int)act & ((int)(improvement < pgs_tol) | (int)(iter >= maxiter));     // (bit operations: no short-circuit region)
 #pragma unroll
       for (int k = 0; k < NS; k++) {
         const R tf = fprev[k] > 0 ? R(0) : R(-1);
         f[k] = conv ? fprev[k] : f[k];
         t[k] = conv ? tf : t[k];
       }
-      const bool go = act && !conv;
+      const bool go = (int)act & (int)!conv;
       iter += go ? 1 : 0;
-      anybad = anybad || (go && bad2);
-      frozen = frozen || conv;
+      anybad = (int)anybad | ((int)go & (int)bad2);
+      frozen = (int)frozen | (int)conv;
       imp = imp2;
       more = dmw::ballot(!frozen) != 0ull;
       if (PROF) prof[6] += 1;
