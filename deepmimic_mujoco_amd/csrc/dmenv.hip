@@ -690,9 +690,9 @@ extern "C" int dm_batch_rollout(dm_batch* b, double* action, double* obs, double
   if (weights && !vpred) return fail(DM_EINVAL, "dm_batch_rollout: a policy needs the value rows");
   const size_t n = (size_t)b->n;
   // ONE launch for the horizon where that wins (measured, profiles/r03_bench_*): batches with constraint rows of up to two packed waves per
-  // SIMD (8 192 envs on an MI355X; at 4 096 envs 16.6 M env-steps/s against 12.2 M for the one-env steps and 11.2 M for the packed ones).
+  // SIMD (8 192 envs on an MI355X; at 4 096 envs 17.3 M env-steps/s against 12.2 M for the one-env steps and 11.4 M for the packed ones).
   // Larger batches keep several rounds of waves busy anyway and gain more from the per-step dispatch order, which puts environments with
-  // similar row counts into one wave (16 384 envs: 18.8 M per step, 16.9 M per horizon); without rows there is no slow wave to wait for.
+  // similar row counts into one wave (16 384 envs: 19.5 M per step, ~17 M per horizon); without rows there is no slow wave to wait for.
   const int simds = b->resident_waves / DM_STEP_WAVES;
   const bool use_packed = b->packed && b->B.reward_mode <= 3 && b->two_tier &&     // (with option 101 the horizon launch records every wave's cycles)
                           (b->horizon_mode == 1 || (b->horizon_mode < 0 && b->has_rows && b->n <= 2 * SLOTS * simds));

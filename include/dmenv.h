@@ -231,7 +231,7 @@ int dm_batch_step_act(dm_batch* b, const double* action, double* obs, double* re
  * Results are those of T dm_batch_step / dm_batch_step_act calls.  With DM_OPT_PACKED (a reward mode that kernel covers, a model with
  * constraint rows, at most two packed waves per SIMD = 8 192 environments on an MI355X; DM option 106 = 1 / 0 forces / forbids it) the
  * horizon is ONE launch: every wavefront steps its four environments T times at its own pace, so the horizon lasts as long as the slowest
- * wave's sum over T steps instead of the sum of every step's slowest wave (4 096 envs: 16.6 M env-steps/s against 12.2 M through
+ * wave's sum over T steps instead of the sum of every step's slowest wave (4 096 envs: 17.3 M env-steps/s against 12.2 M through
  * dm_batch_step); an environment that exceeds the packed path's capacities in some step is re-stepped inside its wave by the one-env code.
  * Otherwise T step launches are issued. */
 int dm_batch_rollout(dm_batch* b, double* action, double* obs, double* reward, uint8_t* done, int32_t T, int32_t n_substeps,
