@@ -528,3 +528,37 @@ def test_segment_collector_chooses_the_kernel_from_its_own_horizons():
         else:
             assert c.kernel_switches >= 2, "handed to the one-env steps after the first horizon (and back only when no env holds more than 30 rows)"
         env.close()
+
+
+@pytest.mark.gpu
+def test_kernels_and_launch_forms_hand_the_state_over_to_each_other():
+    """One trajectory stepped by a MIX of everything that can step a batch — one-env steps (which park the kinematics of the state they leave
+    behind for the next step), a packed horizon launch, per-step packed launches, one-env steps again — against the same trajectory on the
+    one-env kernel only: 5-term imitation reward, frame cursors, cycle and episode counters included.  The kernels agree to rounding
+    (different summation orders), so the comparison is at 1e-9 over a short run."""
+    n = 203
+    g = torch.Generator(device=DEV); g.manual_seed(11)
+    ac = torch.randn((13, n, 28), generator=g, dtype=torch.float64, device=DEV) * 0.6
+    outs = []
+    for mixed in (False, True):
+        env = DPVecEnv(n, motion="walk", device=0, reward="imitation", autoreset="rsi", seed=8, packed=False)
+        b = env.batch
+        b.set_option(106, 1)
+        ob = torch.zeros((12, n, 56), dtype=torch.float64, device=DEV); rew = torch.zeros((12, n), dtype=torch.float64, device=DEV)
+        dn = torch.zeros((12, n), dtype=torch.uint8, device=DEV)
+        env.reset("rsi")
+        plan = [("one", 0, 3), ("horizon", 3, 5), ("packed", 8, 2), ("one", 10, 2)] if mixed else [("one", 0, 12)]
+        for kind, t0, cnt in plan:
+            b.set_option(A.OPT_PACKED, 0 if kind == "one" else 1)
+            if kind == "horizon":
+                b.rollout(ac[t0:t0 + cnt + 1], (ob[t0:t0 + cnt], rew[t0:t0 + cnt], dn[t0:t0 + cnt]), 1)
+            else:
+                for t in range(t0, t0 + cnt):
+                    b.step(ac[t], 1, (ob[t], rew[t], dn[t]))
+        b.join(); b.sync()
+        outs.append((ob.clone(), rew.clone(), dn.clone(), b.get(A.F_QPOS), b.get(A.F_FRAME_IDX), b.get(A.F_CYCLE), b.get(A.F_EPISODE)))
+        env.close()
+    x, y = outs
+    assert torch.equal(x[2], y[2]) and np.array_equal(x[4], y[4]) and np.array_equal(x[5], y[5]) and np.array_equal(x[6], y[6])
+    assert float((x[0] - y[0]).abs().max()) < 1e-9 * max(1.0, float(x[0].abs().max())) and float((x[1] - y[1]).abs().max()) < 1e-9
+    assert float(np.abs(x[3] - y[3]).max()) < 1e-9 and bool(torch.isfinite(y[0]).all())
