@@ -152,6 +152,13 @@ __global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __r
   const bool wr[4] = {dmw::bcast_i(lv, 0) != 0, dmw::bcast_i(lv, 16) != 0, dmw::bcast_i(lv, 32) != 0, dmw::bcast_i(lv, 48) != 0};
   const size_t n = (size_t)B.n_envs;
   const long long t_enter = wave_clk ? dmw::clk() : 0;
+#ifdef DM_ROLLOUT_PROF
+  long long* prof_acc = wave_clk ? wave_clk + (size_t)blockIdx.x * 4 * dm::PROF_SLOTS : (long long*)nullptr;   // four envs' records per wave: [0..31] sums, [32..63] scratch
+  if (prof_acc && lane < 64) prof_acc[lane] = 0;
+  dmw::sync_mem();
+#else
+  long long* prof_acc = nullptr;
+#endif
   slot_rollout<Real, NARROW_ROWS>(*Mp, B, u.sh, tb, u.one.s, u.one.x, env, lane, live, action, obs, reward, done, n_substeps, T, [&](int t) {
     if (!pa.P) return;
     dmp::PolicyArgs p = pa;
@@ -159,9 +166,13 @@ __global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __r
     dmw::sync();
     dmp::policy_wave4<Real>(p, envs, wr, lane, reinterpret_cast<char*>(&u.sh[0]), (unsigned)sizeof(SlotShared<Real>), (unsigned)(offsetof(SlotShared<Real>, qpos) + 7 * sizeof(Real)),
                             (unsigned)(offsetof(SlotShared<Real>, qvel) + 6 * sizeof(Real)), (unsigned)offsetof(SlotShared<Real>, r1));
-  });
+  }, prof_acc);
   // diagnostic (DM option 101): shader-clock cycles this wave spent on its horizon, slot 5 ("total") of workgroup w's profile record
+#ifdef DM_ROLLOUT_PROF
+  if (prof_acc && lane == 0) prof_acc[31] = dmw::clk() - t_enter;        // (this build: per-stage sums in [0..30] of the wave's first record, the horizon's total in [31])
+#else
   if (wave_clk && lane == 0) wave_clk[(size_t)blockIdx.x * dm::PROF_SLOTS + 5] = dmw::clk() - t_enter;
+#endif
 }
 // the same with shader-clock stamps per stage, one record of 16 per wave (DM option 101 with option 105; diagnostic)
 __global__ __launch_bounds__(64) void k_step_packed_prof(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
@@ -691,8 +702,8 @@ extern "C" int dm_batch_rollout(dm_batch* b, double* action, double* obs, double
   const size_t n = (size_t)b->n;
   // ONE launch for the horizon where that wins (measured, profiles/r03_bench_*): batches with constraint rows of up to two packed waves per
   // SIMD (8 192 envs on an MI355X; at 4 096 envs 17.3 M env-steps/s against 12.2 M for the one-env steps and 11.4 M for the packed ones).
-  // Larger batches keep several rounds of waves busy anyway and gain more from the per-step dispatch order, which puts environments with
-  // similar row counts into one wave (16 384 envs: 19.5 M per step, ~17 M per horizon); without rows there is no slow wave to wait for.
+  // Larger batches run several rounds of waves per step, which balances the slow waves by itself, while a horizon launch has its own
+  // end-of-horizon tail (16 384 envs: 19.5 M per step, ~17 M per horizon); without rows there is no slow wave to wait for.
   const int simds = b->resident_waves / DM_STEP_WAVES;
   const bool use_packed = b->packed && b->B.reward_mode <= 3 && b->two_tier &&     // (with option 101 the horizon launch records every wave's cycles)
                           (b->horizon_mode == 1 || (b->horizon_mode < 0 && b->has_rows && b->n <= 2 * SLOTS * simds));

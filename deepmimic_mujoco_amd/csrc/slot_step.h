@@ -354,10 +354,21 @@ DM_DEV_CALL64 bool slot_env_step_call(const DevModel<R>* M, const Batch<R>* B, S
   return slot_env_step<R>(*in_constant(M), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
                           in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0);
 }
+#ifdef DM_ROLLOUT_PROF     // diagnostic build (tools/profile_horizon.py): the step with per-stage shader-clock stamps, one 32-counter record per call
+template <class R>
+DM_DEV_CALL64 bool slot_env_step_call_prof(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
+                                           const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, long long* prof_out) {
+  using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global; using dmw::in_constant;
+  const Batch<R> Bv = *in_constant(B);
+  return slot_env_step<R, true>(*in_constant(M), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
+                                in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0,
+                                in_global(uniform_ptr(prof_out)));
+}
+#endif
 template <class R, int NR, class POLICY>
 DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<R>* sh, SlotTables& tb, Shared<R>& one_s, StepScratch<R>& one_x,
                          int env, int lane, bool live, const double* action, double* obs, double* reward, unsigned char* done,
-                         int n_substeps, int T, POLICY&& policy) {
+                         int n_substeps, int T, POLICY&& policy, long long* prof_acc = 0) {
   const int slot = lane >> 4, sl = lane & 15;
   const size_t n = (size_t)B.n_envs;
   for (int t = 0; t < T; t++) {
@@ -367,7 +378,15 @@ DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<
     double* o_t = obs + (size_t)t * n * NOBS;
     double* r_t = reward + (size_t)t * n;
     unsigned char* d_t = done + (size_t)t * n;
+#ifdef DM_ROLLOUT_PROF
+    bool stored;
+    if (prof_acc) {        // [0..31] sums over the horizon's steps, [32..63] the record of the step just taken
+      stored = slot_env_step_call_prof<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, prof_acc + 32);
+      if (lane == 0) for (int k = 0; k < 31; k++) prof_acc[k] += prof_acc[32 + k];
+    } else stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps);
+#else
     const bool stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps);
+#endif
     const int need = (live && !stored) ? 1 : 0;
     bool any = false;
     for (int k = 0; k < SLOTS; k++) {
