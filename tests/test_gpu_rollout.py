@@ -246,7 +246,7 @@ def test_pipelined_rollouts_equal_the_same_batches_stepped_one_after_the_other()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [["--workload", "cfg4"], ["--workload", "cfg5"], ["--workload", "cfg2", "--pipeline", "1"], ["--dtype", "32"]])
+@pytest.mark.parametrize("extra", [["--workload", "cfg4"], ["--workload", "cfg5"], ["--workload", "cfg2", "--pipeline", "1"], ["--dtype", "32"], ["--horizon-launch"]])
 def test_bench_other_workloads_print_the_contract_line(extra):
     """The single-shard lines of BASELINE.json configs[3] / [4] ('spinkick', 'dance_b'; an interior shard's global env ids), configs[1]
     and the float32 build go through the same code path and print the same contract line."""
@@ -264,7 +264,14 @@ def test_bench_other_workloads_print_the_contract_line(extra):
     if wl in ("cfg4", "cfg5"):
         assert "shard 3 of 8" in j["config"]["workload"] and j["config"]["global_envs"] == 8 * 768
     assert j["dtype"] == ("f32" if "--dtype" in extra else "f64")
+    if "--horizon-launch" in extra:          # the timed leg itself goes through dm_batch_rollout: one launch for the 24 steps
+        assert j["roofline"]["kernel"] == "k_rollout_packed" and j["roofline"]["launch"]["steps_per_launch"] == 24 and j["horizon_launch"] is None
+        return
     assert j["roofline"]["launch"]["launches_per_step"] == (1 if "--pipeline" in extra else 2)
+    hl = j["horizon_launch"]                 # the second leg: whole 256-step horizons of the same workload through dm_batch_rollout
+    assert (hl is None) == ("--dtype" in extra)
+    if hl is not None:
+        assert hl["steps"] == 256 and hl["value"] > 1e5 and hl["unit"] == "env-steps/s"
 
 
 @pytest.mark.gpu
