@@ -18,6 +18,12 @@ default; `gloo` stages the block through pinned host memory and exists so that t
 only one GPU is visible) — asynchronously, double-buffered, so the envs keep stepping while the block travels; every gather
 completes inside the timed region.  Prints ONE JSON line (rank 0).
 
+After the timed steps every step workload times a second leg, reported as `horizon_launch` in the same line: the timed window rounded up to
+whole 256-step horizons of the same workload and state stream through `dm_batch_rollout` — T steps per call, on the packed path ONE launch
+in which every wavefront steps its four environments T times at its own pace (same barriers, max over ranks; results bit-identical to the
+per-step calls).  `value` stays the one-call-per-step figure, the drop-in for `VecEnv.step`; `--horizon-launch` makes the rollout call the
+timed leg itself (with the live PMC passes of its kernel).
+
 Besides the contract fields the line carries (N = 1): `roofline` (HBM fraction from the algorithmic bytes; fp64 fraction from
 a flop count of the kernel's algorithm evaluated on the run's own row / sweep statistics; with rocprofv3 on PATH, live PMC
 passes of this very workload: HBM traffic, VALU issue fraction, lane efficiency), `cpu_baseline` (the oracle on the host
