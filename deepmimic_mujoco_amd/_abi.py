@@ -8,13 +8,17 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NBODY, NJNT, NQ, NV, NU, NGEOM, NOBS, MAXEFC = 14, 29, 35, 34, 28, 16, 56, 64
 DEBUG_DOUBLES = 34 * 34 + 34 * 3 + 42 + 3 + MAXEFC * (34 + 6)
 PTR_HOST, PTR_DEVICE = 0, 1
 FLAG_NO_CONTACT, FLAG_NO_LIMIT = 1, 2
 OPT_REWARD_MODE, OPT_AUTORESET, OPT_ACTION_MODE, OPT_SEED, OPT_DIAGNOSTICS, OPT_PIPELINE, OPT_PACKED, OPT_ENV_OFFSET = 1, 2, 3, 4, 5, 6, 7, 100
+OPT_STEP_QUEUE = 8
 MAX_PIPELINE = 8
+MAX_STEP_QUEUE = 256
+# per-environment capacities of the OPT_PACKED path (include/dmenv.h DM_PACKED_*)
+PACKED_MAXROWS, PACKED_MAXLIMROWS, PACKED_MAXCON, PACKED_MAXFRAME, PACKED_MAXCAND = 32, 16, 13, 8, 32
 (F_QPOS, F_QVEL, F_QACC_WARMSTART, F_TIME, F_FRAME_IDX, F_FRAME_INIT, F_XIPOS, F_COM_Z, F_NCON, F_NEFC,
  F_CONTACT_GEOMS, F_STATUS, F_SOLVER_ITER, F_CTRL, F_EPISODE, F_CYCLE) = range(1, 17)
 
@@ -90,7 +94,7 @@ LIB_PATH = os.environ.get("DMENV_LIB") or os.path.join(_HERE, "csrc", "libdmenv.
 EXPORTS = ["dm_model_create", "dm_model_destroy", "dm_mocap_create", "dm_mocap_set_imitation", "dm_mocap_destroy", "dm_batch_create",
            "dm_batch_destroy", "dm_batch_set_stream", "dm_batch_set_option", "dm_batch_set_state", "dm_batch_reset",
            "dm_batch_step", "dm_batch_get_obs", "dm_batch_get", "dm_batch_set", "dm_batch_debug_forward",
-           "dm_batch_last_step_ms", "dm_batch_enable_timing", "dm_batch_read_profile", "dm_batch_sync", "dm_batch_join", "dm_policy_weight_count", "dm_policy_act", "dm_batch_step_act", "dm_batch_rollout", "dm_vf_param_count", "dm_vf_scratch_bytes", "dm_vf_fit_epoch", "dm_pg_param_count", "dm_pg_scratch_bytes", "dm_pg_losses", "dm_pg_fvp", "dm_batch_redo_total", "dm_gae", "dm_last_error", "dm_abi_version", "dm_real_bits",
+           "dm_batch_last_step_ms", "dm_batch_enable_timing", "dm_batch_read_profile", "dm_batch_sync", "dm_batch_join", "dm_policy_weight_count", "dm_policy_act", "dm_batch_step_act", "dm_batch_rollout", "dm_vf_param_count", "dm_vf_scratch_bytes", "dm_vf_fit_epoch", "dm_pg_param_count", "dm_pg_scratch_bytes", "dm_pg_losses", "dm_pg_fvp", "dm_batch_redo_total", "dm_batch_queue_stats", "dm_gae", "dm_last_error", "dm_abi_version", "dm_real_bits",
            "dm_device_count"]
 _LIB = None
 
@@ -140,6 +144,7 @@ def load(dtype=64):
     L.dm_policy_act.argtypes = [vp, vp, vp, vp, i32, i32, C.c_uint64, C.c_uint64, vp]
     L.dm_vf_scratch_bytes.argtypes = [i32, i32]; L.dm_vf_scratch_bytes.restype = C.c_size_t
     L.dm_batch_redo_total.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.dm_batch_queue_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.dm_pg_scratch_bytes.argtypes = []; L.dm_pg_scratch_bytes.restype = C.c_size_t
     L.dm_pg_losses.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]
     L.dm_pg_fvp.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]

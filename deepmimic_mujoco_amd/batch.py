@@ -79,9 +79,19 @@ class Batch(object):
             raise ValueError("array must be C-contiguous %s of shape %s" % (np.dtype(dtype), shape))
         return C.c_void_p(a.ctypes.data), A.PTR_HOST, a
 
+    _queue_refs = None
+
     def set_option(self, opt, value):
         A.check(self._L.dm_batch_set_option(self._h, int(opt), int(value)), self._L)
         self.__dict__.setdefault("options", {})[int(opt)] = int(value)
+        if int(opt) == A.OPT_STEP_QUEUE:
+            self._queue_refs = [] if int(value) > 0 else None
+
+    def queue_stats(self):
+        """OPT_STEP_QUEUE: (horizon launches issued for queued steps, steps they carried, steps queued now)"""
+        v = (C.c_int64 * 3)()
+        A.check(self._L.dm_batch_queue_stats(self._h, v), self._L)
+        return int(v[0]), int(v[1]), int(v[2])
 
     @property
     def can_step_act(self):
@@ -100,7 +110,7 @@ class Batch(object):
 
     def enable_auto_packed(self, on=True):
         """Let the batch choose between one and four environments per wavefront (DM_OPT_PACKED) from what it is simulating: the packed
-        kernel is 1.4-1.5x faster while environments stay within its per-env capacities (32 rows, 10 contacts), but every environment
+        kernel is 1.4-1.5x faster while environments stay within its per-env capacities (_abi.PACKED_*: 32 rows, 13 contacts), but every environment
         beyond them is re-stepped one per wave AFTER the packed launch — with a policy that stands on both feet (32+ rows most of the
         time) that tail costs more than the packing saves.  Every ADAPT_EVERY steps the redo rate (packed) or the largest row count
         (one-env) of the batch decides; the choice is a deterministic function of the trajectory."""
@@ -144,6 +154,11 @@ class Batch(object):
         if not (kind == k1 == k2 == k3):
             raise ValueError("action and output buffers must all be host arrays or all be device tensors")
         A.check(self._L.dm_batch_step(self._h, ap, op, rp, dp, int(n_substeps), kind), self._L)
+        if self._queue_refs is not None and kind == A.PTR_DEVICE:
+            # OPT_STEP_QUEUE: the call may only have been queued — its tensors must outlive the flush (any other entry point of the batch)
+            self._queue_refs.append((action, obs, rew, done))
+            if len(self._queue_refs) > 2 * A.MAX_STEP_QUEUE:
+                del self._queue_refs[:A.MAX_STEP_QUEUE]      # (older than any step that can still be queued)
         return obs, rew, done
 
     def step_act(self, action, n_substeps, out, weights, next_action, next_vpred, stochastic, seed, counter):
@@ -255,15 +270,18 @@ class Batch(object):
         return self.redo_reasons()[0]
 
     def redo_reasons(self):
-        """[total, > 16 candidate pairs, box slots, > 8 contacts, > 32 rows, PGS cost test] env-steps handed to the one-env kernel"""
+        """[total, then by reason: > PACKED_MAXCAND pairs past the bounding spheres, box staging slots, > PACKED_MAXCON contacts (or > PACKED_MAXFRAME
+        contact pairs), > PACKED_MAXROWS rows (or > PACKED_MAXLIMROWS limits), PGS cost test] env-steps handed to the one-env code (_abi.PACKED_*)"""
         v = (C.c_int64 * 8)()
         A.check(self._L.dm_batch_redo_total(self._h, v), self._L)
         return [int(x) for x in v[:6]]
 
     def sync(self):
         A.check(self._L.dm_batch_sync(self._h), self._L)
+        if self._queue_refs:
+            del self._queue_refs[:]
 
     def join(self):
-        """Pipelined sub-batches (OPT_PIPELINE > 1): make the batch's stream wait for every step launch still in flight, without
-        a host wait.  Call before consuming the outputs of pipelined `step` calls on that stream."""
+        """Run the steps OPT_STEP_QUEUE has queued and make the batch's stream wait for every pipelined step launch still in flight
+        (OPT_PIPELINE > 1), without a host wait.  Call before consuming the outputs of queued / pipelined `step` calls on that stream."""
         A.check(self._L.dm_batch_join(self._h), self._L)

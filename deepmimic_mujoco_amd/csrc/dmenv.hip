@@ -22,6 +22,8 @@
 #include "model_host.h"
 
 using namespace dm;
+static_assert(DM_PACKED_MAXROWS == SLOT_MAXROWS && DM_PACKED_MAXLIMROWS == SLOT_MAXLIMROWS && DM_PACKED_MAXCON == SLOT_MAXCON && DM_PACKED_MAXFRAME == SLOT_MAXFRAME &&
+              DM_PACKED_MAXCAND == SLOT_MAXCAND, "include/dmenv.h documents the packed path's capacities: keep it in step with slot_kernel.h");
 // Arithmetic / device-state type of this build: float64 (libdmenv.so, the parity build) or float32 (libdmenv32.so, -DDM_REAL_FLOAT:
 // the `dtype 32` batch of SURVEY.md section 8b — same kernels, half the registers and LDS per env).  Everything that crosses the
 // C ABI (actions, observations, rewards, field reads / writes, mocap tables) stays float64 (`Ext`) in both builds.
@@ -129,12 +131,21 @@ __global__ __launch_bounds__(64) void k_step_packed_act(const DevModel<Real>* __
 }
 // the batch descriptor into device memory, stream-ordered before the horizon launch that reads it there
 __global__ void k_put_batch(Batch<Real> B, Batch<Real>* __restrict__ dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = B; }
+// the horizon's table of per-step buffers (slot_step.h StepRow), stream-ordered before the launch that reads it: rows of the caller's
+// [T, N, .] tensors (dm_batch_rollout) ...
+__global__ void k_fill_rows(StepRow* __restrict__ dst, const Ext* action, Ext* obs, Ext* reward, unsigned char* done, int T, size_t n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < T) dst[t] = StepRow{action + (size_t)t * n * NU, obs + (size_t)t * n * NOBS, reward + (size_t)t * n, done + (size_t)t * n};
+}
+// ... or the buffers of queued dm_batch_step calls (DM_OPT_STEP_QUEUE), a chunk of them per launch in the kernel-argument segment
+constexpr int ROW_CHUNK = 64;
+struct StepRowChunk { StepRow r[ROW_CHUNK]; };
+__global__ void k_put_rows(StepRowChunk c, StepRow* __restrict__ dst, int count) { const int t = threadIdx.x; if (t < count) dst[t] = c.r[t]; }
 // A whole horizon of T steps in ONE launch (dm_batch_rollout; slot_step.h slot_rollout): every wave steps its four environments T times
 // without waiting for any other wave — optionally with the policy's step in between (pa.P; pa.action = the [T + 1, N, 28] action rows,
 // pa.vpred = the [T, N] value rows, pa.counter = the first step's draw counter) — and re-steps an environment that exceeds a capacity of
 // the packed path itself, with the one-env code, in the LDS the slots leave free between two steps.
-__global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __restrict__ Mp, const Batch<Real>* __restrict__ Bp, const Ext* action,
-                                                       Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
+__global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __restrict__ Mp, const Batch<Real>* __restrict__ Bp, const StepRow* __restrict__ rows,
                                                        int n_substeps, int first, int count, int T, dmp::PolicyArgs pa, long long* __restrict__ wave_clk) {
   __shared__ SlotOrOne<Real> u;
   __shared__ SlotTables tb;
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __r
 #else
   long long* prof_acc = nullptr;
 #endif
-  slot_rollout<Real, NARROW_ROWS>(*Mp, B, u.sh, tb, u.one.s, u.one.x, env, lane, live, action, obs, reward, done, n_substeps, T, [&](int t) {
+  slot_rollout<Real, NARROW_ROWS>(*Mp, B, u.sh, tb, u.one.s, u.one.x, env, lane, live, rows, n_substeps, T, [&](int t) {
     if (!pa.P) return;
     dmp::PolicyArgs p = pa;
     p.action = pa.action + (size_t)(t + 1) * n * NU; p.vpred = pa.vpred + (size_t)t * n; p.counter = pa.counter + (unsigned long long)t;
@@ -364,6 +375,9 @@ struct dm_batch {
   long long* d_prof = nullptr; bool prof = false;
   int redo_phase = 0;    // which of a sub-batch's two redo counters the next packed launch counts into
   int redo_mode = -1;    // 1 / 0: the last packed step was / was not pipelined (the counter pairs are re-zeroed when that changes)
+  // DM_OPT_STEP_QUEUE: dm_batch_step calls with device pointers are queued (nothing is launched) and executed together — one horizon launch,
+  // every wave at its own pace — when the queue is full or any other entry point of the batch is called (dm_batch_join, ...)
+  int queue_cap = 0; std::vector<StepRow> q; int q_nsub = 1; StepRow* d_rows = nullptr; int rows_cap = 0; long long queue_flushes = 0, queue_steps = 0;
   int horizon_mode = -1; // option 106: dm_batch_rollout on the packed path as ONE launch per horizon (1), as step launches (0), by batch size (-1, default)
   bool packed = false;   // option 105: four environments per wavefront (k_step_packed) where that kernel covers the configuration
   bool two_tier = true, reorder = true, has_rows = true; int resident_waves = 2048;   // CUs x 8 single-wave workgroups (LDS-limited)
@@ -377,6 +391,13 @@ static int pipe_join(dm_batch* b) {
   for (int h = 0; h < b->pipe; h++) if (hipStreamWaitEvent(b->stream, b->ev_done[h], 0) != hipSuccess) return DM_EHIP;
   b->pipe_pending = false;
   return DM_OK;
+}
+
+static int flush_queue(dm_batch* b);
+// what every entry point other than a queued dm_batch_step does first: run the queued steps, then make the batch's stream wait for the sub-batch launches
+static int settle(dm_batch* b) {
+  if (!b->q.empty()) { const int rc = flush_queue(b); if (rc != DM_OK) return rc; }
+  return pipe_join(b);
 }
 
 extern "C" const char* dm_last_error(void) { return g_err.c_str(); }
@@ -419,13 +440,14 @@ template <class T> static hipError_t dalloc(T** p, size_t n) { hipError_t e = hi
 extern "C" void dm_batch_destroy(dm_batch* b) {
   if (!b) return;
   hipSetDevice(b->device);
+  b->q.clear();          // queued steps are dropped, not run: their buffers belong to the caller and may be gone
   pipe_join(b);
   if (b->stream) hipStreamSynchronize(b->stream);
   for (int h = 0; h < DM_MAX_PIPELINE; h++) { if (b->ps[h]) hipStreamDestroy(b->ps[h]); if (b->ev_done[h]) hipEventDestroy(b->ev_done[h]); }
   if (b->ev_in) hipEventDestroy(b->ev_in);
   void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
                   b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
-                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order, b->B.kin, b->B.kin_ok, b->B.redo_list, b->B.redo_count, b->B.redo_why, b->d_B};
+                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order, b->B.kin, b->B.kin_ok, b->B.redo_list, b->B.redo_count, b->B.redo_why, b->d_B, b->d_rows};
   for (void* p : ptrs) if (p) hipFree(p);
   if (b->h_out) hipHostFree(b->h_out);
   if (b->h_action) hipHostFree(b->h_action);
@@ -493,7 +515,6 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   if (!ok) { dm_batch_destroy(b); return fail(DM_EHIP, "dm_batch_create: upload failed"); }
   b->B.mocap_cfg = b->d_cfg; b->B.mocap_vel = b->d_vel; b->B.mocap_dt = mc->dt; b->B.n_frames = mc->n_frames; b->B.n_envs = n; b->B.env_offset = 0;
   b->B.reward_mode = 0; b->B.autoreset = 0; b->B.action_mode = 0; b->B.seed = 0; b->B.diag = 1;
-  { const char* ev = getenv("DMENV_PACKED"); if (ev) b->packed = atoi(ev) != 0; }     // default of option 105 (test / A-B hook)
   hipEventCreate(&b->ev0); hipEventCreate(&b->ev1);
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) == hipSuccess && cus > 0) b->resident_waves = cus * 4 * DM_STEP_WAVES; }
   *out = b;
@@ -502,7 +523,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
 
 extern "C" int dm_batch_set_stream(dm_batch* b, void* s) {
   if (!b) return fail(DM_EINVAL, "null batch");
-  pipe_join(b);
+  if (settle(b)) return fail(DM_EHIP, "dm_batch_set_stream: flushing the step queue failed");
   hipStreamSynchronize(b->stream);   /* keep ordering with work already queued on the previous stream */
   if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
   b->stream = (hipStream_t)s; b->own_stream = false;
@@ -511,7 +532,11 @@ extern "C" int dm_batch_set_stream(dm_batch* b, void* s) {
 
 extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
   if (!b) return fail(DM_EINVAL, "null batch");
+  if (!b->q.empty()) { HIPCHK(hipSetDevice(b->device)); const int rc = flush_queue(b); if (rc != DM_OK) return rc; }   /* queued steps ran under the old options */
   switch (opt) {
+    case DM_OPT_STEP_QUEUE:
+      if (v < 0 || v > DM_MAX_STEP_QUEUE) return fail(DM_EINVAL, "step queue depth must be 0..DM_MAX_STEP_QUEUE");
+      b->queue_cap = (int)v; break;
     case DM_OPT_REWARD_MODE:
       if (v < 0 || v > 4) return fail(DM_EINVAL, "reward mode must be 0..4");
       if (v >= 3 && !b->d_imit) return fail(DM_EINVAL, "reward modes 3 and 4 need dm_mocap_set_imitation() before dm_batch_create()");
@@ -523,7 +548,7 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
     case DM_OPT_PIPELINE: {
       if (v < 1 || v > DM_MAX_PIPELINE) return fail(DM_EINVAL, "pipeline depth must be 1..DM_MAX_PIPELINE");
       HIPCHK(hipSetDevice(b->device));
-      if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+      if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
       for (int h = 0; h < (int)v && v > 1; h++) {
         if (!b->ps[h]) HIPCHK(hipStreamCreateWithFlags(&b->ps[h], hipStreamNonBlocking));
         if (!b->ev_done[h]) HIPCHK(hipEventCreateWithFlags(&b->ev_done[h], hipEventDisableTiming));
@@ -531,6 +556,8 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
       if (v > 1 && !b->ev_in) HIPCHK(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
       b->pipe = (int)v;
       b->B.order = nullptr;   /* the stored dispatch order belongs to the previous partition: identity for the next launch */
+      b->redo_mode = -1;      /* sub-batches beyond the new depth keep whatever their redo counters last held: the next packed step re-zeroes all
+                                 2 * DM_MAX_PIPELINE counters and restarts the phase (everything in flight was joined above) */
       break;
     }
     case 106: b->horizon_mode = v < 0 ? -1 : (v != 0 ? 1 : 0); break;   /* dm_batch_rollout on the packed path: 1 one launch per horizon, 0 step launches, -1 (default) by batch size */
@@ -564,7 +591,7 @@ static int stage_in(dm_batch* b, void* dst, const void* src, size_t bytes, int k
 extern "C" int dm_batch_set_state(dm_batch* b, const double* qpos, const double* qvel, const int32_t* fidx, const uint8_t* mask, int32_t kind) {
   if (!b || !qpos || !qvel) return fail(DM_EINVAL, "dm_batch_set_state: null argument");
   HIPCHK(hipSetDevice(b->device));
-  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
   const void *q, *v, *f, *mk; int rc;
   if ((rc = stage_in(b, b->d_qpos_in, qpos, (size_t)b->n * NQ * 8, kind, &q))) return rc;
   if ((rc = stage_in(b, b->d_qvel_in, qvel, (size_t)b->n * NV * 8, kind, &v))) return rc;
@@ -580,7 +607,7 @@ extern "C" int dm_batch_set_state(dm_batch* b, const double* qpos, const double*
 extern "C" int dm_batch_reset(dm_batch* b, int32_t mode, int32_t hard, const uint8_t* mask, int32_t kind) {
   if (!b || mode < 0 || mode > 2) return fail(DM_EINVAL, "dm_batch_reset: bad argument");
   HIPCHK(hipSetDevice(b->device));
-  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
   const void* mk; int rc;
   if ((rc = stage_in(b, b->d_mask, mask, (size_t)b->n, kind, &mk))) return rc;
   HIPCHK(hipMemsetAsync(b->B.kin_ok, 0, (size_t)b->n, b->stream));
@@ -590,10 +617,85 @@ extern "C" int dm_batch_reset(dm_batch* b, int32_t mode, int32_t hard, const uin
   return DM_OK;
 }
 
+// the packed path covers this batch's configuration (reward modes alive / v3-config / v2-pose / imitation, the two-tier kernel family)
+static bool packed_covers(const dm_batch* b) { return b->packed && b->B.reward_mode <= 3 && b->two_tier; }
+// a dm_batch_step call may be queued: device pointers, no fused policy step, no profiling / timing, and a configuration for which ONE launch
+// per horizon is the faster form (rollout_as_one_launch)
+static bool rollout_as_one_launch(const dm_batch* b) {
+  // ONE launch for the horizon where that wins (measured, profiles/r03_bench_*): batches with constraint rows of up to two packed waves per
+  // SIMD (8 192 envs on an MI355X; at 4 096 envs 17.3 M env-steps/s against 12.2 M for the one-env steps and 11.4 M for the packed ones).
+  // Larger batches run several rounds of waves per step, which balances the slow waves by itself, while a horizon launch has its own
+  // end-of-horizon tail (16 384 envs: 19.5 M per step, ~17 M per horizon); without rows there is no slow wave to wait for.
+  const int simds = b->resident_waves / DM_STEP_WAVES;
+  return packed_covers(b) && (b->horizon_mode == 1 || (b->horizon_mode < 0 && b->has_rows && b->n <= 2 * SLOTS * simds));
+}
+static bool can_queue(const dm_batch* b, int kind, const dmp::PolicyArgs* pol) {
+  return kind == DM_PTR_DEVICE && !pol && !b->timing && !b->prof && rollout_as_one_launch(b);
+}
+static int ensure_rows(dm_batch* b, int T) {
+  if (T <= b->rows_cap) return DM_OK;
+  HIPCHK(hipStreamSynchronize(b->stream));            // (a launch still reading the old table)
+  if (b->d_rows) HIPCHK(hipFree(b->d_rows));
+  b->d_rows = nullptr; b->rows_cap = 0;
+  const int cap = (T + 255) / 256 * 256;
+  HIPCHK(hipMalloc((void**)&b->d_rows, (size_t)cap * sizeof(StepRow)));
+  b->rows_cap = cap;
+  return DM_OK;
+}
+// T steps of every environment in ONE launch (k_rollout_packed) on the batch's stream; b->d_rows[0 .. T) has been written on that stream
+static int launch_horizon(dm_batch* b, int T, int nsub, const dmp::PolicyArgs& pa) {
+  hipLaunchKernelGGL(k_put_batch, dim3(1), dim3(64), 0, b->stream, b->B, b->d_B);
+  if (b->timing) HIPCHK(hipEventRecord(b->ev0, b->stream));
+  hipLaunchKernelGGL(k_rollout_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, (const Batch<Real>*)b->d_B, (const StepRow*)b->d_rows, (int)nsub, 0, b->n, (int)T, pa, b->prof ? b->d_prof : (long long*)nullptr);
+  if (b->timing) { HIPCHK(hipEventRecord(b->ev1, b->stream)); b->ev_pending = true; }
+  // dispatch order for the next launch: environments with similar row counts share a wave (and, for per-step launches, longest first)
+  if (b->reorder && b->has_rows) {
+    const int parts = b->pipe > 1 ? b->pipe : 1;
+    for (int h = 0; h < parts; h++) {
+      const int lo = (int)((long long)b->n * h / parts), hi = (int)((long long)b->n * (h + 1) / parts);
+      if (hi > lo) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order, lo, hi - lo);
+    }
+    b->B.order = b->d_order;
+  }
+  HIPCHK(hipGetLastError());
+  return DM_OK;
+}
+static int flush_queue(dm_batch* b) {
+  const int T = (int)b->q.size();
+  if (T == 0) return DM_OK;
+  HIPCHK(hipSetDevice(b->device));
+  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  int rc = ensure_rows(b, T);
+  if (rc != DM_OK) return rc;
+  for (int t0 = 0; t0 < T; t0 += ROW_CHUNK) {
+    StepRowChunk c;
+    const int cnt = T - t0 < ROW_CHUNK ? T - t0 : ROW_CHUNK;
+    for (int k = 0; k < cnt; k++) c.r[k] = b->q[t0 + k];
+    for (int k = cnt; k < ROW_CHUNK; k++) c.r[k] = StepRow{nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(k_put_rows, dim3(1), dim3(ROW_CHUNK), 0, b->stream, c, b->d_rows + t0, cnt);
+  }
+  const int nsub = b->q_nsub;
+  b->q.clear();                                        // (before the launch: an error below must not leave the steps queued for a second run)
+  b->queue_flushes += 1; b->queue_steps += T;
+  const dmp::PolicyArgs nopol{nullptr, nullptr, nullptr, 0, 0ull, 0ull};
+  return launch_horizon(b, T, nsub, nopol);
+}
+
 static int step_impl(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t nsub, int32_t kind, const dmp::PolicyArgs* pol) {
   if (!b || !action || !obs || !reward || !done || nsub < 1) return fail(DM_EINVAL, "dm_batch_step: bad argument");
   if (pol && (kind != DM_PTR_DEVICE || b->prof || !b->two_tier)) return fail(DM_EINVAL, "dm_batch_step_act: device pointers, the two-tier kernel and no profiling");
   HIPCHK(hipSetDevice(b->device));
+  if (b->queue_cap > 0 && can_queue(b, kind, pol)) {
+    // DM_OPT_STEP_QUEUE: remember the call; the queued steps run as ONE horizon launch (flush_queue).  A call that names a buffer an
+    // earlier queued call names (the same action / output tensors step after step) runs that earlier call first: a caller that reuses
+    // buffers has, by the pipelined contract, joined in between and sees plain step-by-step behaviour.
+    bool reuse = nsub != b->q_nsub && !b->q.empty();
+    for (const StepRow& r : b->q) reuse = reuse || r.action == action || r.obs == obs || r.reward == reward || r.done == done;
+    if (reuse || (int)b->q.size() >= b->queue_cap) { const int rc = flush_queue(b); if (rc != DM_OK) return rc; }
+    b->q.push_back(StepRow{action, obs, reward, done}); b->q_nsub = nsub;
+    return DM_OK;
+  }
+  if (!b->q.empty()) { const int rc = flush_queue(b); if (rc != DM_OK) return rc; }
   const void* a = action;
   if (kind == DM_PTR_HOST) {
     memcpy(b->h_action, action, (size_t)b->n * NU * sizeof(Ext));
@@ -608,9 +710,10 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
   if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } if (!piped) HIPCHK(hipEventRecord(b->ev0, b->stream)); }
   const bool reorder = b->reorder && b->has_rows && b->n > b->resident_waves;   // more envs than resident waves: later rounds exist, their tail matters
   // the packed kernel covers: models without constraint rows, reward modes alive / v3-config / v2-pose, no fused policy step
-  const bool use_packed = b->packed && b->B.reward_mode <= 3 && !b->prof && b->two_tier;
+  const bool packed_step = b->packed && b->B.reward_mode <= 3 && b->two_tier;      // this call runs on the packed kernels (profiled or not)
+  const bool use_packed = packed_step && !b->prof;
   const dmp::PolicyArgs nopol{nullptr, nullptr, nullptr, 0, 0ull, 0ull};
-  if (use_packed || (b->prof && b->packed)) {
+  if (packed_step) {
     const int mode = piped ? 1 : 0;
     if (mode != b->redo_mode) {      // (rare: the first packed step, or a host-pointer step between pipelined ones; every earlier launch is ordered before this stream here)
       if (piped && pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
@@ -619,7 +722,7 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     }
   }
   constexpr int REDO_BLOCKS = 64;
-  if (b->prof && b->packed && b->B.reward_mode <= 3) {
+  if (b->prof && packed_step) {
     HIPCHK(hipMemsetAsync(b->d_prof, 0, (size_t)b->n * dm::PROF_SLOTS * sizeof(long long), b->stream));
     int* rc = b->B.redo_count + b->redo_phase; int* rn = b->B.redo_count + (1 - b->redo_phase);
     hipLaunchKernelGGL(k_step_packed_prof, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc, b->d_prof);
@@ -673,7 +776,7 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     }
   } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub);
   HIPCHK(hipGetLastError());
-  if (b->packed && b->B.reward_mode <= 3 && b->two_tier) b->redo_phase ^= 1;
+  if (packed_step) b->redo_phase ^= 1;
   if (b->timing && !piped) { HIPCHK(hipEventRecord(b->ev1, b->stream)); b->ev_pending = true; }
   if (kind == DM_PTR_HOST) {
     HIPCHK(hipMemcpyAsync(b->h_out, b->d_obs, b->out_bytes, hipMemcpyDeviceToHost, b->stream));
@@ -700,14 +803,9 @@ extern "C" int dm_batch_rollout(dm_batch* b, double* action, double* obs, double
   if (!b || !action || !obs || !reward || !done || T < 1 || nsub < 1) return fail(DM_EINVAL, "dm_batch_rollout: bad argument");
   if (weights && !vpred) return fail(DM_EINVAL, "dm_batch_rollout: a policy needs the value rows");
   const size_t n = (size_t)b->n;
-  // ONE launch for the horizon where that wins (measured, profiles/r03_bench_*): batches with constraint rows of up to two packed waves per
-  // SIMD (8 192 envs on an MI355X; at 4 096 envs 17.3 M env-steps/s against 12.2 M for the one-env steps and 11.4 M for the packed ones).
-  // Larger batches run several rounds of waves per step, which balances the slow waves by itself, while a horizon launch has its own
-  // end-of-horizon tail (16 384 envs: 19.5 M per step, ~17 M per horizon); without rows there is no slow wave to wait for.
-  const int simds = b->resident_waves / DM_STEP_WAVES;
-  const bool use_packed = b->packed && b->B.reward_mode <= 3 && b->two_tier &&     // (with option 101 the horizon launch records every wave's cycles)
-                          (b->horizon_mode == 1 || (b->horizon_mode < 0 && b->has_rows && b->n <= 2 * SLOTS * simds));
-  if (!use_packed) {
+  HIPCHK(hipSetDevice(b->device));
+  if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
+  if (!rollout_as_one_launch(b)) {        // (with option 101 the horizon launch records every wave's cycles)
     for (int t = 0; t < T; t++) {
       dmp::PolicyArgs pa{weights, action + (size_t)(t + 1) * n * NU, weights ? vpred + (size_t)t * n : nullptr, (int)stochastic, (unsigned long long)seed, (unsigned long long)counter + t};
       const int rc = step_impl(b, action + (size_t)t * n * NU, obs + (size_t)t * n * NOBS, reward + (size_t)t * n, done + (size_t)t * n, nsub, DM_PTR_DEVICE, weights ? &pa : nullptr);
@@ -715,28 +813,17 @@ extern "C" int dm_batch_rollout(dm_batch* b, double* action, double* obs, double
     }
     return DM_OK;
   }
-  HIPCHK(hipSetDevice(b->device));
-  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  const int rc = ensure_rows(b, (int)T);
+  if (rc != DM_OK) return rc;
+  hipLaunchKernelGGL(k_fill_rows, dim3(((int)T + 63) / 64), dim3(64), 0, b->stream, b->d_rows, (const Ext*)action, obs, reward, done, (int)T, n);
   dmp::PolicyArgs pa{weights, action, vpred, (int)stochastic, (unsigned long long)seed, (unsigned long long)counter};
-  hipLaunchKernelGGL(k_put_batch, dim3(1), dim3(64), 0, b->stream, b->B, b->d_B);
-  hipLaunchKernelGGL(k_rollout_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, (const Batch<Real>*)b->d_B, (const Ext*)action, obs, reward, done, (int)nsub, 0, b->n, (int)T, pa, b->prof ? b->d_prof : (long long*)nullptr);
-  // dispatch order for the next launch: environments with similar row counts share a wave (and, for per-step launches, longest first)
-  if (b->reorder && b->has_rows) {
-    const int parts = b->pipe > 1 ? b->pipe : 1;
-    for (int h = 0; h < parts; h++) {
-      const int lo = (int)((long long)b->n * h / parts), hi = (int)((long long)b->n * (h + 1) / parts);
-      if (hi > lo) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order, lo, hi - lo);
-    }
-    b->B.order = b->d_order;
-  }
-  HIPCHK(hipGetLastError());
-  return DM_OK;
+  return launch_horizon(b, (int)T, (int)nsub, pa);
 }
 
 extern "C" int dm_batch_get_obs(dm_batch* b, double* obs, int32_t kind) {
   if (!b || !obs) return fail(DM_EINVAL, "dm_batch_get_obs: null argument");
   HIPCHK(hipSetDevice(b->device));
-  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
   Ext* o = kind == DM_PTR_DEVICE ? obs : b->d_obs;
   const int tot = b->n * NOBS;
   hipLaunchKernelGGL(k_get_obs, dim3((tot + 255) / 256), dim3(256), 0, b->stream, b->B, o);
@@ -773,7 +860,7 @@ static int field_ptr(dm_batch* b, int field, void** p, size_t* count, bool* is_r
 extern "C" int dm_batch_get(dm_batch* b, int32_t field, void* out, size_t bytes, int32_t kind) {
   if (!b || !out) return fail(DM_EINVAL, "dm_batch_get: null argument");
   HIPCHK(hipSetDevice(b->device));
-  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
   void* p; size_t cnt; bool real; int rc;
   if ((rc = field_ptr(b, field, &p, &cnt, &real))) return rc;
   const size_t need = cnt * (real ? sizeof(Ext) : 4);
@@ -790,7 +877,7 @@ extern "C" int dm_batch_get(dm_batch* b, int32_t field, void* out, size_t bytes,
 extern "C" int dm_batch_set(dm_batch* b, int32_t field, const void* in, size_t bytes, int32_t kind) {
   if (!b || !in) return fail(DM_EINVAL, "dm_batch_set: null argument");
   HIPCHK(hipSetDevice(b->device));
-  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
   void* p; size_t cnt; bool real; int rc;
   if ((rc = field_ptr(b, field, &p, &cnt, &real))) return rc;
   const size_t need = cnt * (real ? sizeof(Ext) : 4);
@@ -811,7 +898,7 @@ extern "C" int dm_batch_set(dm_batch* b, int32_t field, const void* in, size_t b
 extern "C" int dm_batch_debug_forward(dm_batch* b, int32_t env, double* out_host) {
   if (!b || !out_host || env < 0 || env >= b->n) return fail(DM_EINVAL, "dm_batch_debug_forward: bad argument");
   HIPCHK(hipSetDevice(b->device));
-  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
   HIPCHK(hipMemsetAsync(b->d_debug, 0, DM_DEBUG_DOUBLES * 8, b->stream));
   hipLaunchKernelGGL(k_debug_forward, dim3(1), dim3(64), 0, b->stream, b->d_model, b->B, (int)env, b->d_debug);
   HIPCHK(hipGetLastError());
@@ -962,23 +1049,28 @@ extern "C" int dm_pg_fvp(const float* ob, int32_t stride, int32_t n, const float
 extern "C" int dm_batch_redo_total(dm_batch* b, int64_t* out) {
   if (!b || !out) return fail(DM_EINVAL, "dm_batch_redo_total: null argument");
   HIPCHK(hipSetDevice(b->device));
-  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
   int v[8] = {0};
   HIPCHK(hipMemcpyAsync(v, b->B.redo_why, sizeof v, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   for (int k = 0; k < 8; k++) out[k] = v[k];      /* [0] total; [1..5] by reason: candidates, box slots, contacts, rows, PGS cost test */
   return DM_OK;
 }
+extern "C" int dm_batch_queue_stats(dm_batch* b, int64_t* out) {
+  if (!b || !out) return fail(DM_EINVAL, "dm_batch_queue_stats: null argument");
+  out[0] = b->queue_flushes; out[1] = b->queue_steps; out[2] = (int64_t)b->q.size();
+  return DM_OK;
+}
 extern "C" int dm_batch_join(dm_batch* b) {
   if (!b) return fail(DM_EINVAL, "null batch");
   HIPCHK(hipSetDevice(b->device));
-  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
   return DM_OK;
 }
 extern "C" int dm_batch_sync(dm_batch* b) {
   if (!b) return fail(DM_EINVAL, "null batch");
   HIPCHK(hipSetDevice(b->device));
-  if (pipe_join(b)) return fail(DM_EHIP, "pipeline join failed");
+  if (settle(b)) return fail(DM_EHIP, "pipeline join failed");
   HIPCHK(hipStreamSynchronize(b->stream));
   return DM_OK;
 }

@@ -365,19 +365,22 @@ DM_DEV_CALL64 bool slot_env_step_call_prof(const DevModel<R>* M, const Batch<R>*
                                 in_global(uniform_ptr(prof_out)));
 }
 #endif
+// The buffers of ONE step of a horizon: what one dm_batch_step call names (action [N, 28] in; obs [N, 56], reward [N], done [N] out).  A horizon
+// launch reads a table of T of them — rows of the caller's [T, N, .] tensors (dm_batch_rollout) or the buffers of T queued dm_batch_step
+// calls (DM_OPT_STEP_QUEUE), which need not be strided.
+struct StepRow { const double* action; double* obs; double* reward; unsigned char* done; };
 template <class R, int NR, class POLICY>
 DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<R>* sh, SlotTables& tb, Shared<R>& one_s, StepScratch<R>& one_x,
-                         int env, int lane, bool live, const double* action, double* obs, double* reward, unsigned char* done,
-                         int n_substeps, int T, POLICY&& policy, long long* prof_acc = 0) {
+                         int env, int lane, bool live, const StepRow* rows, int n_substeps, int T, POLICY&& policy, long long* prof_acc = 0) {
   const int slot = lane >> 4, sl = lane & 15;
-  const size_t n = (size_t)B.n_envs;
   for (int t = 0; t < T; t++) {
     // (every step reads the model afresh: hoisting those loads out of the loop would keep hundreds of registers alive across it)
     const DevModel<R>& M = *dmw::launder_uniform_ptr(&M_in);
-    const double* a_t = action + (size_t)t * n * NU;
-    double* o_t = obs + (size_t)t * n * NOBS;
-    double* r_t = reward + (size_t)t * n;
-    unsigned char* d_t = done + (size_t)t * n;
+    const StepRow row = rows[t];                                     // (wave-uniform: four scalar loads)
+    const double* a_t = row.action;
+    double* o_t = row.obs;
+    double* r_t = row.reward;
+    unsigned char* d_t = row.done;
 #ifdef DM_ROLLOUT_PROF
     bool stored;
     if (prof_acc) {        // [0..31] sums over the horizon's steps, [32..63] the record of the step just taken

@@ -249,6 +249,34 @@ class DPEnv(object):
 PACKED_FROM_ENVS = 6144       # DPVecEnv(packed=None): batches of at least this many environments step four per wavefront
 
 
+class _Info(dict):
+    """An env's `info` dict that tells its list when something is written into it (so that the list is not rebuilt every step)."""
+    __slots__ = ("_owner",)
+
+    def _touch(self):
+        self._owner.dirty = True
+
+    def __setitem__(self, k, v):
+        self._touch(); dict.__setitem__(self, k, v)
+
+    def update(self, *a, **kw):
+        self._touch(); dict.update(self, *a, **kw)
+
+    def setdefault(self, k, d=None):
+        self._touch(); return dict.setdefault(self, k, d)
+
+    def __ior__(self, other):
+        self._touch(); dict.update(self, other); return self
+
+
+class _InfoList(list):
+    def __init__(self, n):
+        list.__init__(self, (_Info() for _ in range(n)))
+        self.dirty = False
+        for d in self:
+            d._owner = self
+
+
 class DPVecEnv(object):
     """N DeepMimic humanoids in lock step on one GPU (one wavefront per environment)."""
 
@@ -341,7 +369,17 @@ class DPVecEnv(object):
     def step_wait(self, out=None):
         obs, rew, done = self._batch.step(self._pending, self.frame_skip, out)
         self._pending = None
-        return obs, rew, done, [{} for _ in range(self.num_envs)]
+        if getattr(self._batch, "_queue_refs", None) is not None:
+            self._batch.join()      # OPT_STEP_QUEUE: the call was only queued, and what this method returns is read in stream order
+        # `infos`: one dict per env (src/utils/vec_env/dummy_vec_env.py:45-56).  This env never puts anything into them, so the list is
+        # built once and handed out again while every dict is still empty (building 4 096 dicts per step cost more than the step's
+        # launch); a caller that writes into one (bench/monitor.py:73-74 does, at episode ends) gets fresh dicts from the next step on.
+        infos = self._infos
+        if infos is None or infos.dirty:
+            infos = self._infos = _InfoList(self.num_envs)
+        return obs, rew, done, infos
+
+    _infos = None
 
     def step(self, actions, out=None):
         self.step_async(actions)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 3
+#define DM_ABI_VERSION 4
 
 /* fixed sizes of the DeepMimic humanoid (dp_env_v3.xml:21-156): the kernels are specialised to this tree */
 #define DM_NBODY 14
@@ -126,15 +126,37 @@ enum {
                              take the wave slots freed while the previous one drains.  The outputs of such calls are complete
                              once the caller's stream has joined: dm_batch_join() (no host wait), dm_batch_sync(), or any other
                              entry point of the batch.  Results are identical for every P. */
-  DM_OPT_PACKED = 7       /* 0 (default): one environment per wavefront (k_step_narrow).  1: FOUR environments per wavefront, one 16-lane
-                             DPP row each (k_step_packed, csrc/slot_kernel.h) wherever that kernel covers the call — reward modes 0..3, no
-                             fused policy step; an environment that exceeds its per-env capacities in a step (32 constraint rows, 10
-                             contacts, 32 pairs past the bounding spheres) is re-stepped by the one-env code in the same call.  The
-                             throughput kernel for batches of two or more waves per SIMD (>= 8192 envs on one MI355X): 1.4-1.5x; at 4096
-                             envs a launch is one round of lone waves and the one-env kernel stays ahead.  Results agree with the oracle to
-                             the same 1e-9 bar and do not depend on which environments share a wave; they differ from the one-env kernel's
-                             in the last bits (other summation orders). */
+  DM_OPT_PACKED = 7,      /* 0 (default): one environment per wavefront (k_step_narrow).  1: FOUR environments per wavefront, one 16-lane
+                             DPP row each (k_step_packed, csrc/slot_kernel.h) wherever that kernel covers the call: reward modes 0..3 (reward
+                             mode 4, v1-quat, always runs on the one-env kernel), with or without the fused policy step.  Per-environment
+                             capacities of that path (csrc/slot_kernel.h SLOT_*): DM_PACKED_MAXROWS constraint rows (of them at most
+                             DM_PACKED_MAXLIMROWS joint limits), DM_PACKED_MAXCON contacts from at most DM_PACKED_MAXFRAME geom pairs,
+                             DM_PACKED_MAXCAND pairs past the bounding spheres; an environment that exceeds one in some step is re-stepped
+                             by the one-env code in the same call (dm_batch_redo_total counts them).  The throughput kernel for batches
+                             of two or more waves per SIMD (>= 8192 envs on one MI355X): 1.4-1.5x; at 4096 envs a per-step launch is one
+                             round of lone waves and the one-env kernel stays ahead, while horizon launches (dm_batch_rollout,
+                             DM_OPT_STEP_QUEUE) use it at any size.  Results agree with the oracle to the same 1e-9 bar and do not depend
+                             on which environments share a wave; they differ from the one-env kernel's in the last bits (other
+                             summation orders). */
+  DM_OPT_STEP_QUEUE = 8   /* 0 (default): every dm_batch_step call launches.  Q = 1..DM_MAX_STEP_QUEUE: dm_batch_step calls with DEVICE
+                             pointers are QUEUED — nothing is launched — and run together, in call order, as one horizon launch
+                             (k_rollout_packed: every wavefront steps its four environments through all queued steps at its own pace
+                             instead of waiting for the slowest wave of every step) when Q calls are queued or when any other entry
+                             point of the batch is called: dm_batch_join() (no host wait), dm_batch_sync(), dm_batch_get(), ...  The
+                             contract is DM_OPT_PIPELINE's, extended to the inputs: the outputs of a queued call are complete once the
+                             caller's stream has joined, and its action buffer must stay untouched until then.  A call that names a
+                             buffer of a queued call (the same tensors step after step: a closed loop that joins every step) first runs
+                             what is queued, i.e. degenerates to one launch per call.  Results are bit-identical to unqueued DM_OPT_PACKED
+                             steps.  Queuing applies where dm_batch_rollout uses one launch per horizon (DM_OPT_PACKED on, reward modes
+                             0..3, constraint rows, at most two packed waves per SIMD); elsewhere calls launch at once as without it. */
 };
+/* per-environment capacities of the DM_OPT_PACKED path (= csrc/slot_kernel.h SLOT_MAXROWS, SLOT_MAXLIMROWS, SLOT_MAXCON, SLOT_MAXFRAME, SLOT_MAXCAND) */
+#define DM_PACKED_MAXROWS 32
+#define DM_PACKED_MAXLIMROWS 16
+#define DM_PACKED_MAXCON 13
+#define DM_PACKED_MAXFRAME 8
+#define DM_PACKED_MAXCAND 32
+#define DM_MAX_STEP_QUEUE 256
 #define DM_MAX_PIPELINE 8
 /* further option ids (diagnostics / tests; defaults are what the timed path uses):
  *   100 global id of env 0 of this batch (multi-GPU sharding: RNG streams are keyed by the global env id)
@@ -275,12 +297,15 @@ int dm_pg_losses(const float* ob, int32_t n, const float* ac, const float* atarg
 int dm_pg_fvp(const float* ob, int32_t stride, int32_t n, const float* theta, const float* v, const float* rms_mean, const float* rms_std,
               float* out_fv, void* scratch, void* hip_stream);
 
-/* Diagnostics of DM option 105 (four environments per wavefront, csrc/slot_kernel.h): env-steps so far that exceeded a capacity of that
- * path (> 32 constraint rows, > 8 contacts, > 16 pairs past the bounding spheres, a PGS step the cost test would reject) and were
- * re-stepped by the one-env kernel. */
-int dm_batch_redo_total(dm_batch* b, int64_t* out /* [8]: total, then by reason */);
+/* Diagnostics of DM_OPT_PACKED (four environments per wavefront, csrc/slot_kernel.h): env-steps so far that exceeded a capacity of that
+ * path (DM_PACKED_*: rows, contacts / contact pairs, pairs past the bounding spheres, box staging slots; or a PGS step the cost test would
+ * reject) and were re-stepped by the one-env code.  out[0] total; out[1..5] by reason: candidates, box slots, contacts, rows, PGS cost test. */
+int dm_batch_redo_total(dm_batch* b, int64_t* out /* [8] */);
+/* Diagnostics of DM_OPT_STEP_QUEUE: out[0] = horizon launches issued for queued steps so far, out[1] = steps they carried, out[2] = steps queued now. */
+int dm_batch_queue_stats(dm_batch* b, int64_t* out /* [3] */);
 int dm_batch_sync(dm_batch* b);
-/* Make the batch's stream wait (device-side, no host wait) for every pipelined sub-batch launch in flight (DM_OPT_PIPELINE). */
+/* Run what DM_OPT_STEP_QUEUE has queued and make the batch's stream wait (device-side, no host wait) for every pipelined sub-batch launch in
+ * flight (DM_OPT_PIPELINE): afterwards work enqueued on the batch's stream sees the outputs of every earlier dm_batch_step call. */
 int dm_batch_join(dm_batch* b);
 const char* dm_last_error(void);
 int dm_abi_version(void);

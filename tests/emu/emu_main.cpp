@@ -160,6 +160,8 @@ void emu_rollout(void* h, const double* action, double* obs, double* reward, uns
   EmuBatch* e = (EmuBatch*)h;
   const int n = e->B.n_envs;
   const int before = e->B.redo_why[0];
+  std::vector<StepRow> rows((size_t)T);               // the horizon's table of per-step buffers (k_fill_rows)
+  for (int t = 0; t < T; t++) rows[t] = StepRow{action + (size_t)t * n * NU, obs + (size_t)t * n * NOBS, reward + (size_t)t * n, done + (size_t)t * n};
   for (int first = 0; first < n; first += SLOTS)
     run_wave([&](int lane) {
       const int slot = lane >> 4;
@@ -167,7 +169,7 @@ void emu_rollout(void* h, const double* action, double* obs, double* reward, uns
       int pos = first + slot;
       const bool live = pos < n;
       if (!live) pos = n - 1;
-      slot_rollout<double, 32>(e->M, e->B, e->roll.sh, e->slot_tabs, e->roll.one.s, e->roll.one.x, pos, lane, live, action, obs, reward, done, nsub, T, [](int) {});
+      slot_rollout<double, 32>(e->M, e->B, e->roll.sh, e->slot_tabs, e->roll.one.s, e->roll.one.x, pos, lane, live, rows.data(), nsub, T, [](int) {});
     });
   e->redo_total += e->B.redo_why[0] - before;
 }
