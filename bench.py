@@ -331,6 +331,69 @@ def rollout_bench(args, dev, rank, world, local_dev):
                                                                            if env.packed else ("policy step fused into the env step kernel (one launch per step), %d pipelined sub-batch(es)" % P)), HORIZON)}}))
 
 
+def standing_bench(args, dev, rank, world, local_dev):
+    """`--workload standing`: the regime the reference's own trained policy lives in (src/checkpoint_tmp/DeepMimic/trpo-walk-0, a copy under
+    tests/golden/ckpt): the shipped 2x100 tanh policy in the loop (stochastic, as src/trpo.py:49 samples it), noisy-init resets as the trainer's
+    episode protocol (src/trpo.py:77-79), 256-step segments.  A population that stands on both feet holds 8 foot corners x 4 pyramid edges = 32
+    constraint rows most of the time — the packed kernels' two-row-set path, and beyond 32 rows their in-wave re-step.  Three legs on the same
+    protocol: the kernel choice left to the collector (what training gets), four environments per wavefront pinned, one per wavefront pinned."""
+    import torch
+    from deepmimic_mujoco_amd import DPVecEnv, MlpPolicy, _abi as A
+    from deepmimic_mujoco_amd.rollout import SegmentCollector
+    n = args.envs or 4096
+    clip = args.clip or "walk"
+    ckpt = os.path.join(ROOT, "tests", "golden", "ckpt", "trpo-walk-0")
+    segs = max(2, args.steps // HORIZON)
+    legs = {}
+    hist = np.zeros(65, dtype=np.int64)
+    for name, packed in (("auto", None), ("packed", True), ("one_env", False)):
+        pol = MlpPolicy.from_tf_checkpoint(ckpt, device=dev); pol.seed(rank)
+        env = DPVecEnv(n, motion=clip, device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n, packed=packed)
+        env.batch.set_option(A.OPT_PIPELINE, max(1, min(args.pipeline, A.MAX_PIPELINE)))
+        col = SegmentCollector(pol, env, HORIZON, True, None, "init", fused=True)
+
+        def next_seg():
+            col.launch()
+            return col.collect()
+        for _ in range(max(3, args.warmup // HORIZON)):          # the population settles into its steady mix of standing / falling / fresh episodes
+            next_seg()
+        r0 = env.batch.redo_total()
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        t0 = time.perf_counter()
+        eps = 0; lens = []
+        for _ in range(segs):
+            seg = next_seg()
+            eps += len(seg["ep_lens"]); lens += seg["ep_lens"]
+            if name == "auto":                                    # rows of every env's last evaluation, once per segment (one small D2H)
+                hist += np.bincount(np.minimum(env.batch.get(A.F_NEFC), 64), minlength=65)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        redo = env.batch.redo_total() - r0
+        legs[name] = {"value": round(world * n * segs * HORIZON / el, 1), "ms_per_step": round(el / (segs * HORIZON) * 1e3, 4), "episodes": eps,
+                      "mean_episode_length": round(float(np.mean(lens)), 1) if lens else None, "envs_per_wavefront_at_end": 4 if env.packed else 1,
+                      "env_steps_beyond_packed_capacity": redo, "redo_rate": round(redo / float(n * segs * HORIZON), 6)}
+        if name == "auto":
+            legs[name]["kernel_switches"] = col.kernel_switches
+        env.close()
+    if rank == 0:
+        tot = max(1, int(hist.sum()))
+        out = {"metric": "env-steps/sec, shipped policy in the loop (standing population)", "value": legs["auto"]["value"], "unit": "env-steps/s", "n_gpus": world,
+               "steps": segs * HORIZON, "warmup": max(3, args.warmup // HORIZON) * HORIZON, "ms_per_step": legs["auto"]["ms_per_step"], "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "standing: '%s' mocap, %d envs/GPU, full contact + joint-limit PGS solve, alive reward, the reference's shipped trpo-walk-0 policy "
+                                      "(stochastic) + value net inside the step kernels, noisy-init reset on done, %d-step segments (dm_batch_rollout)" % (clip, n, HORIZON),
+                          "envs_per_gpu": n, "clip": clip},
+               "legs": legs,
+               "packed_over_one_env": round(legs["packed"]["value"] / legs["one_env"]["value"], 3),
+               "rows_per_env_histogram": {"sampled": "nefc of every env's last evaluation at the end of each segment of the `auto` leg", "n": tot,
+                                          "frac_le_16": round(float(hist[:17].sum()) / tot, 4), "frac_17_32": round(float(hist[17:33].sum()) / tot, 4),
+                                          "frac_gt_32": round(float(hist[33:].sum()) / tot, 4), "mean": round(float((hist * np.arange(65)).sum()) / tot, 2)}}
+        print(json.dumps(out))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--_cpu-worker":
         return cpu_baseline_worker(sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5]))
@@ -339,7 +402,7 @@ def main():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's: 4096; cfg5 8192)")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "rollout"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "rollout", "standing"])
     ap.add_argument("--clip", default=None, help="override the workload's mocap clip")
     ap.add_argument("--reward", default="imitation", choices=["imitation", "v3-config", "alive"],
                     help="reward of the full-contact workloads: the 5-term DeepMimic imitation reward (default), dp_env_v3's config reward, or the constant 1.0")
@@ -358,6 +421,12 @@ def main():
     ap.add_argument("--horizon-launch", action="store_true",
                     help="step through dm_batch_rollout: up to one %d-step horizon of pre-drawn actions per call (on the packed path ONE launch in which every "
                          "wavefront runs its four environments through all steps at its own pace) instead of one dm_batch_step call per step; implies --packed 1 unless given" % HORIZON)
+    ap.add_argument("--step-queue", type=int, default=HORIZON,
+                    help="DM_OPT_STEP_QUEUE of the timed dm_batch_step calls: up to Q calls are queued and run as ONE horizon launch (every wavefront steps its "
+                         "four environments through the queued steps at its own pace) when the queue is full or the caller joins; implies four environments per "
+                         "wavefront.  0 = every call launches (rounds 1-3).  Applies to the full-contact workloads at up to 8192 envs per GPU")
+    ap.add_argument("--repeats", type=int, default=3, help="timed windows of --steps steps each; `value` is the median window, `value_spread` min / median / max")
+    ap.add_argument("--no-vecenv-leg", action="store_true", help="skip the leg that times the same steps through DPVecEnv.step, one launch per call")
     ap.add_argument("--no-horizon-leg", action="store_true", help="skip the second timed leg (the same steps through dm_batch_rollout, reported as `horizon_launch`)")
     ap.add_argument("--rollout-form", default="auto", choices=["auto", "launch", "steps"],
                     help="dm_batch_rollout on the packed path (DM option 106): one launch per call, the library's step launches, or chosen by batch size (default)")
@@ -403,6 +472,8 @@ def main():
 
     if args.workload == "rollout":
         return rollout_bench(args, dev, rank, world, local_dev)
+    if args.workload == "standing":
+        return standing_bench(args, dev, rank, world, local_dev)
     wl = WORKLOADS[args.workload]
     n = args.envs or wl["envs"]
     clip = args.clip or wl["clip"]
@@ -410,16 +481,22 @@ def main():
     # shard id: the rank when the job is sharded; a single process of a sharded configuration times an interior shard (3), so
     # that the measured shard is not the one whose global env ids start at 0
     shard = rank if world > 1 else (3 if wl["shards"] > 1 else 0)
+    # the timed dm_batch_step calls are queued (DM_OPT_STEP_QUEUE) where the library runs a queue as one horizon launch: the packed kernels, a model
+    # with constraint rows, at most two packed waves per SIMD
+    queue = max(0, min(args.step_queue, A.MAX_STEP_QUEUE)) if (full and args.dtype == 64 and n <= 8192 and args.packed != 0 and not args.horizon_launch) else 0
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", UserWarning)        # frame_skip = 1 with the imitation reward is this benchmark's definition of a step
         env = DPVecEnv(n, motion=clip, device=local_dev, reward=args.reward if full else "alive",
                        autoreset="rsi", seed=0, contacts=full, limits=full,
                        action_mode="raw" if full else "p-control", env_offset=shard * n, frame_skip=1, dtype=args.dtype,
-                       packed=(True if args.horizon_launch else None) if args.packed is None else bool(args.packed))
-    step_kernel = ("k_rollout_packed" if (args.horizon_launch and full and n <= 8192) else "k_step_packed") if env.packed else "k_step_narrow"
+                       packed=(True if (args.horizon_launch or queue) else None) if args.packed is None else bool(args.packed))
+    default_packed = (n >= 6144 or not full) and args.dtype == 64          # what DPVecEnv(packed=None) starts on (dp_env.PACKED_FROM_ENVS)
+    step_kernel = ("k_rollout_packed" if ((args.horizon_launch or queue) and full and n <= 8192) else "k_step_packed") if env.packed else "k_step_narrow"
     stream = torch.cuda.Stream(device=dev)
     env.batch.set_stream(stream.cuda_stream)
     env.batch.set_option(A.OPT_PIPELINE, max(1, min(args.pipeline, A.MAX_PIPELINE)))
+    if queue:
+        env.batch.set_option(A.OPT_STEP_QUEUE, queue)
     if args.no_reorder:
         env.batch.set_option(104, 0)
     if args.rollout_form != "auto":
@@ -484,25 +561,39 @@ def main():
         run_steps(0, args.warmup)
         drain()
         env.batch.sync()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        run_steps(0, args.steps)
-        env.batch.join()                                                   # every sub-batch launch is inside the events
-        drain()                                                            # outstanding gathers finish inside the timed region
-        ev1.record(stream)
-        stream.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
+
+        def timed_window(fn):
+            """one timed window: barrier + synchronize on both sides; returns (host seconds, HIP-event ms on the launch stream)"""
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            w0 = time.perf_counter()
+            e0.record(stream)
+            fn()
+            env.batch.join()                                               # queued steps run, every sub-batch launch is inside the events
+            drain()                                                        # outstanding gathers finish inside the timed region
+            e1.record(stream)
+            stream.synchronize()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            return time.perf_counter() - w0, e0.elapsed_time(e1)
+
+        reps = 1 if args._child else max(1, args.repeats)
+        windows = [timed_window(lambda: run_steps(0, args.steps)) for _ in range(reps)]
         # per-launch duration of the step kernel by HIP events on the stream it is launched on (pipelined: sub-batch 0's launch on
         # its own stream, while the other sub-batches keep the machine busy): untimed, sampled after the clock stopped
         launch_us = []
-        if not args._child and not args.horizon_launch:
+        queue_launch_steps = min(queue, args.steps) if queue else 0        # steps one horizon launch of the timed window carries
+        if not args._child and queue:
+            env.batch.enable_timing(True)
+            for _ in range(3):                                             # the horizon launch of a window-sized queue, by the library's events around it
+                run_steps(0, queue_launch_steps); env.batch.join()
+                launch_us.append(env.batch.last_step_ms() * 1e3)
+            env.batch.enable_timing(False)
+            drain(); env.batch.sync()
+        elif not args._child and not args.horizon_launch:
             env.batch.enable_timing(True)
             for t in range(args.steps, args.steps + 48):
                 one_step(t)
@@ -517,9 +608,32 @@ def main():
                 env.batch.sync()
                 stat_nefc.append(env.batch.get(A.F_NEFC)); stat_iter.append(env.batch.get(A.F_SOLVER_ITER))
             drain()
-        # second leg, reported beside the judged value: the SAME steps (same state stream, same pre-drawn actions, bit-identical results:
-        # tests/test_gpu_rollout.py, tests/test_gpu_fullsize.py) through dm_batch_rollout — one launch per horizon in which every wavefront
-        # runs its four environments through all steps at its own pace instead of waiting for the slowest wave of every step
+        # ---- further legs, reported beside the judged value (same state stream, same pre-drawn actions; max over ranks, same barriers) ----------
+        # (1) `vecenv_step`: the same number of steps through the facade `DPVecEnv.step` (the drop-in for VecEnv.step, src/utils/vec_env/__init__.py:
+        #     26-100), nothing queued: every call launches, on the kernel DPVecEnv(packed=None) picks for this batch size
+        ve_elapsed = None; ve_kernel = None
+        if not args._child and args.dtype == 64 and not args.horizon_launch and not args.no_vecenv_leg:
+            bt = env.batch
+            was_packed = env.packed
+            if queue:
+                bt.set_option(A.OPT_STEP_QUEUE, 0)
+            if args.packed is None:
+                bt.set_option(A.OPT_PACKED, 1 if default_packed else 0)
+            ve_kernel = "k_step_packed" if env.packed else "k_step_narrow"
+
+            def facade_steps():
+                for t in range(args.steps):
+                    k = t % HORIZON
+                    env.step(actions[t % pool], out=(obs_T[k], rew_T[k], done_T[k]))
+                    if k == HORIZON - 1:
+                        bt.join()
+            facade_steps(); bt.join(); bt.sync()                               # untimed: first use of this kernel
+            ve_elapsed = sorted(timed_window(facade_steps)[0] for _ in range(reps))[reps // 2]
+            bt.set_option(A.OPT_PACKED, 1 if was_packed else 0)
+            if queue:
+                bt.set_option(A.OPT_STEP_QUEUE, queue)
+        # (2) `horizon_launch`: whole 256-step horizons through dm_batch_rollout — one launch per horizon in which every wavefront runs its four
+        #     environments through all steps at its own pace (what a queue of 256 steps also becomes)
         hl_elapsed = None; hl_redo = None
         hl_steps = (args.steps + HORIZON - 1) // HORIZON * HORIZON          # whole horizons: a horizon launch shorter than a horizon has not averaged its waves yet
         if not args._child and args.dtype == 64 and not args.horizon_launch and not args.no_horizon_leg:
@@ -530,29 +644,27 @@ def main():
             bt.set_option(A.OPT_PACKED, 1)
             r0 = bt.redo_total()
             run_steps(0, HORIZON, horizon=True); drain(); bt.sync()            # untimed: first use of the kernel
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            h0 = time.perf_counter()
-            run_steps(0, hl_steps, horizon=True)
-            bt.join(); drain(); stream.synchronize(); torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            hl_elapsed = time.perf_counter() - h0
+            hl_elapsed = timed_window(lambda: run_steps(0, hl_steps, horizon=True))[0]
             hl_redo = bt.redo_total() - r0
             bt.set_option(A.OPT_PACKED, 1 if was_packed else 0)
             if was_auto:
                 bt.enable_auto_packed(True)
-    elapsed = t1 - t0
+    order = sorted(range(reps), key=lambda i: windows[i][0])
+    mid = order[reps // 2]                                                  # the median window is the one reported
+    elapsed_all = [w[0] for w in windows]
     if world > 1:
-        tt = torch.tensor([elapsed, hl_elapsed or 0.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        tt = torch.tensor(elapsed_all + [hl_elapsed or 0.0, ve_elapsed or 0.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0].item())
+        elapsed_all = [float(x) for x in tt[:reps].tolist()]
+        order = sorted(range(reps), key=lambda i: elapsed_all[i]); mid = order[reps // 2]
         if hl_elapsed is not None:
-            hl_elapsed = float(tt[1].item())
+            hl_elapsed = float(tt[reps].item())
+        if ve_elapsed is not None:
+            ve_elapsed = float(tt[reps + 1].item())
     if args._child:
         return
-    gpu_ms = ev0.elapsed_time(ev1)
+    elapsed = elapsed_all[mid]
+    gpu_ms = windows[mid][1]
     status = env.batch.get(A.F_STATUS)
     nefc = np.concatenate(stat_nefc); iters = np.concatenate(stat_iter)
 
@@ -577,6 +689,11 @@ def main():
                        "dist_backend": args.dist_backend if world > 1 else None,
                        "rollout_allgather_every": HORIZON if world > 1 else None, "gathers_completed": dbg.completed,
                        "pipeline_sub_batches": max(1, min(args.pipeline, A.MAX_PIPELINE)),
+                       "step_queue": queue, "step_queue_launches": (env.batch.queue_stats()[0] if queue else None),
+                       "step_queue_note": ("DM_OPT_STEP_QUEUE = %d: the timed dm_batch_step calls are queued and run as one horizon launch (k_rollout_packed) per %d steps or at the "
+                                           "join that ends the window — open-loop stepping with pre-drawn actions, the same contract as DM_OPT_PIPELINE (outputs valid after "
+                                           "dm_batch_join); bit-identical to unqueued packed steps (tests/test_gpu_queue.py).  A closed loop that joins every step gets one launch "
+                                           "per call: `vecenv_step`" % (queue, queue)) if queue else None,
                        "sim_steps_per_env_step": 1,
                        "mean_nefc": round(float(nefc.mean()), 2), "mean_pgs_sweeps": round(float(iters.mean()), 2),
                        "overflow_envs": int((status & 1).sum()),
@@ -584,8 +701,19 @@ def main():
                        "actions": ("i.i.d. N(0, 0.9^2) per (env, step) within a %d-step horizon, pre-drawn on the device (%d x %d x 28 f64), the same "
                                    "tensors reused by every horizon" % (pool, pool, n)) if full else "zeros (pure P-controller)",
                        "timed_window": "%s (state / obs / reward / done device-resident)%s" % (
-                           ("%d steps through dm_batch_rollout, %d steps per call" % (args.steps, min(HORIZON, max(1, args.horizon_chunk)))) if args.horizon_launch else "%d dm_batch_step calls" % args.steps, ", %d horizon-end block packings + joins" % (args.steps // HORIZON) if args.steps >= HORIZON
+                           ("%d steps through dm_batch_rollout, %d steps per call" % (args.steps, min(HORIZON, max(1, args.horizon_chunk)))) if args.horizon_launch else
+                           ("%d dm_batch_step calls (Batch.step), queued: %d horizon launch(es)" % (args.steps, (args.steps + queue - 1) // queue)) if queue else "%d dm_batch_step calls (Batch.step), one launch set per call" % args.steps,
+                           ", %d horizon-end block packings + joins" % (args.steps // HORIZON) if args.steps >= HORIZON
                            else "; shorter than the %d-step horizon: no block packing / join inside the window" % HORIZON)},
+            "value_spread": {"windows": reps, "steps_per_window": args.steps, "min": round(total_steps / max(elapsed_all), 1), "median": round(value, 1),
+                             "max": round(total_steps / min(elapsed_all), 1), "unit": "env-steps/s",
+                             "what": "%d timed windows of --steps steps each, every one bracketed by barrier + synchronize (max over ranks); `value` / `ms_per_step` are the median window" % reps},
+            "vecenv_step": None if ve_elapsed is None else {
+                "value": round(total_steps / ve_elapsed, 1), "unit": "env-steps/s", "ms_per_step": round(ve_elapsed / args.steps * 1e3, 4), "steps": args.steps,
+                "kernel": ve_kernel, "envs_per_wavefront": 4 if ve_kernel == "k_step_packed" else 1,
+                "what": "the same number of steps of the same state stream through the facade `DPVecEnv.step(actions, out=...)` (deepmimic_mujoco_amd/dp_env.py: step_async + step_wait, the "
+                        "drop-in for VecEnv.step) with nothing queued: every call launches at once, on the kernel DPVecEnv(packed=None) picks for this batch size, %d pipelined "
+                        "sub-batch(es); median of %d windows.  This is what a caller gets that consumes every step's outputs before the next call" % (P_sub, reps)},
             "horizon_launch": None if hl_elapsed is None else {
                 "value": round(world * n * hl_steps / hl_elapsed, 1), "unit": "env-steps/s", "ms_per_step": round(hl_elapsed / hl_steps * 1e3, 4), "steps": hl_steps,
                 "steps_per_call": min(HORIZON, max(1, args.horizon_chunk)),
@@ -606,7 +734,13 @@ def main():
                                      "algorithmic_bytes": ALGO_BYTES_PER_STEP * n * min(HORIZON, max(1, args.horizon_chunk), args.steps),
                                      "avg_us": round(kernel_ms * 1e3 * min(HORIZON, max(1, args.horizon_chunk), args.steps), 1),
                                      "measured": "HIP events around the timed region / launches (one launch = one horizon of all envs; launches do not overlap)"}
-                                    if args.horizon_launch else None) or {"kernel": step_kernel, "envs_per_launch": n // P_sub, "launches_per_step": P_sub,
+                                    if args.horizon_launch else
+                                    {"kernel": step_kernel, "envs_per_launch": n, "steps_per_launch": queue_launch_steps,
+                                     "algorithmic_bytes": ALGO_BYTES_PER_STEP * n * queue_launch_steps,
+                                     "avg_us": round(float(np.mean(launch_us)), 1) if launch_us else None,
+                                     "measured": "HIP events the library records around the horizon launch on its stream (dm_batch_last_step_ms), %d launches of %d queued steps "
+                                                 "sampled after the timed region" % (len(launch_us), queue_launch_steps)}
+                                    if queue else None) or {"kernel": step_kernel, "envs_per_launch": n // P_sub, "launches_per_step": P_sub,
                                     "algorithmic_bytes": ALGO_BYTES_PER_STEP * (n // P_sub),
                                     "avg_us": round(float(np.mean(launch_us)), 1) if launch_us else None,
                                     "measured": "HIP events on the launch's own stream, %d launches sampled after the timed region" % len(launch_us),
@@ -620,9 +754,9 @@ def main():
                          "fp64_frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5)},
         }
         if world == 1 and not args.no_pmc:
-            hz = args.horizon_launch
-            tail = ["--workload", args.workload, "--reward", args.reward] + (["--steps", str(HORIZON), "--warmup", "0", "--prewarm-horizons", "0", "--horizon-launch"] if hz
-                                                                              else ["--steps", "48", "--warmup", "8", "--prewarm-horizons", "1"]) + [
+            hz = args.horizon_launch or bool(queue)          # the profiled child runs exactly one HORIZON-step launch of k_rollout_packed
+            tail = ["--workload", args.workload, "--reward", args.reward] + (["--steps", str(HORIZON), "--warmup", "0", "--prewarm-horizons", "0"] + (["--horizon-launch"] if args.horizon_launch else ["--step-queue", str(HORIZON)]) if hz
+                                                                              else ["--steps", "48", "--warmup", "8", "--prewarm-horizons", "1", "--step-queue", "0"]) + [
                     "--envs", str(n), "--_child", "--no-pmc", "--no-cpu-baseline", "--no-gym-loop", "--pipeline", str(args.pipeline), "--dtype", str(args.dtype)] + (["--clip", args.clip] if args.clip else [])
             pmc, err = pmc_passes(tail + (["--packed", "1" if env.packed else "0"]), step_kernel)
             r = out["roofline"]

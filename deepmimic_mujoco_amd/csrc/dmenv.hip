@@ -619,7 +619,7 @@ extern "C" int dm_batch_reset(dm_batch* b, int32_t mode, int32_t hard, const uin
 
 // the packed path covers this batch's configuration (reward modes alive / v3-config / v2-pose / imitation, the two-tier kernel family)
 static bool packed_covers(const dm_batch* b) { return b->packed && b->B.reward_mode <= 3 && b->two_tier; }
-// a dm_batch_step call may be queued: device pointers, no fused policy step, no profiling / timing, and a configuration for which ONE launch
+// a dm_batch_step call may be queued: device pointers, no fused policy step, no per-stage profiling, and a configuration for which ONE launch
 // per horizon is the faster form (rollout_as_one_launch)
 static bool rollout_as_one_launch(const dm_batch* b) {
   // ONE launch for the horizon where that wins (measured, profiles/r03_bench_*): batches with constraint rows of up to two packed waves per
@@ -630,7 +630,7 @@ static bool rollout_as_one_launch(const dm_batch* b) {
   return packed_covers(b) && (b->horizon_mode == 1 || (b->horizon_mode < 0 && b->has_rows && b->n <= 2 * SLOTS * simds));
 }
 static bool can_queue(const dm_batch* b, int kind, const dmp::PolicyArgs* pol) {
-  return kind == DM_PTR_DEVICE && !pol && !b->timing && !b->prof && rollout_as_one_launch(b);
+  return kind == DM_PTR_DEVICE && !pol && !b->prof && rollout_as_one_launch(b);      // (with timing on, the events bracket the horizon launch)
 }
 static int ensure_rows(dm_batch* b, int T) {
   if (T <= b->rows_cap) return DM_OK;

@@ -728,8 +728,9 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
   const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
   long long pt0 = 0, pt1 = 0, pt_enter = 0;
   if (PROF) { pt0 = dmw::clk(); pt_enter = pt0; }
-#define SLOT_STAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
+#define SLOT_STAMP(k) if constexpr (NS == 1) { DM_MARK("slot_constraint_ns1_" #k); } else { DM_MARK("slot_constraint_ns2_" #k); } if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
   constexpr int NC = 16 * NS;
+  if constexpr (NS == 1) { DM_MARK("slot_constraint_ns1_rows"); } else { DM_MARK("slot_constraint_ns2_rows"); }
   auto& W = s.r1.rw;
   R y[NS + 1][NV];                     // rows' Jacobians -> Y;  y[NS] = tau -> z (identical in every lane of the slot)
   RowAcc<R> ra[NS];
@@ -848,6 +849,29 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
     diag[k] = active[k] ? dg : R(1);
   }
   SLOT_STAMP(10)
+  // Two row sets: from here to the end of the sweeps the hot data are the 64 entries of A each lane holds (128 registers, read by every
+  // row of every sweep); the three half-solved vectors (204 registers) are not touched again before the force assembly.  Left to the
+  // register allocator, a third of A sits in accumulation registers and is copied out operand by operand inside the sweep loop (74 of a
+  // trip's 277 instructions).  So the vectors are moved out of the architectural file explicitly, once: z — identical in every lane of the
+  // slot — into the slot's `tau` (dead since it was read above), the rows' Y into accumulation registers; both come back after the sweeps.
+  typedef decltype(dmw::park(R(0))) ParkedR;
+  ParkedR ypark[NS == 2 ? NS : 1][NS == 2 ? NV : 1];
+  if constexpr (NS == 2) {
+    if (sl == 0) {
+#pragma unroll
+      for (int d = 0; d < NV; d++) s.tau[d] = y[NS][d];
+    }
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+#pragma unroll
+      for (int d = 0; d < NV; d++) ypark[k][d] = dmw::park(y[k][d]);
+    // (a fresh definition of every entry of A now that registers are free: the values the build left in accumulation registers would
+    //  otherwise stay there, reloaded at each use)
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+#pragma unroll
+      for (int c = 0; c < NC; c++) dmw::pin_value(AR[k][c]);
+  }
   // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ---------------------------------------------------------
   R ndinv[NS], tb[NS], t[NS];
 #pragma unroll
@@ -938,11 +962,16 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
     }
   }
   // ---- qacc = L^-1 D^-1/2 (z + sum_r f_r Y_r) -----------------------------------------------------------------------------------------
+  if constexpr (NS == 2) {
+    dmw::sync();                                   // (z went through LDS)
+#pragma unroll
+    for (int d = 0; d < NV; d++) y[NS][d] = s.tau[d];
+  }
 #pragma unroll
   for (int k = 0; k < NS; k++) {
     const R fk = active[k] ? f[k] : R(0);
 #pragma unroll
-    for (int d = 0; d < NV; d++) { y[k][d] *= fk; dmw::pin_value(y[k][d]); }
+    for (int d = 0; d < NV; d++) { if constexpr (NS == 2) y[k][d] = dmw::unpark(ypark[k][d]); y[k][d] *= fk; dmw::pin_value(y[k][d]); }
   }
   R ws[NV];
 #pragma unroll

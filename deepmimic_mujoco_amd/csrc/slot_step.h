@@ -59,7 +59,14 @@ DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTabl
       }
       dmw::sync();
     }
+    // (the RK state is not touched by the evaluation: out of the architectural registers for its duration — wave.h park)
+    typedef decltype(dmw::park(R(0))) ParkedR;
+    ParkedR pk[5][DOF_PASSES];
+#pragma unroll
+    for (int c = 0; c < DOF_PASSES; c++) { pk[0][c] = dmw::park(x0q.r[c]); pk[1][c] = dmw::park(x0v.r[c]); pk[2][c] = dmw::park(vprev.r[c]); pk[3][c] = dmw::park(sumv.r[c]); pk[4][c] = dmw::park(suma.r[c]); }
     slot_forward<R, PROF>(M, s, tb, sl, lane, lt, xip, ovf, (const DebugOut*)0, prof);
+#pragma unroll
+    for (int c = 0; c < DOF_PASSES; c++) { x0q.r[c] = dmw::unpark(pk[0][c]); x0v.r[c] = dmw::unpark(pk[1][c]); vprev.r[c] = dmw::unpark(pk[2][c]); sumv.r[c] = dmw::unpark(pk[3][c]); suma.r[c] = dmw::unpark(pk[4][c]); }
 #pragma unroll
     for (int c = 0; c < DOF_PASSES; c++) {
       const int d = sl + SW * c;
@@ -388,7 +395,12 @@ DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<
       if (lane == 0) for (int k = 0; k < 31; k++) prof_acc[k] += prof_acc[32 + k];
     } else stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps);
 #else
+#ifdef DM_ROLLOUT_INLINE   // experiment: the step body inlined into the horizon loop (no callee-saved register traffic); the batch descriptor read afresh every step
+    const Batch<R>& Bt = *dmw::launder_uniform_ptr(&B);
+    const bool stored = slot_env_step<R>(M, Bt, sh[slot], *dmw::launder_uniform_ptr(&tb), dmw::launder(env), dmw::launder(sl), dmw::launder(lane), live, a_t, o_t, r_t, d_t, n_substeps, (int*)0, (int*)0);
+#else
     const bool stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps);
+#endif
 #endif
     const int need = (live && !stored) ? 1 : 0;
     bool any = false;

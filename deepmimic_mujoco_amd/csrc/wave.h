@@ -217,6 +217,23 @@ template <int I> DM_DEV void pgs_row2(float& t_own, float& tsave_own, float& t_o
   const float d = max_raw(nf0, t_own); tsave_own += onehot * t_own; const float b = row_bcast<I>(d); t_own += b * a_own; t_other += b * a_other;
 }
 DM_DEV void dpp_settle() { asm volatile("s_nop 4"); }
+// A double parked in two ACCUMULATION registers across a region in which the architectural registers are needed for something hotter (the
+// register allocator does this on its own, but per USE: inside a loop that means one v_accvgpr_read per operand and trip).  park() / unpark()
+// move it once each way; between the two the value occupies no architectural register.
+struct Parked { int lo, hi; };
+DM_DEV Parked park(double v) {
+  Parked p;
+  asm volatile("v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3" : "=a"(p.lo), "=a"(p.hi) : "v"(__double2loint(v)), "v"(__double2hiint(v)));
+  return p;
+}
+DM_DEV double unpark(const Parked& p) {
+  int lo, hi;
+  asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(lo), "=v"(hi) : "a"(p.lo), "a"(p.hi));
+  return __hiloint2double(hi, lo);
+}
+struct ParkedF { int x; };
+DM_DEV ParkedF park(float v) { ParkedF p; asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(p.x) : "v"(__float_as_int(v))); return p; }
+DM_DEV float unpark(const ParkedF& p) { int x; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(p.x)); return __int_as_float(x); }
 // counter in global memory shared by all waves of a launch: returns the value before the increment
 DM_DEV int global_counter_next(int* p) { return atomicAdd(p, 1); }
 // this lane's 16 bits of a wave ballot (bit i = lane i of the own row)

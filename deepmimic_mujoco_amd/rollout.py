@@ -128,6 +128,7 @@ class SegmentCollector(object):
         self.fused = bool(fused)
         self.have_ac0 = False
         self._redo_seen = None
+        self._packed_now = None                    # what _choose_kernel picked for the last horizon (None: none yet)
         self.kernel_switches = 0
         with self._on_stream():
             env.reset(first_reset, out=self.as_buf(self.ob64[0]))                  # trpo.py:32 `ob = env.reset()` (RSI); later episodes: noisy init
@@ -157,10 +158,12 @@ class SegmentCollector(object):
                 if hasattr(env.batch, "rollout"):
                     # the whole horizon in one call (dm_batch_rollout): on the packed path ONE launch in which every wavefront runs its four
                     # environments through all T steps at its own pace; on the one-env path T step launches issued without returning here
-                    self._choose_kernel()
+                    restore = self._choose_kernel()
                     env.batch.rollout(ac64, (ob64[1:], rew64, done8), fs, pi._packed, vpreds[1:], self.stochastic, pi._seed, pi._counter + 1)
                     pi._counter += T
                     env.batch.join()
+                    if restore is not None:
+                        restore()                                   # per-step callers of the same env keep the kernel THEY were given
                     return
                 for t in range(T):                                                                       # :49 + :66, one launch
                     pi._counter += 1
@@ -187,10 +190,14 @@ class SegmentCollector(object):
         from . import _abi as A
         env, b = self.env, self.env.batch
         if not getattr(env, "horizon_packed_ok", False):
-            return
-        if b.__dict__.get("_auto"):
-            b.enable_auto_packed(False)                                     # the per-step chooser would fight this one
-        on = bool(b.__dict__.get("options", {}).get(A.OPT_PACKED, 0))
+            return None
+        # the choice holds for this collector's rollout calls only: what the batch was set to (and its per-step chooser, if on) comes back
+        # after each call, so `DPVecEnv.step` callers of the same env are not moved to a kernel that is the slower one per step
+        was_on = bool(b.__dict__.get("options", {}).get(A.OPT_PACKED, 0))
+        was_auto = bool(b.__dict__.get("_auto"))
+        on = getattr(self, "_packed_now", None)
+        if on is None:
+            on = was_on
         if self._redo_seen is None:                                         # first horizon: start packed
             want = True
         elif on:
@@ -199,9 +206,20 @@ class SegmentCollector(object):
         else:
             want = int(b.get(A.F_NEFC).max()) <= b.HEAVY_ROWS
         if want != on:
-            b.set_option(A.OPT_PACKED, 1 if want else 0)
             self.kernel_switches += 1
+        self._packed_now = want
+        if was_auto:
+            b._auto = False                                                 # (suspended, not reset: its counters go on afterwards)
+        if want != was_on:
+            b.set_option(A.OPT_PACKED, 1 if want else 0)
         self._redo_seen = b.redo_total()
+
+        def restore():
+            if want != was_on:
+                b.set_option(A.OPT_PACKED, 1 if was_on else 0)
+            if was_auto:
+                b._auto = True
+        return restore
 
     def collect(self):
         import torch

@@ -131,6 +131,13 @@ template <int I, class T> inline void pgs_row2(T& t_own, T& tsave_own, T& t_othe
   t_own = t_own + b * a_own; t_other = t_other + b * a_other;
 }
 inline void dpp_settle() {}
+// register parking (wave.h): a value copy here
+template <class T> struct ParkedT { T v; };
+typedef ParkedT<double> Parked;
+typedef ParkedT<float> ParkedF;
+inline Parked park(double v) { return Parked{v}; }
+inline ParkedF park(float v) { return ParkedF{v}; }
+template <class T> inline T unpark(const ParkedT<T>& p) { return p.v; }
 inline int global_counter_next(int* p) { return (*p)++; }
 inline unsigned row_ballot(bool p, int lane_id) { return (unsigned)((ballot(p) >> (lane_id & 48)) & 0xffffull); }
 inline int pin_zero() { return 0; }

@@ -140,6 +140,12 @@ def test_bench_prints_one_contract_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and r["peak"] == 8000.0
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1000 and "sample" in c
+    # the default line: dm_batch_step calls queued into one horizon launch per window; three windows; the facade's figure beside it
+    assert j["config"]["step_queue"] == 256 and r["kernel"] == "k_rollout_packed" and r["launch"]["steps_per_launch"] == 16 and r["launch"]["avg_us"] > 0
+    sp = j["value_spread"]
+    assert sp["windows"] == 3 and sp["min"] <= sp["median"] == j["value"] <= sp["max"]
+    ve = j["vecenv_step"]
+    assert ve["steps"] == 16 and ve["value"] > 1e5 and ve["kernel"] == "k_step_narrow"
 
 
 @pytest.mark.gpu
@@ -246,7 +252,8 @@ def test_pipelined_rollouts_equal_the_same_batches_stepped_one_after_the_other()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [["--workload", "cfg4"], ["--workload", "cfg5"], ["--workload", "cfg2", "--pipeline", "1"], ["--dtype", "32"], ["--horizon-launch"]])
+@pytest.mark.parametrize("extra", [["--workload", "cfg4"], ["--workload", "cfg5"], ["--workload", "cfg2", "--pipeline", "1"], ["--dtype", "32"], ["--horizon-launch"],
+                                   ["--step-queue", "0"], ["--step-queue", "8", "--repeats", "1"]])
 def test_bench_other_workloads_print_the_contract_line(extra):
     """The single-shard lines of BASELINE.json configs[3] / [4] ('spinkick', 'dance_b'; an interior shard's global env ids), configs[1]
     and the float32 build go through the same code path and print the same contract line."""
@@ -267,7 +274,16 @@ def test_bench_other_workloads_print_the_contract_line(extra):
     if "--horizon-launch" in extra:          # the timed leg itself goes through dm_batch_rollout: one launch for the 24 steps
         assert j["roofline"]["kernel"] == "k_rollout_packed" and j["roofline"]["launch"]["steps_per_launch"] == 24 and j["horizon_launch"] is None
         return
-    assert j["roofline"]["launch"]["launches_per_step"] == (1 if "--pipeline" in extra else 2)
+    queued = full_queue = wl != "cfg2" and "--dtype" not in extra and extra[:2] != ["--step-queue", "0"]
+    assert bool(j["config"]["step_queue"]) == queued
+    if queued:                               # the timed dm_batch_step calls ran as horizon launches of the queue's depth
+        depth = 8 if "8" in extra else 24
+        assert j["roofline"]["kernel"] == "k_rollout_packed" and j["roofline"]["launch"]["steps_per_launch"] == depth
+        assert j["config"]["step_queue_launches"] >= 24 // depth
+    else:
+        assert j["roofline"]["launch"]["launches_per_step"] == (1 if "--pipeline" in extra else 2)
+    assert j["value_spread"]["windows"] == (1 if "--repeats" in extra else 3)
+    assert (j["vecenv_step"] is None) == ("--dtype" in extra)
     hl = j["horizon_launch"]                 # the second leg: whole 256-step horizons of the same workload through dm_batch_rollout
     assert (hl is None) == ("--dtype" in extra)
     if hl is not None:
@@ -531,7 +547,8 @@ def test_segment_collector_chooses_the_kernel_from_its_own_horizons():
             assert torch.equal(bseg["prevac"][0], a["ac"][-1])
         assert all(bool(torch.isfinite(sg["ob"]).all()) and bool((sg["rew"] == 1).all()) for sg in segs)
         if tolerate is None:
-            assert env.packed and c.kernel_switches == 1, "stays on the packed horizon launch (switched on once, at the first horizon)"
+            assert c._packed_now and c.kernel_switches == 1, "stays on the packed horizon launch (switched on once, at the first horizon)"
+            assert not env.packed, "the collector's choice is scoped to its rollout calls: per-step callers of the env keep its own kernel"
         else:
             assert c.kernel_switches >= 2, "handed to the one-env steps after the first horizon (and back only when no env holds more than 30 rows)"
         env.close()

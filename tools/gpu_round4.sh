@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-4 gpurun bundles (run from the repo root on the GPU box):  bash tools/gpu_round4.sh <tag> <what...>
+#   what: newtests | tests | ab "<variants>" | stage | bench | standing | train
+# Outputs under gpurun_out/<tag>/ ; summaries worth keeping are copied into profiles/ by hand.
+set -u
+TAG=${1:-r04}; shift || true
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+LIB=deepmimic_mujoco_amd/csrc/libdmenv.so
+Q="--no-pmc --no-cpu-baseline --no-gym-loop"
+for WHAT in "$@"; do case "$WHAT" in
+  newtests)
+    ( timeout 900 python -m pytest tests/test_gpu_queue.py -x -q 2>&1 | tail -15 ) | tee $OUT/pytest_new.log ;;
+  tests)
+    ( timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 2>&1 | tail -40 ) > $OUT/pytest_gpu.log; tail -14 $OUT/pytest_gpu.log
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log ;;
+  ab:*)
+    # A/B of whole-library builds under build_ab/ inside one call: the driver's 20-step window and the 512-step default, alternating
+    for rep in 1 2; do for v in ${WHAT#ab:}; do
+      for st in "20 5" "512 64"; do set -- $st
+        o=$(DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python bench.py $Q --steps $1 --warmup $2 2>$OUT/ab_err.txt | python -c "
+import json,sys
+j=json.loads(sys.stdin.read())
+print('value %.3f M  spread %.2f..%.2f  vecenv %s  horizon %s  launch_us %s' % (j['value']/1e6, j['value_spread']['min']/1e6, j['value_spread']['max']/1e6,
+      j['vecenv_step'] and round(j['vecenv_step']['value']/1e6,3), j['horizon_launch'] and round(j['horizon_launch']['value']/1e6,3), j['roofline']['launch'].get('avg_us')))" 2>>$OUT/ab_err.txt)
+        echo "$v steps=$1 : ${o:-FAILED $(tail -2 $OUT/ab_err.txt | cut -c1-200)}" | tee -a $OUT/ab.log
+      done
+    done; done ;;
+  stage:*)
+    for v in ${WHAT#stage:}; do echo "== $v" | tee -a $OUT/stage.log; DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python tools/profile_packed.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/stage.log; done ;;
+  bench)
+    DM_PROFILE_KEEP=$OUT/raw timeout 900 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-600 $OUT/bench_cfg3.json
+    timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 $Q > $OUT/bench_cfg3_driver_window.json 2>/dev/null; cut -c1-300 $OUT/bench_cfg3_driver_window.json ;;
+  benchall)
+    for rw in alive v3-config; do timeout 300 python bench.py --reward $rw $Q > $OUT/bench_cfg3_$rw.json 2>/dev/null; cut -c1-200 $OUT/bench_cfg3_$rw.json; done
+    for wl in cfg2 cfg4 cfg5; do timeout 300 python bench.py --workload $wl $Q > $OUT/bench_$wl.json 2>/dev/null; cut -c1-200 $OUT/bench_$wl.json; done
+    timeout 300 python bench.py --step-queue 0 $Q > $OUT/bench_cfg3_unqueued.json 2>/dev/null; cut -c1-200 $OUT/bench_cfg3_unqueued.json
+    timeout 300 python bench.py --workload rollout --steps 2048 --warmup 256 > $OUT/bench_rollout_fused.json 2>/dev/null; cut -c1-200 $OUT/bench_rollout_fused.json ;;
+  trace)
+    ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace -- python $OLDPWD/bench.py --steps 512 --warmup 0 --prewarm-horizons 1 --repeats 1 --no-vecenv-leg --no-horizon-leg $Q > /dev/null 2>&1 )
+    ROWS=8 python tools/rocprof_summary.py $OUT/krollout_summary.md "step queue -> horizon launches — $TAG, MI355X (bench.py default: cfg3 + 5-term imitation reward, 4096 envs, dm_batch_step calls queued 256 per launch)" \
+      $(find /tmp/p_trace -name "*.db" | head -1) > /dev/null; head -14 $OUT/krollout_summary.md ;;
+  *) echo "unknown bundle $WHAT" ;;
+esac; done
