@@ -373,7 +373,7 @@ def standing_bench(args, dev, rank, world, local_dev):
         el = time.perf_counter() - t0
         redo = env.batch.redo_total() - r0
         legs[name] = {"value": round(world * n * segs * HORIZON / el, 1), "ms_per_step": round(el / (segs * HORIZON) * 1e3, 4), "episodes": eps,
-                      "mean_episode_length": round(float(np.mean(lens)), 1) if lens else None, "envs_per_wavefront_at_end": 4 if env.packed else 1,
+                      "mean_episode_length": round(float(np.mean(lens)), 1) if lens else None, "envs_per_wavefront_at_end": 4 if (col._packed_now if col._packed_now is not None else env.packed) else 1,
                       "env_steps_beyond_packed_capacity": redo, "redo_rate": round(redo / float(n * segs * HORIZON), 6)}
         if name == "auto":
             legs[name]["kernel_switches"] = col.kernel_switches
@@ -433,6 +433,10 @@ def main():
     ap.add_argument("--horizon-chunk", type=int, default=HORIZON, help="--horizon-launch: steps per dm_batch_rollout call (the dispatch order — which environments share a wavefront — is renewed between calls)")
     ap.add_argument("--packed", type=int, default=None, choices=[0, 1], help="DM option 105: four environments per wavefront (k_step_packed) where that kernel covers the workload (default: the library's)")
     ap.add_argument("--no-reorder", action="store_true", help="experiment: identity dispatch order instead of longest-first (DM option 104 = 0)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank code path with however many ranks there are, ONE included: process group (RCCL with --dist-backend nccl), "
+                         "double-buffered device all-gather of the rollout block every 256 steps, max-reduced timing, the learner's all-mean on a gradient-sized vector")
+    ap.add_argument("--alloc-gather-world", type=int, default=0, help="with --force-dist: also allocate (and touch) the two G-way gathered rollout buffers a G-rank job holds per rank")
     ap.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)   # profiled child of pmc_passes: GPU loop only, prints nothing
     args = ap.parse_args()
 
@@ -454,8 +458,10 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     n_ranks_seen = 1
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -518,7 +524,10 @@ def main():
         rew_T = torch.zeros((HORIZON, n), dtype=torch.float64, device=dev)
         done_T = torch.zeros((HORIZON, n), dtype=torch.uint8, device=dev)
         tidx = torch.arange(HORIZON, device=dev)
-        dbg = DoubleBufferedGather(HORIZON, n, device=dev, world=world)
+        dbg = DoubleBufferedGather(HORIZON, n, device=dev, world=world, collective=dist_on)
+        gather_alloc = None
+        if dist_on and args.alloc_gather_world > 1:                # what a G-rank job holds per rank beside the two blocks: allocated and touched
+            gather_alloc = [torch.zeros((args.alloc_gather_world * HORIZON, n, 87), dtype=torch.float32, device=dev) for _ in range(2)]
         env.reset("rsi")
         stat_nefc, stat_iter = [], []
 
@@ -562,26 +571,30 @@ def main():
         drain()
         env.batch.sync()
 
+        issue_s = []
+
         def timed_window(fn):
             """one timed window: barrier + synchronize on both sides; returns (host seconds, HIP-event ms on the launch stream)"""
-            if world > 1:
+            if dist_on:
                 dist.barrier()
             torch.cuda.synchronize()
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             w0 = time.perf_counter()
             e0.record(stream)
             fn()
+            issue_s.append(time.perf_counter() - w0)                       # host time to issue the window's calls (before the join that ends it)
             env.batch.join()                                               # queued steps run, every sub-batch launch is inside the events
             drain()                                                        # outstanding gathers finish inside the timed region
             e1.record(stream)
             stream.synchronize()
             torch.cuda.synchronize()
-            if world > 1:
+            if dist_on:
                 dist.barrier()
             return time.perf_counter() - w0, e0.elapsed_time(e1)
 
         reps = 1 if args._child else max(1, args.repeats)
         windows = [timed_window(lambda: run_steps(0, args.steps)) for _ in range(reps)]
+        host_issue_us = float(np.median(issue_s[:reps])) / args.steps * 1e6
         # per-launch duration of the step kernel by HIP events on the stream it is launched on (pipelined: sub-batch 0's launch on
         # its own stream, while the other sub-batches keep the machine busy): untimed, sampled after the clock stopped
         launch_us = []
@@ -652,7 +665,13 @@ def main():
     order = sorted(range(reps), key=lambda i: windows[i][0])
     mid = order[reps // 2]                                                  # the median window is the one reported
     elapsed_all = [w[0] for w in windows]
-    if world > 1:
+    allmean_ok = None
+    if dist_on:
+        from deepmimic_mujoco_amd.trpo import allmean
+        gvec = torch.full((18656,), float(rank + 1), dtype=torch.float32, device=dev if args.dist_backend == "nccl" else "cpu")   # the flat gradient's size (src/trpo.py:175-180)
+        allmean(gvec, force=True)
+        allmean_ok = bool(abs(float(gvec[0]) - (world + 1) / 2.0) < 1e-6 and abs(float(gvec[-1]) - (world + 1) / 2.0) < 1e-6)
+    if dist_on:
         tt = torch.tensor(elapsed_all + [hl_elapsed or 0.0, ve_elapsed or 0.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed_all = [float(x) for x in tt[:reps].tolist()]
@@ -686,9 +705,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f%d" % args.dtype, "data": "synthetic",
             "config": {"workload": label, "envs_per_gpu": n, "global_envs": world * n if world > 1 else n * wl["shards"], "clip": clip,
                        "parallelism": "env-shard x%d" % max(world, wl["shards"]), "n_ranks_seen": n_ranks_seen,
-                       "dist_backend": args.dist_backend if world > 1 else None,
-                       "rollout_allgather_every": HORIZON if world > 1 else None, "gathers_completed": dbg.completed,
+                       "dist_backend": args.dist_backend if dist_on else None, "forced_dist": bool(args.force_dist), "learner_allmean_ok": allmean_ok,
+                       "gather_buffers_allocated_bytes": (sum(int(x.numel()) * 4 for x in gather_alloc) if gather_alloc else None),
+                       "rollout_allgather_every": HORIZON if dist_on else None, "gathers_completed": dbg.completed,
                        "pipeline_sub_batches": max(1, min(args.pipeline, A.MAX_PIPELINE)),
+                       "host_issue_us_per_step": round(host_issue_us, 2),
                        "step_queue": queue, "step_queue_launches": (env.batch.queue_stats()[0] if queue else None),
                        "step_queue_note": ("DM_OPT_STEP_QUEUE = %d: the timed dm_batch_step calls are queued and run as one horizon launch (k_rollout_packed) per %d steps or at the "
                                            "join that ends the window — open-loop stepping with pre-drawn actions, the same contract as DM_OPT_PIPELINE (outputs valid after "
@@ -806,7 +827,7 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

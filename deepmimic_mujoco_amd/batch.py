@@ -134,9 +134,42 @@ class Batch(object):
             self._redo_last = self.redo_total()
 
     # ---- the hot path -------------------------------------------------------------------------------
+    def _step_device(self, action, n_substeps, out):
+        """`step` for device tensors with every buffer given: the same checks as `_ptr`, written out once (the generic path costs ~10 us
+        of Python per call — 4 % of a 250 us step).  Returns None when the arguments are not of that form."""
+        obs, rew, done = out
+        try:
+            dev = action.device
+            if not (action.is_cuda and obs.is_cuda and rew.is_cuda and done.is_cuda):
+                return None
+        except AttributeError:
+            return None
+        import torch
+        n = self.n
+        if not (action.dtype == obs.dtype == rew.dtype == torch.float64 and done.dtype == torch.uint8 and action.is_contiguous() and obs.is_contiguous()
+                and rew.is_contiguous() and done.is_contiguous() and action.shape == (n, A.NU) and obs.shape == (n, A.NOBS) and rew.shape == (n,) and done.shape == (n,)):
+            return None                                            # the generic path raises the precise error
+        if (dev.index or 0) != self.device or obs.device != dev or rew.device != dev or done.device != dev:
+            return None
+        cur = torch.cuda.current_stream(dev).cuda_stream
+        if cur != getattr(self, "_stream_handle", None):
+            self.set_stream(cur)
+        rc = self._L.dm_batch_step(self._h, action.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), int(n_substeps), A.PTR_DEVICE)
+        if rc:
+            A.check(rc, self._L)
+        if self._queue_refs is not None:
+            self._queue_refs.append((action, obs, rew, done))
+            if len(self._queue_refs) > 2 * A.MAX_STEP_QUEUE:
+                del self._queue_refs[:A.MAX_STEP_QUEUE]
+        return out
+
     def step(self, action, n_substeps=1, out=None):
         if self.__dict__.get("_auto"):
             self._adapt()
+        if out is not None:
+            r = self._step_device(action, n_substeps, out)
+            if r is not None:
+                return r
         n = self.n
         ap, kind, _ka = self._ptr(action, np.float64, (n, A.NU))
         if out is None:

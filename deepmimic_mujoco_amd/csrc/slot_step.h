@@ -395,12 +395,10 @@ DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<
       if (lane == 0) for (int k = 0; k < 31; k++) prof_acc[k] += prof_acc[32 + k];
     } else stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps);
 #else
-#ifdef DM_ROLLOUT_INLINE   // experiment: the step body inlined into the horizon loop (no callee-saved register traffic); the batch descriptor read afresh every step
-    const Batch<R>& Bt = *dmw::launder_uniform_ptr(&B);
-    const bool stored = slot_env_step<R>(M, Bt, sh[slot], *dmw::launder_uniform_ptr(&tb), dmw::launder(env), dmw::launder(sl), dmw::launder(lane), live, a_t, o_t, r_t, d_t, n_substeps, (int*)0, (int*)0);
-#else
+    // (measured, round 4: the step body inlined here instead of called — the batch descriptor and tables read afresh every step so that nothing is
+    //  hoisted — removes the callee's register save / restore (1.6 KB per lane per call) and is 10 % SLOWER: 15.0 against 16.7 M env-steps/s,
+    //  profiles/r04_ab_kernel_variants.md; the loop around the body costs the allocator more than the calls cost the memory system)
     const bool stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps);
-#endif
 #endif
     const int need = (live && !stored) ? 1 : 0;
     bool any = false;

@@ -346,21 +346,24 @@ class DoubleBufferedGather:
     copied to pinned host memory (stream-ordered), the gather runs between host buffers (async, gloo's own threads) and the
     result stays on the host in `gathered_host[k]` — the path the world-2 tests and single-GPU multi-rank runs use."""
 
-    def __init__(self, horizon, n_local, device="cpu", world=None):
+    def __init__(self, horizon, n_local, device="cpu", world=None, collective=None):
+        """collective: run the multi-rank code path (two blocks, the all-gather into `gathered`) — default: when the process group has more
+        than one rank; True forces it for a group of ONE rank, which executes the same RCCL calls where only one GPU is visible."""
         import torch
         import torch.distributed as dist
         if world is None:
             world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.T, self.n, self.world = int(horizon), int(n_local), int(world)
-        nb = 2 if self.world > 1 else 1
+        self.collective = (self.world > 1) if collective is None else bool(collective)
+        nb = 2 if self.collective else 1
         self.blocks = [torch.zeros((self.T, self.n, ROW), dtype=torch.float32, device=device) for _ in range(nb)]
         on_gpu = torch.device(device).type == "cuda"
-        self.host_staged = self.world > 1 and on_gpu and dist.get_backend() == "gloo"
+        self.host_staged = self.collective and on_gpu and dist.get_backend() == "gloo"
         self.gathered = self.gathered_host = self.host_blocks = None
-        if self.world > 1 and self.host_staged:
+        if self.collective and self.host_staged:
             self.host_blocks = [torch.zeros((self.T, self.n, ROW), dtype=torch.float32).pin_memory() for _ in range(nb)]
             self.gathered_host = [torch.empty((self.world * self.T, self.n, ROW), dtype=torch.float32) for _ in range(nb)]
-        elif self.world > 1:
+        elif self.collective:
             self.gathered = [torch.empty((self.world * self.T, self.n, ROW), dtype=torch.float32, device=device) for _ in range(nb)]
         self.pending = [None] * nb
         self.completed = 0                      # gathers launched so far
@@ -383,7 +386,7 @@ class DoubleBufferedGather:
 
     def commit(self, t):
         """Call after step t's row has been written.  Returns the index of the gathered buffer when a gather was launched."""
-        if self.world > 1 and (t + 1) % self.T == 0:
+        if self.collective and (t + 1) % self.T == 0:
             import torch
             import torch.distributed as dist
             k = self._k(t)

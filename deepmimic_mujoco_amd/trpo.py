@@ -41,11 +41,12 @@ def _world(group=None):
     return 1
 
 
-def allmean(x, group=None):
-    """`allmean` of src/trpo.py:175-180: element-wise mean over ranks (in place; identity for a single process)."""
+def allmean(x, group=None, force=False):
+    """`allmean` of src/trpo.py:175-180: element-wise mean over ranks (in place; identity for a single process).  force: issue the
+    all-reduce even in a group of one rank (executes the collective where only one GPU is visible)."""
     import torch.distributed as dist
     n = _world(group)
-    if n > 1:
+    if n > 1 or (force and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
         x /= n
     return x

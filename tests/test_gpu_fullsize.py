@@ -5,6 +5,10 @@ device's counter-based RNG, two pipelined sub-batches, longest-first dispatch or
 CPU oracle's OpenMP batch step, EVERY env, every step: observations and rewards to 1e-9, done flags, frame cursors, cycle counters,
 constraint-row counts, contact counts and contact (geom1, geom2) lists identical.  The oracle side mirrors the device's auto-reset
 on the host (tests/helpers.device_rsi_frame: the frame `reset_env` draws for (seed, global env id, episode)).
+Round 4 adds: the step-queue form (DM_OPT_STEP_QUEUE: the per-step calls queued and run as one horizon launch), 'spinkick' on the per-step
+packed kernel, a 64-step horizon (second-episode RSI draws and clip wraps for most environments), BASELINE.json configs[1] (contacts and
+limits off, the P-controller of src/env_torque_test.py:14-20) at its full 4 096 envs on the kernels bench.py times it on, and a STANDING
+population (the shipped policy's regime: 32 rows per env most of the time).
 Reference semantics: src/dp_env_v3.py:106-156 (step, is_done, reset_model)."""
 import os
 
@@ -20,9 +24,14 @@ SEED = 11
 STEPS = 16
 
 
-@pytest.mark.parametrize("clip,n,packed", [("walk", 4096, 0), ("spinkick", 4096, 0), ("dance_b", 8192, 0), ("dance_b", 8192, 1), ("walk", 4096, 1), ("walk", 4096, 2), ("spinkick", 4096, 2), ("dance_b", 8192, 2)])
+@pytest.mark.parametrize("clip,n,packed", [("walk", 4096, 0), ("spinkick", 4096, 0), ("dance_b", 8192, 0), ("dance_b", 8192, 1), ("walk", 4096, 1), ("walk", 4096, 2), ("spinkick", 4096, 2), ("dance_b", 8192, 2),
+                                           ("spinkick", 4096, 1), ("walk", 4096, 3), ("dance_b", 8192, 3), ("walk", 4096, 64)])
 def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     import torch
+    STEPS = 16
+    queue = packed == 3                              # 3: four per wave, the 16 dm_batch_step calls QUEUED (DM_OPT_STEP_QUEUE) and run as one horizon launch at the join
+    if packed == 64:                                 # 64: one 64-step horizon launch — most environments see a second episode's RSI draw, 'walk' (39 frames) wraps
+        STEPS, packed = 64, 2
     from deepmimic_mujoco_amd import Batch
     from deepmimic_mujoco_amd.imitation import ImitationSpec
     from oracle import oracle as O
@@ -36,6 +45,8 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     b.set_option(A.OPT_ENV_OFFSET, off); b.set_option(A.OPT_DIAGNOSTICS, 1); b.set_option(A.OPT_PIPELINE, 2)
     b.set_option(A.OPT_PACKED, 1 if packed else 0)   # 0: one environment per wavefront; 1: four (what DPVecEnv picks from 6 144 envs up);
     horizon = packed == 2                            # 2: four, and all 16 steps in ONE launch (dm_batch_rollout: every wave at its own pace)
+    if queue:
+        b.set_option(A.OPT_STEP_QUEUE, 64)
     b.reset(0, 1)                                                 # env.reset(): sim.reset() + RSI
     fidx = b.get(A.F_FRAME_IDX).copy()
     expect0 = np.array([H.device_rsi_frame(SEED, off + e, 0, F) for e in range(n)], dtype=np.int32)
@@ -58,6 +69,13 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     if horizon:
         b.rollout(acts, (obs_T, rew_T, done_T), 1)
         b.join(); torch.cuda.current_stream().synchronize()
+    if queue:
+        for t in range(STEPS):
+            b.step(acts[t], 1, (obs_T[t], rew_T[t], done_T[t]))
+        assert b.queue_stats() == (0, 0, STEPS)
+        b.join(); torch.cuda.current_stream().synchronize()
+        assert b.queue_stats() == (1, STEPS, 0)
+        horizon = True                                            # from here on: the batch's fields are those of the last step
     for t in range(STEPS):
         if not horizon:
             b.step(acts[t], 1, (obs_T[t], rew_T[t], done_T[t]))  # pipelined: two sub-batch launches on their own streams
@@ -104,9 +122,145 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     assert np.abs(w - ow).max() / max(1.0, np.abs(ow).max()) < 1e-7      # accelerations: conditioned like the contact solve
     assert np.abs(tm - ot).max() < 1e-12
     assert ndone > 0 and max_nefc > 16, "the run must contain early terminations and heavy contact (%d done, max nefc %d)" % (ndone, max_nefc)
+    if STEPS == 64:
+        assert int((episode >= 2).sum()) > n // 2, "a 64-step run must reach second-episode RSI draws for most environments"
     assert (b.get(A.F_STATUS) & 1).sum() == 0
     if packed:
         print("   packed: env-steps handed to the one-env code [total, candidates, box slots, contacts, rows, PGS test]:", b.redo_reasons())
     print("full shard %s x %d, %d steps: worst rel err %.2e, %d auto-resets, max nefc %d, oracle threads %d"
           % (clip, n, STEPS, worst, ndone, max_nefc, nthreads))
+    b.close()
+
+
+@pytest.mark.parametrize("form", ["packed", "horizon"])
+def test_config2_full_size_p_controller_matches_oracle_every_env(form):
+    """BASELINE.json configs[1] as bench.py --workload cfg2 runs it — 'walk', 4 096 envs, contacts and joint limits off, the P-controller of
+    src/env_torque_test.py:14-20 as the action front-end (ctrl = 0.8 (mocap_cfg[idx][7:] - qpos[7:]) + action), RSI auto-reset when the
+    falling body leaves the height band — on the kernel that is timed for it (k_step_packed, four environments per wavefront, two pipelined
+    sub-batches) and through one horizon launch, against the oracle: EVERY env, 16 steps, obs 1e-9, done flags, the unclamped ctrl."""
+    import torch
+    from deepmimic_mujoco_amd import Batch
+    from oracle import oracle as O
+    n, STEPS, off = 4096, 16, 0
+    mc = H.mocap("walk")
+    F = mc.data_config.shape[0]
+    b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, flags=A.FLAG_NO_CONTACT | A.FLAG_NO_LIMIT, mocap_dt=float(mc.dt))
+    b.set_option(A.OPT_REWARD_MODE, 0); b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, SEED); b.set_option(A.OPT_ACTION_MODE, 1)
+    b.set_option(A.OPT_PIPELINE, 2); b.set_option(A.OPT_PACKED, 1)
+    if form == "horizon":
+        b.set_option(106, 1)                                     # (a rowless model steps per launch by default: every wave costs the same)
+    b.reset(0, 1)
+    fidx = b.get(A.F_FRAME_IDX).copy()
+    assert np.array_equal(fidx, np.array([H.device_rsi_frame(SEED, off + e, 0, F) for e in range(n)], dtype=np.int32))
+    om = H.oracle_model(enable_contact=0, enable_limit=0)
+    ods = [O.Data(om) for _ in range(n)]
+    for e in range(n):
+        ods[e].reset(); ods[e].set_state(mc.data_config[fidx[e]], mc.data_vel[fidx[e]])
+    episode = np.ones(n, dtype=np.int64)
+    nthreads = max(1, len(os.sched_getaffinity(0)))
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cuda"); g.manual_seed(6)
+    acts = torch.randn((STEPS + 1, n, 28), generator=g, device=dev, dtype=torch.float64) * 0.2
+    obs_T = torch.empty((STEPS, n, 56), dtype=torch.float64, device=dev); rew_T = torch.empty((STEPS, n), dtype=torch.float64, device=dev)
+    done_T = torch.empty((STEPS, n), dtype=torch.uint8, device=dev)
+    if form == "horizon":
+        b.rollout(acts, (obs_T, rew_T, done_T), 1)
+    else:
+        for t in range(STEPS):
+            b.step(acts[t], 1, (obs_T[t], rew_T[t], done_T[t]))
+    b.join(); torch.cuda.current_stream().synchronize()
+    ndone = 0; worst = 0.0
+    for t in range(STEPS):
+        a = acts[t].cpu().numpy(); obs = obs_T[t].cpu().numpy(); rew = rew_T[t].cpu().numpy(); done = done_T[t].cpu().numpy()
+        qnow = np.stack([d.get("qpos") for d in ods])
+        ctrl = a + 0.8 * (mc.data_config[fidx][:, 7:] - qnow[:, 7:])
+        o_obs, o_rew, o_done = O.batch_step(om, ods, ctrl, 1, nthreads=nthreads)
+        assert np.array_equal(done, o_done), "done flags differ at step %d" % t
+        for e in np.nonzero(done)[0]:
+            k = H.device_rsi_frame(SEED, off + int(e), int(episode[e]), F)
+            episode[e] += 1
+            ods[e].reset(); ods[e].set_state(mc.data_config[k], mc.data_vel[k])
+            fidx[e] = k
+            o_obs[e] = np.concatenate([mc.data_config[k][7:], mc.data_vel[k][6:]])
+        ndone += int(done.sum())
+        err = np.abs(obs - o_obs).max(1) / np.maximum(1.0, np.abs(o_obs).max(1))
+        worst = max(worst, float(err.max()))
+        assert err.max() < 1e-9, "obs differ at step %d: env %d rel err %.3e" % (t, int(err.argmax()), err.max())
+        assert np.array_equal(rew, o_rew)
+        if t == STEPS - 1:
+            assert np.abs(b.get(A.F_CTRL) - ctrl).max() < 1e-9       # data.ctrl keeps the unclamped controller output
+    assert np.array_equal(b.get(A.F_FRAME_IDX), fidx) and np.array_equal(b.get(A.F_EPISODE), episode.astype(np.int32))
+    assert np.all(b.get(A.F_NEFC) == 0) and b.redo_total() == 0
+    q = b.get(A.F_QPOS); oq = np.stack([d.get("qpos") for d in ods])
+    assert np.abs(q - oq).max() / max(1.0, np.abs(oq).max()) < 1e-9
+    print("configs[1] full size (%s): worst rel err %.2e, %d auto-resets" % (form, worst, ndone))
+    b.close()
+
+
+@pytest.mark.parametrize("form", ["packed", "horizon", "one-env"])
+def test_standing_population_full_shard_matches_oracle(form):
+    """The regime of a competent policy (src/checkpoint_tmp/DeepMimic/trpo-walk-0: under it 23 % of evaluations hold more than 16 rows):
+    4 096 environments started from the noisy init pose (src/dp_env_v3.py:158-164), standing on both feet — 8 foot corners x 4 pyramid edges =
+    32 constraint rows, plus whatever joint limits are active — and kept there for 16 steps by small actions.  Most packed waves take the
+    two-row-set path, environments beyond 32 rows go through the redo list (per step) or the in-wave re-step (horizon launch).  Every env,
+    every step against the oracle: obs / reward 1e-9, done flags, row and contact counts, contact lists."""
+    import torch
+    from deepmimic_mujoco_amd import Batch
+    from deepmimic_mujoco_amd.imitation import ImitationSpec
+    from oracle import oracle as O
+    n, STEPS, clip = 4096, 16, "walk"
+    mc = H.mocap(clip)
+    T, P = ImitationSpec(H.compiled_model()).table_for(mc)
+    b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
+    b.set_option(A.OPT_REWARD_MODE, 3); b.set_option(A.OPT_AUTORESET, 0); b.set_option(A.OPT_SEED, SEED); b.set_option(A.OPT_DIAGNOSTICS, 1)
+    b.set_option(A.OPT_PIPELINE, 2); b.set_option(A.OPT_PACKED, 0 if form == "one-env" else 1)
+    b.reset(1, 1)                                                 # reset_model_init after sim.reset(): init pose + U(-0.01, 0.01) noise, frame redrawn
+    q0 = b.get(A.F_QPOS); v0 = b.get(A.F_QVEL)
+    fidx = b.get(A.F_FRAME_IDX).copy(); cyc = b.get(A.F_CYCLE).copy()
+    assert np.abs(q0[:, 2] - 0.9).max() < 0.011 and np.abs(v0).max() < 0.011
+    om = H.oracle_model()
+    ods = [O.Data(om) for _ in range(n)]
+    for e in range(n):
+        ods[e].reset(); ods[e].set_state(q0[e], v0[e])
+    nthreads = max(1, len(os.sched_getaffinity(0)))
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cuda"); g.manual_seed(8)
+    acts = torch.randn((STEPS + 1, n, 28), generator=g, device=dev, dtype=torch.float64) * 0.1
+    obs_T = torch.empty((STEPS, n, 56), dtype=torch.float64, device=dev); rew_T = torch.empty((STEPS, n), dtype=torch.float64, device=dev)
+    done_T = torch.empty((STEPS, n), dtype=torch.uint8, device=dev)
+    if form == "horizon":
+        b.rollout(acts, (obs_T, rew_T, done_T), 1)
+        b.join(); torch.cuda.current_stream().synchronize()
+    worst = 0.0
+    peak = np.zeros(n, dtype=np.int32)
+    for t in range(STEPS):
+        if form != "horizon":
+            b.step(acts[t], 1, (obs_T[t], rew_T[t], done_T[t]))
+            b.join(); torch.cuda.current_stream().synchronize()
+        a = acts[t].cpu().numpy(); obs = obs_T[t].cpu().numpy(); rew = rew_T[t].cpu().numpy(); done = done_T[t].cpu().numpy()
+        o_obs, o_rew, o_done = O.batch_step_imitation(om, ods, a, 1, T, P, fidx, cyc, nthreads=nthreads)
+        assert np.array_equal(done, o_done), "done flags differ at step %d" % t
+        o_nefc = np.array([int(d.get("nefc")[0]) for d in ods], dtype=np.int32)
+        peak = np.maximum(peak, o_nefc)
+        if form != "horizon" or t == STEPS - 1:
+            nefc = b.get(A.F_NEFC); ncon = b.get(A.F_NCON); cg = b.get(A.F_CONTACT_GEOMS)
+            o_ncon = np.array([int(d.get("ncon")[0]) for d in ods], dtype=np.int32)
+            assert np.array_equal(nefc, o_nefc), "nefc differs at step %d: envs %s" % (t, np.nonzero(nefc != o_nefc)[0][:8])
+            assert np.array_equal(ncon, o_ncon)
+            for e in range(0, n, 7):
+                k = min(int(o_ncon[e]), A.MAXEFC)
+                if k:
+                    assert np.array_equal(cg[e][:k], ods[e].get("contact_geom").reshape(-1, 2).astype(np.int32)[:k]), "contact list differs: step %d env %d" % (t, e)
+        err_o = np.abs(obs - o_obs).max(1) / np.maximum(1.0, np.abs(o_obs).max(1))
+        err_r = np.abs(rew - o_rew) / np.maximum(1.0, np.abs(o_rew))
+        worst = max(worst, float(err_o.max()), float(err_r.max()))
+        assert err_o.max() < 1e-9, "obs differ at step %d: env %d rel err %.3e (nefc %d)" % (t, int(err_o.argmax()), err_o.max(), int(o_nefc[int(err_o.argmax())]))
+        assert err_r.max() < 1e-9, "reward differs at step %d" % t
+    heavy = float((peak >= 32).mean())
+    assert heavy >= 0.25, "a standing population: %.1f %% of the environments reached 32 rows" % (100 * heavy)
+    assert int(done_T.sum()) == 0
+    q = b.get(A.F_QPOS); oq = np.stack([d.get("qpos") for d in ods])
+    assert np.abs(q - oq).max() / max(1.0, np.abs(oq).max()) < 1e-9
+    print("standing shard (%s): worst rel err %.2e; %.1f %% of envs reached >= 32 rows, %.1f %% > 32 (max %d); beyond the packed capacities: %s"
+          % (form, worst, 100 * heavy, 100 * float((peak > 32).mean()), int(peak.max()), b.redo_reasons() if form != "one-env" else "-"))
     b.close()

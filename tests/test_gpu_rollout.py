@@ -170,6 +170,34 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
 
 
 @pytest.mark.gpu
+def test_bench_rccl_code_path_runs_at_world_size_one():
+    """The RCCL branch of the multi-GPU path (src/train_mpi.sh:1, src/trpo.py:175-186, src/mpi_adam.py:21-50 in the reference: MPI) executed
+    on the one GPU there is: `init_process_group("nccl", device_id=...)`, the double-buffered device-buffer `all_gather_into_tensor` of the
+    [256, 8192, 87] f32 rollout block of configs[4]'s shard, the barriers and the max-reduced timing on device tensors, the learner's all-mean
+    on a gradient-sized vector — with a group of ONE rank, so that no second GPU is needed; and the two 8-way gathered buffers an 8-rank job
+    holds per rank (5.8 GB each) allocate beside the batch.  It gives no scaling number; it removes "never ran" from the first SCALE run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "cfg5", "--steps", "512", "--warmup", "0", "--prewarm-horizons", "0",
+                          "--force-dist", "--dist-backend", "nccl", "--alloc-gather-world", "8", "--repeats", "1", "--no-pmc", "--no-cpu-baseline", "--no-gym-loop",
+                          "--no-vecenv-leg", "--no-horizon-leg"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "nccl process group up, 1 ranks (backend reports nccl)" in out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]       # (RCCL may print to stdout when the group is torn down)
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    c = j["config"]
+    assert c["n_ranks_seen"] == 1 and c["dist_backend"] == "nccl" and c["forced_dist"] is True
+    assert c["gathers_completed"] >= 2, "two horizons: both blocks of the double buffer travelled"
+    assert c["learner_allmean_ok"] is True
+    assert c["gather_buffers_allocated_bytes"] == 2 * 8 * 256 * 8192 * 87 * 4
+    assert j["value"] > 1e6 and j["n_gpus"] == 1 and c["envs_per_gpu"] == 8192
+
+
+@pytest.mark.gpu
 def test_bench_eight_ranks_share_the_gpu_over_gloo():
     """World size 8 — the driver's largest scaling point — on the ONE visible GPU: shard offsets 0 .. 7 N, eight-way gathered rollout
     blocks (DoubleBufferedGather, host-staged over gloo), MAX-reduced timing, exactly one JSON line from rank 0.  BASELINE.json

@@ -29,6 +29,12 @@ print('value %.3f M  spread %.2f..%.2f  vecenv %s  horizon %s  launch_us %s' % (
     done; done ;;
   stage:*)
     for v in ${WHAT#stage:}; do echo "== $v" | tee -a $OUT/stage.log; DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python tools/profile_packed.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/stage.log; done ;;
+  hstage:*)
+    for v in ${WHAT#hstage:}; do echo "== $v" | tee -a $OUT/hstage.log; DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python tools/profile_horizon.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/hstage.log; done ;;
+  standing)
+    timeout 600 python bench.py --workload standing --steps 2048 --warmup 1024 > $OUT/bench_standing.json 2> $OUT/bench_standing.err; cut -c1-1500 $OUT/bench_standing.json; tail -3 $OUT/bench_standing.err ;;
+  pytest:*)
+    ( timeout 1500 python -m pytest ${WHAT#pytest:} -x -q 2>&1 | tail -25 ) | tee -a $OUT/pytest_sel.log ;;
   bench)
     DM_PROFILE_KEEP=$OUT/raw timeout 900 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-600 $OUT/bench_cfg3.json
     timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 $Q > $OUT/bench_cfg3_driver_window.json 2>/dev/null; cut -c1-300 $OUT/bench_cfg3_driver_window.json ;;
