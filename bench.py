@@ -531,9 +531,12 @@ def main():
         env.reset("rsi")
         stat_nefc, stat_iter = [], []
 
+        act_rows = [actions[k] for k in range(pool)]                       # the per-step buffers, as any caller holds them: views made once
+        out_rows = [(obs_T[k], rew_T[k], done_T[k]) for k in range(HORIZON)]
+
         def one_step(t, stats=False):
             k = t % HORIZON
-            env.batch.step(actions[t % pool], 1, (obs_T[k], rew_T[k], done_T[k]))
+            env.batch.step(act_rows[t % pool], 1, out_rows[k])
             if k == HORIZON - 1:
                 env.batch.join()                                              # pipelined sub-batches: this stream now consumes their outputs
                 blk = dbg.block(t)
@@ -637,7 +640,7 @@ def main():
             def facade_steps():
                 for t in range(args.steps):
                     k = t % HORIZON
-                    env.step(actions[t % pool], out=(obs_T[k], rew_T[k], done_T[k]))
+                    env.step(act_rows[t % pool], out=out_rows[k])
                     if k == HORIZON - 1:
                         bt.join()
             facade_steps(); bt.join(); bt.sync()                               # untimed: first use of this kernel

@@ -230,6 +230,9 @@ __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_redo(const DevModel<
 #ifndef DM_ORDER_KEY
 #define DM_ORDER_KEY(nefc, iter) ((nefc) + ((iter) >> 2))
 #endif
+// (measured, round 4: DEALING the sorted list over the waves of a horizon launch — rank r to wave r % W, slot r / W, one environment of each
+//  quartile per wave instead of the four heaviest together — shortens the slowest wave of a 64-step launch by 1.3 % and lengthens the
+//  driver's 20-step window by 2 %: profiles/r04_ab_kernel_variants.md; the grouped order stays)
 __global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__ order, int first, int count) {
   __shared__ int hist[64], start[64];
   const int tid = threadIdx.x, n = count;                // envs first .. first + count - 1 are sorted into order[first ..]
