@@ -11,22 +11,27 @@ Workloads (`--workload`, named in config.workload):
   cfg4 — configs[3]: 'spinkick', 32768 envs sharded 8 x 4096; a single process times ONE shard (shard 3: env_offset = 3 N).
   cfg5 — configs[4]: 'dance_b', reference-state-init + early termination, 65536 envs sharded 8 x 8192; one shard as above.
   rollout — informational: policy in the loop + GAE.
-One "step" = one `dm_batch_step` launch = one DPEnv.step (ONE RK4 mj_step, h = 0.0166 s, as src/dp_env_v3.py:108-112
-hard-codes) of every env of the rank.  With N > 1 the env index range is sharded over ranks (weak scaling, no per-step
-collective) and every 256 steps the [256, n, 87] f32 rollout block is all-gathered (RCCL with `--dist-backend nccl`, the
-default; `gloo` stages the block through pinned host memory and exists so that the multi-rank code path can be executed where
-only one GPU is visible) — asynchronously, double-buffered, so the envs keep stepping while the block travels; every gather
-completes inside the timed region.  Prints ONE JSON line (rank 0).
+  standing — informational: the reference's shipped policy in the loop (the regime a trained population lives in), three kernel legs.
+One "step" = one `dm_batch_step` call = one DPEnv.step (ONE RK4 mj_step, h = 0.0166 s, as src/dp_env_v3.py:108-112 hard-codes) of every env of
+the rank.  The timed calls run under DM_OPT_STEP_QUEUE (`--step-queue`, default 256; include/dmenv.h): they are queued and executed together as
+one horizon launch per 256 calls or at the join that ends a window — every wavefront steps its four environments through the queued steps at its
+own pace instead of waiting for the slowest wave of every step; open-loop stepping with pre-drawn actions, the same contract as the pipelined
+sub-batches of rounds 2-3 (outputs valid after `dm_batch_join`), results bit-identical to unqueued steps (tests/test_gpu_queue.py).  THREE timed
+windows of `--steps` steps each, every one bracketed by barrier + synchronize (`--repeats`); `value` / `ms_per_step` are the median window,
+`value_spread` min / median / max.  With N > 1 the env index range is sharded over ranks (weak scaling, no per-step collective) and every 256
+steps the [256, n, 87] f32 rollout block is all-gathered (RCCL with `--dist-backend nccl`, the default; `gloo` stages the block through pinned host
+memory so that the multi-rank code path can run where only one GPU is visible; `--force-dist` takes that path with ONE rank) — asynchronously,
+double-buffered; every gather completes inside the timed region.  Prints ONE JSON line (rank 0).
 
-After the timed steps every step workload times a second leg, reported as `horizon_launch` in the same line: the timed window rounded up to
-whole 256-step horizons of the same workload and state stream through `dm_batch_rollout` — T steps per call, on the packed path ONE launch
-in which every wavefront steps its four environments T times at its own pace (same barriers, max over ranks; results bit-identical to the
-per-step calls).  `value` stays the one-call-per-step figure, the drop-in for `VecEnv.step`; `--horizon-launch` makes the rollout call the
-timed leg itself (with the live PMC passes of its kernel).
+Further legs in the same line (N = 1 or max over ranks, same barriers):
+  `vecenv_step`     the same number of steps through the facade `DPVecEnv.step(actions, out=...)` with nothing queued: one launch set per call on the
+                    kernel DPVecEnv(packed=None) picks — what a caller gets that consumes every step's outputs (the drop-in for VecEnv.step);
+  `horizon_launch`  the window rounded up to whole 256-step horizons through `dm_batch_rollout` (T steps per call).
+`--step-queue 0` times one launch set per `dm_batch_step` call (rounds 1-3's `value`); `--horizon-launch` makes the rollout call the timed leg.
 
-Besides the contract fields the line carries (N = 1): `roofline` (HBM fraction from the algorithmic bytes; fp64 fraction from
-a flop count of the kernel's algorithm evaluated on the run's own row / sweep statistics; with rocprofv3 on PATH, live PMC
-passes of this very workload: HBM traffic, VALU issue fraction, lane efficiency), `cpu_baseline` (the oracle on the host
+Besides the contract fields the line carries (N = 1): `roofline` (HBM fraction from the algorithmic bytes per launch and the launch's duration by HIP
+events the library records around it; fp64 fraction from a flop count of the kernel's algorithm on the run's own row / sweep statistics; with
+rocprofv3 on PATH, live PMC passes of this very workload: HBM traffic, VALU issue fraction, lane efficiency), `cpu_baseline` (the oracle on the host
 cores), `single_env_gym_loop` (steps/s of a Python `DPEnv.step` loop, the path src/trpo.py:47-80 drives).
 """
 import argparse
@@ -295,11 +300,14 @@ def rollout_bench(args, dev, rank, world, local_dev):
     P = max(1, min(args.pipeline, 8))
     clip = args.clip or "walk"
     pol = MlpPolicy(device=dev, seed=0); pol.seed(rank)
+    horizon_form = False
     if not args.unfused:        # one batch, P pipelined sub-batches, the policy step inside the env step kernel: one launch per step
         from deepmimic_mujoco_amd import _abi as A
         env = DPVecEnv(n, motion=clip, device=local_dev, reward="alive", autoreset="init", seed=0, env_offset=rank * n,
                        packed=None if args.packed is None else bool(args.packed))
         env.batch.set_option(A.OPT_PIPELINE, min(P, A.MAX_PIPELINE))
+        # the collector steps a fused segment through dm_batch_rollout — one horizon launch where the env leaves the kernel choice open or pins the packed one
+        horizon_form = bool(getattr(env, "horizon_packed_ok", False)) or bool(env.packed)
         gen = traj_segment_generator(pol, env, HORIZON, stochastic=True, fused=True)
     elif P > 1:
         cuts = [n * h // P for h in range(P + 1)]
@@ -323,12 +331,12 @@ def rollout_bench(args, dev, rank, world, local_dev):
     if rank == 0:
         print(json.dumps({"metric": "rollout env-steps/sec (policy in the loop + GAE)", "value": round(world * n * segs * HORIZON / el, 1),
                           "unit": "env-steps/s", "n_gpus": world, "steps": segs * HORIZON, "ms_per_step": round(el / (segs * HORIZON) * 1e3, 4),
-                          "episodes": eps, "horizon_launch": (not args.unfused) and bool(env.packed), "packed_redo_env_steps": env.batch.redo_total() if not args.unfused else None,
+                          "episodes": eps, "horizon_launch": (not args.unfused) and horizon_form, "packed_redo_env_steps": env.batch.redo_total() if not args.unfused else None,
                           "config": {"workload": "rollout: %d envs/GPU, %s, untrained 2x100 tanh policy, alive reward, "
                                                                   "noisy-init autoreset, %d-step segments + GAE(0.995, 0.97)"
                                                                   % (n, ("%d concurrently stepped batch(es), one policy launch + one env launch per step" % P) if args.unfused
                                                                      else (("policy step inside the horizon launch: four environments per wavefront, each wave runs its %d steps at its own pace (dm_batch_rollout, k_rollout_packed)" % HORIZON)
-                                                                           if env.packed else ("policy step fused into the env step kernel (one launch per step), %d pipelined sub-batch(es)" % P)), HORIZON)}}))
+                                                                           if horizon_form else ("policy step fused into the env step kernel (one launch per step), %d pipelined sub-batch(es)" % P)), HORIZON)}}))
 
 
 def standing_bench(args, dev, rank, world, local_dev):

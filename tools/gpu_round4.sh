@@ -47,8 +47,12 @@ print('value %.3f M  spread %.2f..%.2f  vecenv %s  horizon %s  launch_us %s' % (
     timeout 300 python bench.py --step-queue 0 $Q > $OUT/bench_cfg3_unqueued.json 2>/dev/null; cut -c1-200 $OUT/bench_cfg3_unqueued.json
     timeout 300 python bench.py --workload rollout --steps 2048 --warmup 256 > $OUT/bench_rollout_fused.json 2>/dev/null; cut -c1-200 $OUT/bench_rollout_fused.json ;;
   trace)
-    ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace -- python $OLDPWD/bench.py --steps 512 --warmup 0 --prewarm-horizons 1 --repeats 1 --no-vecenv-leg --no-horizon-leg $Q > /dev/null 2>&1 )
-    ROWS=8 python tools/rocprof_summary.py $OUT/krollout_summary.md "step queue -> horizon launches — $TAG, MI355X (bench.py default: cfg3 + 5-term imitation reward, 4096 envs, dm_batch_step calls queued 256 per launch)" \
-      $(find /tmp/p_trace -name "*.db" | head -1) > /dev/null; head -14 $OUT/krollout_summary.md ;;
+    # the judged command's kernel trace: the profiled child runs nothing but horizons of 256 queued steps (one untimed + the 512 timed ones = 3 launches)
+    ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace -- python $OLDPWD/bench.py --_child --steps 512 --warmup 0 --prewarm-horizons 1 $Q > /dev/null 2>&1 )
+    ROWS=8 python tools/rocprof_summary.py $OUT/krollout_summary.md "step queue -> horizon launches — $TAG, MI355X (bench.py default: cfg3 + 5-term imitation reward, 4096 envs, dm_batch_step calls queued 256 per launch; 3 launches)" \
+      $(find /tmp/p_trace -name "*.db" | head -1) > /dev/null; head -14 $OUT/krollout_summary.md
+    ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace1 -- python $OLDPWD/bench.py --_child --step-queue 0 --steps 96 --warmup 16 --prewarm-horizons 1 $Q > /dev/null 2>&1 )
+    ROWS=6 python tools/rocprof_summary.py $OUT/kstep_summary.md "one launch set per call — $TAG, MI355X (bench.py --step-queue 0: k_step_narrow, 4096 envs as 2 pipelined sub-batches; what vecenv_step times)" \
+      $(find /tmp/p_trace1 -name "*.db" | head -1) > /dev/null; head -10 $OUT/kstep_summary.md ;;
   *) echo "unknown bundle $WHAT" ;;
 esac; done
