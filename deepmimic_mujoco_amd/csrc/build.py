@@ -18,6 +18,11 @@ def hipcc():
 
 
 OUT32 = os.path.join(HERE, "libdmenv32.so")
+# Backend options (round 4, A/B in profiles/r04_ab_kernel_variants.md).  The step kernels run ONE wave per SIMD with the whole register file: the default
+# scheduling strategy (max-occupancy: keep register pressure low) buys nothing there, scheduling for instruction-level parallelism hides more of a lone
+# wave's LDS / f64 latencies (+1.0 .. +1.6 % env-steps/s); register-class priority in the greedy allocator +0.4 %.  Neither touches floating-point
+# semantics: results are bit-identical.
+BACKEND_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-greedy-regclass-priority-trumps-globalness=1"]
 
 
 def _stale(out, srcs):
@@ -33,7 +38,7 @@ def build(force=False, verbose=False):
         if not force and not _stale(out, srcs):
             continue
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-shift-count-negative",
-               "-Wno-implicit-const-int-float-conversion"] + defs + os.environ.get("DM_BUILD_DEFINES", "").split() + [
+               "-Wno-implicit-const-int-float-conversion"] + BACKEND_FLAGS + defs + os.environ.get("DM_BUILD_DEFINES", "").split() + [
                "-I" + os.path.join(REPO, "include"), "-I" + HERE, os.path.join(HERE, "dmenv.hip"), "-o", out]
         if verbose:
             cmd.insert(-2, "-Rpass-analysis=kernel-resource-usage")

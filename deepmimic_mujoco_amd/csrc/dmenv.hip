@@ -150,6 +150,9 @@ __global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __r
   __shared__ SlotOrOne<Real> u;
   __shared__ SlotTables tb;
   static_assert(sizeof(SlotOrOne<Real>) == sizeof(SlotShared<Real>) * SLOTS, "the one-env code's LDS fits into the four slots'");
+  // the policy step's scratch (464 floats per env at the slot's r1): inside r1 in the float64 build, so a slot's kinematics (xpos, xmat, cdof, r2) survive
+  // it; the float32 build's r1 is smaller and the scratch runs into r2: no kinematics carried over a policy step there (slot_env_step kin_carry)
+  const bool policy_clobbers_kin = pa.P != nullptr && sizeof(((SlotShared<Real>*)0)->r1) < 464 * sizeof(float);
   const Batch<Real>& B = *Bp;       // (in device memory, not a by-value argument: the called step functions are handed its address)
   const int lane = dmw::lane(), slot = lane >> 4;
   stage_slot_tables(tb, lane);
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __r
     dmw::sync();
     dmp::policy_wave4<Real>(p, envs, wr, lane, reinterpret_cast<char*>(&u.sh[0]), (unsigned)sizeof(SlotShared<Real>), (unsigned)(offsetof(SlotShared<Real>, qpos) + 7 * sizeof(Real)),
                             (unsigned)(offsetof(SlotShared<Real>, qvel) + 6 * sizeof(Real)), (unsigned)offsetof(SlotShared<Real>, r1));
-  }, prof_acc);
+  }, prof_acc, policy_clobbers_kin);
   // diagnostic (DM option 101): shader-clock cycles this wave spent on its horizon, slot 5 ("total") of workgroup w's profile record
 #ifdef DM_ROLLOUT_PROF
   if (prof_acc && lane == 0) prof_acc[31] = dmw::clk() - t_enter;        // (this build: per-stage sums in [0..30] of the wave's first record, the horizon's total in [31])

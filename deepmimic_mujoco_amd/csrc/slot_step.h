@@ -31,7 +31,7 @@ DM_DEV void slot_integrate_pos(SlotShared<R>& s, const DofVec<R>& x0q, int sl, R
 }
 
 // [MJ mj_step, integrator RK4] on the state in s.qpos / s.qvel / s.qws / s.act; xip = body COM positions of the 4th stage evaluation
-template <class R, bool PROF = false>
+template <class R, bool PROF = false, bool CARRY = false>
 DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, int lane, const LaneTopo& lt, R* xip, int& ovf, long long* prof = 0) {
   const R h = M.timestep;
   const R A[3] = {R(0.5), R(0.5), R(1)};
@@ -64,7 +64,7 @@ DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTabl
     ParkedR pk[5][DOF_PASSES];
 #pragma unroll
     for (int c = 0; c < DOF_PASSES; c++) { pk[0][c] = dmw::park(x0q.r[c]); pk[1][c] = dmw::park(x0v.r[c]); pk[2][c] = dmw::park(vprev.r[c]); pk[3][c] = dmw::park(sumv.r[c]); pk[4][c] = dmw::park(suma.r[c]); }
-    slot_forward<R, PROF>(M, s, tb, sl, lane, lt, xip, ovf, (const DebugOut*)0, prof);
+    slot_forward<R, PROF, CARRY>(M, s, tb, sl, lane, lt, xip, ovf, (const DebugOut*)0, prof);
 #pragma unroll
     for (int c = 0; c < DOF_PASSES; c++) { x0q.r[c] = dmw::unpark(pk[0][c]); x0v.r[c] = dmw::unpark(pk[1][c]); vprev.r[c] = dmw::unpark(pk[2][c]); sumv.r[c] = dmw::unpark(pk[3][c]); suma.r[c] = dmw::unpark(pk[4][c]); }
 #pragma unroll
@@ -239,19 +239,23 @@ DM_DEV R slot_imitation_reward(const DevModel<R>& M, const Batch<R>& B, SlotShar
 // DPEnv.step for the slot's environment (reward modes alive / v3-config / v2-pose / the 5-term imitation reward; dp_env_v1's reward stays with the one-env kernel).  A slot that is not `live` computes and stores nothing outside LDS.  An environment that exceeded a
 // capacity of the packed path during the step (`ovf`) stores nothing either: it is appended to the launch's redo list
 // (redo[0] = counter, list = redo + 1 ...) and re-stepped from its unchanged state by the one-env kernel.
-template <class R, bool PROF = false>
+// CARRY (horizon launches only) + kin_carry (wave-uniform): the slots' LDS is what this wave's previous step left, so a slot's `kin_ok` flag
+// means what it says and the first evaluation may skip its position stage (slot_forward): one kinematics pass in five less with the 5-term
+// reward, bit-identical results.  Without kin_carry (the first step of a launch, the step after an in-wave re-step) the flags are cleared first.
+template <class R, bool PROF = false, bool CARRY = false>
 DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, SlotTables& tb, int env, int sl, int lane, bool live,
                           const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int* redo_count, int* redo_list,
-                          long long* prof_out = 0) {
+                          long long* prof_out = 0, bool kin_carry = false) {
   long long prof[32];
   for (int k = 0; k < 32; k++) prof[k] = 0;
   long long tstart = 0;
   if (PROF) tstart = dmw::clk();
   const LaneTopo lt = lane_topo(sl);
+  if constexpr (CARRY) { if (!kin_carry && sl == 0) s.kin_ok() = R(0); }       // (ordered before the first read by slot_load_env's hand-off)
   slot_load_env(M, B, s, env, sl, live, action);
   R xip[3];
   int why = 0;
-  for (int k = 0; k < n_substeps; k++) slot_rk4_step<R, PROF>(M, s, tb, sl, lane, lt, xip, why, prof);
+  for (int k = 0; k < n_substeps; k++) slot_rk4_step<R, PROF, CARRY>(M, s, tb, sl, lane, lt, xip, why, prof);
   const bool ovf = dmw::row_ballot(why != 0, lane) != 0u;
   if (dmw::ballot(ovf) != 0ull) {                     // rare: list the environment, tally the reasons (diagnostics)
     unsigned bits = 0;
@@ -311,6 +315,9 @@ DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
     dmw::sync_mem();
     slot_reset_env(M, B, s, env, sl, dn && live, B.autoreset == 1 ? 0 : 1, 1);
   }
+  // the slot's kinematics are those of the state the env is left in: the 5-term reward's pass ran on it and no reset replaced it (a slot that
+  // is not live repeats a live one's environment and computes the same)
+  if constexpr (CARRY) { if (sl == 0) s.kin_ok() = (B.reward_mode == REW_IMITATION && !ovf && !(dn && B.autoreset != 0)) ? R(1) : R(0); }
   if (live) {
 #pragma unroll
     for (int c = 0; c < (NOBS + SW - 1) / SW; c++) {
@@ -355,21 +362,22 @@ DM_DEV_CALL64 void restep_one_env(const DevModel<R>* M, const Batch<R>* B, Share
 //  allocator produced four times the spills and a 27 % slower step)
 template <class R>
 DM_DEV_CALL64 bool slot_env_step_call(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
-                                      const double* action, double* obs, double* reward, unsigned char* done, int n_substeps) {
+                                      const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int kin_carry) {
   using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global; using dmw::in_constant;
   const Batch<R> Bv = *in_constant(B);
-  return slot_env_step<R>(*in_constant(M), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
-                          in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0);
+  return slot_env_step<R, false, true>(*in_constant(M), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
+                                       in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0,
+                                       (long long*)0, dmw::uniform(kin_carry) != 0);
 }
 #ifdef DM_ROLLOUT_PROF     // diagnostic build (tools/profile_horizon.py): the step with per-stage shader-clock stamps, one 32-counter record per call
 template <class R>
 DM_DEV_CALL64 bool slot_env_step_call_prof(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
-                                           const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, long long* prof_out) {
+                                           const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, long long* prof_out, int kin_carry) {
   using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global; using dmw::in_constant;
   const Batch<R> Bv = *in_constant(B);
-  return slot_env_step<R, true>(*in_constant(M), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
-                                in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0,
-                                in_global(uniform_ptr(prof_out)));
+  return slot_env_step<R, true, true>(*in_constant(M), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
+                                      in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0,
+                                      in_global(uniform_ptr(prof_out)), dmw::uniform(kin_carry) != 0);
 }
 #endif
 // The buffers of ONE step of a horizon: what one dm_batch_step call names (action [N, 28] in; obs [N, 56], reward [N], done [N] out).  A horizon
@@ -378,8 +386,9 @@ DM_DEV_CALL64 bool slot_env_step_call_prof(const DevModel<R>* M, const Batch<R>*
 struct StepRow { const double* action; double* obs; double* reward; unsigned char* done; };
 template <class R, int NR, class POLICY>
 DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<R>* sh, SlotTables& tb, Shared<R>& one_s, StepScratch<R>& one_x,
-                         int env, int lane, bool live, const StepRow* rows, int n_substeps, int T, POLICY&& policy, long long* prof_acc = 0) {
+                         int env, int lane, bool live, const StepRow* rows, int n_substeps, int T, POLICY&& policy, long long* prof_acc = 0, bool policy_clobbers_kin = false) {
   const int slot = lane >> 4, sl = lane & 15;
+  int carry = 0;                              // the slots' LDS is what this wave's previous step left (no in-wave re-step overwrote it): slot_env_step kin_carry
   for (int t = 0; t < T; t++) {
     // (every step reads the model afresh: hoisting those loads out of the loop would keep hundreds of registers alive across it)
     const DevModel<R>& M = *dmw::launder_uniform_ptr(&M_in);
@@ -391,14 +400,14 @@ DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<
 #ifdef DM_ROLLOUT_PROF
     bool stored;
     if (prof_acc) {        // [0..31] sums over the horizon's steps, [32..63] the record of the step just taken
-      stored = slot_env_step_call_prof<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, prof_acc + 32);
+      stored = slot_env_step_call_prof<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, prof_acc + 32, carry);
       if (lane == 0) for (int k = 0; k < 31; k++) prof_acc[k] += prof_acc[32 + k];
-    } else stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps);
+    } else stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, carry);
 #else
     // (measured, round 4: the step body inlined here instead of called — the batch descriptor and tables read afresh every step so that nothing is
     //  hoisted — removes the callee's register save / restore (1.6 KB per lane per call) and is 10 % SLOWER: 15.0 against 16.7 M env-steps/s,
     //  profiles/r04_ab_kernel_variants.md; the loop around the body costs the allocator more than the calls cost the memory system)
-    const bool stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps);
+    const bool stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, carry);
 #endif
     const int need = (live && !stored) ? 1 : 0;
     bool any = false;
@@ -420,7 +429,8 @@ DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<
       }
       dmw::sync_mem();
     }
-    policy(t);
+    policy(t);                                                   // (float64 build: its scratch stays inside the slots' r1 region and the kinematics survive it)
+    carry = (any || policy_clobbers_kin) ? 0 : 1;
     dmw::sync_mem();                                             // state / action rows written by other lanes of this wave are read next step
   }
 }

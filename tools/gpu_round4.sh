@@ -27,10 +27,18 @@ print('value %.3f M  spread %.2f..%.2f  vecenv %s  horizon %s  launch_us %s' % (
         echo "$v steps=$1 : ${o:-FAILED $(tail -2 $OUT/ab_err.txt | cut -c1-200)}" | tee -a $OUT/ab.log
       done
     done; done ;;
+  hl:*)
+    # horizon-launch leg only, five windows of 1024 steps, imitation and alive rewards: tight A/B of builds whose difference is a per-cent
+    for rep in 1 2; do for v in ${WHAT#hl:}; do for rw in imitation alive; do
+      o=$(DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python bench.py $Q --no-vecenv-leg --no-horizon-leg --reward $rw --steps 1024 --warmup 0 --repeats 5 2>$OUT/hl_err.txt | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print('value %.3f M  spread %.3f..%.3f  launch_us %s' % (j['value']/1e6, j['value_spread']['min']/1e6, j['value_spread']['max']/1e6, j['roofline']['launch'].get('avg_us')))")
+      echo "$v $rw : ${o:-FAILED $(tail -2 $OUT/hl_err.txt | cut -c1-200)}" | tee -a $OUT/hl.log
+    done; done; done ;;
   stage:*)
     for v in ${WHAT#stage:}; do echo "== $v" | tee -a $OUT/stage.log; DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python tools/profile_packed.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/stage.log; done ;;
   hstage:*)
-    for v in ${WHAT#hstage:}; do echo "== $v" | tee -a $OUT/hstage.log; DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python tools/profile_horizon.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/hstage.log; done ;;
+    for v in ${WHAT#hstage:}; do echo "== $v" | tee -a $OUT/hstage.log; DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python tools/profile_horizon.py ${HSTAGE_ARGS:-} 2>&1 | grep -v amdgpu.ids | tee -a $OUT/hstage.log; done ;;
   train)
     timeout 400 python tools/train_trpo.py --envs 4096 --horizon 128 --seconds 60 --out $OUT/trpo_train_60s.json 2>&1 | tail -3 | tee $OUT/trpo_train.log
     DM_TRPO_PROFILE=1 timeout 300 python tools/train_trpo.py --envs 4096 --horizon 128 --iters 40 --out $OUT/trpo_update_profile.json 2>&1 | tail -1 ;;

@@ -13,7 +13,7 @@ from deepmimic_mujoco_amd import DPVecEnv, _abi as A  # noqa: E402
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 dev = "cuda:0"
-env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="rsi", seed=0, packed=True)
+env = DPVecEnv(n, motion="walk", device=0, reward=os.environ.get("DM_PROF_REWARD", "alive"), autoreset="rsi", seed=0, packed=True, frame_skip=1)
 b = env.batch
 b.set_option(106, 1)
 g = torch.Generator(device=dev); g.manual_seed(1)
