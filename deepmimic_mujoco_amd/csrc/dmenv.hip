@@ -13,29 +13,14 @@
 #include <string>
 #include <vector>
 
-#include "dmenv.h"
-#include "policy_kernel.h"
+#include "kernels.h"
 #include "vf_kernel.h"
 #include "pg_kernel.h"
-#include "env_step.h"
-#include "slot_step.h"
 #include "model_host.h"
 
 using namespace dm;
 static_assert(DM_PACKED_MAXROWS == SLOT_MAXROWS && DM_PACKED_MAXLIMROWS == SLOT_MAXLIMROWS && DM_PACKED_MAXCON == SLOT_MAXCON && DM_PACKED_MAXFRAME == SLOT_MAXFRAME &&
               DM_PACKED_MAXCAND == SLOT_MAXCAND, "include/dmenv.h documents the packed path's capacities: keep it in step with slot_kernel.h");
-// Arithmetic / device-state type of this build: float64 (libdmenv.so, the parity build) or float32 (libdmenv32.so, -DDM_REAL_FLOAT:
-// the `dtype 32` batch of SURVEY.md section 8b — same kernels, half the registers and LDS per env).  Everything that crosses the
-// C ABI (actions, observations, rewards, field reads / writes, mocap tables) stays float64 (`Ext`) in both builds.
-#ifdef DM_REAL_FLOAT
-typedef float Real;
-#define DM_STEP_WAVES 3
-#else
-typedef double Real;
-#define DM_STEP_WAVES 2
-#endif
-typedef double Ext;
-
 // ============================================ kernels ======================================================
 // one 64-lane workgroup (= one wavefront) per environment.
 // k_step_narrow (the timed path) keeps NARROW_ROWS columns of the constraint matrix A per env in registers, which fits
@@ -43,10 +28,6 @@ typedef double Ext;
 // columns in a per-env global-memory strip.  k_step holds all 64 columns in registers (512 VGPRs, 1 wave per SIMD) and is
 // the single-tier fallback (DM option 102 = 0) and the profiling / debug instantiation.  Both perform identical
 // arithmetic on the rows that exist.
-#ifndef DM_NARROW_ROWS
-#define DM_NARROW_ROWS 32
-#endif
-constexpr int NARROW_ROWS = DM_NARROW_ROWS;
 static_assert(AOVF_COLS >= MAXEFC, "memory strip too small");
 __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_narrow(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                                     Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
@@ -88,47 +69,6 @@ __global__ __launch_bounds__(64) void k_step(const DevModel<Real>* __restrict__ 
   env_step<Real, MAXEFC>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
 }
 
-// FOUR environments per wavefront (slot_kernel.h / slot_step.h): workgroup w steps the envs at dispatch positions first + 4 w .. + 3.
-// Environments that exceed a capacity of that path are appended to the sub-batch's redo list instead of being stored ...
-__global__ __launch_bounds__(64) void k_step_packed(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
-                                                    Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
-                                                    int n_substeps, int first, int count, int* __restrict__ redo_count) {
-  __shared__ SlotShared<Real> sh[SLOTS];
-  __shared__ SlotTables tb;
-  const int lane = dmw::lane(), slot = lane >> 4, sl = lane & 15;
-  stage_slot_tables(tb, lane);
-  const int last = first + count - 1;
-  int pos = first + SLOTS * (int)blockIdx.x + slot;
-  const bool live = pos <= last;
-  if (pos > last) pos = last;
-  const int env = B.order ? B.order[pos] : pos;
-  slot_env_step<Real>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first);
-}
-// ... followed, in the same wave, by the policy's step on the four observations it produced (dm_batch_step_act on the packed path): one
-// weight stream per wave serves four environments
-__global__ __launch_bounds__(64) void k_step_packed_act(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
-                                                        Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
-                                                        int n_substeps, int first, int count, int* __restrict__ redo_count, dmp::PolicyArgs pa) {
-  __shared__ SlotShared<Real> sh[SLOTS];
-  __shared__ SlotTables tb;
-  const int lane = dmw::lane(), slot = lane >> 4, sl = lane & 15;
-  stage_slot_tables(tb, lane);
-  const int last = first + count - 1;
-  int pos = first + SLOTS * (int)blockIdx.x + slot;
-  const bool live = pos <= last;
-  if (pos > last) pos = last;
-  const int env = B.order ? B.order[pos] : pos;
-  const bool stored = slot_env_step<Real>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first);
-  // s.qpos / s.qvel of every slot hold the state its observation was written from (the fresh episode's after an auto-reset); r1 is free
-  // the r1 + r2 regions (adjacent) are free
-  static_assert(offsetof(SlotShared<Real>, r2) == offsetof(SlotShared<Real>, r1) + sizeof(sh[0].r1) && sizeof(sh[0].r1) + sizeof(sh[0].r2) >= 464 * sizeof(float), "policy scratch");
-  dmw::sync();
-  const int envs[4] = {dmw::bcast_i(env, 0), dmw::bcast_i(env, 16), dmw::bcast_i(env, 32), dmw::bcast_i(env, 48)};
-  const int st = stored ? 1 : 0;
-  const bool wr[4] = {dmw::bcast_i(st, 0) != 0, dmw::bcast_i(st, 16) != 0, dmw::bcast_i(st, 32) != 0, dmw::bcast_i(st, 48) != 0};
-  dmp::policy_wave4<Real>(pa, envs, wr, lane, reinterpret_cast<char*>(&sh[0]), (unsigned)sizeof(SlotShared<Real>), (unsigned)(offsetof(SlotShared<Real>, qpos) + 7 * sizeof(Real)),
-                          (unsigned)(offsetof(SlotShared<Real>, qvel) + 6 * sizeof(Real)), (unsigned)offsetof(SlotShared<Real>, r1));
-}
 // the batch descriptor into device memory, stream-ordered before the horizon launch that reads it there
 __global__ void k_put_batch(Batch<Real> B, Batch<Real>* __restrict__ dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = B; }
 // the horizon's table of per-step buffers (slot_step.h StepRow), stream-ordered before the launch that reads it: rows of the caller's
@@ -138,71 +78,7 @@ __global__ void k_fill_rows(StepRow* __restrict__ dst, const Ext* action, Ext* o
   if (t < T) dst[t] = StepRow{action + (size_t)t * n * NU, obs + (size_t)t * n * NOBS, reward + (size_t)t * n, done + (size_t)t * n};
 }
 // ... or the buffers of queued dm_batch_step calls (DM_OPT_STEP_QUEUE), a chunk of them per launch in the kernel-argument segment
-constexpr int ROW_CHUNK = 64;
-struct StepRowChunk { StepRow r[ROW_CHUNK]; };
 __global__ void k_put_rows(StepRowChunk c, StepRow* __restrict__ dst, int count) { const int t = threadIdx.x; if (t < count) dst[t] = c.r[t]; }
-// A whole horizon of T steps in ONE launch (dm_batch_rollout; slot_step.h slot_rollout): every wave steps its four environments T times
-// without waiting for any other wave — optionally with the policy's step in between (pa.P; pa.action = the [T + 1, N, 28] action rows,
-// pa.vpred = the [T, N] value rows, pa.counter = the first step's draw counter) — and re-steps an environment that exceeds a capacity of
-// the packed path itself, with the one-env code, in the LDS the slots leave free between two steps.
-__global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __restrict__ Mp, const Batch<Real>* __restrict__ Bp, const StepRow* __restrict__ rows,
-                                                       int n_substeps, int first, int count, int T, dmp::PolicyArgs pa, long long* __restrict__ wave_clk) {
-  __shared__ SlotOrOne<Real> u;
-  __shared__ SlotTables tb;
-  static_assert(sizeof(SlotOrOne<Real>) == sizeof(SlotShared<Real>) * SLOTS, "the one-env code's LDS fits into the four slots'");
-  // the policy step's scratch (464 floats per env at the slot's r1): inside r1 in the float64 build, so a slot's kinematics (xpos, xmat, cdof, r2) survive
-  // it; the float32 build's r1 is smaller and the scratch runs into r2: no kinematics carried over a policy step there (slot_env_step kin_carry)
-  const bool policy_clobbers_kin = pa.P != nullptr && sizeof(((SlotShared<Real>*)0)->r1) < 464 * sizeof(float);
-  const Batch<Real>& B = *Bp;       // (in device memory, not a by-value argument: the called step functions are handed its address)
-  const int lane = dmw::lane(), slot = lane >> 4;
-  stage_slot_tables(tb, lane);
-  const int last = first + count - 1;
-  int pos = first + SLOTS * (int)blockIdx.x + slot;
-  const bool live = pos <= last;
-  if (pos > last) pos = last;
-  const int env = B.order ? B.order[pos] : pos;
-  const int envs[4] = {dmw::bcast_i(env, 0), dmw::bcast_i(env, 16), dmw::bcast_i(env, 32), dmw::bcast_i(env, 48)};
-  const int lv = live ? 1 : 0;
-  const bool wr[4] = {dmw::bcast_i(lv, 0) != 0, dmw::bcast_i(lv, 16) != 0, dmw::bcast_i(lv, 32) != 0, dmw::bcast_i(lv, 48) != 0};
-  const size_t n = (size_t)B.n_envs;
-  const long long t_enter = wave_clk ? dmw::clk() : 0;
-#ifdef DM_ROLLOUT_PROF
-  long long* prof_acc = wave_clk ? wave_clk + (size_t)blockIdx.x * 4 * dm::PROF_SLOTS : (long long*)nullptr;   // four envs' records per wave: [0..31] sums, [32..63] scratch
-  if (prof_acc && lane < 64) prof_acc[lane] = 0;
-  dmw::sync_mem();
-#else
-  long long* prof_acc = nullptr;
-#endif
-  slot_rollout<Real, NARROW_ROWS>(*Mp, B, u.sh, tb, u.one.s, u.one.x, env, lane, live, rows, n_substeps, T, [&](int t) {
-    if (!pa.P) return;
-    dmp::PolicyArgs p = pa;
-    p.action = pa.action + (size_t)(t + 1) * n * NU; p.vpred = pa.vpred + (size_t)t * n; p.counter = pa.counter + (unsigned long long)t;
-    dmw::sync();
-    dmp::policy_wave4<Real>(p, envs, wr, lane, reinterpret_cast<char*>(&u.sh[0]), (unsigned)sizeof(SlotShared<Real>), (unsigned)(offsetof(SlotShared<Real>, qpos) + 7 * sizeof(Real)),
-                            (unsigned)(offsetof(SlotShared<Real>, qvel) + 6 * sizeof(Real)), (unsigned)offsetof(SlotShared<Real>, r1));
-  }, prof_acc, policy_clobbers_kin);
-  // diagnostic (DM option 101): shader-clock cycles this wave spent on its horizon, slot 5 ("total") of workgroup w's profile record
-#ifdef DM_ROLLOUT_PROF
-  if (prof_acc && lane == 0) prof_acc[31] = dmw::clk() - t_enter;        // (this build: per-stage sums in [0..30] of the wave's first record, the horizon's total in [31])
-#else
-  if (wave_clk && lane == 0) wave_clk[(size_t)blockIdx.x * dm::PROF_SLOTS + 5] = dmw::clk() - t_enter;
-#endif
-}
-// the same with shader-clock stamps per stage, one record of 16 per wave (DM option 101 with option 105; diagnostic)
-__global__ __launch_bounds__(64) void k_step_packed_prof(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
-                                                         Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
-                                                         int n_substeps, int first, int count, int* __restrict__ redo_count, long long* __restrict__ prof) {
-  __shared__ SlotShared<Real> sh[SLOTS];
-  __shared__ SlotTables tb;
-  const int lane = dmw::lane(), slot = lane >> 4, sl = lane & 15;
-  stage_slot_tables(tb, lane);
-  const int last = first + count - 1;
-  int pos = first + SLOTS * (int)blockIdx.x + slot;
-  const bool live = pos <= last;
-  if (pos > last) pos = last;
-  const int env = B.order ? B.order[pos] : pos;
-  slot_env_step<Real, true>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first, prof + (size_t)blockIdx.x * 32);
-}
 // ... and stepped here, from their unchanged state, by the one-env code (a handful of persistent single-wave workgroups walk the list)
 __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_redo(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                                   Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,

@@ -49,6 +49,7 @@ __device__ inline void dense32(const float* __restrict__ W, const float* __restr
   }
 }
 
+#ifndef DM_NO_LAUNCH_KERNELS        // (a translation unit that only uses the in-wave policy steps defines it: kernels_packed.hip)
 __global__ __launch_bounds__(256) void k_policy_act(const float* __restrict__ P, const double* __restrict__ obs, double* __restrict__ action,
                                                     float* __restrict__ vpred, int n, int stochastic, unsigned long long seed,
                                                     unsigned long long counter) {
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void k_policy_act(const float* __restrict__ P,
     }
   }
 }
+#endif
 
 // The same policy step for ONE environment by ONE wave, as the epilogue of the env step kernel (dm_batch_step_act): the wave that
 // has just produced an observation turns it into the next action and its value estimate before it exits, so a rollout step is one
@@ -276,6 +278,7 @@ __device__ inline void policy_wave4(const PolicyArgs& pa, const int (&env)[4], c
   }
 }
 
+#ifndef DM_NO_LAUNCH_KERNELS
 // GAE(lambda) of src/trpo.py:83-94 for N environments: thread = env, a backward loop over the T rows of the [T, N] segment
 // (coalesced across envs), instead of T small launches.
 __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, const float* __restrict__ vpred, const int* __restrict__ isnew,
@@ -294,5 +297,6 @@ __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, cons
     vnext = v; nonterminal = 1.0f - (float)isnew[i];         // for row t - 1: new[t]
   }
 }
+#endif
 
 }  // namespace dmp

@@ -6,8 +6,6 @@
 # (a ref from before an entry point was added fails to load: its line then shows the loader's message).
 set -eu
 cd "$(dirname "$0")/.."
-# the product build's backend options (csrc/build.py BACKEND_FLAGS); DM_BACKEND_FLAGS= (empty) builds without them
-DM_BACKEND_FLAGS=${DM_BACKEND_FLAGS--mllvm -amdgpu-sched-strategy=max-ilp -mllvm -greedy-regclass-priority-trumps-globalness=1}
 LIB=deepmimic_mujoco_amd/csrc/libdmenv.so
 case "${1:-}" in
   build)
@@ -17,12 +15,12 @@ case "${1:-}" in
     build_ref() {   # $1 ref ('' = working tree), $2 output
       if [ -n "$1" ]; then
         tmp=$(mktemp -d); git archive "$1" deepmimic_mujoco_amd/csrc include | tar -x -C "$tmp"
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-shift-count-negative \
-          -Wno-implicit-const-int-float-conversion $DM_BACKEND_FLAGS -I"$tmp/include" -I"$tmp/deepmimic_mujoco_amd/csrc" "$tmp/deepmimic_mujoco_amd/csrc/dmenv.hip" -o "$2"
+        if [ -f "$tmp/deepmimic_mujoco_amd/csrc/kernels_packed.hip" ]; then python "$tmp/deepmimic_mujoco_amd/csrc/build.py" --out "$PWD/$2"
+        else /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-shift-count-negative \
+          -Wno-implicit-const-int-float-conversion -I"$tmp/include" -I"$tmp/deepmimic_mujoco_amd/csrc" "$tmp/deepmimic_mujoco_amd/csrc/dmenv.hip" -o "$2"; fi   # (refs from before the two-unit build)
         rm -rf "$tmp"
       else
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-shift-count-negative \
-          -Wno-implicit-const-int-float-conversion $DM_BACKEND_FLAGS -Iinclude -Ideepmimic_mujoco_amd/csrc deepmimic_mujoco_amd/csrc/dmenv.hip -o "$2"
+        python deepmimic_mujoco_amd/csrc/build.py --out "$PWD/$2"
       fi
     }
     build_ref "$A" build_ab/A.so & build_ref "$B" build_ab/B.so & wait

@@ -14,21 +14,25 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
-def code_object(lib):
+def code_objects(lib):
+    """every gfx950 code object of the library: one clang offload bundle per translation unit (dmenv.hip, kernels_packed.hip)"""
     blob = open(lib, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out = []
     at = blob.find(magic)
-    if at < 0:
-        raise SystemExit("no offload bundle in " + lib)
-    n = struct.unpack_from("<Q", blob, at + len(magic))[0]
-    p = at + len(magic) + 8
-    for _ in range(n):
-        off, size, tlen = struct.unpack_from("<QQQ", blob, p)
-        triple = blob[p + 24:p + 24 + tlen].decode()
-        p += 24 + tlen
-        if "gfx950" in triple:
-            return blob[at + off:at + off + size]
-    raise SystemExit("no gfx950 code object in " + lib)
+    while at >= 0:
+        n = struct.unpack_from("<Q", blob, at + len(magic))[0]
+        p = at + len(magic) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, p)
+            triple = blob[p + 24:p + 24 + tlen].decode()
+            p += 24 + tlen
+            if "gfx950" in triple:
+                out.append(blob[at + off:at + off + size])
+        at = blob.find(magic, at + len(magic))
+    if not out:
+        raise SystemExit("no gfx950 code object in " + lib)
+    return out
 
 
 def demangle(sym):
@@ -40,9 +44,11 @@ def demangle(sym):
 
 
 def kernels(lib):
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(code_object(lib)); f.flush()
-        txt = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    txt = ""
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co); f.flush()
+            txt += "\n" + subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
     out = []
     for blk in re.split(r"\n\s+- \.agpr_count:", "\n" + txt)[1:]:
         blk = ".agpr_count:" + blk
