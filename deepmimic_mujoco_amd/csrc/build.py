@@ -40,6 +40,7 @@ def build_one(out, defs=(), extra=(), verbose=False, objdir=None):
     jobs, objs = [], []
     for src, flags in UNITS:
         obj = os.path.join(objdir, "%s_%s.o" % (tag, os.path.splitext(src)[0]))
+        flags = list(flags) + os.environ.get("DM_FLAGS_" + os.path.splitext(src)[0].upper(), "").split()      # experiments: DM_FLAGS_DMENV / DM_FLAGS_KERNELS_PACKED
         cmd = [hipcc()] + COMMON + list(flags) + list(defs) + list(extra) + ["-I" + os.path.join(REPO, "include"), "-I" + HERE, "-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")

@@ -35,6 +35,14 @@ import json,sys
 j=json.loads(sys.stdin.read()); print('value %.3f M  spread %.3f..%.3f  launch_us %s' % (j['value']/1e6, j['value_spread']['min']/1e6, j['value_spread']['max']/1e6, j['roofline']['launch'].get('avg_us')))")
       echo "$v $rw : ${o:-FAILED $(tail -2 $OUT/hl_err.txt | cut -c1-200)}" | tee -a $OUT/hl.log
     done; done; done ;;
+  ps:*)
+    # one launch set per call (k_step_narrow at 4096 envs, k_step_packed at 8192): tight A/B of builds, five windows of 512 steps
+    for rep in 1 2; do for v in ${WHAT#ps:}; do for wl in cfg3 cfg5; do
+      o=$(DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python bench.py $Q --no-vecenv-leg --no-horizon-leg --step-queue 0 --workload $wl --steps 512 --warmup 64 --repeats 5 2>$OUT/ps_err.txt | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print('value %.3f M  spread %.3f..%.3f  kernel %s' % (j['value']/1e6, j['value_spread']['min']/1e6, j['value_spread']['max']/1e6, j['roofline']['kernel']))")
+      echo "$v $wl : ${o:-FAILED $(tail -2 $OUT/ps_err.txt | cut -c1-200)}" | tee -a $OUT/ps.log
+    done; done; done ;;
   stage:*)
     for v in ${WHAT#stage:}; do echo "== $v" | tee -a $OUT/stage.log; DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python tools/profile_packed.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/stage.log; done ;;
   hstage:*)
