@@ -61,6 +61,9 @@ struct SlotShared {
   // horizon launches: qpos[35] — the spare element behind the 35 coordinates — is the slot's `kin_ok` flag: nonzero = the kinematics in this block
   // are those of the env's current state (slot_step.h kin_carry).  (A field of its own changes the slots' stride: measured 1.5 % slower.)
   DM_DEV R& kin_ok() { return qpos[NQ]; }
+#ifdef DM_SLOT_PAD          // experiment: the slots' stride modulo the LDS bank period (profiles/r04_ab_kernel_variants.md)
+  char pad_[DM_SLOT_PAD];
+#endif
 };
 static_assert(NQ == 35, "qpos[36] has one spare element");
 static_assert(sizeof(SlotShared<double>) * SLOTS + 1576 <= 40 * 1024, "four waves of four environments must fit a CU's 160 KB of LDS");
