@@ -178,6 +178,11 @@ __device__ inline void policy_wave(const PolicyArgs& pa, int env, int lane, cons
   }
 }
 
+// (Measured, round 4: the same step on the MATRIX CORE — v_mfma_f32_4x4x1, sixteen 4x4x1 blocks = four environments x 64 output units per
+//  instruction, lane = unit, register = environment, weights as [chunk of four inputs][lane][4] panels (tools/ubench/mfma_f32_4x4.hip has the lane
+//  map) — 824 matrix instructions + 206 loads instead of 2 900 multiply-adds + 1 000 LDS reads + 256 loads, all 33 rollout tests green: exactly as
+//  fast (rollout 14.1 M, standing 12.9–13.0 M either way).  The step is bound by each wave streaming the weights through its CU's L1 — 87 KB here,
+//  211 KB as 64-unit panels — not by the arithmetic; dropped.  profiles/r04_ab_kernel_variants.md)
 // ... and for the FOUR environments of a packed wave (slot_kernel.h) at once: the same lane -> hidden-unit map, every 16-byte weight load
 // now feeds 16 multiply-adds (four environments x four units), so the weight stream that dominated the one-env epilogue is paid once
 // per four environments.  in0..in3 / scratch: one block of >= 464 floats per environment (z[64] | h1[200] | h2[200]).

@@ -43,6 +43,17 @@ import json,sys
 j=json.loads(sys.stdin.read()); print('value %.3f M  spread %.3f..%.3f  kernel %s' % (j['value']/1e6, j['value_spread']['min']/1e6, j['value_spread']['max']/1e6, j['roofline']['kernel']))")
       echo "$v $wl : ${o:-FAILED $(tail -2 $OUT/ps_err.txt | cut -c1-200)}" | tee -a $OUT/ps.log
     done; done; done ;;
+  pol:*)
+    # the policy step inside the horizon launch: rollout workload (untrained policy + GAE) and standing workload (shipped policy), per build
+    for rep in 1 2; do for v in ${WHAT#pol:}; do
+      o=$(DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python bench.py --workload rollout --steps 2048 --warmup 256 2>$OUT/pol_err.txt | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print('rollout %.3f M' % (j['value']/1e6))")
+      o2=$(DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python bench.py --workload standing --steps 1024 --warmup 768 2>>$OUT/pol_err.txt | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print('standing packed %.3f M  one-env %.3f M' % (j['legs']['packed']['value']/1e6, j['legs']['one_env']['value']/1e6))")
+      echo "$v : ${o:-FAILED} ; ${o2:-FAILED $(tail -2 $OUT/pol_err.txt | cut -c1-200)}" | tee -a $OUT/pol.log
+    done; done ;;
   stage:*)
     for v in ${WHAT#stage:}; do echo "== $v" | tee -a $OUT/stage.log; DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python tools/profile_packed.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/stage.log; done ;;
   hstage:*)
