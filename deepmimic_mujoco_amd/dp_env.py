@@ -281,7 +281,8 @@ class DPVecEnv(object):
     """N DeepMimic humanoids in lock step on one GPU (one wavefront per environment)."""
 
     def __init__(self, num_envs, motion="walk", xml_path=None, device=0, reward="alive", autoreset="rsi", seed=0,
-                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=None, diagnostics=False, dtype=64, packed=None):
+                 contacts=True, limits=True, action_mode="raw", env_offset=0, batch_factory=None, frame_skip=None, diagnostics=False, dtype=64, packed=None,
+                 step_queue=0):
         """reward="imitation": the 5-term reward of code.md:1017-1143 (imitation.py) against the frame after the current one.
         frame_skip: sim steps per env step (src/dp_env_v3.py:108-112 hard-codes 1); "mocap" = floor(mocap_dt / timestep), the
         commented intent of :107-110, so that one env step spans one mocap frame.  Default (None): 1, except "mocap" for the
@@ -296,7 +297,8 @@ class DPVecEnv(object):
         1.4-1.5x faster while environments stay within its per-env capacities (the RSI / early-termination regimes), and hands over to
         the one-env kernel when a competent policy keeps most environments on both feet (32+ rows).  Smaller batches: one env per wave —
         except for models without contacts and limits (BASELINE configs[1]): all waves cost the same there and four per wave is 1.5x
-        faster at any size."""
+        faster at any size.
+        step_queue: DM_OPT_STEP_QUEUE depth (0 = off): queue `batch.step` calls and run them as one horizon launch (see below)."""
         self.num_envs = int(num_envs)
         self.mocap = MocapDM()
         self.mocap.load_mocap(motion)
@@ -342,6 +344,13 @@ class DPVecEnv(object):
             b.set_option(A.OPT_PACKED, 1)
         if auto:
             b.enable_auto_packed(True)
+        if step_queue:
+            # DM_OPT_STEP_QUEUE (include/dmenv.h): `batch.step` calls with device tensors are queued and run together as one horizon launch when `step_queue`
+            # calls are queued or at `batch.join()` / any other entry point — for open-loop callers (pre-drawn or scripted actions) that do not read a step's
+            # outputs before the next call.  It rides on the packed kernels; `step()` / `step_wait()` of this class join, so the facade keeps its semantics.
+            if not self.packed:
+                b.set_option(A.OPT_PACKED, 1)
+            b.set_option(A.OPT_STEP_QUEUE, int(step_queue))
         cr = self._cm.actuator_ctrlrange
         self.action_space = Box(low=cr[:, 0], high=cr[:, 1], dtype=np.float32)
         self.observation_space = Box(low=-np.inf, high=np.inf, shape=(A.NOBS,), dtype=np.float32)

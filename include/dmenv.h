@@ -148,7 +148,8 @@ enum {
                              buffer of a queued call (the same tensors step after step: a closed loop that joins every step) first runs
                              what is queued, i.e. degenerates to one launch per call.  Results are bit-identical to unqueued DM_OPT_PACKED
                              steps.  Queuing applies where dm_batch_rollout uses one launch per horizon (DM_OPT_PACKED on, reward modes
-                             0..3, constraint rows, at most two packed waves per SIMD); elsewhere calls launch at once as without it. */
+                             0..3, constraint rows, at most two packed waves per SIMD); elsewhere calls launch at once as without it.
+                             dm_batch_destroy() DROPS what is still queued (the buffers belong to the caller and may be gone). */
 };
 /* per-environment capacities of the DM_OPT_PACKED path (= csrc/slot_kernel.h SLOT_MAXROWS, SLOT_MAXLIMROWS, SLOT_MAXCON, SLOT_MAXFRAME, SLOT_MAXCAND) */
 #define DM_PACKED_MAXROWS 32
