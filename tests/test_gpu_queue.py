@@ -211,3 +211,23 @@ def test_changing_the_pipeline_depth_between_packed_steps_keeps_the_redo_counter
     for i in range(3, 10):
         assert np.array_equal(x[i], y[i]), "final state differs (%d)" % i
     assert x[10] == y[10]
+
+
+def test_dpvecenv_step_queue_argument():
+    """`DPVecEnv(step_queue=Q)` = DM_OPT_PACKED + DM_OPT_STEP_QUEUE on its batch: raw `batch.step` calls queue, the facade's `step` still returns finished results."""
+    n = 96
+    env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="rsi", seed=1, step_queue=16)
+    assert env.packed and env.batch.options[A.OPT_STEP_QUEUE] == 16
+    env.reset("rsi")
+    g = torch.Generator(device=DEV); g.manual_seed(4)
+    acs = torch.randn((5, n, 28), generator=g, dtype=torch.float64, device=DEV) * 0.5
+    outs = [(torch.zeros((n, 56), dtype=torch.float64, device=DEV), torch.zeros(n, dtype=torch.float64, device=DEV), torch.zeros(n, dtype=torch.uint8, device=DEV)) for _ in range(4)]
+    for t in range(4):
+        env.batch.step(acs[t], 1, outs[t])
+    assert env.batch.queue_stats() == (0, 0, 4)
+    ob, rew, done, infos = env.step(acs[4])                 # joins: the four queued steps ran first, then this one
+    assert env.batch.queue_stats()[2] == 0 and env.batch.queue_stats()[1] == 5
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ob).all()) and float(rew.min()) == 1.0 and len(infos) == n
+    assert float(outs[3][0].abs().sum()) > 0
+    env.close()
