@@ -146,8 +146,8 @@ def load(dtype=64):
     L.dm_batch_redo_total.argtypes = [vp, C.POINTER(C.c_int64)]
     L.dm_batch_queue_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.dm_pg_scratch_bytes.argtypes = []; L.dm_pg_scratch_bytes.restype = C.c_size_t
-    L.dm_pg_losses.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]
-    L.dm_pg_fvp.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.dm_pg_losses.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp, i32]
+    L.dm_pg_fvp.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]
     L.dm_vf_fit_epoch.argtypes = [vp, vp, i32, i32, vp, vp, vp, C.POINTER(C.c_float), C.c_double, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp, i32]
     L.dm_batch_step_act.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_uint64, C.c_uint64]
     L.dm_batch_rollout.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, C.c_uint64, C.c_uint64]

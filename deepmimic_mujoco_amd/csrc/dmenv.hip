@@ -890,16 +890,21 @@ static int pg_set_device(const void* p) {
   else (void)hipGetLastError();
   return DM_OK;
 }
+// one block per CU; `max_blocks` (0: all of them) leaves CUs to a kernel of another stream (the value fit beside the policy step)
+static int pg_blocks(int ntiles, int max_blocks) {
+  const int cap = (max_blocks > 0 && max_blocks < dmg::MAX_BLOCKS) ? max_blocks : dmg::MAX_BLOCKS;
+  return ntiles < cap ? ntiles : cap;
+}
 extern "C" int dm_pg_param_count(void) { return dmg::NP; }
 extern "C" size_t dm_pg_scratch_bytes(void) { return (size_t)dmg::MAX_BLOCKS * dmg::NPAD * sizeof(float) + (size_t)dmg::MAX_BLOCKS * 2 * sizeof(double) + 256; }
 extern "C" int dm_pg_losses(const float* ob, int32_t n, const float* ac, const float* atarg, float* old_mean, const float* old_logstd, int32_t write_old,
                             const float* theta, const float* rms_mean, const float* rms_std, double entcoeff, int32_t with_grad,
-                            float* out_grad, double* out_losses, void* scratch, void* hip_stream) {
-  if (!ob || !ac || !atarg || !old_mean || !old_logstd || !theta || !rms_mean || !rms_std || !out_losses || !scratch || n < 1 || (with_grad && !out_grad))
+                            float* out_grad, double* out_losses, void* scratch, void* hip_stream, int32_t max_blocks) {
+  if (!ob || !ac || !atarg || !old_mean || !old_logstd || !theta || !rms_mean || !rms_std || !out_losses || !scratch || n < 1 || (with_grad && !out_grad) || max_blocks < 0)
     return fail(DM_EINVAL, "dm_pg_losses: bad argument");
   if (pg_set_device(theta)) return fail(DM_EHIP, "dm_pg_losses: hipSetDevice failed");
   hipStream_t st = (hipStream_t)hip_stream;
-  const int ntiles = (n + dmg::SB - 1) / dmg::SB, nblk = ntiles < dmg::MAX_BLOCKS ? ntiles : dmg::MAX_BLOCKS;
+  const int ntiles = (n + dmg::SB - 1) / dmg::SB, nblk = pg_blocks(ntiles, max_blocks);
   float* partial = (float*)scratch;
   double* lpart = (double*)((char*)scratch + (((size_t)dmg::MAX_BLOCKS * dmg::NPAD * sizeof(float) + 255) / 256) * 256);
   if (with_grad)
@@ -914,11 +919,11 @@ extern "C" int dm_pg_losses(const float* ob, int32_t n, const float* ac, const f
   return DM_OK;
 }
 extern "C" int dm_pg_fvp(const float* ob, int32_t stride, int32_t n, const float* theta, const float* v, const float* rms_mean, const float* rms_std,
-                         float* out_fv, void* scratch, void* hip_stream) {
-  if (!ob || !theta || !v || !rms_mean || !rms_std || !out_fv || !scratch || n < 1 || stride < 1) return fail(DM_EINVAL, "dm_pg_fvp: bad argument");
+                         float* out_fv, void* scratch, void* hip_stream, int32_t max_blocks) {
+  if (!ob || !theta || !v || !rms_mean || !rms_std || !out_fv || !scratch || n < 1 || stride < 1 || max_blocks < 0) return fail(DM_EINVAL, "dm_pg_fvp: bad argument");
   if (pg_set_device(theta)) return fail(DM_EHIP, "dm_pg_fvp: hipSetDevice failed");
   hipStream_t st = (hipStream_t)hip_stream;
-  const int ntiles = (n + dmg::SB - 1) / dmg::SB, nblk = ntiles < dmg::MAX_BLOCKS ? ntiles : dmg::MAX_BLOCKS;
+  const int ntiles = (n + dmg::SB - 1) / dmg::SB, nblk = pg_blocks(ntiles, max_blocks);
   float* partial = (float*)scratch;
   double* lpart = (double*)((char*)scratch + (((size_t)dmg::MAX_BLOCKS * dmg::NPAD * sizeof(float) + 255) / 256) * 256);
   hipLaunchKernelGGL(dmg::k_pg<dmg::MODE_FVP>, dim3(nblk), dim3(256), 0, st, ob, (int)stride, (int)n, (const float*)nullptr, (const float*)nullptr,

@@ -13,7 +13,17 @@
 //
 // A block owns a fixed set of 32-sample tiles (tile t -> block t mod gridDim.x) and keeps its weight-gradient tiles in REGISTERS across all of
 // them; partial gradients are written once per block and summed in block order by k_pg_reduce: results do not depend on timing.
-// Weights sit in LDS (73.6 KB), activations transposed ([unit][sample]) beside them; the direction v of a Fisher product is streamed from L2.
+//
+// Every product runs on the matrix cores in fp32 (v_mfma_f32_32x32x2_f32; the 28-wide output layer as 16x16x4 tiles), operands straight from
+// LDS with no re-layout between layers:
+//   * activations sit transposed, [unit][sample] with a row stride of 33 floats: a row pair [k, k+1][32 samples] is a B operand (forward,
+//     "units x samples" results), a column pair [32 units][s, s+1] is an A or B operand of the weight-gradient products (sum over samples);
+//     both reads are bank-conflict free;
+//   * the parameters are ONE copy of theta in LDS.  theta's order (W1, b1, W2, b2, W3, b3) makes each bias the row after its matrix, so with a
+//     constant row of ones appended to z / h1 / h2 the biases are part of the products, forward AND backward: the bias gradients are row
+//     56 / 100 / 100 of the weight-gradient tiles, which land in theta order by themselves;
+//   * wave w owns output units 32 w .. 32 w + 31 of the hidden layers (100 padded to 128: rows past 99 read finite junk and are never stored);
+//     a Fisher product keeps ITS slices of the direction v in registers for the whole launch (106 per lane) instead of streaming v per tile.
 // fp32 like the reference's TF graph; loss sums leave the block in float64.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -21,50 +31,35 @@
 
 namespace dmg {
 
-constexpr int OB = 56, H = 100, AC = 28, SB = 32;
+constexpr int OB = 56, H = 100, AC = 28, SB = 32, SBP = SB + 1;
 constexpr int O_W1 = 0, O_B1 = O_W1 + OB * H, O_W2 = O_B1 + H, O_B2 = O_W2 + H * H, O_W3 = O_B2 + H, O_B3 = O_W3 + H * AC, O_LS = O_B3 + AC, NP = O_LS + AC;
 constexpr int NPAD = (NP + 63) / 64 * 64;
+constexpr int NWT = (O_LS + 3) / 4 * 4 + 4;           // theta up to logstd, as float4s (the pad holds the first logstd entries: never used as a weight)
 constexpr int MAX_BLOCKS = 256;                       // one block per CU (LDS-limited)
+constexpr int ZR = OB + 2, HR = H + 4, MR = 32;       // rows: z + {ones, zeros};  h + {ones, 3 x zeros};  action rows padded to a tile
 enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_FVP = 2 };
+static_assert(O_LS % 4 == 0 && NP >= NWT, "theta is copied to LDS as float4s");
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 struct alignas(16) PgShared {
-  float W1[OB * H], W2[H * H], W3[H * AC];
-  float z[OB][SB], h1[H][SB], h2[H][SB];
-  float a1[H][SB], a2[H][SB];                         // FVP: tangents d h1, d h2;  backward: deltas of layer 1, 2
-  float mo[AC][SB];                                   // action mean -> output gradient G
-  float b1[H], b2[H], b3[AC], ls[AC], ols[AC];
+  float Wt[NWT];                                      // theta: W1 [56][100], b1, W2 [100][100], b2, W3 [100][28], b3
+  float z[ZR][SBP];                                   // row 56 = 1, row 57 = 0
+  float h1[HR][SBP], h2[HR][SBP];                     // row 100 = 1, rows 101..103 = 0
+  float a1[HR][SBP], a2[HR][SBP];                     // FVP: tangents d h1, d h2;  backward: deltas of layer 1, 2
+  float mo[MR][SBP];                                  // action mean -> output gradient G
+  float ls[AC], ols[AC];
   float red[SB][2];
 };
 static_assert(sizeof(PgShared) <= 160 * 1024, "PgShared must fit a CU's LDS");
+// operand reads past a buffer's rows (padded unit tiles) must stay inside the struct: the furthest is W3's row 127 as an A operand
+static_assert(O_W3 + 127 * AC + AC <= NWT + ZR * SBP, "padded W3 rows read into z");
 
-__device__ inline float4 f4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ inline void fma4(float4& a, float w, const float4& x) { a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w; }
-__device__ inline float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ inline float4 tanh4(const float4& a) { return make_float4(tanhf(a.x), tanhf(a.y), tanhf(a.z), tanhf(a.w)); }
-__device__ inline float4 dtanh4(const float4& d, const float4& h) { return make_float4(d.x * (1.0f - h.x * h.x), d.y * (1.0f - h.y * h.y), d.z * (1.0f - h.z * h.z), d.w * (1.0f - h.w * h.w)); }
-
-// acc[a][b] += sum_s A[i0 + a][s] B[j0 + b][s]   (both operands [.][SB] in LDS)
-template <int NA, int NB>
-__device__ inline void tile_acc(const float (*A)[SB], const float (*B)[SB], int i0, int j0, float (&acc)[NA][NB]) {
-#pragma unroll 2
-  for (int s4 = 0; s4 < SB; s4 += 4) {
-    float4 av[NA], bv[NB];
-#pragma unroll
-    for (int a = 0; a < NA; a++) av[a] = f4(&A[i0 + a][s4]);
-#pragma unroll
-    for (int b = 0; b < NB; b++) bv[b] = f4(&B[j0 + b][s4]);
-#pragma unroll
-    for (int a = 0; a < NA; a++)
-#pragma unroll
-      for (int b = 0; b < NB; b++) acc[a][b] += dot4(av[a], bv[b]);
-  }
-}
-__device__ inline float row_sum(const float* r) {
-  float a = 0.0f;
-#pragma unroll
-  for (int s4 = 0; s4 < SB; s4 += 4) { const float4 x = f4(r + s4); a += (x.x + x.y) + (x.z + x.w); }
-  return a;
-}
+__device__ inline v16f mfma32(float a, float b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ inline v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// row of a 32x32 result tile held in register r by the lanes of half `hf`
+__device__ inline int row32(int r, int hf) { return 8 * (r / 4) + 4 * hf + (r % 4); }
 
 // ob: [.., 56] f32, sample i at row i * stride.  theta: packed policy parameters (NP).  MODE_LOSS / MODE_GRAD: ac [n, 28], atarg [n],
 // old_logstd [28], old_mean [n, 28] — with write_old != 0 the kernel treats old == new and WRITES old_mean (src/trpo.py:247 assign_old_eq_new).
@@ -74,122 +69,125 @@ __global__ __launch_bounds__(256) void k_pg(const float* __restrict__ ob, int st
                                             float* __restrict__ old_mean, const float* __restrict__ old_logstd, int write_old,
                                             const float* __restrict__ theta, const float* __restrict__ v, const float* __restrict__ mean, const float* __restrict__ stdv,
                                             float inv_n, float* __restrict__ partial, double* __restrict__ lpart) {
-  __shared__ PgShared S;                                      // 137 KB: one block per CU
-  const int tid = threadIdx.x;
+  __shared__ PgShared S;                                      // 141 KB: one block per CU
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, li = l & 31, hf = l >> 5, l16 = l & 15, q = l >> 4;
+  const int u0 = 32 * w;                                      // this wave's hidden-unit tile
+  const int a0 = 16 * (w >> 1), s0 = 16 * (w & 1);            // ... and its 16 actions x 16 samples of the output layer
   {
-    const float4* g1 = reinterpret_cast<const float4*>(theta + O_W1); float4* l1 = reinterpret_cast<float4*>(S.W1);
-    const float4* g2 = reinterpret_cast<const float4*>(theta + O_W2); float4* l2 = reinterpret_cast<float4*>(S.W2);
-    const float4* g3 = reinterpret_cast<const float4*>(theta + O_W3); float4* l3 = reinterpret_cast<float4*>(S.W3);
+    // every pad column / row starts as zero: operands that reach into them must be finite
+    float4* all = reinterpret_cast<float4*>(&S);
+    for (int i = tid; i < (int)(sizeof(PgShared) / 16); i += 256) all[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __syncthreads();
+    const float4* g = reinterpret_cast<const float4*>(theta); float4* d = reinterpret_cast<float4*>(S.Wt);
 #pragma unroll 6
-    for (int i = tid; i < OB * H / 4; i += 256) l1[i] = g1[i];
-#pragma unroll 10
-    for (int i = tid; i < H * H / 4; i += 256) l2[i] = g2[i];
-#pragma unroll 3
-    for (int i = tid; i < H * AC / 4; i += 256) l3[i] = g3[i];
+    for (int i = tid; i < NWT / 4; i += 256) d[i] = g[i];
+    if (tid < SB) { S.z[OB][tid] = 1.0f; S.h1[H][tid] = 1.0f; S.h2[H][tid] = 1.0f; }
+    if (tid < AC) { S.ls[tid] = theta[O_LS + tid]; S.ols[tid] = (MODE != MODE_FVP && !write_old) ? old_logstd[tid] : theta[O_LS + tid]; }
   }
-  if (tid < H) { S.b1[tid] = theta[O_B1 + tid]; S.b2[tid] = theta[O_B2 + tid]; }
-  if (tid < AC) { S.b3[tid] = theta[O_B3 + tid]; S.ls[tid] = theta[O_LS + tid]; S.ols[tid] = (MODE != MODE_FVP && !write_old) ? old_logstd[tid] : theta[O_LS + tid]; }
-  // register-resident partial gradients of this block.  Owners: W1 tiles threads 0..139, W2 tiles 0..249, W3 tiles 0..99, b2 0..99,
-  // b3 100..127, logstd 128..155, b1 156..255
-  float gW1[4][10], gW2[4][10], gW3[4][7], gb2 = 0.0f, gbx = 0.0f;          // gbx: b3 / logstd / b1 by thread range
+  // a Fisher product's direction, as this wave's A operands (v is laid out like theta: its bias entries are the rows the ones multiply)
+  float v1[(OB + 2) / 2], v2[(H + 2) / 2], v3[(H + 4) / 4];
+  if (MODE == MODE_FVP) {
 #pragma unroll
-  for (int a = 0; a < 4; a++) {
+    for (int t = 0; t < (OB + 2) / 2; t++) { const int k = 2 * t + hf; v1[t] = (k <= OB && u0 + li < H) ? v[O_W1 + k * H + u0 + li] : 0.0f; }
 #pragma unroll
-    for (int b = 0; b < 10; b++) { gW1[a][b] = 0.0f; gW2[a][b] = 0.0f; }
+    for (int t = 0; t < (H + 2) / 2; t++) { const int k = 2 * t + hf; v2[t] = (k <= H && u0 + li < H) ? v[O_W2 + k * H + u0 + li] : 0.0f; }
 #pragma unroll
-    for (int b = 0; b < 7; b++) gW3[a][b] = 0.0f;
+    for (int t = 0; t < (H + 4) / 4; t++) { const int k = 4 * t + q; v3[t] = (k <= H && a0 + l16 < AC) ? v[O_W3 + k * AC + a0 + l16] : 0.0f; }
   }
+  // register-resident partial gradients of this block, in theta order: rows k (inputs, + the bias row) x this wave's 32 output columns
+  v16f gW1[2], gW2[4], gW3;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { gW1[0][r] = 0.0f; gW1[1][r] = 0.0f; gW2[0][r] = 0.0f; gW2[1][r] = 0.0f; gW2[2][r] = 0.0f; gW2[3][r] = 0.0f; gW3[r] = 0.0f; }
+  float gls = 0.0f;                                           // d / d logstd_a, threads 128 .. 155
   double lsum0 = 0.0, lsum1 = 0.0;
-  const int sq = (tid % 8) * 4, uq = (tid / 8) * 4;           // this thread's 4 samples x 4 units
-  const bool dense = tid < 200, outl = tid < 56;              // output layer: 7 unit groups x 8 sample groups
   const int ntiles = (n + SB - 1) / SB;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int s0 = tile * SB;
+    const int s0g = tile * SB;
     __syncthreads();                                          // the previous tile's readers are done (first pass: the weights are in place)
 #pragma unroll 7
     for (int i = tid; i < SB * OB; i += 256) {
-      const int sm = i / OB, k = i % OB, r = s0 + sm;
+      const int sm = i / OB, k = i % OB, r = s0g + sm;
       float x = 0.0f;
       if (r < n) x = fminf(fmaxf((ob[(size_t)r * stride * OB + k] - mean[k]) / stdv[k], -5.0f), 5.0f);
       S.z[k][sm] = x;
     }
     __syncthreads();
-    // ---- layer 1 (+ tangent) ----
-    if (dense) {
-      float4 acc[4], dac[4];
+    // ---- layer 1 (+ tangent): h1 = tanh(W1ext^T zext) ----
+    {
+      v16f acc, dac;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const float b = S.b1[uq + u]; acc[u] = make_float4(b, b, b, b);
-        if (MODE == MODE_FVP) { const float c = v[O_B1 + uq + u]; dac[u] = make_float4(c, c, c, c); }
-      }
-#pragma unroll 4
-      for (int k = 0; k < OB; k++) {
-        const float4 x = f4(&S.z[k][sq]), w = f4(&S.W1[k * H + uq]);
-        fma4(acc[0], w.x, x); fma4(acc[1], w.y, x); fma4(acc[2], w.z, x); fma4(acc[3], w.w, x);
-        if (MODE == MODE_FVP) { const float4 q = f4(&v[O_W1 + k * H + uq]); fma4(dac[0], q.x, x); fma4(dac[1], q.y, x); fma4(dac[2], q.z, x); fma4(dac[3], q.w, x); }
+      for (int r = 0; r < 16; r++) { acc[r] = 0.0f; dac[r] = 0.0f; }
+#pragma unroll
+      for (int t = 0; t < (OB + 2) / 2; t++) {
+        const int k = 2 * t + hf;
+        const float a = S.Wt[O_W1 + k * H + u0 + li], b = S.z[k][li];
+        acc = mfma32(a, b, acc);
+        if (MODE == MODE_FVP) dac = mfma32(v1[t], b, dac);
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const float4 h = tanh4(acc[u]);
-        *reinterpret_cast<float4*>(&S.h1[uq + u][sq]) = h;
-        if (MODE == MODE_FVP) *reinterpret_cast<float4*>(&S.a1[uq + u][sq]) = dtanh4(dac[u], h);
+      for (int r = 0; r < 16; r++) {
+        const int u = u0 + row32(r, hf);
+        if (u < H) {
+          const float h = tanhf(acc[r]);
+          S.h1[u][li] = h;
+          if (MODE == MODE_FVP) S.a1[u][li] = dac[r] * (1.0f - h * h);
+        }
       }
     }
     __syncthreads();
-    // ---- layer 2 (+ tangent) ----
-    if (dense) {
-      float4 acc[4], dac[4];
+    // ---- layer 2 (+ tangent: W2^T d h1 + V2ext^T h1ext) ----
+    {
+      v16f acc, dac;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const float b = S.b2[uq + u]; acc[u] = make_float4(b, b, b, b);
-        if (MODE == MODE_FVP) { const float c = v[O_B2 + uq + u]; dac[u] = make_float4(c, c, c, c); }
-      }
-#pragma unroll 4
-      for (int k = 0; k < H; k++) {
-        const float4 x = f4(&S.h1[k][sq]), w = f4(&S.W2[k * H + uq]);
-        fma4(acc[0], w.x, x); fma4(acc[1], w.y, x); fma4(acc[2], w.z, x); fma4(acc[3], w.w, x);
+      for (int r = 0; r < 16; r++) { acc[r] = 0.0f; dac[r] = 0.0f; }
+#pragma unroll
+      for (int t = 0; t < (H + 2) / 2; t++) {
+        const int k = 2 * t + hf;
+        const float a = S.Wt[O_W2 + k * H + u0 + li], b = S.h1[k][li];
+        acc = mfma32(a, b, acc);
         if (MODE == MODE_FVP) {
-          const float4 dx = f4(&S.a1[k][sq]), q = f4(&v[O_W2 + k * H + uq]);
-          fma4(dac[0], w.x, dx); fma4(dac[1], w.y, dx); fma4(dac[2], w.z, dx); fma4(dac[3], w.w, dx);
-          fma4(dac[0], q.x, x); fma4(dac[1], q.y, x); fma4(dac[2], q.z, x); fma4(dac[3], q.w, x);
+          dac = mfma32(v2[t], b, dac);
+          if (t < H / 2) dac = mfma32(a, S.a1[k][li], dac);
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const float4 h = tanh4(acc[u]);
-        *reinterpret_cast<float4*>(&S.h2[uq + u][sq]) = h;
-        if (MODE == MODE_FVP) *reinterpret_cast<float4*>(&S.a2[uq + u][sq]) = dtanh4(dac[u], h);
+      for (int r = 0; r < 16; r++) {
+        const int u = u0 + row32(r, hf);
+        if (u < H) {
+          const float h = tanhf(acc[r]);
+          S.h2[u][li] = h;
+          if (MODE == MODE_FVP) S.a2[u][li] = dac[r] * (1.0f - h * h);
+        }
       }
     }
     __syncthreads();
-    // ---- output layer: the action mean (FVP: its tangent J v) ----
-    if (outl) {
-      float4 acc[4];
+    // ---- output layer: the action mean (FVP: its tangent J v), 16 actions x 16 samples per wave ----
+    {
+      v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      const int ac_col = a0 + l16 < AC ? a0 + l16 : AC - 1;   // (rows 28..31 of the tile: a copy of row 27, not stored)
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const float b = MODE == MODE_FVP ? v[O_B3 + uq + u] : S.b3[uq + u]; acc[u] = make_float4(b, b, b, b); }
-#pragma unroll 4
-      for (int k = 0; k < H; k++) {
-        const float4 w = f4(&S.W3[k * AC + uq]), x = f4(&S.h2[k][sq]);
+      for (int t = 0; t < (H + 4) / 4; t++) {
+        const int k = 4 * t + q, kw = k < H ? k : H;          // rows 101..103 of h2 are zero: any finite weight does
+        const float a = S.Wt[O_W3 + kw * AC + ac_col], b = S.h2[k][s0 + l16];
         if (MODE == MODE_FVP) {
-          const float4 dx = f4(&S.a2[k][sq]), q = f4(&v[O_W3 + k * AC + uq]);
-          fma4(acc[0], w.x, dx); fma4(acc[1], w.y, dx); fma4(acc[2], w.z, dx); fma4(acc[3], w.w, dx);
-          fma4(acc[0], q.x, x); fma4(acc[1], q.y, x); fma4(acc[2], q.z, x); fma4(acc[3], q.w, x);
-        } else { fma4(acc[0], w.x, x); fma4(acc[1], w.y, x); fma4(acc[2], w.z, x); fma4(acc[3], w.w, x); }
+          acc = mfma16(v3[t], b, acc);
+          if (t < H / 4) acc = mfma16(a, S.a2[k][s0 + l16], acc);
+        } else acc = mfma16(a, b, acc);
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) *reinterpret_cast<float4*>(&S.mo[uq + u][sq]) = acc[u];
+      for (int r = 0; r < 4; r++) { const int a = a0 + 4 * q + r; if (a < AC) S.mo[a][s0 + l16] = acc[r]; }
     }
     __syncthreads();
     if (MODE == MODE_FVP) {
       // ---- output gradient of the Fisher product: u = (J v) / sigma^2 / N, in place ----
       for (int i = tid; i < AC * SB; i += 256) {
         const int a = i / SB, sm = i % SB;
-        S.mo[a][sm] = (s0 + sm < n) ? S.mo[a][sm] * __expf(-2.0f * S.ls[a]) * inv_n : 0.0f;
+        S.mo[a][sm] = (s0g + sm < n) ? S.mo[a][sm] * __expf(-2.0f * S.ls[a]) * inv_n : 0.0f;
       }
     } else {
       // ---- per-sample likelihood ratio and KL (src/distributions.py:235-243) ----
       if (tid < SB) {
-        const int r = s0 + tid;
+        const int r = s0g + tid;
         float ra = 0.0f, kl = 0.0f;
         if (r < n) {
           float d = 0.0f;                                     // logp_new - logp_old = neglogp_old - neglogp_new
@@ -207,88 +205,81 @@ __global__ __launch_bounds__(256) void k_pg(const float* __restrict__ ob, int st
         S.red[tid][0] = ra; S.red[tid][1] = kl;
       }
       __syncthreads();
-      if (tid == 0) { double a0 = 0.0, a1 = 0.0; for (int sm = 0; sm < SB; sm++) { a0 += (double)S.red[sm][0]; a1 += (double)S.red[sm][1]; } lsum0 += a0; lsum1 += a1; }
+      if (tid == 0) { double b0 = 0.0, b1 = 0.0; for (int sm = 0; sm < SB; sm++) { b0 += (double)S.red[sm][0]; b1 += (double)S.red[sm][1]; } lsum0 += b0; lsum1 += b1; }
       if (MODE == MODE_LOSS) continue;
       // d optimgain / d logstd_a = sum_s ratio atarg (((x - m) / sigma)^2 - 1) / N   (the entropy bonus's constant is added by the reduction)
       if (tid >= 128 && tid < 128 + AC) {
         const int a = tid - 128;
         const float is = __expf(-S.ls[a]);
         float acc = 0.0f;
-        for (int sm = 0; sm < SB; sm++) { const int r = s0 + sm; if (r < n) { const float e = (ac[(size_t)r * AC + a] - S.mo[a][sm]) * is; acc += S.red[sm][0] * (e * e - 1.0f); } }
-        gbx += acc * inv_n;
+        for (int sm = 0; sm < SB; sm++) { const int r = s0g + sm; if (r < n) { const float e = (ac[(size_t)r * AC + a] - S.mo[a][sm]) * is; acc += S.red[sm][0] * (e * e - 1.0f); } }
+        gls += acc * inv_n;
       }
       __syncthreads();
       for (int i = tid; i < AC * SB; i += 256) {              // G = d optimgain / d mean = ratio atarg (x - m) / sigma^2 / N, in place of the mean
-        const int a = i / SB, sm = i % SB, r = s0 + sm;
+        const int a = i / SB, sm = i % SB, r = s0g + sm;
         S.mo[a][sm] = (r < n) ? S.red[sm][0] * inv_n * (ac[(size_t)r * AC + a] - S.mo[a][sm]) * __expf(-2.0f * S.ls[a]) : 0.0f;
       }
     }
     __syncthreads();
-    // ---- reverse pass with the output gradient G = S.mo ----
-    if (tid < 100) tile_acc<4, 7>(S.h2, S.mo, (tid / 4) * 4, (tid % 4) * 7, gW3);          // dW3 = h2^T G
-    else if (tid < 100 + AC) gbx += row_sum(S.mo[tid - 100]);                                // db3
-    if (dense) {                                                                            // delta2 = (W3 G) (1 - h2^2)   (a2's tangents have been consumed)
-      float4 acc[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-#pragma unroll 7
-      for (int a = 0; a < AC; a += 4) {
-        const float4 g0 = f4(&S.mo[a][sq]), g1 = f4(&S.mo[a + 1][sq]), g2 = f4(&S.mo[a + 2][sq]), g3 = f4(&S.mo[a + 3][sq]);
+    // ---- reverse pass with the output gradient G = S.mo.  Sums over the 32 samples: operands are column pairs [.][s, s + 1] ----
+    {
+      v16f acc;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const float4 w = f4(&S.W3[(uq + u) * AC + a]);
-          fma4(acc[u], w.x, g0); fma4(acc[u], w.y, g1); fma4(acc[u], w.z, g2); fma4(acc[u], w.w, g3);
-        }
+      for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < SB / 2; t++) gW3 = mfma32(S.h2[u0 + li][2 * t + hf], S.mo[li][2 * t + hf], gW3);      // dW3ext = h2ext G^T  (row 100: db3)
+#pragma unroll
+      for (int t = 0; t < AC / 2; t++) acc = mfma32(S.Wt[O_W3 + (u0 + li) * AC + 2 * t + hf], S.mo[2 * t + hf][li], acc);   // W3 G
+#pragma unroll
+      for (int r = 0; r < 16; r++) {                          // delta2 = (W3 G) (1 - h2^2)   (a2's tangents have been consumed)
+        const int u = u0 + row32(r, hf);
+        if (u < H) { const float h = S.h2[u][li]; S.a2[u][li] = acc[r] * (1.0f - h * h); }
       }
-#pragma unroll
-      for (int u = 0; u < 4; u++) *reinterpret_cast<float4*>(&S.a2[uq + u][sq]) = dtanh4(acc[u], f4(&S.h2[uq + u][sq]));
     }
     __syncthreads();
-    if (tid < 250) tile_acc<4, 10>(S.h1, S.a2, (tid / 10) * 4, (tid % 10) * 10, gW2);       // dW2 = h1^T delta2
-    if (tid < H) gb2 += row_sum(S.a2[tid]);                                                  // db2
-    if (dense) {                                                                            // delta1 = (W2 delta2) (1 - h1^2)
-      float4 acc[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-#pragma unroll 2
-      for (int j = 0; j < H; j += 4) {
-        const float4 d0 = f4(&S.a2[j][sq]), d1 = f4(&S.a2[j + 1][sq]), d2 = f4(&S.a2[j + 2][sq]), d3 = f4(&S.a2[j + 3][sq]);
+    {
+      v16f acc;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const float4 w = f4(&S.W2[(uq + u) * H + j]);
-          fma4(acc[u], w.x, d0); fma4(acc[u], w.y, d1); fma4(acc[u], w.z, d2); fma4(acc[u], w.w, d3);
-        }
+      for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < SB / 2; t++) {                      // dW2ext = h1ext delta2^T  (row 100: db2)
+        const float b = S.a2[u0 + li][2 * t + hf];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) gW2[mt] = mfma32(S.h1[32 * mt + li][2 * t + hf], b, gW2[mt]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) *reinterpret_cast<float4*>(&S.a1[uq + u][sq]) = dtanh4(acc[u], f4(&S.h1[uq + u][sq]));
+      for (int t = 0; t < H / 2; t++) acc = mfma32(S.Wt[O_W2 + (u0 + li) * H + 2 * t + hf], S.a2[2 * t + hf][li], acc);    // W2 delta2
+#pragma unroll
+      for (int r = 0; r < 16; r++) {                          // delta1 = (W2 delta2) (1 - h1^2)
+        const int u = u0 + row32(r, hf);
+        if (u < H) { const float h = S.h1[u][li]; S.a1[u][li] = acc[r] * (1.0f - h * h); }
+      }
     }
     __syncthreads();
-    if (tid < 140) tile_acc<4, 10>(S.z, S.a1, (tid / 10) * 4, (tid % 10) * 10, gW1);        // dW1 = z^T delta1
-    else if (tid >= 156) gbx += row_sum(S.a1[tid - 156]);                                    // db1
+#pragma unroll
+    for (int t = 0; t < SB / 2; t++) {                        // dW1ext = zext delta1^T  (row 56: db1)
+      const float b = S.a1[u0 + li][2 * t + hf];
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) gW1[mt] = mfma32(S.z[32 * mt + li][2 * t + hf], b, gW1[mt]);
+    }
   }
   if (tid == 0) { lpart[2 * blockIdx.x] = lsum0; lpart[2 * blockIdx.x + 1] = lsum1; }
   if (MODE == MODE_LOSS) return;
   float* out = partial + (size_t)blockIdx.x * NPAD;
-  if (tid < 140) {
-    const int i0 = (tid / 10) * 4, j0 = (tid % 10) * 10;
+  const int col = u0 + li;
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+  for (int r = 0; r < 16; r++) {
+    const int i = row32(r, hf);
+    if (col < H) {
 #pragma unroll
-      for (int b = 0; b < 10; b++) out[O_W1 + (i0 + a) * H + j0 + b] = gW1[a][b];
+      for (int mt = 0; mt < 2; mt++) if (32 * mt + i <= OB) out[O_W1 + (32 * mt + i) * H + col] = gW1[mt][r];       // row 56 is b1's place in theta
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) if (32 * mt + i <= H) out[O_W2 + (32 * mt + i) * H + col] = gW2[mt][r];        // row 100: b2
+    }
+    if (li < AC && u0 + i <= H) out[O_W3 + (u0 + i) * AC + li] = gW3[r];                                            // row 100: b3
   }
-  if (tid < 250) {
-    const int i0 = (tid / 10) * 4, j0 = (tid % 10) * 10;
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int b = 0; b < 10; b++) out[O_W2 + (i0 + a) * H + j0 + b] = gW2[a][b];
-  }
-  if (tid < 100) {
-    const int i0 = (tid / 4) * 4, j0 = (tid % 4) * 7;
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int b = 0; b < 7; b++) out[O_W3 + (i0 + a) * AC + j0 + b] = gW3[a][b];
-    out[O_B2 + tid] = gb2;
-  } else if (tid < 100 + AC) out[O_B3 + tid - 100] = gbx;
-  else if (tid >= 128 && tid < 128 + AC) out[O_LS + tid - 128] = gbx;       // (Fisher product: zero here; the reduction writes 2 v)
-  else if (tid >= 156) out[O_B1 + tid - 156] = gbx;
+  if (tid >= 128 && tid < 128 + AC) out[O_LS + tid - 128] = gls;            // (Fisher product: zero here; the reduction writes 2 v)
 }
 
 // partial gradients summed in block order (eight loads in flight; the additions stay in order), plus the parts that do not come from the samples:

@@ -52,22 +52,31 @@ def allmean(x, group=None, force=False):
     return x
 
 
-def cg(f_Ax, b, cg_iters=10, residual_tol=1e-10):
-    """Conjugate gradient of src/cg.py:2-34 (Demmel p. 312) on a flat device vector."""
+def cg(f_Ax, b, cg_iters=10, residual_tol=1e-10, sync_free=None):
+    """Conjugate gradient of src/cg.py:2-34 (Demmel p. 312) on a flat device vector.  On a GPU the `rdotr < residual_tol: break` of :30-31 is
+    applied WITHOUT reading the residual back every iteration (ten host round trips per update): once it has fallen below the tolerance the
+    remaining iterations leave x untouched, exactly where the break would have."""
     p = b.clone()
     r = b.clone()
     x = torch.zeros_like(b)
     rdotr = r.dot(r)
+    on_device = (b.device.type == "cuda") if sync_free is None else bool(sync_free)
+    live = torch.ones((), dtype=b.dtype, device=b.device) if on_device else None       # 1 until the residual test would have broken out
     for _ in range(cg_iters):
         z = f_Ax(p)
         v = rdotr / p.dot(z)
-        x += v * p
+        if on_device:
+            x = torch.where(live > 0, x + v * p, x)        # a where on x, not a zero step: past convergence p and v may hold 0/0
+        else:
+            x += v * p
         r -= v * z
         newrdotr = r.dot(r)
         mu = newrdotr / rdotr
         p = r + mu * p
         rdotr = newrdotr
-        if float(rdotr) < residual_tol:
+        if on_device:
+            live = live * (rdotr >= residual_tol).to(b.dtype)
+        elif float(rdotr) < residual_tol:
             break
     return x
 
@@ -233,6 +242,8 @@ class TrpoLearner:
         self.vf_graph = vf_graph
         import os
         self.vf_overlap = os.environ.get("DM_VF_OVERLAP", "1") != "0"     # value fit on a second stream beside the policy step (both on kernels)
+        self.vf_share = os.environ.get("DM_VF_SHARE", "1") != "0"         # ... and the policy launches leave it its CUs while it runs (_pg_share_begin)
+        self._share = None
         self._vf_stream = None
         self._rms_pol = None
         self.vf_epoch_filter = os.environ.get("DM_VF_EPOCH_FILTER", "1") != "0"   # obs-filter sums of an epoch's minibatches up front (False: per minibatch)
@@ -401,6 +412,37 @@ class TrpoLearner:
             self._pg_scratch = torch.empty(int(L.dm_pg_scratch_bytes()), dtype=torch.uint8, device=dev)
         return self._pg_scratch
 
+    # ---- CU sharing between the policy step and the value fit running beside it ----
+    # Both halves' kernels fill a CU's LDS with one workgroup, so a full-grid policy launch (256 blocks) and the fit's gradient kernel never
+    # run side by side: the fit's launches would only squeeze in between policy launches and the two "overlapped" halves take the sum of
+    # their times.  While the fit is expected to be running, the policy launches therefore take only the CUs the fit's grid leaves; once
+    # it should be through they take all of them.  WHICH launches are the narrow ones is decided from a cost model of the launch sequence
+    # (ns per sample on a full MI355X, measured: profiles/r04_train_kernels.md), not from the clock, so that a seeded run reproduces
+    # bit for bit (the gradient sums are taken in block order: a function of the grid size).
+    PG_GRAD_NS, PG_FVP_NS, PG_LOSS_NS = 3.02, 2.92, 1.65
+    VF_STEP_US, VF_EPOCH_US = 33.0, 350.0
+    N_CU = 256
+
+    def _pg_share_begin(self, n, bs):
+        nb = n // bs
+        vf_blocks = (bs + 31) // 32
+        if vf_blocks >= self.N_CU * 3 // 4:
+            self._share = None                                              # the fit wants (nearly) the whole chip anyway: nothing to leave
+            return
+        vf_ms = self.vf_iters * (nb * self.VF_STEP_US * max(1.0, vf_blocks / 128.0) + self.VF_EPOCH_US) * 1e-3
+        self._share = {"t": 0.0, "until": vf_ms, "blocks": self.N_CU - vf_blocks}
+
+    def _pg_grid(self, cost_ns):
+        sh = getattr(self, "_share", None)
+        if sh is None:
+            return 0
+        ms = cost_ns * 1e-6
+        if sh["t"] >= sh["until"]:
+            sh["t"] += ms
+            return 0
+        sh["t"] += ms * self.N_CU / sh["blocks"]
+        return int(sh["blocks"])
+
     def _pg_losses(self, ob, ac, atarg, old_mean, old_logstd, theta, write_old, with_grad):
         """-> (losses [5] float32 like `_losses`: optimgain, meankl, entbonus, surrgain, meanent; flat gradient or None)"""
         import ctypes as C
@@ -411,7 +453,8 @@ class TrpoLearner:
         g = torch.empty(theta.numel(), dtype=torch.float32, device=dev) if with_grad else None
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         self._pg_call("dm_pg_losses", ob, int(ob.shape[0]), ac, atarg, old_mean, old_logstd, 1 if write_old else 0, theta, rms_mean, rms_std,
-                      C.c_double(float(self.entcoeff)), 1 if with_grad else 0, g if with_grad else C.c_void_p(0), out, sc, st)
+                      C.c_double(float(self.entcoeff)), 1 if with_grad else 0, g if with_grad else C.c_void_p(0), out, sc, st,
+                      self._pg_grid((self.PG_GRAD_NS if with_grad else self.PG_LOSS_NS) * ob.shape[0]))
         logstd = theta[-28:]
         meanent = (logstd + 0.5 * math.log(2.0 * math.pi * math.e)).sum()
         surr, kl = out[0].to(torch.float32), out[1].to(torch.float32)
@@ -426,7 +469,8 @@ class TrpoLearner:
         k = int(self.fvp_subsample)
         nf = (int(ob.shape[0]) + k - 1) // k                                # rows of ob[::k]
         hv = torch.empty_like(v)
-        self._pg_call("dm_pg_fvp", ob, k, nf, theta, v.contiguous(), rms_mean, rms_std, hv, sc, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        self._pg_call("dm_pg_fvp", ob, k, nf, theta, v.contiguous(), rms_mean, rms_std, hv, sc, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                      self._pg_grid(self.PG_FVP_NS * nf))
         return hv
 
     # ---- one update ----------------------------------------------------------------------------------------------------------
@@ -482,6 +526,8 @@ class TrpoLearner:
             self._vf_stream.wait_stream(main)
             with torch.cuda.stream(self._vf_stream):
                 fit_value()
+            if self.vf_share:
+                self._pg_share_begin(n, bs)
         self._rms_pol = rms_pol
         if native_pg:
             ob = ob.contiguous(); ac = ac.contiguous(); atarg = atarg.to(torch.float32).contiguous()
@@ -560,6 +606,7 @@ class TrpoLearner:
             stats.update(expectedimprove=expectedimprove, improve=improve, stepsize=stepsize if ok else 0.0)
             tick("line_search")
 
+        self._share = None
         if overlap:
             torch.cuda.current_stream(ob.device).wait_stream(self._vf_stream)   # the fit's parameters / filter state before anything after this update
         else:

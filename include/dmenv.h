@@ -289,14 +289,17 @@ int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, int32_t bs, f
  *                 write_old != 0: old == new, and old_mean [n, 28] is WRITTEN (`assign_old_eq_new`, :247); else it is read, with old_logstd [28].
  *   dm_pg_fvp     `compute_fvp` (:228-230) on the samples ob[i * stride], i < n (`fvpargs = arr[::5]`, :245): out_fv = Hessian of the mean KL
  *                 at new == old times v — exactly J^T diag(1 / sigma^2) J v / n on the mean parameters and 2 v on logstd (pg_kernel.h); the
- *                 caller adds cg_damping * v (:229).  One forward-mode and one reverse pass per sample, no second-order graph. */
+ *                 caller adds cg_damping * v (:229).  One forward-mode and one reverse pass per sample, no second-order graph.
+ * Both run one workgroup per CU (their LDS fills it); max_blocks > 0 caps the grid, which leaves the other CUs to a kernel of another stream
+ * (the learner runs the value fit beside the policy step that way).  Sums are taken in block order: the result is a function of the grid
+ * size, not of timing.  max_blocks = 0: every CU. */
 int dm_pg_param_count(void);
 size_t dm_pg_scratch_bytes(void);
 int dm_pg_losses(const float* ob, int32_t n, const float* ac, const float* atarg, float* old_mean, const float* old_logstd, int32_t write_old,
                  const float* theta, const float* rms_mean, const float* rms_std, double entcoeff, int32_t with_grad,
-                 float* out_grad, double* out_losses, void* scratch, void* hip_stream);
+                 float* out_grad, double* out_losses, void* scratch, void* hip_stream, int32_t max_blocks);
 int dm_pg_fvp(const float* ob, int32_t stride, int32_t n, const float* theta, const float* v, const float* rms_mean, const float* rms_std,
-              float* out_fv, void* scratch, void* hip_stream);
+              float* out_fv, void* scratch, void* hip_stream, int32_t max_blocks);
 
 /* Diagnostics of DM_OPT_PACKED (four environments per wavefront, csrc/slot_kernel.h): env-steps so far that exceeded a capacity of that
  * path (DM_PACKED_*: rows, contacts / contact pairs, pairs past the bounding spheres, box staging slots; or a PGS step the cost test would

@@ -27,6 +27,11 @@ def test_cg_matches_reference_iteration_and_solves_spd():
         x = cg(lambda p: At @ p, torch.from_numpy(b), cg_iters=iters)
         assert np.allclose(x.numpy(), cg_np(lambda p: A @ p, b, iters), rtol=1e-9, atol=1e-12)
     assert np.allclose(cg(lambda p: At @ p, torch.from_numpy(b), cg_iters=40).numpy(), np.linalg.solve(A, b), atol=1e-5)   # stops at r.r < 1e-10, as the reference
+    # the GPU form applies the residual test without reading it back: same x as the break, at every tolerance (incl. one that stops after a single iteration)
+    for tol in (1e-10, 1e-3, 1e3):
+        x_break = cg(lambda p: At @ p, torch.from_numpy(b), cg_iters=40, residual_tol=tol, sync_free=False)
+        x_mask = cg(lambda p: At @ p, torch.from_numpy(b), cg_iters=40, residual_tol=tol, sync_free=True)
+        assert torch.isfinite(x_mask).all() and torch.equal(x_break, x_mask)
 
 
 def test_distribution_formulas_match_reference_definitions():
