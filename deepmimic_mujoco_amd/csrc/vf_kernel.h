@@ -5,7 +5,7 @@
 // MpiAdam rule of src/mpi_adam.py:21-35.  Here:
 //   k_vf_rms   column sums / sums of squares of the minibatch in float64 (fixed reduction order), the LAST block to finish adds
 //              them to the filter's state and refreshes its float32 mean / std,
-//   k_vf_grad  a block takes 16 samples: normalise + clip, forward, backward, all in LDS (weights staged once per block), and
+//   k_vf_grad  a block takes 32 samples: normalise + clip, forward, backward as fp32 MFMA tiles out of LDS (theta staged once per block), and
 //              writes its partial gradient of the 15 901 parameters,
 //   k_vf_adam  partial gradients summed in a fixed order (four quarters of the blocks, each in block order), Adam moments, step.
 // fp32 like the reference's TF graph (sums of the filter in float64 like its numpy arrays).  A whole epoch of minibatches is
@@ -17,7 +17,7 @@
 
 namespace dmv {
 
-constexpr int OB = 56, H = 100, SB = 16;            // SB: samples per block of k_vf_grad (16: a 4 096-sample minibatch is 256 blocks, one per CU of an MI355X)
+constexpr int OB = 56, H = 100, SB = 32;            // SB: samples per block of k_vf_grad (a 4 096-sample minibatch is 128 blocks: the policy step can have the other CUs)
 constexpr int O_W1 = 0, O_B1 = O_W1 + OB * H, O_W2 = O_B1 + H, O_B2 = O_W2 + H * H, O_W3 = O_B2 + H, O_B3 = O_W3 + H, NP = O_B3 + 1;
 constexpr int NPAD = (NP + 63) / 64 * 64;
 constexpr int RMS_BLOCKS = 64;
@@ -72,147 +72,149 @@ __global__ __launch_bounds__(256) void k_vf_rms(const float* __restrict__ ob, in
 }
 
 // ---- forward + backward of 32 samples ------------------------------------------------------------------------------------------
-// Activations are kept TRANSPOSED in LDS ([unit][sample]): a thread of the dense layers owns a 2 units x 4 samples register tile (round 3;
-// 4 x 4 on 32-sample blocks before: half the blocks, half the CUs, twice the serial work per thread — 36 us per 4 096-sample minibatch) and
-// feeds 8 FMAs from a 16-byte and an 8-byte LDS read (four samples of one input, two weights of that input); the weight-gradient products run
-// over the sample axis with 16-byte reads as well (4 x 10 tiles).
+// Every product runs on the matrix cores in fp32 (v_mfma_f32_32x32x2_f32), laid out like the policy kernels (pg_kernel.h): activations
+// transposed in LDS ([unit][sample], row stride 33 floats: conflict-free as the B operand of a layer and as an operand of the weight-gradient
+// products, which sum over the samples), ONE copy of theta in LDS whose order (W1, b1, W2, b2, w3, b3) makes each bias the row after its
+// matrix — a constant row of ones under z / h1 makes the biases part of the products, forward and backward, and the bias gradients rows 56 /
+// 100 of the weight-gradient tiles.  Wave w owns hidden units 32 w .. 32 w + 31 (100 padded to 128: rows past 99 read finite junk and are
+// never stored).  (Rounds 2-3: 4 x 4 / 2 x 4 register tiles of FMAs on 16-sample blocks, 28 us per 4 096-sample minibatch.)
+constexpr int SBP = SB + 1, ZR = OB + 2, HR = H + 4;
+constexpr int NWT = (NP + 3) / 4 * 4;
+typedef float v16f __attribute__((ext_vector_type(16)));
 struct alignas(16) VfShared {
-  float W1[OB * H], W2[H * H];
-  float z[OB][SB], h1[H][SB], h2[H][SB], d1[H][SB], d2[H][SB];
-  float w3[H], b1[H], b2[H], dv[SB];
+  float Wt[NWT];                                      // theta: W1 [56][100], b1, W2 [100][100], b2, w3 [100], b3
+  float z[ZR][SBP];                                   // row 56 = 1, row 57 = 0
+  float h1[HR][SBP], h2[HR][SBP];                     // h1: row 100 = 1, row 101 = 0
+  float d2[HR][SBP], d1[HR][SBP];                     // (as operands of the weight-gradient products their 128-row tiles read on into what follows)
+  float vpart[8][SB], dv[SB];
+  float tail[24 * SBP];                               // ... zeros
 };
-__device__ inline float4 f4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ inline void fma4(float4& a, float w, const float4& x) { a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w; }
-__device__ inline float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+static_assert(SB * OB % 256 == 0, "the observation tile is read in whole rounds of the block");
+static_assert(sizeof(VfShared) <= 160 * 1024, "VfShared must fit a CU's LDS");
+static_assert(O_W2 + 127 * H + H <= NWT + (ZR + HR) * SBP, "padded W2 rows (A operand of the backward product) read into z / h1");
+__device__ inline v16f mfma32(float a, float b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ inline int row32(int r, int hf) { return 8 * (r / 4) + 4 * hf + (r % 4); }      // row of a 32x32 result tile in register r of the lanes of half hf
+__device__ inline float fast_tanh(float x) { return tanhf(x); }
 
-// out[i0 + a][jj + b] = sum_s A[i0 + a][s] B[jj + b][s]  for a 4 x 10 tile (both operands [.][SB] in LDS), row stride H in `out`
-__device__ inline void tile_4x10(const float (*A)[SB], const float (*B)[SB], int i0, int jj, float* out) {
-  float t[4][10];
+// forward + backward of samples s0 .. s0 + SB - 1 of the minibatch; the tile's partial gradient goes to `out` (NPAD floats, theta order)
+__global__ __launch_bounds__(256) void k_vf_grad(const float* __restrict__ ob, const float* __restrict__ ret, int bs, const float* __restrict__ theta,
+                                                 const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ partial) {
+  __shared__ VfShared S;                                      // 126 KB: one block per CU
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, li = l & 31, hf = l >> 5, u0 = 32 * w;
+  const int s0 = blockIdx.x * SB;
+  float* out = partial + (size_t)blockIdx.x * NPAD;
+  {
+    // One round trip for everything the block reads: the tile's observations (with the filter's mean / std) and theta are requested together,
+    // the pads are zeroed while they are in flight (operands that reach into pad rows / columns must be finite).
+    constexpr int NZ = SB * OB / 256, NT = (NP / 4 + 255) / 256;
+    float x[NZ], mu[NZ], sd[NZ];
 #pragma unroll
-  for (int a = 0; a < 4; a++)
+    for (int j = 0; j < NZ; j++) {
+      const int i = tid + 256 * j, sm = i / OB, k = i % OB, r = s0 + sm;
+      x[j] = r < bs ? ob[(size_t)r * OB + k] : 0.0f; mu[j] = mean[k]; sd[j] = stdv[k];
+    }
+    const float4* g = reinterpret_cast<const float4*>(theta);
+    float4 th[NT];
 #pragma unroll
-    for (int b = 0; b < 10; b++) t[a][b] = 0.0f;
-#pragma unroll 2
-  for (int s4 = 0; s4 < SB; s4 += 4) {
-    float4 av[4], bv[10];
+    for (int j = 0; j < NT; j++) { const int i = tid + 256 * j; th[j] = i < NP / 4 ? g[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+    const float last = tid < NWT - NP / 4 * 4 && NP / 4 * 4 + tid < NP ? theta[NP / 4 * 4 + tid] : 0.0f;
+    float4* act = reinterpret_cast<float4*>(&S.z[0][0]);
+    for (int i = tid; i < (int)((sizeof(VfShared) - sizeof(S.Wt)) / 16); i += 256) act[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __syncthreads();
+    float4* d = reinterpret_cast<float4*>(S.Wt);
 #pragma unroll
-    for (int a = 0; a < 4; a++) av[a] = f4(&A[i0 + a][s4]);
+    for (int j = 0; j < NT; j++) { const int i = tid + 256 * j; if (i < NP / 4) d[i] = th[j]; }
+    if (tid < NWT - NP / 4 * 4) S.Wt[NP / 4 * 4 + tid] = last;
+    if (tid < SB) { S.z[OB][tid] = 1.0f; S.h1[H][tid] = 1.0f; }
 #pragma unroll
-    for (int b = 0; b < 10; b++) bv[b] = f4(&B[jj + b][s4]);
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int b = 0; b < 10; b++) t[a][b] += dot4(av[a], bv[b]);
+    for (int j = 0; j < NZ; j++) {                            // coalesced read of [sample][input], transposed store
+      const int i = tid + 256 * j, sm = i / OB, k = i % OB;
+      S.z[k][sm] = (s0 + sm < bs) ? fminf(fmaxf((x[j] - mu[j]) / sd[j], -5.0f), 5.0f) : 0.0f;
+    }
   }
+  __syncthreads();
+  {   // layer 1: h1 = tanh(W1ext^T zext)
+    v16f acc;
 #pragma unroll
-  for (int a = 0; a < 4; a++)
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 #pragma unroll
-    for (int b = 0; b < 10; b++) out[(i0 + a) * H + jj + b] = t[a][b];
-}
-__device__ inline float row_sum(const float* r) {            // sum over the SB samples of one unit
-  float a = 0.0f;
+    for (int t = 0; t < (OB + 2) / 2; t++) { const int k = 2 * t + hf; acc = mfma32(S.Wt[O_W1 + k * H + u0 + li], S.z[k][li], acc); }
 #pragma unroll
-  for (int s4 = 0; s4 < SB; s4 += 4) { const float4 x = f4(r + s4); a += (x.x + x.y) + (x.z + x.w); }
-  return a;
-}
-
-// the value net's weights into LDS (once per block and minibatch)
-__device__ inline void vf_stage_weights(VfShared& S, const float* __restrict__ theta, int tid) {
-  {   // weights: 16-byte loads, several in flight (both blocks start 16-byte aligned in the packed layout)
-    const float4* g1 = reinterpret_cast<const float4*>(theta + O_W1); float4* l1 = reinterpret_cast<float4*>(S.W1);
-    const float4* g2 = reinterpret_cast<const float4*>(theta + O_W2); float4* l2 = reinterpret_cast<float4*>(S.W2);
-#pragma unroll 6
-    for (int i = tid; i < OB * H / 4; i += 256) l1[i] = g1[i];
-#pragma unroll 10
-    for (int i = tid; i < H * H / 4; i += 256) l2[i] = g2[i];
+    for (int r = 0; r < 16; r++) { const int u = u0 + row32(r, hf); if (u < H) S.h1[u][li] = fast_tanh(acc[r]); }
   }
-  if (tid < H) { S.w3[tid] = theta[O_W3 + tid]; S.b1[tid] = theta[O_B1 + tid]; S.b2[tid] = theta[O_B2 + tid]; }
-}
-// forward + backward of samples s0 .. s0 + SB - 1 of the minibatch; the tile's partial gradient goes to `out` (NPAD floats)
-__device__ inline void vf_grad_tile(VfShared& S, const float* __restrict__ ob, const float* __restrict__ ret, int bs, const float* __restrict__ theta,
-                                    const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ out, int s0, int tid) {
-#pragma unroll 4
-  for (int i = tid; i < SB * OB; i += 256) {                  // coalesced read of [sample][input], transposed store
-    const int sm = i / OB, k = i % OB, r = s0 + sm;
+  __syncthreads();
+  {   // layer 2
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < (H + 2) / 2; t++) { const int k = 2 * t + hf; acc = mfma32(S.Wt[O_W2 + k * H + u0 + li], S.h1[k][li], acc); }
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const int u = u0 + row32(r, hf); if (u < H) S.h2[u][li] = fast_tanh(acc[r]); }
+  }
+  __syncthreads();
+  {   // output: vpred = w3 . h2 + b3, eight partial sums per sample
+    const int sm = tid % SB, part = tid / SB;
     float v = 0.0f;
-    if (r < bs) v = fminf(fmaxf((ob[(size_t)r * OB + k] - mean[k]) / stdv[k], -5.0f), 5.0f);
-    S.z[k][sm] = v;
+    for (int j = part; j < H; j += 8) v += S.h2[j][sm] * S.Wt[O_W3 + j];
+    S.vpart[part][sm] = v;
   }
   __syncthreads();
-  static_assert(SB == 16, "thread tiles below: 4 sample quads x 50 unit pairs");
-  const int sq = (tid % 4) * 4, uq = (tid / 4) * 2;           // this thread's 4 samples x 2 units (threads 0..199)
-  const bool dense = tid < 200;
-  // layer 1, layer 2
-  if (dense) {
-    float4 acc[2];
+  if (tid < SB) {                                             // error, d loss / d vpred  (loss = mean over the minibatch of (vpred - ret)^2)
+    float v = S.Wt[O_B3];
 #pragma unroll
-    for (int u = 0; u < 2; u++) { const float b = S.b1[uq + u]; acc[u] = make_float4(b, b, b, b); }
-#pragma unroll 8
-    for (int k = 0; k < OB; k++) {
-      const float4 x = f4(&S.z[k][sq]); const float2 w = *reinterpret_cast<const float2*>(&S.W1[k * H + uq]);
-      fma4(acc[0], w.x, x); fma4(acc[1], w.y, x);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(&S.h1[uq + u][sq]) = make_float4(tanhf(acc[u].x), tanhf(acc[u].y), tanhf(acc[u].z), tanhf(acc[u].w));
-  }
-  __syncthreads();
-  if (dense) {
-    float4 acc[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) { const float b = S.b2[uq + u]; acc[u] = make_float4(b, b, b, b); }
-#pragma unroll 10
-    for (int k = 0; k < H; k++) {
-      const float4 x = f4(&S.h1[k][sq]); const float2 w = *reinterpret_cast<const float2*>(&S.W2[k * H + uq]);
-      fma4(acc[0], w.x, x); fma4(acc[1], w.y, x);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(&S.h2[uq + u][sq]) = make_float4(tanhf(acc[u].x), tanhf(acc[u].y), tanhf(acc[u].z), tanhf(acc[u].w));
-  }
-  __syncthreads();
-  // output, error, d loss / d vpred  (loss = mean over the minibatch of (vpred - ret)^2)
-  if (tid < SB) {
-    float v = theta[O_B3];
-    for (int j = 0; j < H; j++) v += S.h2[j][tid] * S.w3[j];
+    for (int p = 0; p < 8; p++) v += S.vpart[p][tid];
     S.dv[tid] = (s0 + tid < bs) ? 2.0f * (v - ret[s0 + tid]) / (float)bs : 0.0f;
   }
   __syncthreads();
-  // d a2 = dv w3 (1 - h2^2);  dw3, db3
-  for (int i = tid; i < SB * H; i += 256) { const int j = i / SB, sm = i % SB; const float h = S.h2[j][sm]; S.d2[j][sm] = S.dv[sm] * S.w3[j] * (1.0f - h * h); }
+  // delta2 = dv w3 (1 - h2^2);  dw3, db3
+  for (int i = tid; i < SB * H; i += 256) { const int j = i / SB, sm = i % SB; const float h = S.h2[j][sm]; S.d2[j][sm] = S.dv[sm] * S.Wt[O_W3 + j] * (1.0f - h * h); }
   if (tid < H) { float a = 0.0f; for (int sm = 0; sm < SB; sm++) a += S.h2[tid][sm] * S.dv[sm]; out[O_W3 + tid] = a; }
   if (tid == H) { float a = 0.0f; for (int sm = 0; sm < SB; sm++) a += S.dv[sm]; out[O_B3] = a; }
   __syncthreads();
-  // dW2 = h1^T d2 (250 tiles), db2
-  if (tid < 250) tile_4x10(S.h1, S.d2, (tid / 10) * 4, (tid % 10) * 10, out + O_W2);
-  if (tid < H) out[O_B2 + tid] = row_sum(S.d2[tid]);
-  // d h1 = d2 W2^T, d a1 = d h1 (1 - h1^2): 4 samples x 2 units per thread, four j at a time
-  if (dense) {
-    float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-#pragma unroll 5
-    for (int j = 0; j < H; j += 4) {
-      const float4 d0 = f4(&S.d2[j][sq]), d1 = f4(&S.d2[j + 1][sq]), d2 = f4(&S.d2[j + 2][sq]), d3 = f4(&S.d2[j + 3][sq]);
+  const int col = u0 + li;
+  {
+    v16f g2[4], acc;
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const float4 w = f4(&S.W2[(uq + u) * H + j]);
-        fma4(acc[u], w.x, d0); fma4(acc[u], w.y, d1); fma4(acc[u], w.z, d2); fma4(acc[u], w.w, d3);
-      }
+    for (int r = 0; r < 16; r++) { g2[0][r] = 0.0f; g2[1][r] = 0.0f; g2[2][r] = 0.0f; g2[3][r] = 0.0f; acc[r] = 0.0f; }
+#pragma unroll
+    for (int t = 0; t < SB / 2; t++) {                        // dW2ext = h1ext delta2^T  (row 100: db2)
+      const float b = S.d2[u0 + li][2 * t + hf];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) g2[mt] = mfma32(S.h1[32 * mt + li][2 * t + hf], b, g2[mt]);
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const float4 h = f4(&S.h1[uq + u][sq]);
-      *reinterpret_cast<float4*>(&S.d1[uq + u][sq]) = make_float4(acc[u].x * (1.0f - h.x * h.x), acc[u].y * (1.0f - h.y * h.y), acc[u].z * (1.0f - h.z * h.z), acc[u].w * (1.0f - h.w * h.w));
+    for (int t = 0; t < H / 2; t++) acc = mfma32(S.Wt[O_W2 + (u0 + li) * H + 2 * t + hf], S.d2[2 * t + hf][li], acc);    // W2 delta2
+#pragma unroll
+    for (int r = 0; r < 16; r++) {                            // delta1 = (W2 delta2) (1 - h1^2)
+      const int u = u0 + row32(r, hf);
+      if (u < H) { const float h = S.h1[u][li]; S.d1[u][li] = acc[r] * (1.0f - h * h); }
+    }
+    if (col < H) {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) { const int i = 32 * mt + row32(r, hf); if (i <= H) out[O_W2 + i * H + col] = g2[mt][r]; }
     }
   }
   __syncthreads();
-  // dW1 = z^T d1 (140 tiles), db1
-  if (tid < 140) tile_4x10(S.z, S.d1, (tid / 10) * 4, (tid % 10) * 10, out + O_W1);
-  else if (tid >= 156) out[O_B1 + tid - 156] = row_sum(S.d1[tid - 156]);
-}
-__global__ __launch_bounds__(256) void k_vf_grad(const float* __restrict__ ob, const float* __restrict__ ret, int bs, const float* __restrict__ theta,
-                                                 const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ partial) {
-  __shared__ VfShared S;                                      // 93 KB: one block per CU (a gfx950 workgroup may hold up to 160 KB)
-  const int tid = threadIdx.x;
-  vf_stage_weights(S, theta, tid);
-  vf_grad_tile(S, ob, ret, bs, theta, mean, stdv, partial + (size_t)blockIdx.x * NPAD, blockIdx.x * SB, tid);
+  {
+    v16f g1[2];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { g1[0][r] = 0.0f; g1[1][r] = 0.0f; }
+#pragma unroll
+    for (int t = 0; t < SB / 2; t++) {                        // dW1ext = zext delta1^T  (row 56: db1)
+      const float b = S.d1[u0 + li][2 * t + hf];
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) g1[mt] = mfma32(S.z[32 * mt + li][2 * t + hf], b, g1[mt]);
+    }
+    if (col < H) {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) { const int i = 32 * mt + row32(r, hf); if (i <= OB) out[O_W1 + i * H + col] = g1[mt][r]; }
+    }
+  }
 }
 
 // ---- gradient reduction + MpiAdam step (src/mpi_adam.py:21-35) -----------------------------------------------------------------

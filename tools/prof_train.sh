@@ -16,6 +16,10 @@ keys=h[0]["profile_ms"].keys()
 print("share=$sh", {k: round(sum(x["profile_ms"][k] for x in h)/len(h),2) for k in keys})
 PY
     done ;;
+  vfbatch)
+    for vb in ${VFB:-4096 8192 16384}; do
+      timeout 300 python tools/train_trpo.py --envs 4096 --horizon 128 --iters 120 --vf-batch $vb --out gpurun_out/$TAG/train120_vfb$vb.json 2>&1 | tail -1 | sed "s/^/vf_batch=$vb /"
+    done ;;
   trace)
     ( cd /tmp && DM_VF_SHARE=${SHARE:-0} rocprofv3 --kernel-trace --stats -d /tmp/p_train -- python $OLDPWD/tools/train_trpo.py --envs 4096 --horizon 128 --iters 20 --out /tmp/t.json > /dev/null 2>&1 )
     ROWS=9 python tools/rocprof_summary.py gpurun_out/$TAG/train_kernels.md "training loop, 20 iterations (4096 envs x 128 steps) — MI355X" $(find /tmp/p_train -name "*.db" | head -1) | head -16
