@@ -49,7 +49,9 @@ struct alignas(16) PgShared {
   float h1[HR][SBP], h2[HR][SBP];                     // row 100 = 1, rows 101..103 = 0
   float a1[HR][SBP], a2[HR][SBP];                     // FVP: tangents d h1, d h2;  backward: deltas of layer 1, 2
   float mo[MR][SBP];                                  // action mean -> output gradient G
-  float ls[AC], ols[AC];
+  float act[AC][SBP], om[AC][SBP];                    // the tile's actions and old means, transposed like mo
+  float ls[AC], ols[AC], at[SB];
+  float redp[8][SB][2];                               // partial sums of the per-sample log-ratio / KL over eight action groups
   float red[SB][2];
 };
 static_assert(sizeof(PgShared) <= 160 * 1024, "PgShared must fit a CU's LDS");
@@ -58,6 +60,13 @@ static_assert(O_W3 + 127 * AC + AC <= NWT + ZR * SBP, "padded W3 rows read into 
 
 __device__ inline v16f mfma32(float a, float b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ inline v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2 |x|): the hardware exponential and reciprocal, absolute error ~1e-7 — an ulp of the
+// activation's range, like the float32 graph of the reference.  (The library tanhf is ~60 instructions with two divergent branches: with the
+// products on the matrix cores it was a quarter of a tile's time.)
+__device__ inline float tanh_fast(float x) {
+  const float t = __expf(-2.0f * fabsf(x));
+  return copysignf((1.0f - t) * __frcp_rn(1.0f + t), x);
+}
 // row of a 32x32 result tile held in register r by the lanes of half `hf`
 __device__ inline int row32(int r, int hf) { return 8 * (r / 4) + 4 * hf + (r % 4); }
 
@@ -98,19 +107,47 @@ __global__ __launch_bounds__(256) void k_pg(const float* __restrict__ ob, int st
   v16f gW1[2], gW2[4], gW3;
 #pragma unroll
   for (int r = 0; r < 16; r++) { gW1[0][r] = 0.0f; gW1[1][r] = 0.0f; gW2[0][r] = 0.0f; gW2[1][r] = 0.0f; gW2[2][r] = 0.0f; gW2[3][r] = 0.0f; gW3[r] = 0.0f; }
-  float gls = 0.0f;                                           // d / d logstd_a, threads 128 .. 155
   double lsum0 = 0.0, lsum1 = 0.0;
   const int ntiles = (n + SB - 1) / SB;
+  // A tile's inputs are contiguous in memory (32 rows of ob / ac / old_mean): every thread fetches its share of the NEXT tile while the block
+  // works on this one, and hands it to LDS (transposed) at the top of the loop.
+  constexpr int NZ = SB * OB / 256, NA = (SB * AC + 255) / 256;
+  static_assert(SB * OB % 256 == 0, "the observation tile is read in whole rounds of the block");
+  float mu[NZ], sd[NZ], obx[NZ], acx[NA], omx[NA], atx = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NZ; j++) { const int k = (tid + 256 * j) % OB; mu[j] = mean[k]; sd[j] = stdv[k]; }
+  auto fetch = [&](int tile) {
+    const int s0n = tile * SB;
+#pragma unroll
+    for (int j = 0; j < NZ; j++) { const int i = tid + 256 * j, r = s0n + i / OB; obx[j] = r < n ? ob[(size_t)r * stride * OB + i % OB] : 0.0f; }
+    if (MODE != MODE_FVP) {
+#pragma unroll
+      for (int j = 0; j < NA; j++) {
+        const int i = tid + 256 * j; const bool ok = i < SB * AC && s0n + i / AC < n;
+        acx[j] = ok ? ac[(size_t)s0n * AC + i] : 0.0f;
+        omx[j] = (ok && !write_old) ? old_mean[(size_t)s0n * AC + i] : 0.0f;
+      }
+      if (tid < SB) atx = s0n + tid < n ? atarg[s0n + tid] : 0.0f;
+    }
+  };
+  fetch(blockIdx.x);
+  float gls[NA];                                              // d / d logstd_a: lanes 0 and 32 of wave w hold actions 2 w + (lane / 32) + 8 j
+#pragma unroll
+  for (int j = 0; j < NA; j++) gls[j] = 0.0f;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int s0g = tile * SB;
     __syncthreads();                                          // the previous tile's readers are done (first pass: the weights are in place)
-#pragma unroll 7
-    for (int i = tid; i < SB * OB; i += 256) {
-      const int sm = i / OB, k = i % OB, r = s0g + sm;
-      float x = 0.0f;
-      if (r < n) x = fminf(fmaxf((ob[(size_t)r * stride * OB + k] - mean[k]) / stdv[k], -5.0f), 5.0f);
-      S.z[k][sm] = x;
+#pragma unroll
+    for (int j = 0; j < NZ; j++) {
+      const int i = tid + 256 * j, sm = i / OB, k = i % OB;
+      S.z[k][sm] = (s0g + sm < n) ? fminf(fmaxf((obx[j] - mu[j]) / sd[j], -5.0f), 5.0f) : 0.0f;
     }
+    if (MODE != MODE_FVP) {
+#pragma unroll
+      for (int j = 0; j < NA; j++) { const int i = tid + 256 * j; if (i < SB * AC) { S.act[i % AC][i / AC] = acx[j]; S.om[i % AC][i / AC] = omx[j]; } }
+      if (tid < SB) S.at[tid] = atx;
+    }
+    fetch(tile + gridDim.x);
     __syncthreads();
     // ---- layer 1 (+ tangent): h1 = tanh(W1ext^T zext) ----
     {
@@ -128,7 +165,7 @@ __global__ __launch_bounds__(256) void k_pg(const float* __restrict__ ob, int st
       for (int r = 0; r < 16; r++) {
         const int u = u0 + row32(r, hf);
         if (u < H) {
-          const float h = tanhf(acc[r]);
+          const float h = tanh_fast(acc[r]);
           S.h1[u][li] = h;
           if (MODE == MODE_FVP) S.a1[u][li] = dac[r] * (1.0f - h * h);
         }
@@ -154,7 +191,7 @@ __global__ __launch_bounds__(256) void k_pg(const float* __restrict__ ob, int st
       for (int r = 0; r < 16; r++) {
         const int u = u0 + row32(r, hf);
         if (u < H) {
-          const float h = tanhf(acc[r]);
+          const float h = tanh_fast(acc[r]);
           S.h2[u][li] = h;
           if (MODE == MODE_FVP) S.a2[u][li] = dac[r] * (1.0f - h * h);
         }
@@ -185,40 +222,57 @@ __global__ __launch_bounds__(256) void k_pg(const float* __restrict__ ob, int st
         S.mo[a][sm] = (s0g + sm < n) ? S.mo[a][sm] * __expf(-2.0f * S.ls[a]) * inv_n : 0.0f;
       }
     } else {
-      // ---- per-sample likelihood ratio and KL (src/distributions.py:235-243) ----
-      if (tid < SB) {
-        const int r = s0g + tid;
-        float ra = 0.0f, kl = 0.0f;
-        if (r < n) {
-          float d = 0.0f;                                     // logp_new - logp_old = neglogp_old - neglogp_new
-          for (int a = 0; a < AC; a++) {
-            const float m = S.mo[a][tid], x = ac[(size_t)r * AC + a];
-            float mold = m;
-            if (write_old) old_mean[(size_t)r * AC + a] = m; else mold = old_mean[(size_t)r * AC + a];
+      // ---- per-sample likelihood ratio and KL (src/distributions.py:235-243): thread = (sample, one of eight action groups) ----
+      const int sm = tid % SB, grp = tid / SB;
+      {
+        float d = 0.0f, kl = 0.0f;                            // logp_new - logp_old = neglogp_old - neglogp_new
+#pragma unroll
+        for (int j = 0; j < NA; j++) {
+          const int a = grp + 8 * j;
+          if (a < AC) {
+            const float m = S.mo[a][sm], x = S.act[a][sm], mold = write_old ? m : S.om[a][sm];
             const float ls = S.ls[a], lo = S.ols[a];
             const float en = (x - m) * __expf(-ls), eo = (x - mold) * __expf(-lo);
             d += 0.5f * (eo * eo - en * en) + (lo - ls);
             kl += ls - lo + (__expf(2.0f * lo) + (mold - m) * (mold - m)) * 0.5f * __expf(-2.0f * ls) - 0.5f;
           }
-          ra = __expf(d) * atarg[r];
         }
+        S.redp[grp][sm][0] = d; S.redp[grp][sm][1] = kl;
+      }
+      if (write_old) {                                        // oldpi <- pi: the tile's means, rows contiguous in old_mean
+#pragma unroll
+        for (int j = 0; j < NA; j++) { const int i = tid + 256 * j; if (i < SB * AC && s0g + i / AC < n) old_mean[(size_t)s0g * AC + i] = S.mo[i % AC][i / AC]; }
+      }
+      __syncthreads();
+      if (tid < SB) {
+        float d = 0.0f, kl = 0.0f;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; g8++) { d += S.redp[g8][tid][0]; kl += S.redp[g8][tid][1]; }
+        const bool ok = s0g + tid < n;
+        const float ra = ok ? __expf(d) * S.at[tid] : 0.0f;
+        if (!ok) kl = 0.0f;
         S.red[tid][0] = ra; S.red[tid][1] = kl;
+        double b0 = (double)ra, b1 = (double)kl;              // the tile's loss sums: a butterfly over the 32 lanes, in float64
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) { b0 += __shfl_xor(b0, o, 32); b1 += __shfl_xor(b1, o, 32); }
+        lsum0 += b0; lsum1 += b1;
       }
-      __syncthreads();
-      if (tid == 0) { double b0 = 0.0, b1 = 0.0; for (int sm = 0; sm < SB; sm++) { b0 += (double)S.red[sm][0]; b1 += (double)S.red[sm][1]; } lsum0 += b0; lsum1 += b1; }
       if (MODE == MODE_LOSS) continue;
-      // d optimgain / d logstd_a = sum_s ratio atarg (((x - m) / sigma)^2 - 1) / N   (the entropy bonus's constant is added by the reduction)
-      if (tid >= 128 && tid < 128 + AC) {
-        const int a = tid - 128;
-        const float is = __expf(-S.ls[a]);
-        float acc = 0.0f;
-        for (int sm = 0; sm < SB; sm++) { const int r = s0g + sm; if (r < n) { const float e = (ac[(size_t)r * AC + a] - S.mo[a][sm]) * is; acc += S.red[sm][0] * (e * e - 1.0f); } }
-        gls += acc * inv_n;
-      }
       __syncthreads();
-      for (int i = tid; i < AC * SB; i += 256) {              // G = d optimgain / d mean = ratio atarg (x - m) / sigma^2 / N, in place of the mean
-        const int a = i / SB, sm = i % SB, r = s0g + sm;
-        S.mo[a][sm] = (r < n) ? S.red[sm][0] * inv_n * (ac[(size_t)r * AC + a] - S.mo[a][sm]) * __expf(-2.0f * S.ls[a]) : 0.0f;
+      // G = d optimgain / d mean = ratio atarg (x - m) / sigma^2 / N, in place of the mean;  on the way
+      // d optimgain / d logstd_a = sum_s ratio atarg (((x - m) / sigma)^2 - 1) / N   (the entropy bonus's constant is added by the reduction)
+#pragma unroll
+      for (int j = 0; j < NA; j++) {
+        const int a = grp + 8 * j;
+        float e2 = 0.0f;
+        if (a < AC) {
+          const float ra = S.red[sm][0], dx = S.act[a][sm] - S.mo[a][sm], is = __expf(-S.ls[a]);
+          e2 = ra * (dx * is * dx * is - 1.0f);
+          S.mo[a][sm] = ra * inv_n * dx * is * is;
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) e2 += __shfl_xor(e2, o, 32);
+        gls[j] += e2 * inv_n;
       }
     }
     __syncthreads();
@@ -279,7 +333,10 @@ __global__ __launch_bounds__(256) void k_pg(const float* __restrict__ ob, int st
     }
     if (li < AC && u0 + i <= H) out[O_W3 + (u0 + i) * AC + li] = gW3[r];                                            // row 100: b3
   }
-  if (tid >= 128 && tid < 128 + AC) out[O_LS + tid - 128] = gls;            // (Fisher product: zero here; the reduction writes 2 v)
+  if (tid % SB == 0) {                                                      // (Fisher product: zero here; the reduction writes 2 v)
+#pragma unroll
+    for (int j = 0; j < NA; j++) if (tid / SB + 8 * j < AC) out[O_LS + tid / SB + 8 * j] = gls[j];
+  }
 }
 
 // partial gradients summed in block order (eight loads in flight; the additions stay in order), plus the parts that do not come from the samples:

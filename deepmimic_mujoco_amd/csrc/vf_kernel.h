@@ -94,7 +94,11 @@ static_assert(sizeof(VfShared) <= 160 * 1024, "VfShared must fit a CU's LDS");
 static_assert(O_W2 + 127 * H + H <= NWT + (ZR + HR) * SBP, "padded W2 rows (A operand of the backward product) read into z / h1");
 __device__ inline v16f mfma32(float a, float b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ inline int row32(int r, int hf) { return 8 * (r / 4) + 4 * hf + (r % 4); }      // row of a 32x32 result tile in register r of the lanes of half hf
-__device__ inline float fast_tanh(float x) { return tanhf(x); }
+// tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2 |x|), on the hardware exponential / reciprocal (absolute error ~1e-7; pg_kernel.h)
+__device__ inline float fast_tanh(float x) {
+  const float t = __expf(-2.0f * fabsf(x));
+  return copysignf((1.0f - t) * __frcp_rn(1.0f + t), x);
+}
 
 // forward + backward of samples s0 .. s0 + SB - 1 of the minibatch; the tile's partial gradient goes to `out` (NPAD floats, theta order)
 __global__ __launch_bounds__(256) void k_vf_grad(const float* __restrict__ ob, const float* __restrict__ ret, int bs, const float* __restrict__ theta,

@@ -264,6 +264,7 @@ class TrpoLearner:
         self._perm_gen = torch.Generator(device=pi.device)
         self._perm_gen.manual_seed(int(seed))
         self.perm_source = None        # tests: callable(n) -> index tensor replacing the shuffles of `dataset.iterbatches` (:289)
+        self._perms = []               # shuffles drawn ahead of the update that uses them (`_prefetch_perms`)
         self.last = {}                 # flat g / stepdir / fullstep of the last update (diagnostics, parity tests)
         self.sync_from_root()
 
@@ -419,8 +420,8 @@ class TrpoLearner:
     # it should be through they take all of them.  WHICH launches are the narrow ones is decided from a cost model of the launch sequence
     # (ns per sample on a full MI355X, measured: profiles/r04_train_kernels.md), not from the clock, so that a seeded run reproduces
     # bit for bit (the gradient sums are taken in block order: a function of the grid size).
-    PG_GRAD_NS, PG_FVP_NS, PG_LOSS_NS = 3.02, 2.92, 1.65
-    VF_STEP_US, VF_EPOCH_US = 33.0, 350.0
+    PG_GRAD_NS, PG_FVP_NS, PG_LOSS_NS = 2.06, 2.53, 0.89
+    VF_STEP_US, VF_EPOCH_US = 29.0, 350.0
     N_CU = 256
 
     def _pg_share_begin(self, n, bs):
@@ -473,6 +474,22 @@ class TrpoLearner:
                       self._pg_grid(self.PG_FVP_NS * nf))
         return hv
 
+    def _next_perm(self, n, dev):
+        """The next shuffle of `dataset.iterbatches` (:289) from this learner's generator — taken from the ones drawn ahead when they fit."""
+        while self._perms:
+            p = self._perms.pop(0)
+            if p.numel() == n and p.device == dev:
+                return p
+            self._perms = []           # the segment size changed: the generator's stream goes on from here (nothing drawn is re-used)
+        return torch.randperm(n, device=dev, generator=self._perm_gen)
+
+    def _prefetch_perms(self, n, dev):
+        """A shuffle of half a million indices is a 19-pass radix sort (0.65 ms): the next update's three are drawn on the fit's stream once this
+        update no longer waits for it — they run beside the rollout's bookkeeping instead of at the head of every epoch of the fit.  Same
+        generator, same order of draws: the shuffles are the ones an update drawing them itself would get."""
+        if self.perm_source is None and not self._perms:
+            self._perms = [torch.randperm(n, device=dev, generator=self._perm_gen) for _ in range(self.vf_iters)]
+
     # ---- one update ----------------------------------------------------------------------------------------------------------
     def update(self, seg):
         pi = self.pi
@@ -505,7 +522,7 @@ class TrpoLearner:
 
         def fit_value():
             for _ in range(self.vf_iters):
-                inds = self.perm_source(n).to(ob.device) if self.perm_source is not None else torch.randperm(n, device=ob.device, generator=self._perm_gen)
+                inds = self.perm_source(n).to(ob.device) if self.perm_source is not None else self._next_perm(n, ob.device)
                 if vf_native:
                     self._vf_native_epoch(ob, tdlamret, inds, bs)
                     continue
@@ -609,6 +626,8 @@ class TrpoLearner:
         self._share = None
         if overlap:
             torch.cuda.current_stream(ob.device).wait_stream(self._vf_stream)   # the fit's parameters / filter state before anything after this update
+            with torch.cuda.stream(self._vf_stream):
+                self._prefetch_perms(n, ob.device)
         else:
             fit_value()
         tick("value_fit")

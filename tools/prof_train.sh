@@ -23,5 +23,7 @@ PY
   trace)
     ( cd /tmp && DM_VF_SHARE=${SHARE:-0} rocprofv3 --kernel-trace --stats -d /tmp/p_train -- python $OLDPWD/tools/train_trpo.py --envs 4096 --horizon 128 --iters 20 --out /tmp/t.json > /dev/null 2>&1 )
     ROWS=9 python tools/rocprof_summary.py gpurun_out/$TAG/train_kernels.md "training loop, 20 iterations (4096 envs x 128 steps) — MI355X" $(find /tmp/p_train -name "*.db" | head -1) | head -16
-    python tools/gpu_gaps.py $(find /tmp/p_train -name "*.db" | head -1) | head -3 | tee gpurun_out/$TAG/gaps.txt ;;
+    python tools/gpu_gaps.py $(find /tmp/p_train -name "*.db" | head -1) | head -3 | tee gpurun_out/$TAG/gaps.txt
+    python tools/gpu_span.py $(find /tmp/p_train -name "*.db" | head -1) k_rollout_packed "k_pg<1>" > gpurun_out/$TAG/span_rollout_to_grad.txt
+    python tools/gpu_span.py $(find /tmp/p_train -name "*.db" | head -1) "k_pg<0>" k_fill_rows > gpurun_out/$TAG/span_linesearch_to_rollout.txt ;;
 esac; done
