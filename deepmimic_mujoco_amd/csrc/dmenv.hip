@@ -821,6 +821,16 @@ extern "C" int dm_gae(const float* rew, const float* vpred, const int32_t* isnew
   HIPCHK(hipGetLastError());
   return DM_OK;
 }
+extern "C" int dm_episode_scan(const double* reward, const uint8_t* done, int32_t T, int32_t n, double* cur_ret, int64_t* cur_len, int32_t* count,
+                               int32_t cap, int64_t* records, void* hip_stream) {
+  if (!reward || !done || !cur_ret || !cur_len || !count || !records || T <= 0 || n <= 0 || cap < 0) return fail(DM_EINVAL, "dm_episode_scan: bad argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIPCHK(hipMemsetAsync(count, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(dmp::k_episodes, dim3((n + 255) / 256), dim3(256), 0, st, reward, done, (int)T, (int)n, cur_ret, (long long*)cur_len, (int*)count, (int)cap,
+                     (long long*)records);
+  HIPCHK(hipGetLastError());
+  return DM_OK;
+}
 extern "C" int dm_vf_param_count(void) { return dmv::NP; }
 static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 struct VfScratch { size_t partial, rpart, part_all, means, stds, total; };

@@ -302,6 +302,33 @@ __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, cons
     vnext = v; nonterminal = 1.0f - (float)isnew[i];         // for row t - 1: new[t]
   }
 }
+// Episode bookkeeping of the generator (src/trpo.py:68-79: `cur_ep_ret += rew; cur_ep_len += 1; if new: ep_rets.append(...)`) for N environments
+// over a [T, N] segment: thread = env walks its column, adds rewards in float64 in step order (the sums a per-env host loop would form) and
+// appends a record {t << 32 | env, return (bits), length} of every episode that ends to a list — in arrival order; the host sorts the few
+// records by their first word (t, then env).  The open episode's return / length are carried in cur_ret / cur_len to the next segment.
+__global__ __launch_bounds__(256) void k_episodes(const double* __restrict__ rew, const uint8_t* __restrict__ done, int T, int n, double* __restrict__ cur_ret,
+                                                  long long* __restrict__ cur_len, int* __restrict__ count, int cap, long long* __restrict__ rec) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  double r = cur_ret[e];
+  long long len = cur_len[e];
+  for (int t0 = 0; t0 < T; t0 += 8) {
+    double x[8]; uint8_t d[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const bool in = t0 + u < T; const size_t i = (size_t)(in ? t0 + u : 0) * n + e; x[u] = in ? rew[i] : 0.0; d[u] = in ? done[i] : 0; }   // eight rows in flight
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (t0 + u >= T) break;
+      r += x[u]; len += 1;
+      if (d[u]) {
+        const int slot = atomicAdd(count, 1);
+        if (slot < cap) { rec[3 * (size_t)slot] = ((long long)(t0 + u) << 32) | (long long)e; rec[3 * (size_t)slot + 1] = __double_as_longlong(r); rec[3 * (size_t)slot + 2] = len; }
+        r = 0.0; len = 0;
+      }
+    }
+  }
+  cur_ret[e] = r; cur_len[e] = len;
+}
 #endif
 
 }  // namespace dmp

@@ -96,6 +96,69 @@ def can_fuse(pi, env, device=None):
             and getattr(env.batch, "can_step_act", True) and getattr(pi, "ob_dim", 0) == 56 and getattr(pi, "ac_dim", 0) == 28 and getattr(pi, "hid_size", 0) == 100)
 
 
+class _PendingEpisodes:
+    """Episode statistics of a segment whose records are still on their way to the host (SegmentCollector._episodes_native)."""
+
+    def __init__(self, collector, event):
+        self.c, self.event, self.out = collector, event, None
+
+    def result(self):
+        if self.out is None:
+            import numpy as np
+            cnt, rec, h_cnt, h_rec = self.c._ep_buf
+            self.event.synchronize()
+            k = min(int(h_cnt[0]), rec.shape[0])
+            r = h_rec[:min(k, h_rec.shape[0])].numpy()
+            if k > h_rec.shape[0]:
+                r = np.concatenate([r, rec[h_rec.shape[0]:k].cpu().numpy()], 0)
+            order = np.argsort(r[:, 0], kind="stable")                     # word 0 = t << 32 | env: time-major, then env
+            self.out = (r[order, 1].copy().view(np.float64).tolist(), r[order, 2].tolist())
+            if self.c._ep_pending is self:
+                self.c._ep_pending = None
+        return self.out
+
+
+class Segment(dict):
+    """The generator's segment dict.  "ep_rets" / "ep_lens" materialise on first access when the collector left them pending
+    (`finish_episode_stats()` does it explicitly — the learner calls it where the host would otherwise wait for the device)."""
+
+    pending_episodes = None
+
+    def finish_episode_stats(self):
+        if self.pending_episodes is not None:
+            rets, lens = self.pending_episodes.result()
+            self.pending_episodes = None
+            dict.__setitem__(self, "ep_rets", rets); dict.__setitem__(self, "ep_lens", lens)
+
+    def __missing__(self, key):
+        if key in ("ep_rets", "ep_lens") and self.pending_episodes is not None:
+            self.finish_episode_stats()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (key in ("ep_rets", "ep_lens") and self.pending_episodes is not None)
+
+    # whoever walks the dict sees all of it
+    def __iter__(self):
+        self.finish_episode_stats(); return dict.__iter__(self)
+
+    def __len__(self):
+        self.finish_episode_stats(); return dict.__len__(self)
+
+    def keys(self):
+        self.finish_episode_stats(); return dict.keys(self)
+
+    def items(self):
+        self.finish_episode_stats(); return dict.items(self)
+
+    def values(self):
+        self.finish_episode_stats(); return dict.values(self)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 class SegmentCollector(object):
     """One env batch's side of `traj_segment_generator`, split into `launch()` (enqueue T policy + env steps, no host wait) and
     `collect()` (episode bookkeeping, the one host transfer per segment) so that several env batches can be in flight at once.
@@ -239,6 +302,58 @@ class SegmentCollector(object):
         prevacs = torch.cat([self.last_ac[None], acs[:-1]], 0)
         # episode statistics: return / length of every episode that ended inside the segment, in time-major order
         # (= the order in which a single-env loop would have appended them, :72-76)
+        native_eps = device.type == "cuda" and rew64.dtype == torch.float64 and rew64.is_contiguous() and done8.is_contiguous()
+        seg = Segment()
+        if native_eps:
+            seg.pending_episodes = self._episodes_native(rew64, done8)
+        else:
+            seg["ep_rets"], seg["ep_lens"] = self._episodes_torch(rew64, done, T, n, device)
+        seg.update({"ob": ob64[:T].to(f32), "rew": rew64.to(f32), "vpred": vpreds[:T].clone(), "new": new, "ac": acs, "prevac": prevacs,
+                    "nextvpred": vpreds[T] * (1 - done8[-1].to(f32))})
+        self.first = done8[-1].to(torch.int32)
+        self.last_ac = acs[-1].clone()
+        ob64[0].copy_(ob64[T])
+        if self.fused:
+            ac64[0].copy_(ac64[T]); self.have_ac0 = True
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))   # the copies above are ordered before the next launch
+        if prof:
+            torch.cuda.synchronize(device); self.collect_ms = (time.perf_counter() - t_c) * 1e3
+            seg["collect_ms"] = self.collect_ms
+        return seg
+
+    EP_HEAD = 16384                      # episode records fetched with the count in one asynchronous copy (more than that: a second copy)
+
+    def _episodes_native(self, rew64, done8):
+        """One launch (dm_episode_scan: thread = env walks its column of the segment) and a host sort of the few episodes that ended, instead
+        of ~100 launch-bound tensor ops.  Returns are float64 sums in step order, like the reference's `cur_ep_ret += rew`.  Nothing waits
+        here: the records travel to pinned memory behind the kernel, and `_PendingEpisodes.result()` sorts them when somebody asks — the
+        learner does while the device is busy with the update's first kernels."""
+        import ctypes as C
+        import torch
+        from . import _abi as A
+        T, n, dev = self.T, self.n, self.device
+        if getattr(self, "_ep_buf", None) is None:
+            cap = T * n
+            head = min(cap, self.EP_HEAD)
+            self._ep_buf = (torch.zeros(1, dtype=torch.int32, device=dev), torch.empty((cap, 3), dtype=torch.int64, device=dev),
+                            torch.zeros(1, dtype=torch.int32).pin_memory(), torch.empty((head, 3), dtype=torch.int64).pin_memory())
+            self._ep_pending = None
+        if self._ep_pending is not None:
+            self._ep_pending.result()                                      # (its pinned buffers are about to be overwritten)
+        cnt, rec, h_cnt, h_rec = self._ep_buf
+        p = lambda x: C.c_void_p(x.data_ptr())
+        L = A.load()
+        A.check(L.dm_episode_scan(p(rew64), p(done8), T, n, p(self.cur_ret), p(self.cur_len), p(cnt), rec.shape[0], p(rec),
+                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), L)
+        h_cnt.copy_(cnt, non_blocking=True)
+        h_rec.copy_(rec[:h_rec.shape[0]], non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(dev))
+        self._ep_pending = _PendingEpisodes(self, ev)
+        return self._ep_pending
+
+    def _episodes_torch(self, rew64, done, T, n, device):
+        import torch
         csum = torch.cumsum(rew64, 0)
         ends = done.nonzero()                                              # [K, 2] (t, env), sorted by t then env
         ep_rets, ep_lens = [], []
@@ -263,19 +378,7 @@ class SegmentCollector(object):
         tail_ret = csum[-1] - torch.where(last_end > 0, csum[(last_end - 1).clamp(min=0), torch.arange(n, device=device)], torch.zeros_like(csum[-1]))
         self.cur_ret = torch.where(last_end > 0, tail_ret, cur_ret + tail_ret)
         self.cur_len = torch.where(last_end > 0, T - last_end, cur_len + T)
-        seg = {"ob": ob64[:T].to(f32), "rew": rew64.to(f32), "vpred": vpreds[:T].clone(), "new": new, "ac": acs, "prevac": prevacs,
-               "nextvpred": vpreds[T] * (1 - done8[-1].to(f32)), "ep_rets": ep_rets, "ep_lens": ep_lens}
-        self.first = done8[-1].to(torch.int32)
-        self.last_ac = acs[-1].clone()
-        ob64[0].copy_(ob64[T])
-        if self.fused:
-            ac64[0].copy_(ac64[T]); self.have_ac0 = True
-        if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))   # the copies above are ordered before the next launch
-        if prof:
-            torch.cuda.synchronize(device); self.collect_ms = (time.perf_counter() - t_c) * 1e3
-            seg["collect_ms"] = self.collect_ms
-        return seg
+        return ep_rets, ep_lens
 
 
 def traj_segment_generator(pi, env, horizon, stochastic=True, device=None, first_reset="rsi", fused=False):
@@ -314,6 +417,8 @@ def pipelined_segment_generator(pi, envs, horizon, stochastic=True, first_reset=
         for c in cols:
             c.launch()
         segs = [c.collect() for c in cols]
+        for sg in segs:
+            sg.finish_episode_stats()                  # (the lists are concatenated below)
         out = {}
         for k in segs[0]:
             if k in ("ep_rets", "ep_lens"):

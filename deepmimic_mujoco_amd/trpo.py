@@ -564,6 +564,8 @@ class TrpoLearner:
             g = flat(torch.autograd.grad(losses[0], self.pol))
             lossbefore = allmean(torch.stack([l.detach() for l in losses]), self.group)
         g = allmean(g, self.group)
+        if hasattr(seg, "finish_episode_stats"):
+            seg.finish_episode_stats()                                      # host work (sorting the segment's episode records) while the gradient kernel runs
         tick("gae_filter_losses_grad")
         stats = {}
         if bool(torch.allclose(g, torch.zeros_like(g))):

@@ -265,6 +265,14 @@ int dm_batch_rollout(dm_batch* b, double* action, double* obs, double* reward, u
 int dm_gae(const float* rew, const float* vpred, const int32_t* isnew, const float* nextvpred, float* adv, float* tdlamret,
            int32_t T, int32_t n, double gamma, double lam, void* hip_stream);
 
+/* Replaces: the episode bookkeeping of the generator's loop (src/trpo.py:68-79) over a [T, N] segment that dm_batch_rollout / T dm_batch_step
+ * calls wrote (reward f64, done u8).  cur_ret [N] f64 / cur_len [N] i64: return and length of every environment's open episode, read and
+ * updated.  Every episode that ends inside the segment appends a record of three int64 words to `records` [cap][3] — {t << 32 | env, the
+ * float64 return's bits, length} — in arrival order (*count = number of episodes, which may exceed cap: the rest is dropped); sorted by the
+ * first word they are in the order a one-env loop appends them (t, then env).  Device pointers; returns are float64 sums in step order. */
+int dm_episode_scan(const double* reward, const uint8_t* done, int32_t T, int32_t n, double* cur_ret, int64_t* cur_len, int32_t* count,
+                    int32_t cap, int64_t* records, void* hip_stream);
+
 /* Replaces: one epoch of the value fit of src/trpo.py:288-296 — for each of `nb` minibatches of `bs` samples (already shuffled:
  * ob [nb*bs, 56] float32, ret [nb*bs] float32): `pi.ob_rms.update(mbob)` (src/utils/misc_util.py:53-70: rms_sum / rms_sumsq [56] and
  * rms_count float64, rms_mean / rms_std [56] float32 refreshed), the gradient of mean((vpred - ret)^2) w.r.t. the 56-100-100-1 tanh

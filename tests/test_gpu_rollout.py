@@ -614,3 +614,45 @@ def test_kernels_and_launch_forms_hand_the_state_over_to_each_other():
     assert torch.equal(x[2], y[2]) and np.array_equal(x[4], y[4]) and np.array_equal(x[5], y[5]) and np.array_equal(x[6], y[6])
     assert float((x[0] - y[0]).abs().max()) < 1e-9 * max(1.0, float(x[0].abs().max())) and float((x[1] - y[1]).abs().max()) < 1e-9
     assert float(np.abs(x[3] - y[3]).max()) < 1e-9 and bool(torch.isfinite(y[0]).all())
+
+
+@pytest.mark.gpu
+def test_episode_scan_kernel_equals_the_generators_bookkeeping_loop():
+    """dm_episode_scan (SegmentCollector._episodes_native) against `cur_ep_ret += rew; cur_ep_len += 1; if new: append, reset` of
+    src/trpo.py:68-79 run env by env on the host, over three consecutive segments (episodes that span segments, several ends per env
+    and segment, envs that never end): the same returns (float64 sums in step order: exact), lengths and time-major order — and the torch
+    formulation it replaces on the device agrees to rounding."""
+    import torch
+    from deepmimic_mujoco_amd.rollout import SegmentCollector
+    T, n = 37, 301
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(5)
+
+    def fresh():
+        c = SegmentCollector.__new__(SegmentCollector)
+        c.T, c.n, c.device = T, n, dev
+        c.cur_ret = torch.zeros(n, dtype=torch.float64, device=dev); c.cur_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        c.step_idx = torch.arange(1, T + 1, device=dev, dtype=torch.int64)[:, None]
+        return c
+    a, b = fresh(), fresh()
+    a.EP_HEAD = 64                                                            # (most segments below end more episodes than the first copy holds)
+    ret = np.zeros(n); ln = np.zeros(n, dtype=np.int64)
+    for seg in range(3):
+        rew = rng.randn(T, n)
+        done = (rng.rand(T, n) < 0.04).astype(np.uint8)
+        done[:, :7] = 0                                                       # envs that never end
+        done[:, 7] = 1                                                        # ... and one that ends every step
+        want_r, want_l = [], []
+        for t in range(T):
+            for e in range(n):
+                ret[e] += rew[t, e]; ln[e] += 1
+                if done[t, e]:
+                    want_r.append(ret[e]); want_l.append(int(ln[e])); ret[e] = 0.0; ln[e] = 0
+        rew_t, done_t = torch.as_tensor(rew, device=dev), torch.as_tensor(done, device=dev)
+        got_r, got_l = a._episodes_native(rew_t, done_t).result()
+        assert got_l == want_l and got_r == want_r
+        assert np.array_equal(a.cur_len.cpu().numpy(), ln) and np.array_equal(a.cur_ret.cpu().numpy(), ret)
+        old_r, old_l = b._episodes_torch(rew_t, done_t.to(torch.bool), T, n, dev)
+        assert old_l == want_l and np.allclose(old_r, want_r, rtol=0, atol=1e-9)
+    empty_r, empty_l = a._episodes_native(torch.zeros((T, n), dtype=torch.float64, device=dev), torch.zeros((T, n), dtype=torch.uint8, device=dev)).result()
+    assert empty_r == [] and empty_l == [] and np.array_equal(a.cur_len.cpu().numpy(), ln + T)

@@ -376,7 +376,7 @@ def _pg_case(n, seed=0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1000, 32 * 256 * 3 + 7])       # a ragged last tile; more tiles than blocks (every block loops) + a ragged tail
+@pytest.mark.parametrize("n", [1, 33, 1000, 32 * 256 * 3 + 7])    # one sample; one tile + one row; a ragged last tile; more tiles than blocks (every block loops) + a ragged tail
 def test_native_policy_gradient_and_fisher_product_match_the_analytic_float64_formulas_on_gpu(n):
     """dm_pg_losses / dm_pg_fvp against tests/trpo_numpy.py (src/trpo.py:224-230 written out by hand in float64): surrogate gradient at
     pi == oldpi, F v = J^T Sigma^-1 J v / N_f (+) 2 v on every 5th sample, and the losses at a moved policy — float32 tolerances."""
@@ -434,6 +434,60 @@ def test_native_policy_gradient_and_fisher_product_match_the_analytic_float64_fo
     # deterministic: the same launch twice gives the same bits
     _, g2 = learner._pg_losses(ob_t, ac_t, at_t, old_mean, old_logstd, theta0, write_old=False, with_grad=True)
     assert torch.equal(g, g2) and torch.equal(fv, learner._pg_fvp(ob_t, theta0, v_t))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks", [1, 7, 128])
+def test_native_policy_kernels_on_a_capped_grid_on_gpu(blocks):
+    """dm_pg_losses / dm_pg_fvp with max_blocks (the CUs the learner leaves to the value fit beside it): the same sums in another block
+    order — equal to the full grid's within float32 rounding, bit-identical launch to launch, and the losses (float64 sums) almost exactly."""
+    n = 32 * 300 + 5
+    learner, pi, p, rms, ob, ac, atarg = _pg_case(n, seed=4)
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(a, device=dev)
+    ob_t, ac_t, at_t = t(ob), t(ac), t(atarg)
+    theta0 = learner.get_flat().contiguous()
+    old_logstd = pi.params["logstd"].detach().reshape(-1).clone()
+    old_mean = torch.empty((n, 28), dtype=torch.float32, device=dev)
+    v = torch.randn(theta0.numel(), device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 1e-2
+
+    def run(cap):
+        learner._share = None if cap is None else {"t": 0.0, "until": 1e9, "blocks": cap}
+        om = torch.empty_like(old_mean)
+        losses, g = learner._pg_losses(ob_t, ac_t, at_t, om, old_logstd, theta0, write_old=True, with_grad=True)
+        fv = learner._pg_fvp(ob_t, theta0, v)
+        learner._share = None
+        return losses, g, fv, om
+    full, capped, again = run(None), run(blocks), run(blocks)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert rel(capped[1], full[1]) < 2e-5 and rel(capped[2], full[2]) < 2e-5
+    assert torch.equal(capped[3], full[3])                                      # the means do not depend on the grid
+    assert torch.allclose(capped[0], full[0], rtol=1e-6, atol=1e-7)
+    for a, b in zip(capped, again):
+        assert torch.equal(a, b)
+
+
+def test_cu_sharing_plan_is_a_function_of_the_launch_sequence():
+    """TrpoLearner._pg_share_begin / _pg_grid: which policy launches run on the narrow grid beside the value fit comes from a cost model of
+    the launches issued so far — the same sequence gives the same grids (a seeded run reproduces), the narrow phase ends once the modelled
+    fit is over, and a fit that wants the whole chip turns sharing off."""
+    pi = MlpPolicy(device="cpu", seed=0)
+    L = TrpoLearner(pi, vf_batch_size=4096, vf_iters=1)                      # (one epoch: the modelled fit ends inside the CG iterations)
+    n = 4096 * 128
+
+    def plan():
+        L._pg_share_begin(n, 4096)
+        seq = [L._pg_grid(L.PG_GRAD_NS * n)] + [L._pg_grid(L.PG_FVP_NS * (n // 5)) for _ in range(11)] + [L._pg_grid(L.PG_LOSS_NS * n) for _ in range(3)]
+        L._share = None
+        return seq
+    a, b = plan(), plan()
+    assert a == b and a[0] == 128 and a[-1] == 0                              # narrow first (the fit runs), every CU at the end
+    k = a.index(0)
+    assert all(x == 128 for x in a[:k]) and all(x == 0 for x in a[k:])        # one switch, never back
+    L._pg_share_begin(n, 8192)                                                # 256 blocks of the fit's gradient kernel: nothing to leave
+    assert L._share is None and L._pg_grid(1e6) == 0
+    L._pg_share_begin(1024, 128)                                              # the reference's sizes: four blocks for the fit, 252 for the policy step
+    assert L._share["blocks"] == 252
 
 
 @pytest.mark.gpu

@@ -4,7 +4,7 @@ mkdir -p gpurun_out/$TAG
 export TMPDIR=/tmp
 for WHAT in "$@"; do case $WHAT in
   ubench) build_ab/mfma_f32_gemm | tee gpurun_out/$TAG/mfma_layout.txt ;;
-  tests) ( timeout 900 python -m pytest tests/test_trpo.py -x -q -m gpu 2>&1 | tail -15 ) | tee gpurun_out/$TAG/pytest.log ;;
+  tests) ( timeout 900 python -m pytest tests/test_trpo.py tests/test_gpu_rollout.py -x -q -m gpu 2>&1 | tail -15 ) | tee gpurun_out/$TAG/pytest.log ;;
   train)
     for sh in ${SHARES:-0 1}; do
       DM_VF_SHARE=$sh timeout 300 python tools/train_trpo.py --envs 4096 --horizon 128 --iters 80 --out gpurun_out/$TAG/train80_share$sh.json 2>&1 | tail -1 | sed "s/^/share=$sh /"
