@@ -94,7 +94,7 @@ LIB_PATH = os.environ.get("DMENV_LIB") or os.path.join(_HERE, "csrc", "libdmenv.
 EXPORTS = ["dm_model_create", "dm_model_destroy", "dm_mocap_create", "dm_mocap_set_imitation", "dm_mocap_destroy", "dm_batch_create",
            "dm_batch_destroy", "dm_batch_set_stream", "dm_batch_set_option", "dm_batch_set_state", "dm_batch_reset",
            "dm_batch_step", "dm_batch_get_obs", "dm_batch_get", "dm_batch_set", "dm_batch_debug_forward",
-           "dm_batch_last_step_ms", "dm_batch_enable_timing", "dm_batch_read_profile", "dm_batch_sync", "dm_batch_join", "dm_policy_weight_count", "dm_policy_act", "dm_batch_step_act", "dm_batch_rollout", "dm_vf_param_count", "dm_vf_scratch_bytes", "dm_vf_fit_epoch", "dm_pg_param_count", "dm_pg_scratch_bytes", "dm_pg_losses", "dm_pg_fvp", "dm_batch_redo_total", "dm_batch_queue_stats", "dm_gae", "dm_episode_scan", "dm_last_error", "dm_abi_version", "dm_real_bits",
+           "dm_batch_last_step_ms", "dm_batch_enable_timing", "dm_batch_read_profile", "dm_batch_sync", "dm_batch_join", "dm_policy_weight_count", "dm_policy_act", "dm_batch_step_act", "dm_batch_rollout", "dm_vf_param_count", "dm_vf_scratch_bytes", "dm_vf_fit_epoch", "dm_pg_param_count", "dm_pg_scratch_bytes", "dm_pg_losses", "dm_pg_fvp", "dm_batch_redo_total", "dm_batch_queue_stats", "dm_gae", "dm_episode_scan", "dm_rms_scratch_bytes", "dm_rms_update", "dm_last_error", "dm_abi_version", "dm_real_bits",
            "dm_device_count"]
 _LIB = None
 
@@ -152,6 +152,8 @@ def load(dtype=64):
     L.dm_batch_step_act.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_uint64, C.c_uint64]
     L.dm_batch_rollout.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, C.c_uint64, C.c_uint64]
     L.dm_gae.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, C.c_double, C.c_double, vp]
+    L.dm_rms_scratch_bytes.restype = C.c_size_t
+    L.dm_rms_update.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.dm_episode_scan.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp]
     if L.dm_abi_version() != ABI_VERSION:
         raise DmenvError("libdmenv.so ABI version %d != %d" % (L.dm_abi_version(), ABI_VERSION))

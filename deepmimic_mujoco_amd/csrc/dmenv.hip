@@ -893,6 +893,22 @@ extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, in
   }
   return DM_OK;
 }
+// the obs filter's update with a whole batch (src/trpo.py:242 `pi.ob_rms.update(ob)`): k_vf_rms on a grid sized to the batch — one launch
+constexpr int RMS_UPDATE_BLOCKS = 1024;
+extern "C" size_t dm_rms_scratch_bytes(void) { return (size_t)RMS_UPDATE_BLOCKS * 2 * dmv::OB * sizeof(double) + 64; }
+extern "C" int dm_rms_update(const float* ob, int32_t n, double* rms_sum, double* rms_sumsq, double* rms_count, float* rms_mean, float* rms_std,
+                             void* scratch, void* hip_stream) {
+  if (!ob || n < 1 || !rms_sum || !rms_sumsq || !rms_count || !rms_mean || !rms_std || !scratch) return fail(DM_EINVAL, "dm_rms_update: bad argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  int blocks = (n + 255) / 256;                               // >= 64 rows per row group of a block
+  if (blocks > RMS_UPDATE_BLOCKS) blocks = RMS_UPDATE_BLOCKS;
+  double* part = (double*)scratch;
+  unsigned* ticket = (unsigned*)(part + (size_t)RMS_UPDATE_BLOCKS * 2 * dmv::OB);
+  HIPCHK(hipMemsetAsync(ticket, 0, sizeof(unsigned), st));
+  hipLaunchKernelGGL(dmv::k_vf_rms, dim3(blocks), dim3(256), 0, st, ob, (int)n, part, ticket, rms_sum, rms_sumsq, rms_count, rms_mean, rms_std);
+  HIPCHK(hipGetLastError());
+  return DM_OK;
+}
 // ---- policy half of the TRPO update (csrc/pg_kernel.h) -------------------------------------------------------------------------
 static int pg_set_device(const void* p) {
   hipPointerAttribute_t at;

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_vf_rms(const float* __restrict__ ob, in
   __shared__ double red[4][2 * OB];
   __shared__ bool last;
   const int tid = threadIdx.x, col = tid % OB, rg = tid / OB;            // 224 working threads: 4 row groups x 56 columns
-  const int rows = (bs + RMS_BLOCKS - 1) / RMS_BLOCKS, r0 = blockIdx.x * rows, r1 = min(bs, r0 + rows);
+  const int rows = (bs + (int)gridDim.x - 1) / (int)gridDim.x, r0 = blockIdx.x * rows, r1 = min(bs, r0 + rows);
   if (rg < 4) {
     double s = 0.0, q = 0.0;
     int r = r0 + rg;

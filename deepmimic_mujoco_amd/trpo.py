@@ -474,6 +474,22 @@ class TrpoLearner:
                       self._pg_grid(self.PG_FVP_NS * nf))
         return hv
 
+    def _rms_update(self, ob):
+        """`pi.ob_rms.update(ob)` (:242): one launch (dm_rms_update) for a float32 batch on the GPU of a single-process run, else the tensor ops."""
+        rms = self.pi.ob_rms
+        if (ob.device.type == "cuda" and ob.dtype == torch.float32 and ob.dim() == 2 and ob.shape[1] == 56 and ob.is_contiguous() and _world(self.group) == 1
+                and tuple(rms.shape) == (56,) and torch.is_tensor(rms.count) and rms.sum.is_cuda and getattr(self.pi, "native", False)):
+            import ctypes as C
+            from . import _abi as A
+            L = A.load()
+            if getattr(self, "_rms_scratch", None) is None or self._rms_scratch.device != ob.device:
+                self._rms_scratch = torch.empty(int(L.dm_rms_scratch_bytes()), dtype=torch.uint8, device=ob.device)
+            p = lambda x: C.c_void_p(x.data_ptr())
+            A.check(L.dm_rms_update(p(ob), int(ob.shape[0]), p(rms.sum), p(rms.sumsq), p(rms.count), p(rms.mean), p(rms.std), p(self._rms_scratch),
+                                    C.c_void_p(torch.cuda.current_stream(ob.device).cuda_stream)), L)
+            return
+        rms.update(ob, group=self.group)
+
     def _next_perm(self, n, dev):
         """The next shuffle of `dataset.iterbatches` (:289) from this learner's generator — taken from the ones drawn ahead when they fit."""
         while self._perms:
@@ -509,8 +525,7 @@ class TrpoLearner:
         add_vtarg_and_adv(seg, self.gamma, self.lam)
         fl = flatten_segment(seg)
         ob, ac, atarg, tdlamret, vpredbefore = fl["ob"], fl["ac"], fl["adv"], fl["tdlamret"], fl["vpred"]
-        atarg = (atarg - atarg.mean()) / atarg.std(unbiased=False)          # :240
-        pi.ob_rms.update(ob, group=self.group)                              # :242
+        self._rms_update(ob)                                                # :242 (before :240 here: the value fit's stream forks right after it)
         native_pg = self._pg_native_ready(ob, ac)
         # ---- value function (:288-296).  It shares nothing with the policy step but the obs filter, which it moves on minibatch by minibatch:
         # with both halves on kernels the fit is enqueued NOW on a second stream and runs beside the policy step (its gradient kernel holds one
@@ -546,6 +561,7 @@ class TrpoLearner:
             if self.vf_share:
                 self._pg_share_begin(n, bs)
         self._rms_pol = rms_pol
+        atarg = (atarg - atarg.mean()) / atarg.std(unbiased=False)          # :240
         if native_pg:
             ob = ob.contiguous(); ac = ac.contiguous(); atarg = atarg.to(torch.float32).contiguous()
             theta0 = self.get_flat().contiguous()

@@ -288,6 +288,13 @@ int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, int32_t bs, f
                     const float* step_scale_host, double beta1, double beta2, double eps, double* rms_sum, double* rms_sumsq,
                     double* rms_count, float* rms_mean, float* rms_std, void* scratch, void* hip_stream, int32_t epoch_filter);
 
+/* Replaces: `pi.ob_rms.update(ob)` of src/trpo.py:242 with the whole batch (RunningMeanStd.update, src/utils/misc_util.py:47-70) in one launch:
+ * column sums / sums of squares of ob [n, 56] float32 in float64 (fixed order), added to the filter's state; mean / std (float32, the
+ * variance floored at 1e-2) refreshed.  Device pointers; `scratch`: dm_rms_scratch_bytes() bytes on the device. */
+size_t dm_rms_scratch_bytes(void);
+int dm_rms_update(const float* ob, int32_t n, double* rms_sum, double* rms_sumsq, double* rms_count, float* rms_mean, float* rms_std,
+                  void* scratch, void* hip_stream);
+
 /* Replaces: the policy half of one TRPO update (src/trpo.py:228-230, 245-283) for the 56-100-100-28 tanh Gaussian policy of
  * src/mlp_policy_trpo.py:50-60.  theta: dm_pg_param_count() floats = polfc1/w, polfc1/b, polfc2/w, polfc2/b, polfinal/w, polfinal/b, logstd
  * (weights row-major [in][out]: the learner's flat `var_list` order, :139); ob [n, 56] float32 raw observations, normalised inside with

@@ -491,6 +491,30 @@ def test_cu_sharing_plan_is_a_function_of_the_launch_sequence():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 255, 4096 * 128 + 3])
+def test_native_obs_filter_update_equals_running_mean_std_on_gpu(n):
+    """dm_rms_update (TrpoLearner._rms_update) against RunningMeanStd.update (src/utils/misc_util.py:47-70): float64 sums of a float32 batch
+    (another summation order: equal to ~1e-13 relative), the count exactly, mean / std to float32 rounding — twice in a row (state carried)."""
+    from deepmimic_mujoco_amd.policy import MlpPolicy, RunningMeanStd
+    dev = "cuda:0"
+    pi = MlpPolicy(device=dev, seed=0)
+    L = TrpoLearner(pi)
+    ref = RunningMeanStd((56,), device=dev)
+    g = torch.Generator(device=dev).manual_seed(n)
+    for k in range(2):
+        ob = (torch.randn((n, 56), device=dev, generator=g) * torch.linspace(0.3, 4.0, 56, device=dev) + 1.5 * k).contiguous()
+        L._rms_update(ob)
+        ref.update(ob)
+        assert L._rms_scratch is not None                                     # the kernel ran, not the tensor ops
+        assert float(pi.ob_rms.count) == float(ref.count)
+        assert torch.allclose(pi.ob_rms.sum, ref.sum, rtol=1e-12, atol=1e-9) and torch.allclose(pi.ob_rms.sumsq, ref.sumsq, rtol=1e-12, atol=1e-9)
+        assert torch.allclose(pi.ob_rms.mean, ref.mean, rtol=1e-6, atol=1e-7)
+        # var = float32(sumsq / count) - mean^2 cancels (the reference's formula): an ulp of mean^2 is what a last-bit difference of the sums can move it by
+        ulp = 4e-7 * (ref.mean ** 2 + (ref.sumsq / ref.count).float())
+        assert bool(((pi.ob_rms.std ** 2 - ref.std ** 2).abs() <= ulp + 1e-9).all())
+
+
+@pytest.mark.gpu
 def test_learner_update_through_torch_autograd_matches_the_float64_restatement_on_gpu():
     """The path the kernels replace stays covered on the device (multi-backend fallback of the learner: pg_native=False)."""
     _check_against_golden(*_golden_update("cuda:0", pg_native=False))
