@@ -123,6 +123,7 @@ class Segment(dict):
     (`finish_episode_stats()` does it explicitly — the learner calls it where the host would otherwise wait for the device)."""
 
     pending_episodes = None
+    info = None                          # how the segment was produced (launch form, overflow rate of the packed path): diagnostics, not data
 
     def finish_episode_stats(self):
         if self.pending_episodes is not None:
@@ -191,6 +192,9 @@ class SegmentCollector(object):
         self.fused = bool(fused)
         self.have_ac0 = False
         self._redo_seen = None
+        import os
+        if os.environ.get("DM_HORIZON_REDO_RATE_MAX"):                   # (experiments: tools/prof_train.sh)
+            self.HORIZON_REDO_RATE_MAX = float(os.environ["DM_HORIZON_REDO_RATE_MAX"])
         self._packed_now = None                    # what _choose_kernel picked for the last horizon (None: none yet)
         self.kernel_switches = 0
         with self._on_stream():
@@ -240,9 +244,12 @@ class SegmentCollector(object):
             vpreds[T] = pi.forward(ob64[T])[1]                                      # value of the observation after the segment (:49-52);
         # the action for it is sampled at the top of the next segment, i.e. from the policy as updated in between
 
-    # horizon launch -> one-env steps: an in-wave re-step holds a wave (four environments) for about one lone one-env step, so a
-    # rate r of overflowing env-steps costs about 4 r of the horizon (2 % here: 8 %) — far more tolerant than the per-step redo list
-    HORIZON_REDO_RATE_MAX = 2e-2
+    # horizon launch -> one-env steps: an in-wave re-step holds a wave (four environments) for about one lone one-env step.  Measured on a
+    # population learning to stand (tools/train_trpo.py, 4 096 envs x 128 steps, MI355X; profiles/r04_ab_kernel_variants.md): 38 / 42 / 46 /
+    # 52 / 55 / 58-60 ms per horizon at 0.2 / 0.8 / 1.3 / 2.6 / 3.7 / 5 % of env-steps re-stepped (the rate levels off near 5 %) against
+    # 67 ms for the same population through one-env launches — the packed horizon stays ahead to about 7 %.  (Round 3's 2 % came from a cost
+    # estimate; a run that crossed it at 2.02 % lost a quarter of its rollout throughput for the rest of the training.)
+    HORIZON_REDO_RATE_MAX = 7e-2
 
     def _choose_kernel(self):
         """Four environments per wavefront or one, for the next horizon (envs that leave the choice open: DPVecEnv.horizon_packed_ok).
@@ -265,7 +272,8 @@ class SegmentCollector(object):
             want = True
         elif on:
             redo = b.redo_total()
-            want = (redo - self._redo_seen) / float(self.T * self.n) <= self.HORIZON_REDO_RATE_MAX
+            self._last_redo_rate = (redo - self._redo_seen) / float(self.T * self.n)
+            want = self._last_redo_rate <= self.HORIZON_REDO_RATE_MAX
         else:
             want = int(b.get(A.F_NEFC).max()) <= b.HEAVY_ROWS
         if want != on:
@@ -304,6 +312,7 @@ class SegmentCollector(object):
         # (= the order in which a single-env loop would have appended them, :72-76)
         native_eps = device.type == "cuda" and rew64.dtype == torch.float64 and rew64.is_contiguous() and done8.is_contiguous()
         seg = Segment()
+        seg.info = {"packed": self._packed_now, "kernel_switches": self.kernel_switches, "redo_rate": getattr(self, "_last_redo_rate", None)}
         if native_eps:
             seg.pending_episodes = self._episodes_native(rew64, done8)
         else:

@@ -720,6 +720,8 @@ def learn(env, pi, *, timesteps_per_batch=256, max_iters=0, max_timesteps=0, max
             stats["profile_ms"]["rollout_segment"] = round(t_seg, 3)
             if "collect_ms" in seg:
                 stats["profile_ms"]["of_which_segment_bookkeeping"] = round(float(seg["collect_ms"]), 3)
+        if getattr(seg, "info", None):
+            stats["rollout"] = dict(seg.info)
         lens, rets = seg["ep_lens"], seg["ep_rets"]
         n_eps = torch.tensor([len(lens), sum(lens), sum(rets)], dtype=torch.float64, device=pi.device)
         if world > 1:                                            # :300-302 allgather of (ep_lens, ep_rets): the sums suffice here

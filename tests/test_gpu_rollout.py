@@ -656,3 +656,4 @@ def test_episode_scan_kernel_equals_the_generators_bookkeeping_loop():
         assert old_l == want_l and np.allclose(old_r, want_r, rtol=0, atol=1e-9)
     empty_r, empty_l = a._episodes_native(torch.zeros((T, n), dtype=torch.float64, device=dev), torch.zeros((T, n), dtype=torch.uint8, device=dev)).result()
     assert empty_r == [] and empty_l == [] and np.array_equal(a.cur_len.cpu().numpy(), ln + T)
+

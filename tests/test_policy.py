@@ -371,10 +371,10 @@ def test_collector_kernel_choice_is_a_function_of_the_last_horizons_statistics()
     b = c.env.batch
     c._choose_kernel()                                                   # first horizon: packed, the per-step chooser switched off
     assert b.options[A.OPT_PACKED] == 1 and b._auto is False and c.kernel_switches == 1
-    b.redo += 10                                                         # 10 / 800 = 1.25 % of env-steps: tolerated (2 %)
+    b.redo += 10                                                         # 10 / 800 = 1.25 % of env-steps: tolerated (7 %)
     c._choose_kernel()
     assert b.options[A.OPT_PACKED] == 1 and c.kernel_switches == 1
-    b.redo += 40                                                         # 5 %: to the one-env steps
+    b.redo += 80                                                         # 10 %: to the one-env steps
     c._choose_kernel()
     assert b.options[A.OPT_PACKED] == 0 and c.kernel_switches == 2
     b.nefc[3] = 36                                                       # an environment beyond a slot's rows: stays

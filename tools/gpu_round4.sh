@@ -60,7 +60,8 @@ j=json.loads(sys.stdin.read()); print('standing packed %.3f M  one-env %.3f M' %
     for v in ${WHAT#hstage:}; do echo "== $v" | tee -a $OUT/hstage.log; DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python tools/profile_horizon.py ${HSTAGE_ARGS:-} 2>&1 | grep -v amdgpu.ids | tee -a $OUT/hstage.log; done ;;
   train)
     timeout 400 python tools/train_trpo.py --envs 4096 --horizon 128 --seconds 60 --out $OUT/trpo_train_60s.json 2>&1 | tail -3 | tee $OUT/trpo_train.log
-    DM_TRPO_PROFILE=1 timeout 300 python tools/train_trpo.py --envs 4096 --horizon 128 --iters 40 --out $OUT/trpo_update_profile.json 2>&1 | tail -1 ;;
+    DM_TRPO_PROFILE=1 timeout 300 python tools/train_trpo.py --envs 4096 --horizon 128 --iters 40 --out $OUT/trpo_update_profile.json 2>&1 | tail -1
+    timeout 400 python tools/train_trpo.py --envs 4096 --horizon 128 --seconds 60 --reward imitation --frame-skip mocap --out $OUT/trpo_imitation_60s.json 2>&1 | tail -2 | tee $OUT/trpo_imitation.log ;;
   standing)
     timeout 600 python bench.py --workload standing --steps 2048 --warmup 1024 > $OUT/bench_standing.json 2> $OUT/bench_standing.err; cut -c1-1500 $OUT/bench_standing.json; tail -3 $OUT/bench_standing.err ;;
   pytest:*)
