@@ -868,7 +868,8 @@ extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, in
     double* part_all = (double*)(base + L.part_all);
     float* means = (float*)(base + L.means); float* stds = (float*)(base + L.stds);
     hipLaunchKernelGGL(dmv::k_vf_rms_part, dim3(dmv::RMS_BLOCKS, nb), dim3(256), 0, st, ob, (int)bs, part_all);
-    hipLaunchKernelGGL(dmv::k_vf_rms_scan, dim3(1), dim3(128), 0, st, (const double*)part_all, (int)nb, (int)bs, rms_sum, rms_sumsq, rms_count, rms_mean, rms_std, means, stds);
+    hipLaunchKernelGGL(dmv::k_vf_rms_fold, dim3(nb), dim3(128), 0, st, part_all);
+    hipLaunchKernelGGL(dmv::k_vf_rms_scan, dim3(1), dim3(64), 0, st, (const double*)part_all, (int)nb, (int)bs, rms_sum, rms_sumsq, rms_count, rms_mean, rms_std, means, stds);
     for (int i = 0; i < nb; i++) {
       hipLaunchKernelGGL(dmv::k_vf_grad, dim3(nblk), dim3(256), 0, st, ob + (size_t)i * bs * dmv::OB, ret + (size_t)i * bs, (int)bs, (const float*)theta,
                          (const float*)(means + (size_t)i * dmv::OB), (const float*)(stds + (size_t)i * dmv::OB), partial);
@@ -894,7 +895,7 @@ extern "C" int dm_vf_fit_epoch(const float* ob, const float* ret, int32_t nb, in
   return DM_OK;
 }
 // the obs filter's update with a whole batch (src/trpo.py:242 `pi.ob_rms.update(ob)`): k_vf_rms on a grid sized to the batch — one launch
-constexpr int RMS_UPDATE_BLOCKS = 1024;
+constexpr int RMS_UPDATE_BLOCKS = 256;              // (the last block adds the partials up column by column: 32 rounds of 8 loads)
 extern "C" size_t dm_rms_scratch_bytes(void) { return (size_t)RMS_UPDATE_BLOCKS * 2 * dmv::OB * sizeof(double) + 64; }
 extern "C" int dm_rms_update(const float* ob, int32_t n, double* rms_sum, double* rms_sumsq, double* rms_count, float* rms_mean, float* rms_std,
                              void* scratch, void* hip_stream) {

@@ -282,40 +282,51 @@ __global__ __launch_bounds__(256) void k_vf_rms_part(const float* __restrict__ o
   __syncthreads();
   if (tid < 2 * OB) part[blockIdx.x * 2 * OB + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
-__global__ __launch_bounds__(128) void k_vf_rms_scan(const double* __restrict__ part_all, int nb, int bs, double* __restrict__ sum, double* __restrict__ sumsq,
-                                                     double* __restrict__ count, float* __restrict__ mean, float* __restrict__ stdv,
-                                                     float* __restrict__ means /*[nb][OB]*/, float* __restrict__ stds /*[nb][OB]*/) {
-  __shared__ double st[2 * OB];
+// Two launches: k_vf_rms_fold adds every (minibatch, column) pair's 64 partials up in block order, one block per minibatch (the sums replace the
+// first partial in place); k_vf_rms_scan is one wave of 56 threads that walks the minibatches, each carrying its column's sum AND sum of squares:
+// no exchange between threads, eight minibatches' sums in flight.  (Round 3's form added each minibatch's partials inside the walk, two block
+// barriers per minibatch: 193 us per epoch of 128 minibatches on the fit's critical path; folding inside the scan's own block — one CU pulling
+// 7 MB through its L2 port — still 123 us.)
+__global__ __launch_bounds__(128) void k_vf_rms_fold(double* __restrict__ part_all) {
+  const int c = threadIdx.x;
+  if (c >= 2 * OB) return;
+  double* part = part_all + (size_t)blockIdx.x * RMS_BLOCKS * 2 * OB;
+  double a = 0.0;
+  for (int b = 0; b < RMS_BLOCKS; b += 8) {
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) x[u] = part[(b + u) * 2 * OB + c];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a += x[u];
+  }
+  part[c] = a;                                                                  // (this thread is the only reader of column c of this minibatch)
+}
+__global__ __launch_bounds__(64) void k_vf_rms_scan(const double* __restrict__ part_all, int nb, int bs, double* __restrict__ sum, double* __restrict__ sumsq,
+                                                    double* __restrict__ count, float* __restrict__ mean, float* __restrict__ stdv,
+                                                    float* __restrict__ means /*[nb][OB]*/, float* __restrict__ stds /*[nb][OB]*/) {
   const int tid = threadIdx.x;
-  if (tid < 2 * OB) st[tid] = tid < OB ? sum[tid] : sumsq[tid - OB];
-  double c = *count;
+  if (tid >= OB) return;
+  double s = sum[tid], q = sumsq[tid], c = *count;
   float m = 0.0f, sd = 1.0f;
-  __syncthreads();
-  for (int i = 0; i < nb; i++) {
-    const double* part = part_all + (size_t)i * RMS_BLOCKS * 2 * OB;
-    if (tid < 2 * OB) {
-      double a = 0.0;
-      for (int b = 0; b < RMS_BLOCKS; b += 8) {
-        double x[8];
+  for (int i0 = 0; i0 < nb; i0 += 8) {
+    double as[8], aq[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) x[u] = part[(b + u) * 2 * OB + tid];
-#pragma unroll
-        for (int u = 0; u < 8; u++) a += x[u];
-      }
-      st[tid] += a;
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u < nb ? i0 + u : nb - 1;
+      as[u] = part_all[(size_t)i * RMS_BLOCKS * 2 * OB + tid]; aq[u] = part_all[(size_t)i * RMS_BLOCKS * 2 * OB + OB + tid];
     }
-    c += (double)bs;
-    __syncthreads();
-    if (tid < OB) {                                                             // RunningMeanStd._refresh (policy.py)
-      m = (float)(st[tid] / c);
-      const float var = (float)(st[OB + tid] / c) - m * m;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u;
+      if (i >= nb) break;
+      s += as[u]; q += aq[u]; c += (double)bs;
+      m = (float)(s / c);                                                       // RunningMeanStd._refresh (policy.py)
+      const float var = (float)(q / c) - m * m;
       sd = sqrtf(fmaxf(var, 1e-2f));
       means[(size_t)i * OB + tid] = m; stds[(size_t)i * OB + tid] = sd;
     }
-    __syncthreads();
   }
-  if (tid < OB) { sum[tid] = st[tid]; mean[tid] = m; stdv[tid] = sd; }
-  else if (tid < 2 * OB) sumsq[tid - OB] = st[tid];
+  sum[tid] = s; sumsq[tid] = q; mean[tid] = m; stdv[tid] = sd;
   if (tid == 0) *count = c;
 }
 }  // namespace dmv

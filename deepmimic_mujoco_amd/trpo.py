@@ -421,7 +421,7 @@ class TrpoLearner:
     # (ns per sample on a full MI355X, measured: profiles/r04_train_kernels.md), not from the clock, so that a seeded run reproduces
     # bit for bit (the gradient sums are taken in block order: a function of the grid size).
     PG_GRAD_NS, PG_FVP_NS, PG_LOSS_NS = 2.06, 2.53, 0.89
-    VF_STEP_US, VF_EPOCH_US = 29.0, 350.0
+    VF_STEP_US, VF_EPOCH_US = 26.5, 170.0
     N_CU = 256
 
     def _pg_share_begin(self, n, bs):
@@ -495,6 +495,8 @@ class TrpoLearner:
         while self._perms:
             p = self._perms.pop(0)
             if p.numel() == n and p.device == dev:
+                if self._vf_stream is not None:
+                    torch.cuda.current_stream(dev).wait_stream(self._vf_stream)   # (drawn on the fit's stream; a no-op when that is the consumer)
                 return p
             self._perms = []           # the segment size changed: the generator's stream goes on from here (nothing drawn is re-used)
         return torch.randperm(n, device=dev, generator=self._perm_gen)
