@@ -1,6 +1,7 @@
 """Per-stage shader-clock profile of the packed step INSIDE a horizon launch (k_rollout_packed), summed per wave over the horizon — the
 counterpart of tools/profile_packed.py (one launch per step, dispatch order renewed every step).  Needs the diagnostic build:
-    tools/build_variant.sh rprof -DDM_ROLLOUT_PROF ;  DMENV_LIB=build_ab/rprof.so python tools/profile_horizon.py [T] [envs]"""
+    tools/build_variant.sh rprof -DDM_ROLLOUT_PROF ;  DMENV_LIB=build_ab/rprof.so python tools/profile_horizon.py [T] [envs]
+DM_PROF_STANDING=1: a standing population (training's steady state) instead of the bench's falling one."""
 import os
 import sys
 
@@ -13,14 +14,15 @@ from deepmimic_mujoco_amd import DPVecEnv, _abi as A  # noqa: E402
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 dev = "cuda:0"
-env = DPVecEnv(n, motion="walk", device=0, reward=os.environ.get("DM_PROF_REWARD", "alive"), autoreset="rsi", seed=0, packed=True, frame_skip=1)
+STANDING = bool(os.environ.get("DM_PROF_STANDING"))      # a population that stands: noisy init pose, small actions, falls restart from the init pose
+env = DPVecEnv(n, motion="walk", device=0, reward=os.environ.get("DM_PROF_REWARD", "alive"), autoreset="init" if STANDING else "rsi", seed=0, packed=True, frame_skip=1)
 b = env.batch
 b.set_option(106, 1)
 g = torch.Generator(device=dev); g.manual_seed(1)
-ac = torch.randn((T + 1, n, 28), generator=g, dtype=torch.float64, device=dev) * 0.9
+ac = torch.randn((T + 1, n, 28), generator=g, dtype=torch.float64, device=dev) * (0.1 if STANDING else 0.9)
 ob = torch.zeros((T, n, 56), dtype=torch.float64, device=dev); rew = torch.zeros((T, n), dtype=torch.float64, device=dev)
 dn = torch.zeros((T, n), dtype=torch.uint8, device=dev)
-env.reset("rsi")
+env.reset("init" if STANDING else "rsi")
 for _ in range(2):
     b.rollout(ac, (ob, rew, dn), 1)
 b.sync()
