@@ -28,6 +28,15 @@ typedef double Ext;
 #define DM_NARROW_ROWS 32
 #endif
 constexpr int NARROW_ROWS = DM_NARROW_ROWS;
+// The one-env step a packed horizon launch falls back to for an environment beyond the packed path's 32 rows (restep_one_env, slot_step.h): those
+// environments hold 33 .. 37 rows (a standing humanoid: 8 foot corners x 4 pyramid edges + joint limits; profiles/r04_ab_kernel_variants.md).  With the
+// 32-column register tier every PGS sweep fetches their last columns of A from the memory strip; the wave is alone on its SIMD here, so the tier is 48
+// columns: no strip below 49 rows.  Worth 4 % of a re-step (734 k -> 705 k cycles: the one-env step of such an environment is 680 k cycles by itself,
+// 300 k of it the 36-row sweeps), 1.4 % of a standing population's horizon.
+#ifndef DM_RESTEP_ROWS
+#define DM_RESTEP_ROWS 48
+#endif
+constexpr int RESTEP_ROWS = DM_RESTEP_ROWS;
 
 // the table of per-step buffers of a horizon launch arrives a chunk per launch in the kernel-argument segment (k_put_rows)
 constexpr int ROW_CHUNK = 64;

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __r
 #else
   long long* prof_acc = nullptr;
 #endif
-  slot_rollout<Real, NARROW_ROWS>(*Mp, B, u.sh, tb, u.one.s, u.one.x, env, lane, live, rows, n_substeps, T, [&](int t) {
+  slot_rollout<Real, RESTEP_ROWS>(*Mp, B, u.sh, tb, u.one.s, u.one.x, env, lane, live, rows, n_substeps, T, [&](int t) {
     if (!pa.P) return;
     dmp::PolicyArgs p = pa;
     p.action = pa.action + (size_t)(t + 1) * n * NU; p.vpred = pa.vpred + (size_t)t * n; p.counter = pa.counter + (unsigned long long)t;
