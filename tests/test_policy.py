@@ -387,3 +387,32 @@ def test_collector_kernel_choice_is_a_function_of_the_last_horizons_statistics()
     c2.env, c2.T, c2.n, c2._redo_seen, c2.kernel_switches = FakeEnv(False), 100, 8, None, 0
     c2._choose_kernel()                                                  # DPVecEnv(packed=False / True), float32, v1-quat reward: not touched
     assert c2.env.batch.options == {} and c2.kernel_switches == 0 and c2.env.batch._auto is True
+
+
+def test_segment_dict_materialises_pending_episode_lists_on_access():
+    """`rollout.Segment`: the generator's segment dict whose "ep_rets" / "ep_lens" may still be on their way from the device (the collector's
+    episode scan): they appear on the first read, on iteration, in `in`, in `dict(seg)` — and exactly once; a segment without pending lists
+    is a plain dict (KeyError for what is not there)."""
+    from deepmimic_mujoco_amd.rollout import Segment
+
+    class Pending:
+        calls = 0
+
+        def result(self):
+            Pending.calls += 1
+            return [1.5, 2.5], [3, 4]
+
+    s = Segment(); s["ob"] = 0; s.pending_episodes = Pending()
+    assert "ep_rets" in s and "ep_lens" in s and "nope" not in s and Pending.calls == 0
+    assert s["ep_lens"] == [3, 4] and s["ep_rets"] == [1.5, 2.5] and Pending.calls == 1 and s.pending_episodes is None
+    s2 = Segment(); s2["ob"] = 0; s2.pending_episodes = Pending()
+    assert sorted(s2) == ["ep_lens", "ep_rets", "ob"] and Pending.calls == 2          # whoever walks the dict sees all of it
+    s3 = Segment(); s3.pending_episodes = Pending()
+    assert dict(s3) == {"ep_rets": [1.5, 2.5], "ep_lens": [3, 4]} and s3.get("ep_rets") == [1.5, 2.5] and s3.get("x", 7) == 7 and len(s3) == 2
+    s4 = Segment(); s4.pending_episodes = Pending()
+    s4.finish_episode_stats(); s4.finish_episode_stats()
+    assert Pending.calls == 4 and s4["ep_rets"] == [1.5, 2.5]
+    plain = Segment(ob=1)
+    with pytest.raises(KeyError):
+        plain["ep_rets"]
+    assert "ep_rets" not in plain and list(plain) == ["ob"]
