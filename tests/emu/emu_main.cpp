@@ -169,7 +169,7 @@ void emu_rollout(void* h, const double* action, double* obs, double* reward, uns
       int pos = first + slot;
       const bool live = pos < n;
       if (!live) pos = n - 1;
-      slot_rollout<double, 32>(e->M, e->B, e->roll.sh, e->slot_tabs, e->roll.one.s, e->roll.one.x, pos, lane, live, rows.data(), nsub, T, [](int) {});
+      slot_rollout<double, 48 /* = csrc/kernels.h RESTEP_ROWS: the in-wave re-step's register tier */>(e->M, e->B, e->roll.sh, e->slot_tabs, e->roll.one.s, e->roll.one.x, pos, lane, live, rows.data(), nsub, T, [](int) {});
     });
   e->redo_total += e->B.redo_why[0] - before;
 }

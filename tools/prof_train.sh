@@ -1,4 +1,5 @@
-# learner bundle on the GPU box:  bash tools/prof_train.sh <tag> [tests] [train] [trace]
+# learner bundles on the GPU box:  [SHARES="1 0"] bash tools/prof_train.sh <tag> [ubench] [tests] [train] [vfbatch] [trace]
+#   train: 80 iterations + update phase times per DM_VF_SHARE setting;  trace: kernel trace of 20 iterations -> train_kernels.md, idle gaps, kernel spans
 TAG=$1; shift
 mkdir -p gpurun_out/$TAG
 export TMPDIR=/tmp
