@@ -467,6 +467,28 @@ def test_native_policy_kernels_on_a_capped_grid_on_gpu(blocks):
         assert torch.equal(a, b)
 
 
+def test_shuffles_drawn_ahead_are_the_ones_an_update_would_draw_itself():
+    """TrpoLearner._prefetch_perms / _next_perm: the value fit's shuffles come from one generator in one order whether they are drawn ahead
+    (after the previous update) or on demand; a changed segment size drops what was drawn ahead and goes on from the generator's state."""
+    n = 1000
+    def learner():
+        return TrpoLearner(MlpPolicy(device="cpu", seed=0), vf_iters=3, seed=7)
+    a, b = learner(), learner()
+    want = [b._next_perm(n, torch.device("cpu")) for _ in range(6)]                       # on demand
+    a._prefetch_perms(n, torch.device("cpu"))
+    assert len(a._perms) == 3
+    got = [a._next_perm(n, torch.device("cpu")) for _ in range(3)]
+    a._prefetch_perms(n, torch.device("cpu")); a._prefetch_perms(n, torch.device("cpu"))  # (a second call with a full list draws nothing)
+    got += [a._next_perm(n, torch.device("cpu")) for _ in range(3)]
+    assert all(torch.equal(x, y) for x, y in zip(got, want)) and a._perms == []
+    a._prefetch_perms(n, torch.device("cpu"))
+    p = a._next_perm(n + 1, torch.device("cpu"))                                          # another size: the three drawn ahead are dropped
+    assert p.numel() == n + 1 and sorted(p.tolist()) == list(range(n + 1)) and a._perms == []
+    a.perm_source = lambda k: torch.arange(k)
+    a._prefetch_perms(n, torch.device("cpu"))                                             # tests' injected shuffles: nothing is drawn ahead
+    assert a._perms == []
+
+
 def test_cu_sharing_plan_is_a_function_of_the_launch_sequence():
     """TrpoLearner._pg_share_begin / _pg_grid: which policy launches run on the narrow grid beside the value fit comes from a cost model of
     the launches issued so far — the same sequence gives the same grids (a seeded run reproduces), the narrow phase ends once the modelled
