@@ -402,6 +402,9 @@ def standing_bench(args, dev, rank, world, local_dev):
         print(json.dumps(out))
 
 
+RANK_DEVICES = []      # per rank: PCI address of its GPU, gathered over the process group at start-up (multi-rank runs)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--_cpu-worker":
         return cpu_baseline_worker(sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5]))
@@ -476,7 +479,17 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         n_ranks_seen = dist.get_world_size()
         assert n_ranks_seen == args.gpus, "process group has %d ranks, --gpus says %d" % (n_ranks_seen, args.gpus)
+        # which physical GPU every rank sits on (PCI domain:bus:device of its HIP device), gathered over the process group itself: a SCALE record then
+        # shows that the collective backend saw N distinct GPUs (src/train_mpi.sh:1 starts one worker per slot; src/trpo.py:175-186 sums over them)
+        pr = torch.cuda.get_device_properties(dev)
+        mine = torch.tensor([int(getattr(pr, "pci_domain_id", -1)), int(getattr(pr, "pci_bus_id", -1)), int(getattr(pr, "pci_device_id", -1)), local_dev],
+                            dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(n_ranks_seen)]
+        dist.all_gather(every, mine)
+        RANK_DEVICES[:] = ["%04x:%02x:%02x.hip%d" % tuple(int(v) & 0xffff for v in t.tolist()) for t in every]
         if rank == 0:       # start-up line for the scaling log (stderr: stdout carries exactly one JSON line)
+            sys.stderr.write("bench.py: rank -> GPU (pci domain:bus:device.hip-ordinal): %s; %d distinct GPU(s) for %d rank(s)\n"
+                             % (" ".join("%d=%s" % (i, d) for i, d in enumerate(RANK_DEVICES)), len(set(d.rsplit(".", 1)[0] for d in RANK_DEVICES)), n_ranks_seen))
             n_log = args.envs or WORKLOADS.get(args.workload, WORKLOADS["cfg3"])["envs"]
             sys.stderr.write("bench.py: %s process group up, %d ranks (backend reports %s), device %s; rollout gather every %d steps: "
                              "[%d, %d, 87] f32 = %.1f MB per rank, %.1f MB gathered per rank\n"
@@ -716,6 +729,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f%d" % args.dtype, "data": "synthetic",
             "config": {"workload": label, "envs_per_gpu": n, "global_envs": world * n if world > 1 else n * wl["shards"], "clip": clip,
                        "parallelism": "env-shard x%d" % max(world, wl["shards"]), "n_ranks_seen": n_ranks_seen,
+                       "rank_devices": list(RANK_DEVICES) or None, "distinct_gpus": (len(set(d.rsplit(".", 1)[0] for d in RANK_DEVICES)) if RANK_DEVICES else 1),
+                       "non_default_options": (["DM_OPT_STEP_QUEUE=%d" % queue] if queue else []) + (["DM_OPT_PIPELINE=%d" % P_sub] if (P_sub > 1 and not queue) else []),
+                       "value_is": ("queued dm_batch_step calls (open loop, outputs valid after dm_batch_join): the library's horizon launch reached through the per-step entry point; "
+                                    "the closed-loop figure — one launch set per call, default options apart from the pipeline depth DPVecEnv sets — is `vecenv_step`") if queue
+                                   else "one launch set per dm_batch_step call",
                        "dist_backend": args.dist_backend if dist_on else None, "forced_dist": bool(args.force_dist), "learner_allmean_ok": allmean_ok,
                        "gather_buffers_allocated_bytes": (sum(int(x.numel()) * 4 for x in gather_alloc) if gather_alloc else None),
                        "rollout_allgather_every": HORIZON if dist_on else None, "gathers_completed": dbg.completed,
@@ -755,11 +773,12 @@ def main():
                 "what": "%d steps (the timed window rounded up to whole 256-step horizons) of the same workload and state stream through dm_batch_rollout (max over ranks, same barriers): ONE launch per horizon of pre-drawn actions, every wavefront "
                         "steps its four environments through the whole horizon at its own pace; results bit-identical to the dm_batch_step calls of `value` on the packed "
                         "kernel (tests/test_gpu_rollout.py::test_horizon_launch_equals_step_by_step) and oracle-checked at full shard size "
-                        "(tests/test_gpu_fullsize.py [*-2]).  `value` stays the one-call-per-step figure: the drop-in for VecEnv.step" % hl_steps},
+                        "(tests/test_gpu_fullsize.py [*-2]).  With a step queue (`config.step_queue`) `value` reaches this same kernel through dm_batch_step calls; the "
+                        "one-launch-set-per-call figure, the drop-in for VecEnv.step, is `vecenv_step`" % hl_steps},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                          "kernel": step_kernel, "kernel_ms": round(kernel_ms, 4),
-                         "kernel_ms_covers": "HIP events around the timed region / steps: one dm_batch_step = the step kernel (all sub-batches; the packed kernel is followed by k_step_redo) + k_order + 1/256 of a horizon's block packing; "
+                         "kernel_ms_covers": "HIP events around the timed region / steps: one dm_batch_step = the step kernel (all sub-batches; the packed kernel is followed by k_step_redo; the kernels order themselves — no k_order launch since round 5) + 1/256 of a horizon's block packing; "
                                              "with --pipeline > 1 consecutive steps overlap, so this is the per-step issue interval, not a lone launch's latency",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_STEP,
                          "launch": ({"kernel": step_kernel, "envs_per_launch": n, "steps_per_launch": min(HORIZON, max(1, args.horizon_chunk), args.steps),

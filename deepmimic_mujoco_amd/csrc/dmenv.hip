@@ -31,27 +31,28 @@ static_assert(DM_PACKED_MAXROWS == SLOT_MAXROWS && DM_PACKED_MAXLIMROWS == SLOT_
 static_assert(AOVF_COLS >= MAXEFC, "memory strip too small");
 __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_narrow(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                                     Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
-                                                    int n_substeps, int first) {
+                                                    int n_substeps, int first, int count) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
 #ifdef DM_LDS_PAD      // experiment (profiles/r02_slot16_ubench.md): extra LDS per workgroup lowers the residency (6 880 -> 6 envs per CU,
   __shared__ volatile char lds_pad[DM_LDS_PAD];   // 20 500 -> 4) without touching the code path; build with DM_BUILD_DEFINES=-DDM_LDS_PAD=...
   if (n_substeps < 0) lds_pad[threadIdx.x] = 1;
 #endif
-  const int slot = first + (int)blockIdx.x;          // position in the dispatch order (a pipelined sub-batch starts at `first`)
-  if (slot >= B.n_envs) return;
-  const int env = B.order ? B.order[slot] : slot;
+  // position blockIdx.x in the dispatch order of the part [first, first + count) (a pipelined sub-batch, or the whole batch)
+  if ((int)blockIdx.x >= count) return;
+  int env;
+  dispatch_env<1>(B, first, count, (int)blockIdx.x, dmw::lane(), blockIdx.x == 0, &env);
   env_step<Real, NARROW_ROWS>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
 }
 // the same step followed, in the same wave, by the policy's step on the observation it produced (dm_batch_step_act)
 __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_act(const DevModel<Real>* __restrict__ Mp, Batch<Real> B, const Ext* __restrict__ action,
                                                  Ext* __restrict__ obs, Ext* __restrict__ reward, unsigned char* __restrict__ done,
-                                                 int n_substeps, int first, dmp::PolicyArgs pa) {
+                                                 int n_substeps, int first, int count, dmp::PolicyArgs pa) {
   __shared__ Shared<Real> s;
   __shared__ StepScratch<Real> x;
-  const int slot = first + (int)blockIdx.x;
-  if (slot >= B.n_envs) return;
-  const int env = B.order ? B.order[slot] : slot;
+  if ((int)blockIdx.x >= count) return;
+  int env;
+  dispatch_env<1>(B, first, count, (int)blockIdx.x, dmw::lane(), blockIdx.x == 0, &env);
   env_step<Real, NARROW_ROWS>(*Mp, B, s, x, env, dmw::lane(), action, obs, reward, done, n_substeps);
   // s.qpos / s.qvel hold the state the observation was written from (the fresh episode's after an auto-reset); the row-descriptor
   // region is free
@@ -98,24 +99,27 @@ __global__ __launch_bounds__(64, DM_STEP_WAVES) void k_step_redo(const DevModel<
   }
 }
 
-// (Measured alternatives: having the launch's LAST workgroup sort the order before it exits — a device-scope counter, no ordering launch at
-//  all — is no faster at two sub-batches (11.65 M) and slower at one launch per step (8.53 vs 8.93 M: one wave sorting 4096 keys takes longer than
-//  this 16-wave kernel on an idle machine).  Recomputing the order only every 2 / 4 / 8 steps: 11.2 / 10.95 / 10.8 M env-steps/s against 11.6 M every step.)
-// Dispatch order for the NEXT step: envs with more constraint rows (a good proxy for their step time: 0.32 .. 0.72 M
-// shader ticks from 0 to 32 rows) first.  4096 envs are two rounds of resident waves, so the launch ends when the last wave
-// of round two does; longest-first list scheduling trims that tail (measured -9 % kernel time).  Counting sort by
-// min(nefc, 63), descending; the order inside a bucket is arbitrary — results never depend on the dispatch order.
-// cost key of an environment for the dispatch order: constraint rows + a quarter of the PGS sweeps of its last evaluation
-#ifndef DM_ORDER_KEY
-#define DM_ORDER_KEY(nefc, iter) ((nefc) + ((iter) >> 2))
-#endif
+// Dispatch order of a HORIZON launch (k_rollout_packed): environments with similar cost keys (env_step.h DM_ORDER_KEY: constraint rows + a quarter
+// of the PGS sweeps of the last evaluation) share a wave — a wave pays for its largest row count and its slowest PGS.  Counting sort, descending;
+// the order inside a bucket is arbitrary — results never depend on the dispatch order.  One launch per horizon: off the per-step path, where the
+// step kernels order themselves (env_step.h dispatch_env / order_ticket; rounds 1-4 ran this kernel — or its one-wave form — between every two steps:
+// 9 % of the GPU time of the one-launch-per-call form).
 // (measured, round 4: DEALING the sorted list over the waves of a horizon launch — rank r to wave r % W, slot r / W, one environment of each
 //  quartile per wave instead of the four heaviest together — shortens the slowest wave of a 64-step launch by 1.3 % and lengthens the
 //  driver's 20-step window by 2 %: profiles/r04_ab_kernel_variants.md; the grouped order stays)
+#ifndef DM_GROUP_KEY
+#define DM_GROUP_KEY(nefc, iter) DM_ORDER_KEY(nefc, iter)
+#endif
+#ifndef DM_GROUP_BUCKETS
+#define DM_GROUP_BUCKETS 64
+#endif
+DM_DEV int group_bucket(int nefc, int iter) { const int k = DM_GROUP_KEY(nefc, iter); return k < 0 ? 0 : (k > DM_GROUP_BUCKETS - 1 ? DM_GROUP_BUCKETS - 1 : k); }
 __global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__ order, int first, int count) {
-  __shared__ int hist[64], start[64];
+  constexpr int NBK = DM_GROUP_BUCKETS;
+  static_assert(NBK <= 1024, "one thread per bucket");
+  __shared__ int hist[NBK], start[NBK];
   const int tid = threadIdx.x, n = count;                // envs first .. first + count - 1 are sorted into order[first ..]
-  if (tid < 64) hist[tid] = 0;
+  if (tid < NBK) hist[tid] = 0;
   __syncthreads();
   constexpr int PER = 8;                 // keys of up to 8192 envs stay in registers between the two passes
   int key[PER];
@@ -123,43 +127,15 @@ __global__ __launch_bounds__(1024) void k_order(Batch<Real> B, int* __restrict__
   for (int j = 0; j < PER; j++) {
     const int e = tid + j * 1024;
     key[j] = -1;
-    if (e < n) { const int k = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]); key[j] = k < 0 ? 0 : (k > 63 ? 63 : k); atomicAdd(&hist[key[j]], 1); }
+    if (e < n) { key[j] = group_bucket(B.nefc[first + e], B.solver_iter[first + e]); atomicAdd(&hist[key[j]], 1); }
   }
-  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
+  for (int e = tid + PER * 1024; e < n; e += 1024) atomicAdd(&hist[group_bucket(B.nefc[first + e], B.solver_iter[first + e])], 1);
   __syncthreads();
-  if (tid == 0) { int acc = 0; for (int k = 63; k >= 0; k--) { start[k] = acc; acc += hist[k]; } }
+  if (tid == 0) { int acc = 0; for (int k = NBK - 1; k >= 0; k--) { start[k] = acc; acc += hist[k]; } }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < PER; j++) if (key[j] >= 0) order[first + atomicAdd(&start[key[j]], 1)] = first + tid + j * 1024;
-  for (int e = tid + PER * 1024; e < n; e += 1024) { const int k0 = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[first + atomicAdd(&start[k], 1)] = first + e; }
-}
-
-// The same ordering for the pipelined path, where the step kernel of ANOTHER sub-batch is resident while it runs: ONE wave, so that
-// its workgroup is placed into a freed wave slot like any step workgroup.  (k_order's 16-wave workgroup needs a whole CU's worth
-// of free registers at one instant; beside a resident step kernel it waited 67 us on average — rocprofv3 — on its sub-batch's
-// critical path.)  Up to 64 keys per lane stay in registers between the two passes: all loads of a lane are issued together.
-__global__ __launch_bounds__(64) void k_order_wave(Batch<Real> B, int* __restrict__ order, int first, int count) {
-  __shared__ int hist[64], start[64];
-  const int lane = threadIdx.x;
-  hist[lane] = 0;
-  __syncthreads();
-  constexpr int PER = 64;                // 4096 envs per sub-batch in registers; beyond that the keys are read again
-  int key[PER];
-#pragma unroll
-  for (int j = 0; j < PER; j++) {
-    const int e = lane + j * 64;
-    key[j] = -1;
-    if (e < count) key[j] = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]);
-  }
-#pragma unroll
-  for (int j = 0; j < PER; j++) if (key[j] >= 0 || (lane + j * 64) < count) { key[j] = key[j] < 0 ? 0 : (key[j] > 63 ? 63 : key[j]); atomicAdd(&hist[key[j]], 1); }
-  for (int e = lane + PER * 64; e < count; e += 64) { const int k = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]); atomicAdd(&hist[k < 0 ? 0 : (k > 63 ? 63 : k)], 1); }
-  __syncthreads();
-  if (lane == 0) { int acc = 0; for (int k = 63; k >= 0; k--) { start[k] = acc; acc += hist[k]; } }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < PER; j++) if ((lane + j * 64) < count) order[first + atomicAdd(&start[key[j]], 1)] = first + lane + j * 64;
-  for (int e = lane + PER * 64; e < count; e += 64) { const int k0 = DM_ORDER_KEY(B.nefc[first + e], B.solver_iter[first + e]); const int k = k0 < 0 ? 0 : (k0 > 63 ? 63 : k0); order[first + atomicAdd(&start[k], 1)] = first + e; }
+  for (int e = tid + PER * 1024; e < n; e += 1024) order[first + atomicAdd(&start[group_bucket(B.nefc[first + e], B.solver_iter[first + e])], 1)] = first + e;
 }
 
 // same step with per-stage shader-clock accounting (DM_OPT 101); not used on the timed path
@@ -246,6 +222,9 @@ struct dm_batch {
   Batch<Real> B{};
   Batch<Real>* d_B = nullptr;   // a copy of B in device memory for the horizon launch (refreshed before each: its code is reached through calls, which take a pointer)
   Real *d_cfg = nullptr, *d_vel = nullptr, *d_imit = nullptr; int* d_order = nullptr;
+  // self-ordering per-step launches (env_step.h dispatch_env): per pipelined part three phases of 64 bucket counters, and three phases of bucket
+  // lists ([phase][bucket][n], a part's entries at its first env); ord_phase = the phase the part's last launch counted into, valid once one did
+  int* d_ord_cnt = nullptr; int* d_ord_list = nullptr; int ord_phase[DM_MAX_PIPELINE] = {}; bool ord_valid[DM_MAX_PIPELINE] = {};
   // staging for DM_PTR_HOST callers
   Ext *d_action = nullptr, *d_obs = nullptr, *d_reward = nullptr; unsigned char *d_done = nullptr, *d_mask = nullptr;
   // host-pointer steps: obs | reward | done are ONE device block (d_obs points at its start) mirrored in pinned host memory, so a
@@ -329,7 +308,7 @@ extern "C" void dm_batch_destroy(dm_batch* b) {
   if (b->ev_in) hipEventDestroy(b->ev_in);
   void* ptrs[] = {b->d_model, b->B.qpos, b->B.qvel, b->B.qws, b->B.time, b->B.ctrl, b->B.xipos, b->B.comz, b->B.frame_idx, b->B.frame_init,
                   b->B.ncon, b->B.nefc, b->B.cong, b->B.status, b->B.solver_iter, b->B.episode, b->d_cfg, b->d_vel, b->d_action, b->d_obs,
-                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order, b->B.kin, b->B.kin_ok, b->B.redo_list, b->B.redo_count, b->B.redo_why, b->d_B, b->d_rows};
+                  b->d_mask, b->d_cvt, b->d_qpos_in, b->d_qvel_in, b->d_fidx_in, b->d_debug, b->d_prof, b->B.aovf, b->B.cycle, b->d_imit, b->d_order, b->B.kin, b->B.kin_ok, b->B.redo_list, b->B.redo_count, b->B.redo_why, b->d_B, b->d_rows, b->d_ord_cnt, b->d_ord_list};
   for (void* p : ptrs) if (p) hipFree(p);
   if (b->h_out) hipHostFree(b->h_out);
   if (b->h_action) hipHostFree(b->h_action);
@@ -372,6 +351,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   A(b->B.aovf, (size_t)n * AOVF_COLS * 64);
   A(b->B.kin, (size_t)n * KIN_DOUBLES); A(b->B.kin_ok, n);
   A(b->B.redo_list, n); A(b->B.redo_count, 2 * DM_MAX_PIPELINE); A(b->B.redo_why, 8);
+  A(b->d_ord_cnt, DM_MAX_PIPELINE * 3 * ORD_BUCKETS);
   A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
   if (sizeof(Real) != sizeof(Ext)) A(b->d_cvt, (size_t)n * NB * 3);   // largest Real field per env: xipos (42)
 #undef A
@@ -438,6 +418,7 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
       if (v > 1 && !b->ev_in) HIPCHK(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
       b->pipe = (int)v;
       b->B.order = nullptr;   /* the stored dispatch order belongs to the previous partition: identity for the next launch */
+      for (int h = 0; h < DM_MAX_PIPELINE; h++) b->ord_valid[h] = false;   /* ... and so do the tickets of the per-step launches */
       b->redo_mode = -1;      /* sub-batches beyond the new depth keep whatever their redo counters last held: the next packed step re-zeroes all
                                  2 * DM_MAX_PIPELINE counters and restarts the phase (everything in flight was joined above) */
       break;
@@ -563,6 +544,26 @@ static int flush_queue(dm_batch* b) {
   return launch_horizon(b, T, nsub, nopol);
 }
 
+// Self-ordering per-step launches (env_step.h dispatch_env / order_ticket): the descriptor a step launch of part h = [lo, ...) gets — it reads the
+// tickets the part's previous launch left (phase p), its envs take theirs from phase p + 1, its first workgroup clears phase p + 2 for the launch
+// after it.  `st` = the stream the launch goes to.  A part's tickets stay a permutation of the part whatever runs in between (horizon launches,
+// resets: only their keys grow stale); a new partition (DM_OPT_PIPELINE) starts afresh.
+static int ord_bind(dm_batch* b, Batch<Real>& Bh, int h, int lo, hipStream_t st) {
+  if (!b->d_ord_list) { if (hipMalloc((void**)&b->d_ord_list, (size_t)3 * ORD_BUCKETS * b->n * sizeof(int)) != hipSuccess) return fail(DM_ENOMEM, "dispatch-order lists"); }
+  int* cnt = b->d_ord_cnt + (size_t)h * 3 * ORD_BUCKETS;
+  if (!b->ord_valid[h]) { HIPCHK(hipMemsetAsync(cnt, 0, 3 * ORD_BUCKETS * sizeof(int), st)); b->ord_phase[h] = 0; }
+  const int p = b->ord_phase[h], pn = (p + 1) % 3, pz = (p + 2) % 3;
+  const size_t n = (size_t)b->n;
+  Bh.ord_in = b->ord_valid[h] ? cnt + p * ORD_BUCKETS : nullptr;
+  Bh.ordl_in = b->d_ord_list + (size_t)p * ORD_BUCKETS * n + lo;
+  Bh.ord_out = cnt + pn * ORD_BUCKETS;
+  Bh.ordl_out = b->d_ord_list + (size_t)pn * ORD_BUCKETS * n + lo;
+  Bh.ord_zero = cnt + pz * ORD_BUCKETS;
+  Bh.ord_stride = b->n;
+  b->ord_phase[h] = pn; b->ord_valid[h] = true;
+  return DM_OK;
+}
+
 static int step_impl(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t nsub, int32_t kind, const dmp::PolicyArgs* pol) {
   if (!b || !action || !obs || !reward || !done || nsub < 1) return fail(DM_EINVAL, "dm_batch_step: bad argument");
   if (pol && (kind != DM_PTR_DEVICE || b->prof || !b->two_tier)) return fail(DM_EINVAL, "dm_batch_step_act: device pointers, the two-tier kernel and no profiling");
@@ -571,8 +572,21 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     // DM_OPT_STEP_QUEUE: remember the call; the queued steps run as ONE horizon launch (flush_queue).  A call that names a buffer an
     // earlier queued call names (the same action / output tensors step after step) runs that earlier call first: a caller that reuses
     // buffers has, by the pipelined contract, joined in between and sees plain step-by-step behaviour.
+    // "names a buffer" = its bytes overlap the bytes of ANY buffer of a queued call, in whatever role: the same tensors step after step, a view that
+    // starts elsewhere in one of them, a queued call's observations handed in as this call's action.
     bool reuse = nsub != b->q_nsub && !b->q.empty();
-    for (const StepRow& r : b->q) reuse = reuse || r.action == action || r.obs == obs || r.reward == reward || r.done == done;
+    {
+      const size_t n = (size_t)b->n;
+      const char* p[4] = {(const char*)action, (const char*)obs, (const char*)reward, (const char*)done};
+      const size_t len[4] = {n * NU * sizeof(Ext), n * NOBS * sizeof(Ext), n * sizeof(Ext), n};
+      for (const StepRow& r : b->q) {
+        const char* qp[4] = {(const char*)r.action, (const char*)r.obs, (const char*)r.reward, (const char*)r.done};
+        for (int i = 0; i < 4 && !reuse; i++) for (int j = 0; j < 4; j++) {
+          if (p[i] < qp[j] + len[j] && qp[j] < p[i] + len[i]) { reuse = true; break; }
+        }
+        if (reuse) break;
+      }
+    }
     if (reuse || (int)b->q.size() >= b->queue_cap) { const int rc = flush_queue(b); if (rc != DM_OK) return rc; }
     b->q.push_back(StepRow{action, obs, reward, done}); b->q_nsub = nsub;
     return DM_OK;
@@ -620,42 +634,36 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
       const int lo = (int)((long long)b->n * h / b->pipe), hi = (int)((long long)b->n * (h + 1) / b->pipe);
       if (hi <= lo) continue;
       HIPCHK(hipStreamWaitEvent(b->ps[h], b->ev_in, 0));
+      Batch<Real> Bh = b->B;                                                   // this part's launch orders itself from the tickets its previous launch left
+      if (reorder) { const int rc2 = ord_bind(b, Bh, h, lo, b->ps[h]); if (rc2 != DM_OK) return rc2; }
       if (b->timing && h == 0) HIPCHK(hipEventRecord(b->ev0, b->ps[0]));     // timing: sub-batch 0's kernel on ITS stream
       if (use_packed) {
         int* rc = b->B.redo_count + 2 * h + b->redo_phase; int* rn = b->B.redo_count + 2 * h + (1 - b->redo_phase);
-        if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, rc, *pol);
-        else hipLaunchKernelGGL(k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, rc);
-        if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, (const int*)rc, rn, pol ? *pol : nopol);
+        if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, rc, *pol);
+        else hipLaunchKernelGGL(k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, rc);
+        if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, (const int*)rc, rn, pol ? *pol : nopol);
       }
-      else if (pol) hipLaunchKernelGGL(k_step_act, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo, *pol);
-      else hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, lo);
+      else if (pol) hipLaunchKernelGGL(k_step_act, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, *pol);
+      else hipLaunchKernelGGL(k_step_narrow, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo);
       if (b->timing && h == 0) { HIPCHK(hipEventRecord(b->ev1, b->ps[0])); b->ev_pending = true; }
-      if (reorder) hipLaunchKernelGGL(k_order_wave, dim3(1), dim3(64), 0, b->ps[h], b->B, b->d_order, lo, hi - lo);
       HIPCHK(hipEventRecord(b->ev_done[h], b->ps[h]));
     }
-    if (reorder) b->B.order = b->d_order;  // valid from the next launch on (same streams: ordered after each part's k_order)
     b->pipe_pending = true;
   } else if (b->two_tier) {
+    // (one launch over the whole batch.  With a pipeline depth configured the tickets are kept per part — a pipelined launch must find exactly its
+    //  part's envs in them, otherwise two streams could step one env at once — so this launch takes none and falls back to the stored order.)
+    Batch<Real> Bh = b->B;
+    if (reorder && b->pipe <= 1) { const int rc2 = ord_bind(b, Bh, 0, 0, b->stream); if (rc2 != DM_OK) return rc2; }
     if (use_packed) {
       // (a step that is not pipelined has joined every sub-batch stream: all of them are idle, so ONE pair of counters is clean — pair 0's
       //  two are cleared here once if a pipelined step used them before)
       int* rc = b->B.redo_count + b->redo_phase; int* rn = b->B.redo_count + (1 - b->redo_phase);
-      if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc, *pol);
-      else hipLaunchKernelGGL(k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc);
-      if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)rc, rn, pol ? *pol : nopol);
+      if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc, *pol);
+      else hipLaunchKernelGGL(k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc);
+      if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)rc, rn, pol ? *pol : nopol);
     }
-    else if (pol) hipLaunchKernelGGL(k_step_act, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0, *pol);
-    else hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub, 0);
-    if (reorder) {
-      // (with a pipeline depth configured, every sub-batch's range is sorted on its own: a later pipelined launch reads order[lo..hi)
-      //  of ITS part only, which must then name exactly that part's envs — otherwise two streams could step one env at once)
-      const int parts = b->pipe > 1 ? b->pipe : 1;
-      for (int h = 0; h < parts; h++) {
-        const int lo = (int)((long long)b->n * h / parts), hi = (int)((long long)b->n * (h + 1) / parts);
-        if (hi > lo) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, b->stream, b->B, b->d_order, lo, hi - lo);
-      }
-      b->B.order = b->d_order;             // valid from the next launch on (same stream: ordered after k_order)
-    }
+    else if (pol) hipLaunchKernelGGL(k_step_act, dim3(b->n), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, *pol);
+    else hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n);
   } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub);
   HIPCHK(hipGetLastError());
   if (packed_step) b->redo_phase ^= 1;
@@ -798,6 +806,8 @@ extern "C" int dm_batch_read_profile(dm_batch* b, long long* out_host) {   /* [N
 extern "C" int dm_batch_enable_timing(dm_batch* b, int32_t on) { if (!b) return fail(DM_EINVAL, "null batch"); b->timing = on != 0; b->ev_pending = false; return DM_OK; }
 extern "C" int dm_batch_last_step_ms(dm_batch* b, float* ms) {
   if (!b || !ms) return fail(DM_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  if (settle(b)) return fail(DM_EHIP, "dm_batch_last_step_ms: running the queued steps failed");      // (queued steps are timed by the launch that runs them)
   if (!b->ev_pending) return fail(DM_EINVAL, "no timed step recorded");
   HIPCHK(hipEventSynchronize(b->ev1));
   HIPCHK(hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));
@@ -821,9 +831,11 @@ extern "C" int dm_gae(const float* rew, const float* vpred, const int32_t* isnew
   HIPCHK(hipGetLastError());
   return DM_OK;
 }
+static int pg_set_device(const void* p);
 extern "C" int dm_episode_scan(const double* reward, const uint8_t* done, int32_t T, int32_t n, double* cur_ret, int64_t* cur_len, int32_t* count,
                                int32_t cap, int64_t* records, void* hip_stream) {
   if (!reward || !done || !cur_ret || !cur_len || !count || !records || T <= 0 || n <= 0 || cap < 0) return fail(DM_EINVAL, "dm_episode_scan: bad argument");
+  if (pg_set_device(reward)) return fail(DM_EHIP, "dm_episode_scan: hipSetDevice failed");      // (the launches go to the device that owns the arrays, whatever the thread's current one)
   hipStream_t st = (hipStream_t)hip_stream;
   HIPCHK(hipMemsetAsync(count, 0, sizeof(int32_t), st));
   hipLaunchKernelGGL(dmp::k_episodes, dim3((n + 255) / 256), dim3(256), 0, st, reward, done, (int)T, (int)n, cur_ret, (long long*)cur_len, (int*)count, (int)cap,
@@ -900,6 +912,7 @@ extern "C" size_t dm_rms_scratch_bytes(void) { return (size_t)RMS_UPDATE_BLOCKS 
 extern "C" int dm_rms_update(const float* ob, int32_t n, double* rms_sum, double* rms_sumsq, double* rms_count, float* rms_mean, float* rms_std,
                              void* scratch, void* hip_stream) {
   if (!ob || n < 1 || !rms_sum || !rms_sumsq || !rms_count || !rms_mean || !rms_std || !scratch) return fail(DM_EINVAL, "dm_rms_update: bad argument");
+  if (pg_set_device(ob)) return fail(DM_EHIP, "dm_rms_update: hipSetDevice failed");
   hipStream_t st = (hipStream_t)hip_stream;
   int blocks = (n + 255) / 256;                               // >= 64 rows per row group of a block
   if (blocks > RMS_UPDATE_BLOCKS) blocks = RMS_UPDATE_BLOCKS;

@@ -27,6 +27,15 @@ struct Batch {
   int* solver_iter; // [N]
   int* episode;     // [N]
   int* order;       // [N] dispatch order: workgroup w steps env order[w] (nullptr: identity) — costly envs first shortens the tail
+  // self-ordering per-step launches (dispatch_env / order_ticket below): every env stepped by launch t takes a ticket in the bucket of its cost
+  // key; launch t + 1 turns (bucket counts, bucket lists) into its dispatch order on the fly — no ordering kernel between two steps.
+  // All null: off.  The pointers are those of ONE launch (one pipelined part, one phase): the host rotates three phases per part.
+  const int* ord_in;       // [64] bucket counts the previous launch of this part left (nullptr: no order yet -> `order` / identity)
+  const int* ordl_in;      // its bucket lists: env of (bucket k, ticket p) at ordl_in[k * ord_stride + p]
+  int* ord_out;            // [64] bucket counters this launch's envs take their tickets from (zero when the launch starts)
+  int* ordl_out;           // this launch's bucket lists
+  int* ord_zero;           // [64] the counters the NEXT launch will count into: cleared by this launch's first workgroup
+  int ord_stride;
   int* cycle;       // [N] completed motion cycles since the episode started (imitation reward: root advance of the reference)
   R* kin;           // [N, KIN_DOUBLES] kinematics of the state an env was left in (see save_kin), valid where kin_ok[env] != 0
   unsigned char* kin_ok;   // [N]
@@ -58,7 +67,62 @@ DM_DEV Batch<R> global_members(Batch<R> b) {
   b.kin = in_global(b.kin); b.kin_ok = in_global(b.kin_ok); b.redo_list = in_global(b.redo_list); b.redo_count = in_global(b.redo_count);
   b.redo_why = in_global(b.redo_why); b.mocap_cfg = in_global(b.mocap_cfg); b.mocap_vel = in_global(b.mocap_vel);
   b.imit_table = in_global(b.imit_table); b.imit_pdev = in_global(b.imit_pdev);
+  b.ord_in = in_global(b.ord_in); b.ordl_in = in_global(b.ordl_in); b.ord_out = in_global(b.ord_out); b.ordl_out = in_global(b.ordl_out); b.ord_zero = in_global(b.ord_zero);
   return b;
+}
+
+// ---- self-ordering per-step launches ---------------------------------------------------------------------------------------------
+// Dispatch order of a per-step launch: environments with more constraint rows (a good proxy for their step time: 0.32 .. 0.72 M shader
+// ticks from 0 to 32 rows) first — 4 096 envs are two rounds of resident one-env waves, so a launch ends when the last wave of round two
+// does, and longest-first list scheduling trims that tail (measured: -9 % kernel time).  Rounds 1-4 computed the order with a counting-sort
+// kernel between two step launches (k_order / k_order_wave: 9 % of the GPU time of the one-launch-per-call form, all of it on the stream's
+// critical path).  Now the step kernels do it themselves: an env's last lane-0 act in launch t is to take a ticket in the bucket of its cost
+// key (order_ticket: one atomic + one store); a workgroup of launch t + 1 reads the 64 bucket counts (one coalesced load), finds the bucket
+// its dispatch position falls into by a wave scan, and reads its env from that bucket's list (dispatch_env).  The order inside a bucket is
+// the order of arrival — arbitrary, as before: results never depend on the dispatch order.
+// cost key of an environment: constraint rows + a quarter of the PGS sweeps of its last evaluation, 64 buckets
+#ifndef DM_ORDER_KEY
+#define DM_ORDER_KEY(nefc, iter) ((nefc) + ((iter) >> 2))
+#endif
+constexpr int ORD_BUCKETS = 64;
+DM_DEV int order_bucket(int nefc, int iter) { const int k = DM_ORDER_KEY(nefc, iter); return k < 0 ? 0 : (k > ORD_BUCKETS - 1 ? ORD_BUCKETS - 1 : k); }
+// one lane per stepped env, once per launch
+template <class R>
+DM_DEV void order_ticket(const Batch<R>& B, int env, int nefc, int iter) {
+  if (!B.ord_out) return;
+  const int k = order_bucket(nefc, iter);
+  const int p = dmw::global_counter_next(B.ord_out + k);
+  B.ordl_out[(size_t)k * B.ord_stride + p] = env;
+}
+// The envs at the dispatch positions first + r0 .. first + r0 + NPOS - 1 of a part of `count` envs starting at `first` (wave-collective;
+// NPOS = 1: one env per wave, 4: one per slot).  Buckets in DESCENDING key order.  Falls back to B.order / the identity when the previous
+// launch left no tickets — or not exactly `count` of them (cannot happen while the host's bookkeeping is right; a permutation is never
+// assumed on faith: stepping an env twice would corrupt it).
+template <int NPOS, class R>
+DM_DEV void dispatch_env(const Batch<R>& B, int first, int count, int r0, int lane, bool first_group, int* env_out) {
+  if (B.ord_zero && first_group) B.ord_zero[lane] = 0;
+  bool have = false;
+  int c = 0, start = 0;
+  if (B.ord_in) {
+    c = B.ord_in[lane];                               // bucket `lane`
+    int incl = c;                                     // sum over the buckets >= lane
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = dmw::shfl_i(incl, lane + d < 64 ? lane + d : lane); if (lane + d < 64) incl += o; }
+    start = incl - c;                                 // envs in buckets with a larger key
+    have = dmw::bcast_i(incl, 0) == count;
+  }
+#pragma unroll
+  for (int j = 0; j < NPOS; j++) {
+    int r = r0 + j;
+    if (r > count - 1) r = count - 1;                 // (spare slots of the last wave repeat the last env)
+    int e = first + r;
+    if (have) {
+      const unsigned long long m = dmw::ballot(c > 0 && start <= r && r < start + c);
+      const int k = __builtin_ctzll(m | (1ull << 63));
+      e = B.ordl_in[(size_t)k * B.ord_stride + (r - dmw::bcast_i(start, k))];
+    } else if (B.order) e = B.order[e];
+    env_out[j] = e;
+  }
 }
 
 // counter-based RNG: splitmix64 finaliser over (seed, global env, episode, k) -> U[0,1)
@@ -404,7 +468,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
   load_env(M, B, s, env, lane, action);
   if (kin0) { place_kin(s, kreg, lane); dmw::sync(); }
   for (int k = 0; k < n_substeps; k++)   // do_simulation(action, n)
-    if (!rk4_step<R, ROWS, PROF>(M, s, x, lane, lt, prof, k == 0 && kin0)) return false;
+    if (!rk4_step<R, ROWS, PROF>(M, s, x, lane, lt, prof, k == 0 && kin0)) { if (lane == 0) order_ticket(B, env, s.nefc, s.solver_iter); return false; }
   bool kin_saved = false;
   const R z = com_z(M, s);
   bool dn = (z < R(0.7)) || (z > R(2.0));
@@ -462,6 +526,7 @@ DM_DEV bool env_step(const DevModel<R>& M, const Batch<R>& B, Shared<R>& s, Step
   if (lane < 28) obs[(size_t)env * NOBS + lane] = s.qpos[7 + lane];
   else if (lane < NOBS) obs[(size_t)env * NOBS + lane] = s.qvel[6 + (lane - 28)];
   store_state(B, s, env, lane);
+  if (lane == 0) order_ticket(B, env, s.nefc, s.solver_iter);
   if (PROF && lane == 0) {
     prof[5] = dmw::clk() - tstart;
     prof[6] = s.nefc; prof[7] = s.solver_iter;

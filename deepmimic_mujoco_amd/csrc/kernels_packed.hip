@@ -13,11 +13,10 @@ __global__ __launch_bounds__(64) void k_step_packed(const DevModel<Real>* __rest
   __shared__ SlotTables tb;
   const int lane = dmw::lane(), slot = lane >> 4, sl = lane & 15;
   stage_slot_tables(tb, lane);
-  const int last = first + count - 1;
-  int pos = first + SLOTS * (int)blockIdx.x + slot;
-  const bool live = pos <= last;
-  if (pos > last) pos = last;
-  const int env = B.order ? B.order[pos] : pos;
+  const bool live = SLOTS * (int)blockIdx.x + slot < count;
+  int envs4[SLOTS];
+  dispatch_env<SLOTS>(B, first, count, SLOTS * (int)blockIdx.x, lane, blockIdx.x == 0, envs4);
+  const int env = slot == 0 ? envs4[0] : slot == 1 ? envs4[1] : slot == 2 ? envs4[2] : envs4[3];
   slot_env_step<Real>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first);
 }
 // ... followed, in the same wave, by the policy's step on the four observations it produced (dm_batch_step_act on the packed path): one
@@ -29,11 +28,10 @@ __global__ __launch_bounds__(64) void k_step_packed_act(const DevModel<Real>* __
   __shared__ SlotTables tb;
   const int lane = dmw::lane(), slot = lane >> 4, sl = lane & 15;
   stage_slot_tables(tb, lane);
-  const int last = first + count - 1;
-  int pos = first + SLOTS * (int)blockIdx.x + slot;
-  const bool live = pos <= last;
-  if (pos > last) pos = last;
-  const int env = B.order ? B.order[pos] : pos;
+  const bool live = SLOTS * (int)blockIdx.x + slot < count;
+  int envs4[SLOTS];
+  dispatch_env<SLOTS>(B, first, count, SLOTS * (int)blockIdx.x, lane, blockIdx.x == 0, envs4);
+  const int env = slot == 0 ? envs4[0] : slot == 1 ? envs4[1] : slot == 2 ? envs4[2] : envs4[3];
   const bool stored = slot_env_step<Real>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first);
   // s.qpos / s.qvel of every slot hold the state its observation was written from (the fresh episode's after an auto-reset); r1 is free
   // the r1 + r2 regions (adjacent) are free
@@ -60,11 +58,10 @@ __global__ __launch_bounds__(64) void k_rollout_packed(const DevModel<Real>* __r
   const Batch<Real>& B = *Bp;       // (in device memory, not a by-value argument: the called step functions are handed its address)
   const int lane = dmw::lane(), slot = lane >> 4;
   stage_slot_tables(tb, lane);
-  const int last = first + count - 1;
-  int pos = first + SLOTS * (int)blockIdx.x + slot;
-  const bool live = pos <= last;
-  if (pos > last) pos = last;
-  const int env = B.order ? B.order[pos] : pos;
+  const bool live = SLOTS * (int)blockIdx.x + slot < count;
+  int envs4[SLOTS];
+  dispatch_env<SLOTS>(B, first, count, SLOTS * (int)blockIdx.x, lane, blockIdx.x == 0, envs4);
+  const int env = slot == 0 ? envs4[0] : slot == 1 ? envs4[1] : slot == 2 ? envs4[2] : envs4[3];
   const int envs[4] = {dmw::bcast_i(env, 0), dmw::bcast_i(env, 16), dmw::bcast_i(env, 32), dmw::bcast_i(env, 48)};
   const int lv = live ? 1 : 0;
   const bool wr[4] = {dmw::bcast_i(lv, 0) != 0, dmw::bcast_i(lv, 16) != 0, dmw::bcast_i(lv, 32) != 0, dmw::bcast_i(lv, 48) != 0};
@@ -100,10 +97,9 @@ __global__ __launch_bounds__(64) void k_step_packed_prof(const DevModel<Real>* _
   __shared__ SlotTables tb;
   const int lane = dmw::lane(), slot = lane >> 4, sl = lane & 15;
   stage_slot_tables(tb, lane);
-  const int last = first + count - 1;
-  int pos = first + SLOTS * (int)blockIdx.x + slot;
-  const bool live = pos <= last;
-  if (pos > last) pos = last;
-  const int env = B.order ? B.order[pos] : pos;
+  const bool live = SLOTS * (int)blockIdx.x + slot < count;
+  int envs4[SLOTS];
+  dispatch_env<SLOTS>(B, first, count, SLOTS * (int)blockIdx.x, lane, blockIdx.x == 0, envs4);
+  const int env = slot == 0 ? envs4[0] : slot == 1 ? envs4[1] : slot == 2 ? envs4[2] : envs4[3];
   slot_env_step<Real, true>(*Mp, B, sh[slot], tb, env, sl, lane, live, action, obs, reward, done, n_substeps, redo_count, B.redo_list + first, prof + (size_t)blockIdx.x * 32);
 }

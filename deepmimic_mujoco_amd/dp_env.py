@@ -270,11 +270,27 @@ class _Info(dict):
 
 
 class _InfoList(list):
+    """The list `step_wait` hands out every step while nobody has written into it.  The reference's DummyVecEnv returns a fresh copy per step
+    (src/utils/vec_env/dummy_vec_env.py:56): any write — into a dict (_Info) or into the list itself — marks it dirty, and the next step starts a new one."""
+
     def __init__(self, n):
         list.__init__(self, (_Info() for _ in range(n)))
         self.dirty = False
         for d in self:
             d._owner = self
+
+    def _w(name):                                      # every list mutator marks the list before it acts
+        f = getattr(list, name)
+
+        def g(self, *a, **kw):
+            self.dirty = True
+            return f(self, *a, **kw)
+        g.__name__ = name
+        return g
+
+    for _m in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove", "clear", "sort", "reverse"):
+        locals()[_m] = _w(_m)
+    del _w, _m
 
 
 class DPVecEnv(object):
@@ -300,6 +316,10 @@ class DPVecEnv(object):
         faster at any size.
         step_queue: DM_OPT_STEP_QUEUE depth (0 = off): queue `batch.step` calls and run them as one horizon launch (see below)."""
         self.num_envs = int(num_envs)
+        if reward == "v1-quat" and (packed or step_queue):
+            # dp_env_v1's reward (mode 4) exists on the one-env kernel only (include/dmenv.h DM_OPT_PACKED): asking for the four-per-wave kernels — or for
+            # the step queue, which rides on them — with it used to fall back silently; now it is refused
+            raise ValueError("reward='v1-quat' runs on the one-environment-per-wavefront kernel only: use packed=None / False and no step_queue")
         self.mocap = MocapDM()
         self.mocap.load_mocap(motion)
         self.mocap_dt = self.mocap.dt

@@ -226,11 +226,13 @@ class SegmentCollector(object):
                     # the whole horizon in one call (dm_batch_rollout): on the packed path ONE launch in which every wavefront runs its four
                     # environments through all T steps at its own pace; on the one-env path T step launches issued without returning here
                     restore = self._choose_kernel()
-                    env.batch.rollout(ac64, (ob64[1:], rew64, done8), fs, pi._packed, vpreds[1:], self.stochastic, pi._seed, pi._counter + 1)
-                    pi._counter += T
-                    env.batch.join()
-                    if restore is not None:
-                        restore()                                   # per-step callers of the same env keep the kernel THEY were given
+                    try:
+                        env.batch.rollout(ac64, (ob64[1:], rew64, done8), fs, pi._packed, vpreds[1:], self.stochastic, pi._seed, pi._counter + 1)
+                        pi._counter += T
+                        env.batch.join()
+                    finally:                                        # (also when the rollout raises: the batch must not be left on the collector's kernel choice)
+                        if restore is not None:
+                            restore()                               # per-step callers of the same env keep the kernel THEY were given
                     return
                 for t in range(T):                                                                       # :49 + :66, one launch
                     pi._counter += 1

@@ -422,11 +422,26 @@ class TrpoLearner:
     # bit for bit (the gradient sums are taken in block order: a function of the grid size).
     PG_GRAD_NS, PG_FVP_NS, PG_LOSS_NS = 2.06, 2.53, 0.89
     VF_STEP_US, VF_EPOCH_US = 26.5, 170.0
-    N_CU = 256
+    N_CU = 256                  # the chip the cost constants above were measured on (MI355X)
 
-    def _pg_share_begin(self, n, bs):
+    def _cu_count(self, dev):
+        """Compute units of the device the update runs on; the sharing plan is only valid where it equals N_CU (the constants are MI355X measurements and
+        'the CUs the fit leaves' means nothing on another chip): elsewhere sharing is off and every policy launch takes its full grid."""
+        c = getattr(self, "_cus", None)
+        if c is None or c[0] != dev:
+            try:
+                c = (dev, int(torch.cuda.get_device_properties(dev).multi_processor_count))
+            except Exception:       # noqa: BLE001 — unknown device: no sharing
+                c = (dev, 0)
+            self._cus = c
+        return c[1]
+
+    def _pg_share_begin(self, n, bs, dev=None):
         nb = n // bs
         vf_blocks = (bs + 31) // 32
+        if dev is not None and self._cu_count(dev) != self.N_CU:
+            self._share = None                                              # not the chip the plan was measured on
+            return
         if vf_blocks >= self.N_CU * 3 // 4:
             self._share = None                                              # the fit wants (nearly) the whole chip anyway: nothing to leave
             return
@@ -561,7 +576,7 @@ class TrpoLearner:
             with torch.cuda.stream(self._vf_stream):
                 fit_value()
             if self.vf_share:
-                self._pg_share_begin(n, bs)
+                self._pg_share_begin(n, bs, ob.device)
         self._rms_pol = rms_pol
         atarg = (atarg - atarg.mean()) / atarg.std(unbiased=False)          # :240
         if native_pg:

@@ -144,9 +144,10 @@ enum {
                              instead of waiting for the slowest wave of every step) when Q calls are queued or when any other entry
                              point of the batch is called: dm_batch_join() (no host wait), dm_batch_sync(), dm_batch_get(), ...  The
                              contract is DM_OPT_PIPELINE's, extended to the inputs: the outputs of a queued call are complete once the
-                             caller's stream has joined, and its action buffer must stay untouched until then.  A call that names a
-                             buffer of a queued call (the same tensors step after step: a closed loop that joins every step) first runs
-                             what is queued, i.e. degenerates to one launch per call.  Results are bit-identical to unqueued DM_OPT_PACKED
+                             caller's stream has joined, and its action buffer must stay untouched until then.  A call one of whose four
+                             buffers OVERLAPS (byte ranges, in any role) a buffer of a queued call — the same tensors step after step,
+                             a view into them, a queued call's observations handed in as actions: a closed loop — first runs what is
+                             queued, i.e. degenerates to one launch per call.  Results are bit-identical to unqueued DM_OPT_PACKED
                              steps.  Queuing applies where dm_batch_rollout uses one launch per horizon (DM_OPT_PACKED on, reward modes
                              0..3, constraint rows, at most two packed waves per SIMD); elsewhere calls launch at once as without it.
                              dm_batch_destroy() DROPS what is still queued (the buffers belong to the caller and may be gone). */

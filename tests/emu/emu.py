@@ -31,6 +31,7 @@ def lib():
         L.emu_redo_total.argtypes = [C.c_void_p]; L.emu_redo_total.restype = C.c_long
         L.emu_rollout.argtypes = [C.c_void_p, A._dp, A._dp, A._dp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
         L.emu_debug_forward.argtypes = [C.c_void_p, C.c_int, A._dp]
+        L.emu_dispatch.argtypes = [C.c_int, C.c_int, C.c_int, A._ip, A._ip, A._ip, C.c_int, A._ip, C.c_int, A._ip, A._ip]
         _LIB = L
     return _LIB
 
@@ -128,3 +129,15 @@ class EmuBatch(object):
         buf = np.zeros(A.DEBUG_DOUBLES)
         lib().emu_debug_forward(self.h, env, buf.ctypes.data_as(A._dp))
         return A.parse_debug(buf)
+
+
+def dispatch(n, first, count, nefc, solver_iter, arrival, order=None, with_tickets=True):
+    """env_step.h order_ticket + dispatch_env on the testbench: the dispatch order of the launch after one in which the envs `arrival` (in that order)
+    took their tickets.  Returns (one env per wave [count], four per wave [4 * ceil(count / 4)])."""
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    ne, it, ar = i32(nefc), i32(solver_iter), i32(arrival)
+    od = None if order is None else i32(order)
+    out1 = np.full(count, -1, np.int32); out4 = np.full(4 * ((count + 3) // 4), -1, np.int32)
+    lib().emu_dispatch(n, first, count, ne.ctypes.data_as(A._ip), it.ctypes.data_as(A._ip), ar.ctypes.data_as(A._ip), len(ar),
+                       None if od is None else od.ctypes.data_as(A._ip), 1 if with_tickets else 0, out1.ctypes.data_as(A._ip), out4.ctypes.data_as(A._ip))
+    return out1, out4

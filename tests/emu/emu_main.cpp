@@ -174,6 +174,26 @@ void emu_rollout(void* h, const double* action, double* obs, double* reward, uns
   e->redo_total += e->B.redo_why[0] - before;
 }
 long emu_redo_total(void* h) { return ((EmuBatch*)h)->redo_total; }
+// Self-ordering per-step launches (env_step.h order_ticket / dispatch_env) without the physics: `count` envs first .. first + count - 1 of a batch of n take
+// their tickets in the order `arrival` names them (n_arrival of them; keys from nefc / iter), then the waves of the next launch look their envs up — one env per wave
+// (out1[count]) and four per wave (out4[4 * ceil(count / 4)], spare slots repeat the last position).  with_tickets = 0: no tickets -> `order` / identity.
+void emu_dispatch(int n, int first, int count, const int* nefc, const int* iter, const int* arrival, int n_arrival, const int* order, int with_tickets, int* out1, int* out4) {
+  std::vector<int> cnt(3 * ORD_BUCKETS, 0), list((size_t)3 * ORD_BUCKETS * n, -1);
+  Batch<double> B{};
+  B.order = const_cast<int*>(order);
+  B.ord_stride = n;
+  B.ord_out = cnt.data() + ORD_BUCKETS; B.ordl_out = list.data() + (size_t)ORD_BUCKETS * n + first;
+  if (with_tickets) for (int i = 0; i < n_arrival; i++) { const int e = arrival[i]; order_ticket(B, e, nefc[e], iter[e]); }
+  B.ord_in = with_tickets ? cnt.data() + ORD_BUCKETS : nullptr; B.ordl_in = list.data() + (size_t)ORD_BUCKETS * n + first;
+  B.ord_out = cnt.data() + 2 * ORD_BUCKETS; B.ordl_out = list.data() + (size_t)2 * ORD_BUCKETS * n + first;
+  B.ord_zero = cnt.data();
+  for (int k = 0; k < ORD_BUCKETS; k++) cnt[k] = 12345;              // the phase the launch's first workgroup clears
+  for (int w = 0; w < count; w++)
+    run_wave([&](int lane) { int e; dispatch_env<1>(B, first, count, w, lane, w == 0, &e); if (lane == 0) out1[w] = e; });
+  for (int k = 0; k < ORD_BUCKETS; k++) if (cnt[k] != 0) out1[0] = -1000 - k;   // (reported as a bad env)
+  for (int w = 0; w * SLOTS < count; w++)
+    run_wave([&](int lane) { int e[SLOTS]; dispatch_env<SLOTS>(B, first, count, SLOTS * w, lane, false, e); if (lane == 0) for (int j = 0; j < SLOTS; j++) out4[SLOTS * w + j] = e[j]; });
+}
 void emu_set_state(void* h, const double* qpos, const double* qvel, const int* fidx, const unsigned char* mask) {
   EmuBatch* e = (EmuBatch*)h;
   std::fill(e->kin_ok.begin(), e->kin_ok.end(), 0);

@@ -276,3 +276,9 @@ def test_vec_env_step_wait_host_overhead_is_small_at_4096_envs():
         cur = env.step(act)[3]
         write(cur[0])
         assert env.step(act)[3] is not cur
+    # ... nor is a write into the LIST (the reference hands out a copy per step: src/utils/vec_env/dummy_vec_env.py:56)
+    for write in (lambda l: l.__setitem__(3, {"x": 1}), lambda l: l.append({}), lambda l: l.__delitem__(0), lambda l: l.extend([{}]), lambda l: l.pop()):
+        cur = env.step(act)[3]
+        write(cur)
+        nxt = env.step(act)[3]
+        assert nxt is not cur and len(nxt) == n and all(not d for d in nxt)

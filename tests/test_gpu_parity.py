@@ -548,3 +548,57 @@ def test_packed_kernel_matches_oracle_full_contact(clip):
             k = min(int(onc[e]), A.MAXEFC)
             assert np.array_equal(cg[e][:k], ods[e].get("contact_geom").reshape(-1, 2).astype(np.int32)[:k]) and np.all(cg[e][k:] == -1)
     b.close()
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_self_ordering_launches_step_every_env_exactly_once_whatever_runs_in_between(packed):
+    """Per-step launches order themselves (env_step.h dispatch_env / order_ticket; dmenv.hip ord_bind): three rotating ticket phases per pipelined
+    part.  Device-pointer steps of 4 096 + 37 envs (more than the resident waves, so the order is active) through every hand-over of the host's
+    bookkeeping — one launch per step, two and three pipelined parts, a partition change, a horizon launch, a reset and a host-pointer step in
+    between: after every step each env's clock has advanced by exactly one time step (an env stepped twice or not at all shows there), and the
+    whole run is bit-identical to the same run with the dispatch order off (option 104)."""
+    import torch
+    n, dt = 4096 + 37, 0.0166
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    T = 26
+    ac = torch.randn((T, n, 28), generator=g, dtype=torch.float64, device=dev) * 0.9
+    finals = []
+    for on in (1, 0):
+        b = make_batch(n)
+        b.set_option(A.OPT_PACKED, 1 if packed else 0); b.set_option(104, on); b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, 9)
+        b.set_option(A.OPT_DIAGNOSTICS, 0)
+        b.reset(0, 1)
+        ob = torch.zeros((n, 56), dtype=torch.float64, device=dev); rw = torch.zeros(n, dtype=torch.float64, device=dev); dn = torch.zeros(n, dtype=torch.uint8, device=dev)
+        t_prev = b.get(A.F_TIME).copy(); ep_prev = b.get(A.F_EPISODE).copy()
+        hist = []
+        for t in range(T):
+            if t == 4: b.set_option(A.OPT_PIPELINE, 2)
+            if t == 10: b.set_option(A.OPT_PIPELINE, 3)          # a new partition: the old parts' tickets must not be used
+            if t == 14: b.set_option(A.OPT_PIPELINE, 1)
+            if t == 18: b.set_option(A.OPT_PIPELINE, 2)
+            if t == 16:                                          # a horizon launch in between (packed only): tickets grow stale, stay a permutation
+                if packed:
+                    o2 = torch.zeros((3, n, 56), dtype=torch.float64, device=dev); r2 = torch.zeros((3, n), dtype=torch.float64, device=dev); d2 = torch.zeros((3, n), dtype=torch.uint8, device=dev)
+                    b.set_option(106, 1); b.rollout(ac[:4].contiguous(), (o2, r2, d2), 1); b.set_option(106, -1)
+                    b.join(); b.sync()
+                    hist.append(o2.cpu().numpy().copy())
+                    t_prev = b.get(A.F_TIME).copy(); ep_prev = b.get(A.F_EPISODE).copy()
+            if t == 20:                                          # a host-pointer step (one launch over the whole batch while two parts are configured)
+                o, r, d = b.step(ac[t].cpu().numpy())
+                hist.append(o.copy())
+            else:
+                b.step(ac[t], 1, (ob, rw, dn)); b.join(); b.sync()
+                hist.append(ob.cpu().numpy().copy())
+            tm = b.get(A.F_TIME); ep = b.get(A.F_EPISODE)
+            fresh = ep != ep_prev                                # auto-reset: the clock restarts
+            assert np.allclose(np.where(fresh, dt, tm - t_prev), dt, rtol=0, atol=1e-12), "step %d: an env was stepped twice or not at all" % t
+            t_prev, ep_prev = tm.copy(), ep.copy()
+            if t == 7: b.reset(0, 1); t_prev = b.get(A.F_TIME).copy(); ep_prev = b.get(A.F_EPISODE).copy()
+        finals.append((hist, b.get(A.F_QPOS), b.get(A.F_QVEL), b.get(A.F_NEFC)))
+        b.close()
+    for x, y in zip(finals[0][0], finals[1][0]):
+        assert np.array_equal(x, y)
+    for i in (1, 2, 3):
+        assert np.array_equal(finals[0][i], finals[1][i])
+    assert finals[0][3].max() > 8

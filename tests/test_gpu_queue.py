@@ -231,3 +231,37 @@ def test_dpvecenv_step_queue_argument():
     assert bool(torch.isfinite(ob).all()) and float(rew.min()) == 1.0 and len(infos) == n
     assert float(outs[3][0].abs().sum()) > 0
     env.close()
+
+
+def test_a_call_that_overlaps_a_queued_buffer_in_any_role_runs_the_queue_first():
+    """dmenv.h DM_OPT_STEP_QUEUE: "overlaps" is a byte-range test over all four buffers of every queued call (round 4 compared base pointers per role).
+    Views that start elsewhere in a queued call's tensors and a buffer that changes its role are handed in; each such call must flush (queue_stats),
+    and the results equal the same calls with the queue off."""
+    n = 512
+    g = torch.Generator(device=DEV); g.manual_seed(2)
+    ac = torch.randn((6, n, 28), generator=g, dtype=torch.float64, device=DEV) * 0.9
+    res = []
+    for qd in (0, 16):
+        env = _make(n, reward="alive", queue=qd)
+        b = env.batch
+        env.reset("rsi")
+        big_o = torch.zeros((2 * n + 8, 56), dtype=torch.float64, device=DEV)     # overlapping [n, 56] windows live in here
+        big_r = torch.zeros(2 * n, dtype=torch.float64, device=DEV); big_d = torch.zeros(2 * n, dtype=torch.uint8, device=DEV)
+        o1 = torch.zeros((n, 56), dtype=torch.float64, device=DEV); r1 = torch.zeros(n, dtype=torch.float64, device=DEV); d1 = torch.zeros(2 * n, dtype=torch.uint8, device=DEV)
+        fl = []
+        flushes = lambda: b.queue_stats()[0] if qd else 0
+        b.step(ac[0], 1, (big_o[:n], big_r[:n], big_d[:n])); fl.append(flushes())
+        b.step(ac[1], 1, (big_o[8:n + 8], big_r[n:], big_d[n:])); fl.append(flushes())                        # obs window overlaps step 0's at another base address
+        b.step(ac[2], 1, (o1, big_r[n // 2:n // 2 + n], d1[:n])); fl.append(flushes())                        # reward window straddles step 1's reward buffer
+        obs3 = big_o[n + 8:2 * n + 8]
+        b.step(ac[3], 1, (obs3, r1, d1[n // 2:n // 2 + n])); fl.append(flushes())                             # done window overlaps step 2's
+        b.step(obs3.view(-1)[:n * 28].view(n, 28), 1, (big_o[:n], big_r[:n], big_d[:n])); fl.append(flushes())  # a queued call's OUTPUT bytes as this call's action
+        b.join(); b.sync()
+        res.append((fl, big_o.clone(), big_r.clone(), big_d.clone(), o1.clone(), r1.clone(), d1.clone()) + _state(b))
+        env.close()
+    x, y = res
+    assert y[0] == [0, 1, 2, 3, 4], y[0]            # every overlapping call ran what was queued before it was queued itself
+    for i in range(1, 7):
+        assert torch.equal(x[i], y[i]), i
+    for i in range(7, len(x)):
+        assert np.array_equal(x[i], y[i]), i

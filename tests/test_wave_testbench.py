@@ -257,3 +257,33 @@ def test_packed_horizon_in_one_wave_equals_step_by_step(mode):
     assert outs[0][-1] == outs[1][-1] > 0, "the horizon must contain capacity overflows (%d / %d)" % (outs[0][-1], outs[1][-1])
     if mode == 3:
         assert int(outs[1][2].sum()) > 0, "the imitation horizon must contain auto-resets (kin_carry invalidated)"
+
+
+def test_self_ordering_launches_dispatch_a_permutation_longest_first():
+    """env_step.h order_ticket / dispatch_env (per-step launches order themselves; no k_order between two steps): whatever the arrival order of the
+    previous launch's envs, the next launch's waves find every env of the part exactly once, cost keys descending — one env per wave and four per
+    wave — and the launch's first workgroup clears the counters of the launch after it.  Without tickets: the stored order, else the identity."""
+    from tests.emu import emu
+    rng = np.random.RandomState(11)
+    n = 300
+    for first, count in ((0, 300), (64, 131), (297, 3), (10, 1)):
+        nefc = rng.randint(0, 70, n); it = rng.randint(0, 51, n)
+        arrival = first + rng.permutation(count)
+        o1, o4 = emu.dispatch(n, first, count, nefc, it, arrival)
+        key = np.clip(nefc + (it >> 2), 0, 63)
+        assert sorted(o1.tolist()) == list(range(first, first + count))
+        assert np.all(np.diff(key[o1]) <= 0)                       # longest first
+        assert np.array_equal(o4[:count], o1)                      # the four-per-wave lookup is the same order ...
+        assert np.all(o4[count:] == o1[-1])                        # ... spare slots repeat the last position
+        # inside a bucket: the order of arrival
+        for k in np.unique(key[o1]):
+            assert [e for e in o1 if key[e] == k] == [e for e in arrival if key[e] == k]
+    # no tickets yet: the stored order of the part, or the identity
+    order = np.arange(n, dtype=np.int32); order[64:195] = 64 + rng.permutation(131)
+    o1, o4 = emu.dispatch(n, 64, 131, np.zeros(n), np.zeros(n), np.arange(64, 195), order=order, with_tickets=False)
+    assert np.array_equal(o1, order[64:195]) and np.array_equal(o4[:131], o1)
+    o1, _ = emu.dispatch(n, 64, 131, np.zeros(n), np.zeros(n), np.arange(64, 195), with_tickets=False)
+    assert np.array_equal(o1, np.arange(64, 195))
+    # tickets that do not cover the part exactly (an env missing) are not trusted: identity
+    o1, _ = emu.dispatch(n, 0, 50, rng.randint(0, 30, n), np.zeros(n), np.arange(49))
+    assert np.array_equal(o1, np.arange(50))
