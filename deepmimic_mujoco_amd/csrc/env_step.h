@@ -67,7 +67,7 @@ DM_DEV Batch<R> global_members(Batch<R> b) {
   b.kin = in_global(b.kin); b.kin_ok = in_global(b.kin_ok); b.redo_list = in_global(b.redo_list); b.redo_count = in_global(b.redo_count);
   b.redo_why = in_global(b.redo_why); b.mocap_cfg = in_global(b.mocap_cfg); b.mocap_vel = in_global(b.mocap_vel);
   b.imit_table = in_global(b.imit_table); b.imit_pdev = in_global(b.imit_pdev);
-  b.ord_in = in_global(b.ord_in); b.ordl_in = in_global(b.ordl_in); b.ord_out = in_global(b.ord_out); b.ordl_out = in_global(b.ordl_out); b.ord_zero = in_global(b.ord_zero);
+  // (the ord_* members stay as they are: code behind a call runs inside horizon launches, which take no tickets — the members are null there)
   return b;
 }
 

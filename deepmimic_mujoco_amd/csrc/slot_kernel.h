@@ -15,12 +15,15 @@
 // take over the LDS region of the inertias.
 #pragma once
 
+#include <cstddef>
+
 #include "env_kernel.h"
 
 namespace dm {
 
 constexpr int SLOTS = 4, SW = 16;            // environments per wavefront, lanes per environment
-constexpr int SLOT_MAXROWS = 32, SLOT_MAXLIMROWS = 16, SLOT_MAXCON = 13, SLOT_MAXFRAME = 8, SLOT_MAXCAND = 32, SLOT_BOXSLOTS = 3;   // per-environment capacities of the packed path; beyond: fix-up by the one-env kernel
+constexpr int SLOT_MAXROWS = 40, SLOT_MAXLIMROWS = 16, SLOT_MAXCON = 13, SLOT_MAXFRAME = 8, SLOT_MAXCAND = 32, SLOT_BOXSLOTS = 3;   // per-environment capacities of the packed path; beyond: fix-up by the one-env kernel
+constexpr int SLOT_EXTROWS = SLOT_MAXROWS - 2 * SW;     // rows 32 .. 39: the partial third row set of slot_constraint<3> (owned by the even lanes)
 constexpr int PAIR_PASSES = MAXPAIR / SW;
 constexpr int DOF_PASSES = (NV + SW - 1) / SW, HINGE_PASSES = (NU + SW - 1) / SW, Q_PASSES = (NQ + SW - 1) / SW, ENT_PASSES = (310 + SW - 1) / SW;
 
@@ -66,6 +69,10 @@ struct SlotShared {
 #endif
 };
 static_assert(NQ == 35, "qpos[36] has one spare element");
+static_assert(offsetof(SlotShared<double>, cdof) == offsetof(SlotShared<double>, qd) + sizeof(((SlotShared<double>*)0)->qd) &&
+              offsetof(SlotShared<float>, cdof) == offsetof(SlotShared<float>, qd) + sizeof(((SlotShared<float>*)0)->qd) &&
+              sizeof(((SlotShared<double>*)0)->qd) + sizeof(((SlotShared<double>*)0)->cdof) >= sizeof(double) * NV * (SLOT_MAXROWS - 2 * SW),
+              "slot_constraint<3> parks the surplus rows' half-solved vectors in the adjacent qd + cdof regions");
 static_assert(sizeof(SlotShared<double>) * SLOTS + 1576 <= 40 * 1024, "four waves of four environments must fit a CU's 160 KB of LDS");
 // index tables shared by the four slots of a workgroup (compile-time topology; see LaneTables)
 struct SlotTables {
@@ -723,6 +730,156 @@ struct SlotAssemble {
   }
 };
 
+// ---- the partial third row set (rows 32 .. 39; slot_constraint<3>) ------------------------------------------------------------------
+// A standing humanoid holds 8 foot corners x 4 pyramid edges = 32 contact rows plus one to five joint limits: 33 .. 37 rows, ~5 % of a learning
+// run's env-steps (profiles/r04_ab_kernel_variants.md), which rounds 3-4 re-stepped one env per wave at ~785 k cycles each.  A third full row set
+// does not fit a lane's registers (3 x 34 doubles of Y and 3 x 48 of A); what fits is the SYMMETRIC part of it: row 32 + j lives on lane 2 j of the
+// slot (j < 8) and only the two blocks of A that touch the surplus rows are kept —
+//   U[k][j] = A[row (sl, k)][32 + j]   (every lane, both full sets: the column block; scaled by -1 / A_rr like the rest of the lane's rows)
+//   B[j]    = A[32 + sl / 2][32 + j]   (the 8 x 8 corner, rows on the even lanes)
+// — the row block A[32 + j][c < 32] is the column block transposed, so a surplus row's residual is FORMED once per sweep from the forces
+// (sum over the 16 lanes of U[k][j] f_k: a reduce-scatter whose natural landing lanes are 2 j, 2 j + 1 — hence the ownership) instead of being carried
+// through the 32 rows before it.  The 32 rows themselves run the two-set code unchanged: an environment with <= 32 rows that shares its wave
+// with a heavier one gets bit-identical results (its surplus terms are exact zeros).
+// sum over the 16 lanes of the own DPP row of eight values at once; p[j]'s total lands on lanes 2 j and 2 j + 1 (returned)
+template <class R>
+DM_DEV R row_reduce8(const R* p, int sl) {
+  const bool b3 = (sl & 8) != 0, b2 = (sl & 4) != 0, b1 = (sl & 2) != 0;
+  R q[4], r2[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { const R keep = b3 ? p[4 + i] : p[i], send = b3 ? p[i] : p[4 + i]; q[i] = keep + dmw::perm_row_mirror(send); }       // partner 15 - sl keeps the other half
+#pragma unroll
+  for (int i = 0; i < 2; i++) { const R keep = b2 ? q[2 + i] : q[i], send = b2 ? q[i] : q[2 + i]; r2[i] = keep + dmw::perm_half_mirror(send); }      // partner (sl ^ 7): same bit 3, other bit 2
+  const R keep = b1 ? r2[1] : r2[0], send = b1 ? r2[0] : r2[1];
+  R v = keep + dmw::perm_xor2(send);                                                                                                                // partner sl ^ 2
+  v += dmw::perm_xor1(v);                                                                                                                           // sl ^ 1 holds the same index
+  return v;
+}
+// column block / corner entries of A for surplus row J: U[k][J] = Y_(own row, set k) . Y_(32 + J), B[J] = Y_(own surplus row) . Y_(32 + J)
+template <int J, class R>
+DM_DEV void slot_ext_col(R (*U)[SLOT_EXTROWS], R* B, const R (*y)[NV], const R* y3) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const R* mine = k < 2 ? y[k] : y3;
+    R acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int d = 0; d + 8 <= NV; d += 8) dmw::row_fmac8<2 * J>(acc0, acc1, &y3[d], &mine[d]);
+#pragma unroll
+    for (int d = NV / 8 * 8; d < NV; d += 2) { dmw::row_fmac_old<2 * J>(acc0, y3[d], mine[d]); dmw::row_fmac_old<2 * J>(acc1, y3[d + 1], mine[d + 1]); }
+    if (k < 2) U[k][J] = acc0 + acc1; else B[J] = acc0 + acc1;
+  }
+}
+template <int J, class R>
+struct SlotExtCols {
+  static DM_DEV void run(R (*U)[SLOT_EXTROWS], R* B, const R (*y)[NV], const R* y3, int next) {
+    if constexpr (J < SLOT_EXTROWS) {
+      slot_ext_col<J, R>(U, B, y, y3); slot_ext_col<J + 1, R>(U, B, y, y3); slot_ext_col<J + 2, R>(U, B, y, y3); slot_ext_col<J + 3, R>(U, B, y, y3);
+      if (J + 4 < next) SlotExtCols<J + 4, R>::run(U, B, y, y3, next);
+    }
+  }
+};
+// warm start: the surplus columns scaled in place (rows by -1 / A_rr), t_k += A_s[k][32 + J] f3_J
+template <int J, class R>
+struct SlotExtWarm {
+  static DM_DEV void run(R (*U)[SLOT_EXTROWS], R* B, R* t, R f3, const R* ndinv, R ndinv3, int next) {
+    if constexpr (J < SLOT_EXTROWS) {
+#pragma unroll
+      for (int j = J; j < J + 4; j++) { U[0][j] *= ndinv[0]; U[1][j] *= ndinv[1]; B[j] *= ndinv3; }
+      dmw::row_fmac_old<2 * J>(t[0], f3, U[0][J]); dmw::row_fmac_old<2 * J>(t[1], f3, U[1][J]);
+      dmw::row_fmac_old<2 * J + 2>(t[0], f3, U[0][J + 1]); dmw::row_fmac_old<2 * J + 2>(t[1], f3, U[1][J + 1]);
+      dmw::row_fmac_old<2 * J + 4>(t[0], f3, U[0][J + 2]); dmw::row_fmac_old<2 * J + 4>(t[1], f3, U[1][J + 2]);
+      dmw::row_fmac_old<2 * J + 6>(t[0], f3, U[0][J + 3]); dmw::row_fmac_old<2 * J + 6>(t[1], f3, U[1][J + 3]);
+      if (J + 4 < next) SlotExtWarm<J + 4, R>::run(U, B, t, f3, ndinv, ndinv3, next);
+    }
+  }
+};
+// scaled residual of the own surplus row from the forces:  tb3 + (-1 / A_rr) sum_(c < 32) A[32 + j][c] f_c + sum_i B_s[i] f3_i
+// (U holds A_s[c][32 + j] = -A[c][32 + j] / A_cc: times g_c = -A_cc f_c it is the entry of A times the force again)
+template <class R>
+DM_DEV R slot_ext_residual(const R (*U)[SLOT_EXTROWS], const R* B, const R* f, const R* diag, R f3, R tb3, R ndinv3, int sl) {
+  const R g0 = -(diag[0] * f[0]), g1 = -(diag[1] * f[1]);
+  R p[SLOT_EXTROWS];
+#pragma unroll
+  for (int j = 0; j < SLOT_EXTROWS; j++) p[j] = U[0][j] * g0 + U[1][j] * g1;
+  R t3 = tb3 + ndinv3 * row_reduce8(p, sl);
+  dmw::dpp_settle();
+  dmw::row_fmac_old<0>(t3, f3, B[0]); dmw::row_fmac_old<2>(t3, f3, B[1]); dmw::row_fmac_old<4>(t3, f3, B[2]); dmw::row_fmac_old<6>(t3, f3, B[3]);
+  dmw::row_fmac_old<8>(t3, f3, B[4]); dmw::row_fmac_old<10>(t3, f3, B[5]); dmw::row_fmac_old<12>(t3, f3, B[6]); dmw::row_fmac_old<14>(t3, f3, B[7]);
+  return t3;
+}
+// the surplus rows of one Gauss-Seidel sweep, in order, after the 32 rows before them: their steps also move the residuals of both full sets
+template <int J, class R>
+struct SlotExtSweep {
+  static DM_DEV void run(const R (*U)[SLOT_EXTROWS], const R* B, R& t3, R& tsave3, R* t, R nf03, const R* oh, int next) {
+    if constexpr (J < SLOT_EXTROWS) {
+      dmw::pgs_row3<2 * J>(t3, tsave3, t[0], t[1], nf03, B[J], U[0][J], U[1][J], oh[2 * J]);
+      dmw::pgs_row3<2 * J + 2>(t3, tsave3, t[0], t[1], nf03, B[J + 1], U[0][J + 1], U[1][J + 1], oh[2 * J + 2]);
+      dmw::pgs_row3<2 * J + 4>(t3, tsave3, t[0], t[1], nf03, B[J + 2], U[0][J + 2], U[1][J + 2], oh[2 * J + 4]);
+      dmw::pgs_row3<2 * J + 6>(t3, tsave3, t[0], t[1], nf03, B[J + 3], U[0][J + 3], U[1][J + 3], oh[2 * J + 6]);
+      if (J + 4 < next) SlotExtSweep<J + 4, R>::run(U, B, t3, tsave3, t, nf03, oh, next);
+    }
+  }
+};
+template <int I, class R>
+DM_DEV void slot_assemble_lane(R* ws, const R* fy, R one) {          // ws[d] += (lane I of the row's fy[d])
+#pragma unroll
+  for (int d = 0; d + 8 <= NV; d += 8) dmw::row_add8<I>(&ws[d], &fy[d], one);
+#pragma unroll
+  for (int d = NV / 8 * 8; d < NV; d++) dmw::row_fmac_old<I>(ws[d], fy[d], one);
+}
+template <int J, class R>
+struct SlotExtAssemble {
+  static DM_DEV void run(R* ws, const R* fy3, R one, int next) {
+    if constexpr (J < SLOT_EXTROWS) {
+      slot_assemble_lane<2 * J, R>(ws, fy3, one); slot_assemble_lane<2 * J + 2, R>(ws, fy3, one); slot_assemble_lane<2 * J + 4, R>(ws, fy3, one); slot_assemble_lane<2 * J + 6, R>(ws, fy3, one);
+      if (J + 4 < next) SlotExtAssemble<J + 4, R>::run(ws, fy3, one, next);
+    }
+  }
+};
+
+// Jacobian wrench, distance and regularisation constants of constraint row r of the slot (what the row's lane needs before the dof loop)
+template <class R>
+DM_DEV void slot_row_setup(const DevModel<R>& M, const SlotShared<R>& s, int r, bool active, RowAcc<R>& ra, R& pos, R& margin, R& dA, R& rscale) {
+  const auto& W = s.r1.rw;
+  const int code = active ? W.rowi[r] : 0;
+  const int type = code & 0xff;
+  R w[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long mplus = 0, mminus = 0;
+  pos = 0; margin = 0; dA = 0; rscale = 1;
+  R w7 = 0;
+  if (type == ROW_LIMIT) {
+    const int d = (code >> 8) & 0xff;
+    w7 = ((code >> 16) & 1) ? R(1) : R(-1);
+    pos = W.rowv[r]; dA = M.dof_invw[d]; mplus = 1ull << d;
+  } else if (type == ROW_CONTACT) {
+    const int ci = (code >> 8) & 0xff, q = (code >> 16) & 0xf, cdim = (code >> 20) & 0xf;
+    const R* c = W.con[ci];
+    const int cw = W.coni[ci];
+    const R* fm = W.frm[(cw >> 8) & 0xff];
+    const auto& rec = M.pair_rec[cw & 0xff];
+    const R cmu = rec.mu, ctran = rec.tran;
+    const int meta = rec.meta;
+    R dir[3] = {fm[0], fm[1], fm[2]};
+    if (cdim != 1) {
+      const R n[3] = {fm[0], fm[1], fm[2]}, t1[3] = {fm[3], fm[4], fm[5]};
+      R t2[3];
+      cross3(t2, n, t1);
+      const R sg = (q & 1) ? -cmu : cmu;
+      const R* tg = (q >> 1) ? t2 : t1;
+      dir[0] += sg * tg[0]; dir[1] += sg * tg[1]; dir[2] += sg * tg[2];
+    }
+    cross3(w, c, dir);
+    w[3] = dir[0]; w[4] = dir[1]; w[5] = dir[2];
+    pos = c[3]; margin = rec.margin;
+    dA = cdim == 1 ? ctran : ctran + cmu * cmu * ctran;
+    rscale = cdim == 1 ? R(1) : 2 * cmu * cmu;
+    mminus = TOPO.chain[meta & 0xff]; mplus = TOPO.chain[(meta >> 8) & 0xff];
+  }
+  for (int r6 = 0; r6 < 6; r6++) ra.w[r6] = w[r6];
+  ra.w7 = w7; ra.w8 = 0; ra.vel = 0; ra.jws = 0;
+  ra.plus_lo = (unsigned)mplus; ra.plus_hi = (unsigned)(mplus >> 32); ra.minus_lo = (unsigned)mminus; ra.minus_hi = (unsigned)(mminus >> 32);
+}
+
 // ---- constraint solve of the slot's environment; lane sl owns rows sl + 16 k, k < NS (limits first, then contacts in list order)
 //      [MJ mj_fwdAcceleration, mj_projectConstraint, mj_fwdConstraint (warmstart, mj_solPGS)] -----------------------------------------
 // Same mathematics as env_kernel.h stage_constraint (half-solved vectors Y = D^-1/2 L^-T J^T, A = Y Y^T + R, scaled-residual PGS,
@@ -730,81 +887,48 @@ struct SlotAssemble {
 // smooth force's half solve z is carried by EVERY lane beside its rows (same factor loads), and the final L^-1 pass runs on a
 // register vector that all 16 lanes of the slot hold.  `nefc` is the slot's row count, `nmax` the wave's largest (row loops run to it;
 // a slot's absent rows are exact zeros).  The sweeps of a converged environment are frozen, so its result does not depend on its partners.
+// NS = 3: the two full sets plus the partial third one (rows 32 .. 39 on the even lanes; see "the partial third row set" above).
 template <class R, int NS, bool PROF = false>
 DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int nefc, int nmax, int& ovf, const DebugOut* dbg, long long* prof = 0) {
   const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
   long long pt0 = 0, pt1 = 0, pt_enter = 0;
   if (PROF) { pt0 = dmw::clk(); pt_enter = pt0; }
-#define SLOT_STAMP(k) if constexpr (NS == 1) { DM_MARK("slot_constraint_ns1_" #k); } else { DM_MARK("slot_constraint_ns2_" #k); } if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
-  constexpr int NC = 16 * NS;
-  if constexpr (NS == 1) { DM_MARK("slot_constraint_ns1_rows"); } else { DM_MARK("slot_constraint_ns2_rows"); }
-  auto& W = s.r1.rw;
-  R y[NS + 1][NV];                     // rows' Jacobians -> Y;  y[NS] = tau -> z (identical in every lane of the slot)
-  RowAcc<R> ra[NS];
-  bool active[NS];
-  R pos[NS], margin[NS], dA[NS], rscale[NS];
+#define SLOT_STAMP(k) if constexpr (NS == 1) { DM_MARK("slot_constraint_ns1_" #k); } else if constexpr (NS == 2) { DM_MARK("slot_constraint_ns2_" #k); } else { DM_MARK("slot_constraint_ns3_" #k); } if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
+  constexpr bool EXT = NS == 3;              // the partial third row set is there
+  constexpr int NF = EXT ? 2 : NS;           // full row sets
+  constexpr int NC = 16 * NF;
+  constexpr int NX = EXT ? SLOT_EXTROWS : 1;
+  if constexpr (NS == 1) { DM_MARK("slot_constraint_ns1_rows"); } else if constexpr (NS == 2) { DM_MARK("slot_constraint_ns2_rows"); } else { DM_MARK("slot_constraint_ns3_rows"); }
+  R y[NF + 1][NV];                     // rows' Jacobians -> Y;  y[NF] = tau -> z (identical in every lane of the slot)
+  RowAcc<R> ra[NF];
+  bool active[NF];
+  R pos[NF], margin[NF], dA[NF], rscale[NF];
 #pragma unroll
-  for (int k = 0; k < NS; k++) {
+  for (int k = 0; k < NF; k++) {
     const int r = sl + 16 * k;
     active[k] = r < nefc;
-    const int code = active[k] ? W.rowi[r] : 0;
-    const int type = code & 0xff;
-    R w[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long mplus = 0, mminus = 0;
-    pos[k] = 0; margin[k] = 0; dA[k] = 0; rscale[k] = 1;
-    R w7 = 0;
-    if (type == ROW_LIMIT) {
-      const int d = (code >> 8) & 0xff;
-      w7 = ((code >> 16) & 1) ? R(1) : R(-1);
-      pos[k] = W.rowv[r]; dA[k] = M.dof_invw[d]; mplus = 1ull << d;
-    } else if (type == ROW_CONTACT) {
-      const int ci = (code >> 8) & 0xff, q = (code >> 16) & 0xf, cdim = (code >> 20) & 0xf;
-      const R* c = W.con[ci];
-      const int cw = W.coni[ci];
-      const R* fm = W.frm[(cw >> 8) & 0xff];
-      const auto& rec = M.pair_rec[cw & 0xff];
-      const R cmu = rec.mu, ctran = rec.tran;
-      const int meta = rec.meta;
-      R dir[3] = {fm[0], fm[1], fm[2]};
-      if (cdim != 1) {
-        const R n[3] = {fm[0], fm[1], fm[2]}, t1[3] = {fm[3], fm[4], fm[5]};
-        R t2[3];
-        cross3(t2, n, t1);
-        const R sg = (q & 1) ? -cmu : cmu;
-        const R* tg = (q >> 1) ? t2 : t1;
-        dir[0] += sg * tg[0]; dir[1] += sg * tg[1]; dir[2] += sg * tg[2];
-      }
-      cross3(w, c, dir);
-      w[3] = dir[0]; w[4] = dir[1]; w[5] = dir[2];
-      pos[k] = c[3]; margin[k] = rec.margin;
-      dA[k] = cdim == 1 ? ctran : ctran + cmu * cmu * ctran;
-      rscale[k] = cdim == 1 ? R(1) : 2 * cmu * cmu;
-      mminus = TOPO.chain[meta & 0xff]; mplus = TOPO.chain[(meta >> 8) & 0xff];
-    }
-    for (int r6 = 0; r6 < 6; r6++) ra[k].w[r6] = w[r6];
-    ra[k].w7 = w7; ra[k].w8 = 0; ra[k].vel = 0; ra[k].jws = 0;
-    ra[k].plus_lo = (unsigned)mplus; ra[k].plus_hi = (unsigned)(mplus >> 32); ra[k].minus_lo = (unsigned)mminus; ra[k].minus_hi = (unsigned)(mminus >> 32);
+    slot_row_setup(M, s, r, active[k], ra[k], pos[k], margin[k], dA[k], rscale[k]);
   }
   {
     R cur[8];
     dmw::reload_fence();
     slot_load_dof_operands<0>(cur, s);
-    SlotRowStep<0, NS, R>::run(y, ra, s, cur);
+    SlotRowStep<0, NF, R>::run(y, ra, s, cur);
   }
 #pragma unroll
-  for (int d = 0; d < NV; d++) y[NS][d] = s.tau[d];
+  for (int d = 0; d < NV; d++) y[NF][d] = s.tau[d];
   if (dbg) {
 #pragma unroll
-    for (int k = 0; k < NS; k++) if (active[k]) {
+    for (int k = 0; k < NF; k++) if (active[k]) {
       double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + (sl + 16 * k) * (34 + 6);
 #pragma unroll
       for (int d = 0; d < NV; d++) o[d] = (double)y[k][d];
     }
   }
   SLOT_STAMP(8)
-  R Rr[NS], aref[NS], f[NS];
+  R Rr[NF], aref[NF], f[NF];
 #pragma unroll
-  for (int k = 0; k < NS; k++) {
+  for (int k = 0; k < NF; k++) {
     const R imp = impedance(M, pos[k] - margin[k]);
     Rr[k] = fmax(R(DM_MINVAL), (1 - imp) * dA[k] / imp);
     if (rscale[k] != R(1)) Rr[k] = fmax(R(DM_MINVAL), rscale[k] * Rr[k]);
@@ -813,43 +937,100 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
     f[k] = (active[k] && jar < 0) ? -jar / Rr[k] : R(0);
   }
   // half solves: rows J^T -> Y, tau -> z
-  slot_solve_LT<NS + 1>(y, s.r2.qLD);
+  slot_solve_LT<NF + 1>(y, s.r2.qLD);
 #pragma unroll
   for (int d = 0; d < NV; d++) {
     const R sc = s.dsq[d];
 #pragma unroll
-    for (int k = 0; k <= NS; k++) { y[k][d] *= sc; dmw::pin_value(y[k][d]); }
+    for (int k = 0; k <= NF; k++) { y[k][d] *= sc; dmw::pin_value(y[k][d]); }
   }
   if (dbg) {      // debug dump only: qacc_smooth = L^-1 D^-1/2 z next to a constrained solve
     R x[NV];
 #pragma unroll
-    for (int d = 0; d < NV; d++) x[d] = y[NS][d] * s.dsq[d];
+    for (int d = 0; d < NV; d++) x[d] = y[NF][d] * s.dsq[d];
     solve_L(x, s.r2.qLD);
     if (sl == 0) {
 #pragma unroll
       for (int d = 0; d < NV; d++) dbg->out[34 * 34 + 34 + d] = (double)x[d];
     }
   }
-  R bb[NS];
+  R bb[NF];
 #pragma unroll
-  for (int k = 0; k < NS; k++) {
+  for (int k = 0; k < NF; k++) {
     R acc0 = 0, acc1 = 0;
 #pragma unroll
-    for (int d = 0; d < NV; d++) { if (d & 1) acc1 += y[k][d] * y[NS][d]; else acc0 += y[k][d] * y[NS][d]; }
+    for (int d = 0; d < NV; d++) { if (d & 1) acc1 += y[k][d] * y[NF][d]; else acc0 += y[k][d] * y[NF][d]; }
     bb[k] = active[k] ? (acc0 + acc1) - aref[k] : R(0);
+  }
+  // ---- the surplus rows (32 + sl / 2 on the even lanes): their own row build and half solve, once z is out of the registers ---------------
+  R y3[EXT ? NV : 1];
+  bool active3 = false;
+  R Rr3 = 0, f3 = 0, bb3 = 0;
+  if constexpr (EXT) {
+    dmw::sync();                                                  // (every lane has read tau)
+    if (sl == 0) {
+#pragma unroll
+      for (int d = 0; d < NV; d++) s.tau[d] = y[NF][d];           // z: identical in every lane of the slot; read back at the force assembly
+    }
+    const int r3 = 2 * SW + (sl >> 1);
+    active3 = (sl & 1) == 0 && r3 < nefc;
+    RowAcc<R> ra3[1];
+    R pos3, margin3, dA3, rscale3;
+    slot_row_setup(M, s, r3, active3, ra3[0], pos3, margin3, dA3, rscale3);
+    R yy[1][NV];
+    {
+      R cur[8];
+      dmw::reload_fence();
+      slot_load_dof_operands<0>(cur, s);
+      SlotRowStep<0, 1, R>::run(yy, ra3, s, cur);
+    }
+    const R imp = impedance(M, pos3 - margin3);
+    Rr3 = fmax(R(DM_MINVAL), (1 - imp) * dA3 / imp);
+    if (rscale3 != R(1)) Rr3 = fmax(R(DM_MINVAL), rscale3 * Rr3);
+    const R aref3 = -M.B * ra3[0].vel - M.K * imp * (pos3 - margin3);
+    const R jar = ra3[0].jws - aref3;
+    f3 = (active3 && jar < 0) ? -jar / Rr3 : R(0);
+    slot_solve_LT<1>(yy, s.r2.qLD);
+    dmw::sync();                                                  // (z went through LDS)
+    R acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int d = 0; d < NV; d++) {
+      y3[d] = yy[0][d] * s.dsq[d]; dmw::pin_value(y3[d]);
+      if (d & 1) acc1 += y3[d] * s.tau[d]; else acc0 += y3[d] * s.tau[d];
+    }
+    bb3 = active3 ? (acc0 + acc1) - aref3 : R(0);
+  }
+  // (the surplus blocks are built BEFORE the 32 x 32 part: Y of all three sets is in registers now and none of A yet; afterwards the surplus rows' Y
+  //  goes to LDS and the 64 entries of A per lane take its place)
+  R U[EXT ? 2 : 1][NX], B3[NX];      // surplus columns of the lane's two rows; the corner row of the lane's surplus row
+  R diag3 = 1;
+  if constexpr (EXT) {
+#pragma unroll
+    for (int j = 0; j < NX; j++) { U[0][j] = 0; U[1][j] = 0; B3[j] = 0; dmw::pin_value(U[0][j]); dmw::pin_value(U[1][j]); dmw::pin_value(B3[j]); }
+    dmw::dpp_settle();
+    SlotExtCols<0, R>::run(U, B3, y, y3, nmax - 2 * SW);
+    R dg = 1;
+#pragma unroll
+    for (int j = 0; j < NX; j++) { if (sl == 2 * j) { B3[j] += active3 ? Rr3 : R(0); dg = B3[j]; } }
+    diag3 = active3 ? dg : R(1);
+    R* y3lds = &s.qd.o.qacc[0];
+    if ((sl & 1) == 0) {
+#pragma unroll
+      for (int d = 0; d < NV; d++) y3lds[d * SLOT_EXTROWS + (sl >> 1)] = y3[d];
+    }
   }
   SLOT_STAMP(9)
   // ---- A = Y Y^T + diag(R) --------------------------------------------------------------------------------------------------------
-  R AR[NS][NC];
+  R AR[NF][NC];
 #pragma unroll
-  for (int k = 0; k < NS; k++)
+  for (int k = 0; k < NF; k++)
 #pragma unroll
     for (int c = 0; c < NC; c++) { AR[k][c] = 0; dmw::pin_value(AR[k][c]); }
   dmw::dpp_settle();
-  SlotACols<0, NS, R>::run(AR, y, nmax);
-  R diag[NS];
+  SlotACols<0, NF, R>::run(AR, y, nmax);
+  R diag[NF];
 #pragma unroll
-  for (int k = 0; k < NS; k++) {
+  for (int k = 0; k < NF; k++) {
     R dg = 1;
 #pragma unroll
     for (int c = 0; c < 16; c++) { if (sl == c) { AR[k][16 * k + c] += active[k] ? Rr[k] : R(0); dg = AR[k][16 * k + c]; } }
@@ -861,37 +1042,57 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
   // register allocator, a third of A sits in accumulation registers and is copied out operand by operand inside the sweep loop (74 of a
   // trip's 277 instructions).  So the vectors are moved out of the architectural file explicitly, once: z — identical in every lane of the
   // slot — into the slot's `tau` (dead since it was read above), the rows' Y into accumulation registers; both come back after the sweeps.
+  // (Three: z went to `tau` before the surplus rows were built; their Y goes to the slot's qd + cdof regions in LDS — dead since the row builds.)
   typedef decltype(dmw::park(R(0))) ParkedR;
-  ParkedR ypark[NS == 2 ? NS : 1][NS == 2 ? NV : 1];
-  if constexpr (NS == 2) {
-    if (sl == 0) {
+  ParkedR ypark[NF == 2 ? NF : 1][NF == 2 ? NV : 1];
+  if constexpr (NF == 2) {
+    if constexpr (!EXT) {
+      if (sl == 0) {
 #pragma unroll
-      for (int d = 0; d < NV; d++) s.tau[d] = y[NS][d];
+        for (int d = 0; d < NV; d++) s.tau[d] = y[NF][d];
+      }
     }
 #pragma unroll
-    for (int k = 0; k < NS; k++)
+    for (int k = 0; k < NF; k++)
 #pragma unroll
       for (int d = 0; d < NV; d++) ypark[k][d] = dmw::park(y[k][d]);
     // (a fresh definition of every entry of A now that registers are free: the values the build left in accumulation registers would
     //  otherwise stay there, reloaded at each use)
 #pragma unroll
-    for (int k = 0; k < NS; k++)
+    for (int k = 0; k < NF; k++)
 #pragma unroll
       for (int c = 0; c < NC; c++) dmw::pin_value(AR[k][c]);
+    if constexpr (EXT) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) { dmw::pin_value(U[0][j]); dmw::pin_value(U[1][j]); dmw::pin_value(B3[j]); }
+    }
   }
   // ---- warm start: keep f(qacc_warmstart) only if its dual cost beats f = 0 ---------------------------------------------------------
-  R ndinv[NS], tb[NS], t[NS];
+  R ndinv[NF], tb[NF], t[NF];
 #pragma unroll
-  for (int k = 0; k < NS; k++) { ndinv[k] = active[k] ? R(-1) / diag[k] : R(0); dmw::pin_value(ndinv[k]); tb[k] = bb[k] * ndinv[k]; t[k] = tb[k]; }
-  SlotWarm<0, NS, R>::run(AR, t, f, ndinv, nmax);
+  for (int k = 0; k < NF; k++) { ndinv[k] = active[k] ? R(-1) / diag[k] : R(0); dmw::pin_value(ndinv[k]); tb[k] = bb[k] * ndinv[k]; t[k] = tb[k]; }
+  SlotWarm<0, NF, R>::run(AR, t, f, ndinv, nmax);
+  R ndinv3 = 0, tb3 = 0;
+  if constexpr (EXT) {
+    ndinv3 = active3 ? R(-1) / diag3 : R(0); dmw::pin_value(ndinv3);
+    tb3 = bb3 * ndinv3;
+    dmw::dpp_settle();
+    SlotExtWarm<0, R>::run(U, B3, t, f3, ndinv, ndinv3, nmax - 2 * SW);
+  }
   {
     R c = 0;
 #pragma unroll
-    for (int k = 0; k < NS; k++) { const R res = -t[k] * diag[k]; c += active[k] ? f[k] * (R(0.5) * (res - bb[k]) + bb[k]) : R(0); }
+    for (int k = 0; k < NF; k++) { const R res = -t[k] * diag[k]; c += active[k] ? f[k] * (R(0.5) * (res - bb[k]) + bb[k]) : R(0); }
+    if constexpr (EXT) {
+      const R t3 = slot_ext_residual(U, B3, f, diag, f3, tb3, ndinv3, sl);
+      const R res = -t3 * diag3;
+      c += active3 ? f3 * (R(0.5) * (res - bb3) + bb3) : R(0);
+    }
     const R cost = dmw::sum16(c);
     if (cost > 0) {
 #pragma unroll
-      for (int k = 0; k < NS; k++) { f[k] = 0; t[k] = tb[k]; }
+      for (int k = 0; k < NF; k++) { f[k] = 0; t[k] = tb[k]; }
+      f3 = 0;
     }
   }
   SLOT_STAMP(11)
@@ -903,7 +1104,7 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
   bool frozen = nefc == 0 || maxiter <= 0, anybad = false;
   if (frozen) {
 #pragma unroll
-    for (int k = 0; k < NS; k++) t[k] = 0;
+    for (int k = 0; k < NF; k++) t[k] = 0;
   }
   R oh[16];
 #pragma unroll
@@ -911,16 +1112,27 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
   // one sweep: forces f, scaled residuals t; returns this lane's share of the cost improvement and whether [MJ costChange] would object
   auto sweep = [&](R& imp, bool& bad) {
     const int nm = dmw::launder_uniform(nmax);
-    R nf0[NS], tsave[NS];
+    R nf0[NF], tsave[NF];
 #pragma unroll
-    for (int k = 0; k < NS; k++) { nf0[k] = -f[k]; tsave[k] = 0; }
-    SlotSweep<0, NS, R>::run(AR, t, tsave, nf0, oh, nm);
+    for (int k = 0; k < NF; k++) { nf0[k] = -f[k]; tsave[k] = 0; }
+    SlotSweep<0, NF, R>::run(AR, t, tsave, nf0, oh, nm);
     imp = 0; bad = false;
 #pragma unroll
-    for (int k = 0; k < NS; k++) {
+    for (int k = 0; k < NF; k++) {
       const R delta = dmw::max_raw(nf0[k], tsave[k]);
       const R change = (delta * diag[k]) * (R(0.5) * delta - tsave[k]);
       f[k] += delta; imp -= change; bad = bad || (change > pgs_detect);
+    }
+    if constexpr (EXT) {
+      // the surplus rows: residual formed from the forces as they stand after the 32 rows before them (a frozen environment: no step)
+      R t3 = slot_ext_residual(U, B3, f, diag, f3, tb3, ndinv3, sl);
+      t3 = frozen ? R(0) : t3;
+      const R nf03 = -f3;
+      R tsave3 = 0;
+      SlotExtSweep<0, R>::run(U, B3, t3, tsave3, t, nf03, oh, nm - 2 * SW);
+      const R delta = dmw::max_raw(nf03, tsave3);
+      const R change = (delta * diag3) * (R(0.5) * delta - tsave3);
+      f3 += delta; imp -= change; bad = bad || (change > pgs_detect);
     }
   };
   // The termination test of sweep k (a DPP reduction) is independent of the rows of sweep k + 1: sweep k + 1 is issued speculatively
@@ -933,9 +1145,9 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
     if (!frozen) { iter = 1; anybad = bad; }
     bool more = true;
     while (more) {
-      R fprev[NS];
+      R fprev[NF], fprev3 = f3;
 #pragma unroll
-      for (int k = 0; k < NS; k++) fprev[k] = f[k];
+      for (int k = 0; k < NF; k++) fprev[k] = f[k];
       const R improvement = dmw::sum16(imp) * pgs_scale;          // of the last accepted sweep
       R imp2; bool bad2;
       sweep(imp2, bad2);                                          // speculative
@@ -943,11 +1155,12 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
       const bool act = !frozen;
       const bool conv = (int)act & ((int)(improvement < pgs_tol) | (int)(iter >= maxiter));     // (bit operations: no short-circuit region)
 #pragma unroll
-      for (int k = 0; k < NS; k++) {
+      for (int k = 0; k < NF; k++) {
         const R tf = fprev[k] > 0 ? R(0) : R(-1);
         f[k] = conv ? fprev[k] : f[k];
         t[k] = conv ? tf : t[k];
       }
+      if constexpr (EXT) f3 = conv ? fprev3 : f3;
       const bool go = (int)act & (int)!conv;
       iter += go ? 1 : 0;
       anybad = (int)anybad | ((int)go & (int)bad2);
@@ -957,28 +1170,35 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
       if (PROF) prof[6] += 1;
     }
   }
-  if (PROF && NS == 2) { prof[22] += dmw::clk() - pt0; }
+  if (PROF && NS >= 2) { prof[22] += dmw::clk() - pt0; }
   SLOT_STAMP(12)
   if (PROF) { prof[14] += nmax; prof[15] += 1; }
   if (dmw::row_ballot(anybad, lane) != 0u) ovf |= 16 | 64;        // [MJ costChange] would have rejected a step: the one-env kernel's guarded replay decides
   if (dbg) {
 #pragma unroll
-    for (int k = 0; k < NS; k++) if (active[k]) {
+    for (int k = 0; k < NF; k++) if (active[k]) {
       double* o = dbg->out + (34 * 34 + 34 * 3 + 42 + 3) + (sl + 16 * k) * (34 + 6) + 34;
       o[0] = (double)pos[k]; o[1] = (double)margin[k]; o[2] = (double)Rr[k]; o[3] = (double)aref[k]; o[4] = (double)bb[k]; o[5] = (double)f[k];
     }
   }
   // ---- qacc = L^-1 D^-1/2 (z + sum_r f_r Y_r) -----------------------------------------------------------------------------------------
-  if constexpr (NS == 2) {
+  R fy3[EXT ? NV : 1];
+  if constexpr (EXT) {            // the surplus rows' Y back from LDS (own lane's words), times their forces
+    const R* y3lds = &s.qd.o.qacc[0];
+    const R f3a = active3 ? f3 : R(0);
+#pragma unroll
+    for (int d = 0; d < NV; d++) { fy3[d] = ((sl & 1) == 0 ? y3lds[d * SLOT_EXTROWS + (sl >> 1)] : R(0)) * f3a; dmw::pin_value(fy3[d]); }
+  }
+  if constexpr (NF == 2) {
     dmw::sync();                                   // (z went through LDS)
 #pragma unroll
-    for (int d = 0; d < NV; d++) y[NS][d] = s.tau[d];
+    for (int d = 0; d < NV; d++) y[NF][d] = s.tau[d];
   }
 #pragma unroll
-  for (int k = 0; k < NS; k++) {
+  for (int k = 0; k < NF; k++) {
     const R fk = active[k] ? f[k] : R(0);
 #pragma unroll
-    for (int d = 0; d < NV; d++) { if constexpr (NS == 2) y[k][d] = dmw::unpark(ypark[k][d]); y[k][d] *= fk; dmw::pin_value(y[k][d]); }
+    for (int d = 0; d < NV; d++) { if constexpr (NF == 2) y[k][d] = dmw::unpark(ypark[k][d]); y[k][d] *= fk; dmw::pin_value(y[k][d]); }
   }
   R ws[NV];
 #pragma unroll
@@ -986,9 +1206,10 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
   R one = 1;
   dmw::pin_value(one);
   dmw::dpp_settle();
-  SlotAssemble<0, NS, R>::run(ws, y, one, nmax);
+  SlotAssemble<0, NF, R>::run(ws, y, one, nmax);
+  if constexpr (EXT) SlotExtAssemble<0, R>::run(ws, fy3, one, nmax - 2 * SW);
 #pragma unroll
-  for (int d = 0; d < NV; d++) ws[d] = (ws[d] + y[NS][d]) * s.dsq[d];
+  for (int d = 0; d < NV; d++) ws[d] = (ws[d] + y[NF][d]) * s.dsq[d];
   solve_L(ws, s.r2.qLD);
   if (sl == 0) {
 #pragma unroll
@@ -997,8 +1218,18 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
   }
   dmw::sync();
   SLOT_STAMP(13)
-  if (PROF && NS == 2) prof[24] += dmw::clk() - pt_enter;
+  if (PROF && NS >= 2) prof[24] += dmw::clk() - pt_enter;
 #undef SLOT_STAMP
+}
+
+// The three-set instantiation as a REAL call: it is the rare path (a few per cent of a standing population's evaluations, none elsewhere) and the
+// one with the largest register appetite — inlined, every step function pays for it (more callee-saved registers to save and restore per step call,
+// a larger frame); called, only the evaluations that need it do.  Returns the overflow bits to add.
+template <class R>
+DM_DEV_CALL64 int slot_constraint3_call(const DevModel<R>* M, SlotShared<R>* s, int sl, int lane, int nefc, int nmax) {
+  int ovf = 0;
+  slot_constraint<R, 3, false>(*dmw::in_constant(M), *dmw::in_lds(s), sl, lane, nefc, dmw::uniform(nmax), ovf, (const DebugOut*)0, (long long*)0);
+  return ovf;
 }
 
 // ---- no rows anywhere in the wave: qacc = L^-1 D^-1/2 (D^-1/2 L^-T tau), the constrained formula with an empty sum (so that an
@@ -1060,8 +1291,15 @@ DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTable
   DM_MARK("slot_constraint");
   const int nmax = rows_max(nefc);
   if (nmax == 0) slot_smooth_solve(s, sl, dbg);
+#ifdef DM_FORCE_EXT      // test hook (testbench builds only): every constrained evaluation through the three-set code — results must not change
+  else if (nmax > 0) slot_constraint<R, 3, PROF>(M, s, sl, lane, nefc, nmax > 2 * SW ? nmax : 2 * SW + 1, ovf, dbg, prof);
+#endif
   else if (nmax <= 16) slot_constraint<R, 1, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof);
-  else { slot_constraint<R, 2, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof); if (PROF) prof[7] += 1; }
+  else if (nmax <= 2 * SW) { slot_constraint<R, 2, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof); if (PROF) prof[7] += 1; }
+  else {                  // 33 .. 40 rows somewhere in the wave: the three-set code, behind a call (see slot_constraint3_call)
+    if constexpr (PROF) { slot_constraint<R, 3, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof); prof[7] += 1; prof[25] += 1; }
+    else ovf |= slot_constraint3_call<R>(&M, &s, sl, lane, nefc, nmax);
+  }
   SLOT_FSTAMP(4)
   DM_MARK("slot_forward_end");
 #undef SLOT_FSTAMP

@@ -286,7 +286,7 @@ DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
         B.cong[(size_t)env * MAXEFC * 2 + k] = gid;
       }
     }
-    if (sl == 0) { B.comz[env] = z; B.ncon[env] = s.ncon; B.nefc[env] = s.nefc; B.status[env] = s.status; B.solver_iter[env] = s.solver_iter; order_ticket(B, env, s.nefc, s.solver_iter); }
+    if (sl == 0) { B.comz[env] = z; B.ncon[env] = s.ncon; B.nefc[env] = s.nefc; B.status[env] = s.status; B.solver_iter[env] = s.solver_iter; if constexpr (!CARRY) order_ticket(B, env, s.nefc, s.solver_iter); }   // (CARRY = inside a horizon launch: no tickets)
   }
   R rew = 1;
   if (B.reward_mode == REW_V3_CONFIG) {

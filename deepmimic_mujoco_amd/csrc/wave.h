@@ -212,6 +212,16 @@ template <int I> DM_DEV void pgs_row2(double& t_own, double& tsave_own, double& 
                "v_fmac_f64_dpp %3, %0, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
                : "=&v"(delta), "+v"(t_own), "+v"(tsave_own), "+v"(t_other) : "v"(nf0), "v"(a_own), "v"(a_other), "v"(onehot), "n"(I));
 }
+// a surplus row (slot_kernel.h slot_constraint<3>): its step also moves the residuals of both full row sets
+template <int I> DM_DEV void pgs_row3(double& t3, double& tsave3, double& t0, double& t1, double nf0, double b, double u0, double u1, double onehot) {
+  double delta;
+  asm volatile("v_max_f64 %0, %5, %1\n\tv_fma_f64 %2, %9, %1, %2\n\ts_nop 0\n\tv_fmac_f64_dpp %1, %0, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f64_dpp %3, %0, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %0, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
+               : "=&v"(delta), "+v"(t3), "+v"(tsave3), "+v"(t0), "+v"(t1) : "v"(nf0), "v"(b), "v"(u0), "v"(u1), "v"(onehot), "n"(I));
+}
+template <int I> DM_DEV void pgs_row3(float& t3, float& tsave3, float& t0, float& t1, float nf0, float b, float u0, float u1, float onehot) {
+  const float d = max_raw(nf0, t3); tsave3 += onehot * t3; const float bc = row_bcast<I>(d); t3 += bc * b; t0 += bc * u0; t1 += bc * u1;
+}
 template <int I> DM_DEV void pgs_row(float& t, float& tsave, float nf0, float a, float onehot) { const float d = max_raw(nf0, t); tsave += onehot * t; t += row_bcast<I>(d) * a; }
 template <int I> DM_DEV void pgs_row2(float& t_own, float& tsave_own, float& t_other, float nf0, float a_own, float a_other, float onehot) {
   const float d = max_raw(nf0, t_own); tsave_own += onehot * t_own; const float b = row_bcast<I>(d); t_own += b * a_own; t_other += b * a_other;

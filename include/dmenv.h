@@ -153,7 +153,7 @@ enum {
                              dm_batch_destroy() DROPS what is still queued (the buffers belong to the caller and may be gone). */
 };
 /* per-environment capacities of the DM_OPT_PACKED path (= csrc/slot_kernel.h SLOT_MAXROWS, SLOT_MAXLIMROWS, SLOT_MAXCON, SLOT_MAXFRAME, SLOT_MAXCAND) */
-#define DM_PACKED_MAXROWS 32
+#define DM_PACKED_MAXROWS 40
 #define DM_PACKED_MAXLIMROWS 16
 #define DM_PACKED_MAXCON 13
 #define DM_PACKED_MAXFRAME 8

@@ -130,6 +130,10 @@ template <int I, class T> inline void pgs_row2(T& t_own, T& tsave_own, T& t_othe
   const T d = std::fmax(nf0, t_own); tsave_own = tsave_own + onehot * t_own; const T b = row_bcast<I>(d);
   t_own = t_own + b * a_own; t_other = t_other + b * a_other;
 }
+template <int I, class T> inline void pgs_row3(T& t3, T& tsave3, T& t0, T& t1, T nf0, T b, T u0, T u1, T onehot) {
+  const T d = std::fmax(nf0, t3); tsave3 = tsave3 + onehot * t3; const T bc = row_bcast<I>(d);
+  t3 = t3 + bc * b; t0 = t0 + bc * u0; t1 = t1 + bc * u1;
+}
 inline void dpp_settle() {}
 // register parking (wave.h): a value copy here
 template <class T> struct ParkedT { T v; };

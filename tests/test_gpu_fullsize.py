@@ -233,6 +233,7 @@ def test_standing_population_full_shard_matches_oracle(form):
         b.join(); torch.cuda.current_stream().synchronize()
     worst = 0.0
     peak = np.zeros(n, dtype=np.int32)
+    above32 = near_cap = 0                   # env-steps whose last evaluation held more than 32 rows / came within two rows of the packed capacity
     for t in range(STEPS):
         if form != "horizon":
             b.step(acts[t], 1, (obs_T[t], rew_T[t], done_T[t]))
@@ -242,6 +243,7 @@ def test_standing_population_full_shard_matches_oracle(form):
         assert np.array_equal(done, o_done), "done flags differ at step %d" % t
         o_nefc = np.array([int(d.get("nefc")[0]) for d in ods], dtype=np.int32)
         peak = np.maximum(peak, o_nefc)
+        above32 += int((o_nefc > 32).sum()); near_cap += int((o_nefc >= A.PACKED_MAXROWS - 2).sum())
         if form != "horizon" or t == STEPS - 1:
             nefc = b.get(A.F_NEFC); ncon = b.get(A.F_NCON); cg = b.get(A.F_CONTACT_GEOMS)
             o_ncon = np.array([int(d.get("ncon")[0]) for d in ods], dtype=np.int32)
@@ -263,4 +265,12 @@ def test_standing_population_full_shard_matches_oracle(form):
     assert np.abs(q - oq).max() / max(1.0, np.abs(oq).max()) < 1e-9
     print("standing shard (%s): worst rel err %.2e; %.1f %% of envs reached >= 32 rows, %.1f %% > 32 (max %d); beyond the packed capacities: %s"
           % (form, worst, 100 * heavy, 100 * float((peak > 32).mean()), int(peak.max()), b.redo_reasons() if form != "one-env" else "-"))
+    if form != "one-env":
+        # round 5: 33 .. 40 rows (both feet flat + joint limits) are solved by the packed path itself (slot_kernel.h slot_constraint<3>): the population's
+        # environments above 32 rows were NOT handed to the one-env code
+        rr = b.redo_reasons()
+        print("   env-steps above 32 rows: %d; within two rows of the capacity (%d): %d; handed to the one-env code for rows: %d" % (above32, A.PACKED_MAXROWS, near_cap, rr[4]))
+        assert above32 > 0.01 * n * STEPS, "the standing population must hold environments above 32 rows"
+        assert rr[4] <= near_cap, "environments well within %d rows left the packed path: %s" % (A.PACKED_MAXROWS, rr)
+        assert rr[0] < 0.2 * above32, "most env-steps above 32 rows must stay on the packed path: %s of %d" % (rr, above32)
     b.close()

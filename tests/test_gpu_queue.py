@@ -30,7 +30,7 @@ def test_queued_steps_equal_unqueued_packed_steps(n, queue):
     environments planted beyond the packed path's capacities (re-stepped inside their wave)."""
     from tests import helpers as H
     T = 45
-    hi, hq, hv = H.many_row_states(32, 64, want=2)
+    hi, hq, hv = H.many_row_states(40, 64, want=2)
     g = torch.Generator(device=DEV); g.manual_seed(11)
     ac = torch.randn((T, n, 28), generator=g, dtype=torch.float64, device=DEV) * 0.9
     outs = []
@@ -181,7 +181,7 @@ def test_changing_the_pipeline_depth_between_packed_steps_keeps_the_redo_counter
     for the sub-batches beyond the smaller depth — some environments were then stepped twice in one call.  Against one launch per step."""
     from tests import helpers as H
     n, T = 520, 14
-    hi, hq, hv = H.many_row_states(32, 64, want=4)
+    hi, hq, hv = H.many_row_states(40, 64, want=4)
     g = torch.Generator(device=DEV); g.manual_seed(9)
     ac = torch.randn((T, n, 28), generator=g, dtype=torch.float64, device=DEV) * 0.9
     depths = [4, 4, 4, 2, 2, 2, 4, 4, 4, 2, 4, 2, 4, 4]

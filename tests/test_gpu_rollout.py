@@ -472,7 +472,7 @@ def test_horizon_launch_equals_step_by_step(packed, policy):
     rows than a slot holds, so the in-wave re-step by the one-env code runs too); on the one-env path the library issues the T launches."""
     from tests import helpers as H
     n, T = 642, 40
-    hi, hq, hv = H.many_row_states(32, 64, want=2)
+    hi, hq, hv = H.many_row_states(40, 64, want=2)
     pol = MlpPolicy(device=DEV, seed=2); pol.seed(5)
     outs = []
     for horizon in (False, True):

@@ -235,7 +235,7 @@ def test_packed_horizon_in_one_wave_equals_step_by_step(mode):
         from deepmimic_mujoco_amd.imitation import ImitationSpec
         imit = ImitationSpec(H.compiled_model()).table_for(mc)
     idx, q, v, _ws, _c = H.varied_states(n, seed=5)
-    hi, hq, hv = H.many_row_states(32, 64, want=2)          # more rows than a slot holds: these are re-stepped by the one-env code
+    hi, hq, hv = H.many_row_states(40, 64, want=2)          # more rows than a slot holds: these are re-stepped by the one-env code
     idx[1], q[1], v[1] = hi[0], hq[0], hv[0]
     idx[9], q[9], v[9] = hi[-1], hq[-1], hv[-1]
     acts = np.random.RandomState(3).randn(T, n, 28) * 0.9
@@ -287,3 +287,57 @@ def test_self_ordering_launches_dispatch_a_permutation_longest_first():
     # tickets that do not cover the part exactly (an env missing) are not trusted: identity
     o1, _ = emu.dispatch(n, 0, 50, rng.randint(0, 30, n), np.zeros(n), np.arange(49))
     assert np.array_equal(o1, np.arange(50))
+
+
+def _heavy_states(lo, hi, want, seeds=(13, 5, 7)):
+    out = []
+    for sd in seeds:
+        try:
+            i, q, v = H.many_row_states(lo, hi, want=want, seed=sd)
+        except AssertionError:
+            continue
+        out += [(i[k], q[k], v[k]) for k in range(len(i))]
+    return out
+
+
+def test_packed_third_row_set_33_to_40_rows_stays_on_the_packed_path():
+    """slot_kernel.h slot_constraint<3>: environments with 33 .. 40 constraint rows (a standing humanoid: 32 contact rows + joint limits) are solved by
+    the packed path itself — two full row sets plus the partial third one whose residuals are formed from the forces once per sweep — instead of
+    being handed to the one-env code.  On the fibre testbench: states with 34 .. 40 rows share waves with lighter ones; every env agrees with the
+    oracle step by step, nothing is re-stepped (redo total 0), and an environment with <= 32 rows gets bit-identical results whether or not a heavier
+    one shares its wave (its surplus terms are exact zeros)."""
+    from tests.emu.emu import EmuBatch
+    mc = H.mocap()
+    heavy = [h for h in _heavy_states(32, 40, want=4)]
+    assert len(heavy) >= 3
+    n = 8
+    idx, q, v, _ws, _c = H.varied_states(n, seed=21)
+    light = (idx.copy(), q.copy(), v.copy())
+    slots = [1, 4, 6, 7][:len(heavy)]                    # wave 0: one heavy + three light; wave 1: up to three heavy + one light
+    for sl_, h in zip(slots, heavy):
+        idx[sl_], q[sl_], v[sl_] = h
+    b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0)
+    b.set_option(A.OPT_PACKED, 1)
+    b.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); b.set(A.F_TIME, np.zeros(n))
+    b.set_state(q, v, frame_idx=idx)
+    ne0 = b.get(A.F_NEFC)
+    assert all(32 < ne0[s_] <= 40 for s_ in slots), ne0
+    worst, _nd = H.compare_rollout(b, H.oracle_model(), idx, q, v, steps=3, seed=4)
+    assert worst < 1e-10
+    assert b.redo_total() == 0, "an environment within 40 rows left the packed path"
+    # the light environments next to a heavy one: the same bits as among themselves
+    acts = np.random.RandomState(6).randn(2, n, 28) * 0.9
+    res = []
+    for states in ((idx, q, v), light):
+        bb = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0)
+        bb.set_option(A.OPT_PACKED, 1)
+        bb.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); bb.set(A.F_TIME, np.zeros(n))
+        bb.set_state(states[1], states[2], frame_idx=states[0])
+        o = [bb.step(acts[t])[0].copy() for t in range(2)]
+        res.append((o, bb.get(A.F_QPOS), bb.get(A.F_QACC_WARMSTART), bb.get(A.F_NEFC), bb.get(A.F_SOLVER_ITER)))
+    same = [e for e in range(n) if e not in slots]
+    assert res[1][3].max() <= 32
+    for e in same:
+        for t in range(2):
+            assert np.array_equal(res[0][0][t][e], res[1][0][t][e]), (e, t)
+        assert np.array_equal(res[0][1][e], res[1][1][e]) and np.array_equal(res[0][2][e], res[1][2][e]) and res[0][4][e] == res[1][4][e]
