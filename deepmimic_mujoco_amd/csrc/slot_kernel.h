@@ -22,16 +22,23 @@
 namespace dm {
 
 constexpr int SLOTS = 4, SW = 16;            // environments per wavefront, lanes per environment
-constexpr int SLOT_MAXROWS = 40, SLOT_MAXLIMROWS = 16, SLOT_MAXCON = 13, SLOT_MAXFRAME = 8, SLOT_MAXCAND = 32, SLOT_BOXSLOTS = 3;   // per-environment capacities of the packed path; beyond: fix-up by the one-env kernel
-constexpr int SLOT_EXTROWS = SLOT_MAXROWS - 2 * SW;     // rows 32 .. 39: the partial third row set of slot_constraint<3> (owned by the even lanes)
+#ifndef DM_SLOT_MAXROWS
+#define DM_SLOT_MAXROWS 40          // (32: the two-set capacity of rounds 3-4 — the three-set code is then not compiled; experiments only)
+#endif
+constexpr int SLOT_MAXROWS = DM_SLOT_MAXROWS, SLOT_MAXLIMROWS = 16, SLOT_MAXCON = 13, SLOT_MAXFRAME = 8, SLOT_MAXCAND = 32, SLOT_BOXSLOTS = 3;   // per-environment capacities of the packed path; beyond: fix-up by the one-env kernel
+constexpr int SLOT_EXTROWS = SLOT_MAXROWS - 2 * SW;
+static_assert(SLOT_EXTROWS == 8 || SLOT_EXTROWS == 0, "the partial third row set holds eight rows (or is absent)");     // rows 32 .. 39: the partial third row set of slot_constraint<3> (owned by the even lanes)
 constexpr int PAIR_PASSES = MAXPAIR / SW;
 constexpr int DOF_PASSES = (NV + SW - 1) / SW, HINGE_PASSES = (NU + SW - 1) / SW, Q_PASSES = (NQ + SW - 1) / SW, ENT_PASSES = (310 + SW - 1) / SW;
 
 // per-slot LDS working set.  r1 / r2 are reused along one forward evaluation:
 //   r1: kinematics scratch (body quaternions, hinge half-angle sines, frame offsets) | RNE scratch | M-build scratch (fdof)
 //   r2: spatial / composite inertias (kinematics .. M build)                        | the L^T D L factor (M build .. end of the evaluation)
+// (alignas(16): the slots' stride must stay a multiple of 16 bytes — a lane's LDS address is slot base + constant, and only then can the compiler prove
+//  the 16-byte alignment its ds_read_b128 / ds_write_b128 need.  A stride of 9 720 B — the first round-5 layout, 24 B more than round 4's 9 696 — turned
+//  all 1 350 of them into pairs of 8-byte accesses and cost every workload 8 %: gpurun calls h2 / h3.)
 template <class R>
-struct SlotShared {
+struct alignas(16) SlotShared {
   R qpos[36], qvel[NV];
   R xpos[NB][3], xmat[NB][9];
   R tau[NV];
@@ -52,8 +59,12 @@ struct SlotShared {
       R frm[SLOT_MAXFRAME][6];                                  // contact frames, one per pair with contacts: normal[3], tangent 1 [3]
       R rowv[SLOT_MAXLIMROWS];                                  // limit rows (they come first): distance
       int rowi[SLOT_MAXROWS];                                   // row codes (see slot_rows)
-      int cand[SLOT_MAXCAND];                                   // candidate pair numbers past the broad phase, in pair-list order
+      unsigned short cand[SLOT_MAXCAND];                        // candidate pair numbers past the broad phase, in pair-list order (16 bits each: the eight more
+                                                                //  row codes of round 5 must not move anything behind them — see the layout note below)
       int coni[SLOT_MAXCON + 1];                                // pair number | frame << 8 of a staged contact
+#if DM_SLOT_MAXROWS == 40 && !defined(DM_NO_LAYOUT_PAD)
+      char keep_r4_layout_[32];
+#endif
     } rw;
   } r1;
   union {
@@ -69,6 +80,13 @@ struct SlotShared {
 #endif
 };
 static_assert(NQ == 35, "qpos[36] has one spare element");
+static_assert(sizeof(SlotShared<double>) % 16 == 0 && sizeof(SlotShared<float>) % 16 == 0, "slot stride: a multiple of 16 bytes");
+// Layout note (round 5, gpurun calls h2-h5): the float64 slot is kept at round 4's 9 696 bytes with `r2` at its old offset.  Growing `rowi` from 32 to 40
+// codes in place (r2 and the tail 32 B further back, stride 9 720 or 9 728) made EVERY workload 8 % slower — 16.5 against 18.2 M env-steps/s on the judged
+// line, with or without the three-set code compiled in — while the same code on the old offsets is 1.7 % faster than round 4.
+#if DM_SLOT_MAXROWS == 40 && !defined(DM_NO_LAYOUT_PAD) && !defined(DM_SLOT_PAD)
+static_assert(sizeof(SlotShared<double>) == 9696, "the float64 slot layout is a measured quantity: see the layout note");
+#endif
 static_assert(offsetof(SlotShared<double>, cdof) == offsetof(SlotShared<double>, qd) + sizeof(((SlotShared<double>*)0)->qd) &&
               offsetof(SlotShared<float>, cdof) == offsetof(SlotShared<float>, qd) + sizeof(((SlotShared<float>*)0)->qd) &&
               sizeof(((SlotShared<double>*)0)->qd) + sizeof(((SlotShared<double>*)0)->cdof) >= sizeof(double) * NV * (SLOT_MAXROWS - 2 * SW),
@@ -454,8 +472,10 @@ DM_DEV int row_exclusive_scan(int v, int sl, int lane, int* total) {
 // Capacities (SLOT_MAXCAND candidates, SLOT_MAXCON contacts, SLOT_MAXROWS rows): an environment that exceeds one is flagged (`ovf`: bit 0
 // candidates, 1 box slots, 2 contacts, 3 rows, 4 a PGS step the cost test would reject, 6 any) and re-stepped by the one-env kernel;
 // nothing of it is stored by this wave.  Returns the slot's row count.
-template <class R, bool PROF = false>
+// MAXR = the row capacity of the instantiation: 2 * SW (the two-set code only) or SLOT_MAXROWS (with the partial third set, slot_constraint<3>).
+template <class R, bool PROF = false, int MAXR = 2 * SW>
 DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int& ovf, long long* prof = 0) {
+  static_assert(MAXR == 2 * SW || MAXR == SLOT_MAXROWS, "row capacity: two sets, or two and the partial third");
   const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
   long long pt0 = 0, pt1 = 0;
   if (PROF) pt0 = dmw::clk();
@@ -523,7 +543,7 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
           } else cand = dot3(d, d) <= pbound[p] * pbound[p];
         }
         const unsigned mask = dmw::row_ballot(cand, lane);
-        if (cand) { const int k = ncand + __builtin_popcount(mask & below); if (k < SLOT_MAXCAND) W.cand[k] = pidx; }
+        if (cand) { const int k = ncand + __builtin_popcount(mask & below); if (k < SLOT_MAXCAND) W.cand[k] = (unsigned short)pidx; }
         ncand += __builtin_popcount(mask);
       }
     }
@@ -576,7 +596,7 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
           if (fi < SLOT_MAXFRAME) { R* o = W.frm[fi]; for (int t = 0; t < 6; t++) o[t] = fr[t]; }
           for (int k = 0; k < pc.n; k++) {
             const int ci = c0 + k, rk = r0 + k * rows_per;
-            if (ci >= SLOT_MAXCON || fi >= SLOT_MAXFRAME || rk + rows_per > SLOT_MAXROWS) { ovf |= (ci >= SLOT_MAXCON || fi >= SLOT_MAXFRAME) ? 4 : 8; continue; }
+            if (ci >= SLOT_MAXCON || fi >= SLOT_MAXFRAME || rk + rows_per > MAXR) { ovf |= (ci >= SLOT_MAXCON || fi >= SLOT_MAXFRAME) ? 4 : 8; continue; }
             R cdist, cpos[3];
             if (pc.boxslot >= 0) { const R* o = W.boxc[pc.boxslot][k]; cdist = o[0]; cpos[0] = o[1]; cpos[1] = o[2]; cpos[2] = o[3]; }
             else if (k == 0) { cdist = pc.d0; cpos[0] = pc.p0[0]; cpos[1] = pc.p0[1]; cpos[2] = pc.p0[2]; }
@@ -592,7 +612,7 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
     }
   }
   // an overflow anywhere in the row -> the whole environment is flagged (ovf is per lane so far)
-  if (nrow > SLOT_MAXROWS) ovf |= 8;
+  if (nrow > MAXR) ovf |= 8;
   if (dmw::row_ballot(ovf != 0, lane) != 0u) { ovf |= 64; nrow = 0; ncon = 0; }    // (bit 6: some lane of the row holds a reason)                             // nothing of this evaluation is used: no row may be read (some were never staged)
   if (sl == 0) { s.nefc = nrow; s.ncon = ncon; }
   dmw::sync();
@@ -798,7 +818,7 @@ struct SlotExtWarm {
 template <class R>
 DM_DEV R slot_ext_residual(const R (*U)[SLOT_EXTROWS], const R* B, const R* f, const R* diag, R f3, R tb3, R ndinv3, int sl) {
   const R g0 = -(diag[0] * f[0]), g1 = -(diag[1] * f[1]);
-  R p[SLOT_EXTROWS];
+  R p[SLOT_EXTROWS > 0 ? SLOT_EXTROWS : 1];
 #pragma unroll
   for (int j = 0; j < SLOT_EXTROWS; j++) p[j] = U[0][j] * g0 + U[1][j] * g1;
   R t3 = tb3 + ndinv3 * row_reduce8(p, sl);
@@ -1171,6 +1191,7 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
     }
   }
   if (PROF && NS >= 2) { prof[22] += dmw::clk() - pt0; }
+  if (PROF && NS == 3) { prof[27] += dmw::clk() - pt0; }
   SLOT_STAMP(12)
   if (PROF) { prof[14] += nmax; prof[15] += 1; }
   if (dmw::row_ballot(anybad, lane) != 0u) ovf |= 16 | 64;        // [MJ costChange] would have rejected a step: the one-env kernel's guarded replay decides
@@ -1219,17 +1240,8 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
   dmw::sync();
   SLOT_STAMP(13)
   if (PROF && NS >= 2) prof[24] += dmw::clk() - pt_enter;
+  if (PROF && NS == 3) prof[26] += dmw::clk() - pt_enter;
 #undef SLOT_STAMP
-}
-
-// The three-set instantiation as a REAL call: it is the rare path (a few per cent of a standing population's evaluations, none elsewhere) and the
-// one with the largest register appetite — inlined, every step function pays for it (more callee-saved registers to save and restore per step call,
-// a larger frame); called, only the evaluations that need it do.  Returns the overflow bits to add.
-template <class R>
-DM_DEV_CALL64 int slot_constraint3_call(const DevModel<R>* M, SlotShared<R>* s, int sl, int lane, int nefc, int nmax) {
-  int ovf = 0;
-  slot_constraint<R, 3, false>(*dmw::in_constant(M), *dmw::in_lds(s), sl, lane, nefc, dmw::uniform(nmax), ovf, (const DebugOut*)0, (long long*)0);
-  return ovf;
 }
 
 // ---- no rows anywhere in the wave: qacc = L^-1 D^-1/2 (D^-1/2 L^-T tau), the constrained formula with an empty sum (so that an
@@ -1259,7 +1271,7 @@ DM_DEV void slot_smooth_solve(SlotShared<R>& s, int sl, const DebugOut* dbg) {
 // reward ended the previous step with the kinematics pass of exactly the state this evaluation starts from — and the stage is skipped (xip is
 // then left alone: only the 4th evaluation's is used).  The flag is read and cleared HERE, from LDS, so that no register carries the decision
 // across the stages (a flag handed down through the RK loop cost the collision stage 49 more spill instructions: measured 1.5 % slower).
-template <class R, bool PROF = false, bool CARRY = false>
+template <class R, bool PROF = false, bool CARRY = false, int MAXR = 2 * SW>
 DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, int lane, const LaneTopo& lt, R* xip, int& ovf, const DebugOut* dbg, long long* prof = 0) {
   long long t0 = 0, t1 = 0;
   if (PROF) t0 = dmw::clk();
@@ -1285,21 +1297,25 @@ DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTable
   SLOT_FSTAMP(2)
   DM_MARK("slot_rows");
   int nefc = 0;
-  if (M.enable_contact || M.enable_limit) nefc = slot_rows<R, PROF>(M, s, sl, lane, ovf, prof);
+  if (M.enable_contact || M.enable_limit) nefc = slot_rows<R, PROF, MAXR>(M, s, sl, lane, ovf, prof);
   else { if (sl == 0) { s.nefc = 0; s.ncon = 0; } dmw::sync(); }
   SLOT_FSTAMP(3)
   DM_MARK("slot_constraint");
   const int nmax = rows_max(nefc);
   if (nmax == 0) slot_smooth_solve(s, sl, dbg);
 #ifdef DM_FORCE_EXT      // test hook (testbench builds only): every constrained evaluation through the three-set code — results must not change
-  else if (nmax > 0) slot_constraint<R, 3, PROF>(M, s, sl, lane, nefc, nmax > 2 * SW ? nmax : 2 * SW + 1, ovf, dbg, prof);
+  else if (nmax > 0 && MAXR > 2 * SW) slot_constraint<R, MAXR > 2 * SW ? 3 : 2, PROF>(M, s, sl, lane, nefc, nmax > 2 * SW ? nmax : 2 * SW + 1, ovf, dbg, prof);
 #endif
   else if (nmax <= 16) slot_constraint<R, 1, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof);
   else if (nmax <= 2 * SW) { slot_constraint<R, 2, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof); if (PROF) prof[7] += 1; }
-  else {                  // 33 .. 40 rows somewhere in the wave: the three-set code, behind a call (see slot_constraint3_call)
-    if constexpr (PROF) { slot_constraint<R, 3, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof); prof[7] += 1; prof[25] += 1; }
-    else ovf |= slot_constraint3_call<R>(&M, &s, sl, lane, nefc, nmax);
-  }
+  // 33 .. 40 rows somewhere in the wave: the three-set code — in the instantiations that carry it (MAXR = SLOT_MAXROWS; elsewhere slot_rows has flagged such
+  // an environment and dropped its rows).  Two lessons of round 5 (profiles/r05_ab_kernel_variants.md): (1) behind a REAL call it kept its register appetite
+  // to itself, but a call inside the step function stops the allocator from spilling into accumulation registers anywhere in it (slot_rows 19 -> 125 scratch
+  // instructions, the two-set assembly 1 -> 239): -8 %; (2) INLINED, the one- and two-set paths keep their instruction sequences (99 % identical opcode
+  // streams) and are 8 % slower all the same — the larger function perturbs the register ASSIGNMENT of the hot constraint stage (one-set evaluations 48.7 ->
+  // 55.7 k cycles, two-set 108 -> 143 k).  So the three-set code lives in its own instantiation of the step function, which a wave calls only while one
+  // of its environments is near the two-set capacity (slot_step.h slot_rollout); every other wave-step runs the lean instantiation.
+  else if constexpr (MAXR > 2 * SW) { slot_constraint<R, 3, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof); if (PROF) { prof[7] += 1; prof[25] += 1; } }
   SLOT_FSTAMP(4)
   DM_MARK("slot_forward_end");
 #undef SLOT_FSTAMP

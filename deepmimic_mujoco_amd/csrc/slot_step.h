@@ -31,7 +31,7 @@ DM_DEV void slot_integrate_pos(SlotShared<R>& s, const DofVec<R>& x0q, int sl, R
 }
 
 // [MJ mj_step, integrator RK4] on the state in s.qpos / s.qvel / s.qws / s.act; xip = body COM positions of the 4th stage evaluation
-template <class R, bool PROF = false, bool CARRY = false>
+template <class R, bool PROF = false, bool CARRY = false, int MAXR = 2 * SW>
 DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl, int lane, const LaneTopo& lt, R* xip, int& ovf, long long* prof = 0) {
   const R h = M.timestep;
   const R A[3] = {R(0.5), R(0.5), R(1)};
@@ -66,7 +66,7 @@ DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTabl
 #pragma unroll
     for (int c = 0; c < DOF_PASSES; c++) { pk[0][c] = dmw::park(x0q.r[c]); pk[1][c] = dmw::park(x0v.r[c]); pk[2][c] = dmw::park(vprev.r[c]); pk[3][c] = dmw::park(sumv.r[c]); pk[4][c] = dmw::park(suma.r[c]); }
 #endif
-    slot_forward<R, PROF, CARRY>(M, s, tb, sl, lane, lt, xip, ovf, (const DebugOut*)0, prof);
+    slot_forward<R, PROF, CARRY, MAXR>(M, s, tb, sl, lane, lt, xip, ovf, (const DebugOut*)0, prof);
 #ifndef DM_NO_RK_PARK
 #pragma unroll
     for (int c = 0; c < DOF_PASSES; c++) { x0q.r[c] = dmw::unpark(pk[0][c]); x0v.r[c] = dmw::unpark(pk[1][c]); vprev.r[c] = dmw::unpark(pk[2][c]); sumv.r[c] = dmw::unpark(pk[3][c]); suma.r[c] = dmw::unpark(pk[4][c]); }
@@ -246,7 +246,7 @@ DM_DEV R slot_imitation_reward(const DevModel<R>& M, const Batch<R>& B, SlotShar
 // CARRY (horizon launches only) + kin_carry (wave-uniform): the slots' LDS is what this wave's previous step left, so a slot's `kin_ok` flag
 // means what it says and the first evaluation may skip its position stage (slot_forward): one kinematics pass in five less with the 5-term
 // reward, bit-identical results.  Without kin_carry (the first step of a launch, the step after an in-wave re-step) the flags are cleared first.
-template <class R, bool PROF = false, bool CARRY = false>
+template <class R, bool PROF = false, bool CARRY = false, int MAXR = 2 * SW>
 DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, SlotTables& tb, int env, int sl, int lane, bool live,
                           const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int* redo_count, int* redo_list,
                           long long* prof_out = 0, bool kin_carry = false) {
@@ -259,7 +259,7 @@ DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
   slot_load_env(M, B, s, env, sl, live, action);
   R xip[3];
   int why = 0;
-  for (int k = 0; k < n_substeps; k++) slot_rk4_step<R, PROF, CARRY>(M, s, tb, sl, lane, lt, xip, why, prof);
+  for (int k = 0; k < n_substeps; k++) slot_rk4_step<R, PROF, CARRY, MAXR>(M, s, tb, sl, lane, lt, xip, why, prof);
   const bool ovf = dmw::row_ballot(why != 0, lane) != 0u;
   if (dmw::ballot(ovf) != 0ull) {                     // rare: list the environment, tally the reasons (diagnostics)
     unsigned bits = 0;
@@ -364,35 +364,51 @@ DM_DEV_CALL64 void restep_one_env(const DevModel<R>* M, const Batch<R>* B, Share
 }
 // (the packed step as a call too: its body is then compiled exactly as in k_step_packed — inlined into the horizon loop the register
 //  allocator produced four times the spills and a 27 % slower step)
-template <class R>
-DM_DEV_CALL64 bool slot_env_step_call(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
-                                      const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int kin_carry) {
+// Two instantiations: MAXR = 2 * SW — the lean step of rounds 3-4 (one and two row sets; an environment beyond 32 rows is flagged and re-stepped) — and
+// MAXR = SLOT_MAXROWS — the same step with the partial third row set compiled in (33 .. 40 rows stay in the wave), 8 % slower on everything else (see
+// slot_forward).  slot_rollout picks per wave-step.  Returns (stored ? 1 : 0) | row count of the slot's environment << 8.
+template <class R, int MAXR>
+DM_DEV_CALL64 int slot_env_step_call(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
+                                     const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int kin_carry) {
   using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global; using dmw::in_constant;
   const Batch<R> Bv = *in_constant(B);
-  return slot_env_step<R, false, true>(*in_constant(M), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
-                                       in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0,
-                                       (long long*)0, dmw::uniform(kin_carry) != 0);
+  SlotShared<R>& sr = *in_lds(s);
+  const bool stored = slot_env_step<R, false, true, MAXR>(*in_constant(M), global_members(Bv), sr, *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
+                                                          in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0,
+                                                          (long long*)0, dmw::uniform(kin_carry) != 0);
+  return (stored ? 1 : 0) | (sr.nefc << 8);
 }
 #ifdef DM_ROLLOUT_PROF     // diagnostic build (tools/profile_horizon.py): the step with per-stage shader-clock stamps, one 32-counter record per call
-template <class R>
-DM_DEV_CALL64 bool slot_env_step_call_prof(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
-                                           const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, long long* prof_out, int kin_carry) {
+template <class R, int MAXR>
+DM_DEV_CALL64 int slot_env_step_call_prof(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
+                                          const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, long long* prof_out, int kin_carry) {
   using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global; using dmw::in_constant;
   const Batch<R> Bv = *in_constant(B);
-  return slot_env_step<R, true, true>(*in_constant(M), global_members(Bv), *in_lds(s), *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
-                                      in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0,
-                                      in_global(uniform_ptr(prof_out)), dmw::uniform(kin_carry) != 0);
+  SlotShared<R>& sr = *in_lds(s);
+  const bool stored = slot_env_step<R, true, true, MAXR>(*in_constant(M), global_members(Bv), sr, *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
+                                                         in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0,
+                                                         in_global(uniform_ptr(prof_out)), dmw::uniform(kin_carry) != 0);
+  return (stored ? 1 : 0) | (sr.nefc << 8);
 }
 #endif
 // The buffers of ONE step of a horizon: what one dm_batch_step call names (action [N, 28] in; obs [N, 56], reward [N], done [N] out).  A horizon
 // launch reads a table of T of them — rows of the caller's [T, N, .] tensors (dm_batch_rollout) or the buffers of T queued dm_batch_step
 // calls (DM_OPT_STEP_QUEUE), which need not be strided.
 struct StepRow { const double* action; double* obs; double* reward; unsigned char* done; };
+#ifndef DM_EXT_MARGIN
+#define DM_EXT_MARGIN 9
+#endif
+// slot_rollout calls the three-set instantiation of the step from 2 * SW - EXT_MARGIN + 1 = 24 rows up.  Measured (gpurun call h9; a synthetic standing
+// population / the judged line, M env-steps/s): margin 3 (30 rows): 9.45 / 17.95, 1.4 % of env-steps still re-stepped (a foot landing takes an env from 28 to
+// 33 rows in one step); margin 9 (24 rows): 9.68 / 17.94, 0.26 %; margin 15 (18 rows): 9.74 / 17.76, 0.05 %; round 4's kernel: 6.98 / 17.83, 13.9 %.
+constexpr int EXT_MARGIN = DM_EXT_MARGIN;
 template <class R, int NR, class POLICY>
 DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<R>* sh, SlotTables& tb, Shared<R>& one_s, StepScratch<R>& one_x,
                          int env, int lane, bool live, const StepRow* rows, int n_substeps, int T, POLICY&& policy, long long* prof_acc = 0, bool policy_clobbers_kin = false) {
   const int slot = lane >> 4, sl = lane & 15;
   int carry = 0;                              // the slots' LDS is what this wave's previous step left (no in-wave re-step overwrote it): slot_env_step kin_carry
+  // rows the slot's environment held after its last step: decides which instantiation of the step this wave calls next (wave-uniform: the largest of the four)
+  int last_rows = B.nefc[env];
   for (int t = 0; t < T; t++) {
     // (every step reads the model afresh: hoisting those loads out of the loop would keep hundreds of registers alive across it)
     const DevModel<R>& M = *dmw::launder_uniform_ptr(&M_in);
@@ -401,18 +417,24 @@ DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<
     double* o_t = row.obs;
     double* r_t = row.reward;
     unsigned char* d_t = row.done;
+    // an environment within EXT_MARGIN rows of the two-set capacity: the step with the third row set compiled in (standing humanoids sit at 32 .. 37 rows
+    // for hundreds of steps: the prediction misses on the step that takes one there — that env-step is re-stepped by the one-env code, as all were before)
+    const bool heavy = rows_max(last_rows) > 2 * SW - EXT_MARGIN;
+    int ret;
 #ifdef DM_ROLLOUT_PROF
-    bool stored;
     if (prof_acc) {        // [0..31] sums over the horizon's steps, [32..63] the record of the step just taken
-      stored = slot_env_step_call_prof<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, prof_acc + 32, carry);
-      if (lane == 0) for (int k = 0; k < 31; k++) prof_acc[k] += prof_acc[32 + k];
-    } else stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, carry);
-#else
+      ret = heavy ? slot_env_step_call_prof<R, SLOT_MAXROWS>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, prof_acc + 32, carry)
+                  : slot_env_step_call_prof<R, 2 * SW>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, prof_acc + 32, carry);
+      if (lane == 0) { for (int k = 0; k < 31; k++) prof_acc[k] += prof_acc[32 + k]; if (heavy) prof_acc[28] += 1; }
+    } else
+#endif
     // (measured, round 4: the step body inlined here instead of called — the batch descriptor and tables read afresh every step so that nothing is
     //  hoisted — removes the callee's register save / restore (1.6 KB per lane per call) and is 10 % SLOWER: 15.0 against 16.7 M env-steps/s,
     //  profiles/r04_ab_kernel_variants.md; the loop around the body costs the allocator more than the calls cost the memory system)
-    const bool stored = slot_env_step_call<R>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, carry);
-#endif
+    ret = heavy ? slot_env_step_call<R, SLOT_MAXROWS>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, carry)
+                : slot_env_step_call<R, 2 * SW>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, carry);
+    const bool stored = (ret & 1) != 0;
+    last_rows = (stored || !live) ? (ret >> 8) : SLOT_MAXROWS;       // (an environment that left the packed path: assume it is heavy)
     const int need = (live && !stored) ? 1 : 0;
     bool any = false;
     for (int k = 0; k < SLOTS; k++) {

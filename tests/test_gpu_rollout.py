@@ -437,9 +437,10 @@ def test_fused_policy_step_on_tiny_and_odd_batches(n, pipeline):
 @pytest.mark.gpu
 def test_auto_packed_follows_the_workload():
     """DPVecEnv(packed=None) at 8192 envs starts four-per-wave and re-decides from the batch's own row statistics: RSI + random actions
-    (the benchmark regime: envs fall, few rows) stays packed; a population standing on both feet (the init pose under zero actions:
-    8 foot corners x 4 pyramid rows = 32 rows, more with any limit or self-contact) overflows the packed path's 32-row capacity and is
-    handed to the one-env kernel; once the rows are gone (RSI + random actions again) the batch returns to the packed kernel."""
+    (the benchmark regime: envs fall, few rows) stays packed; since round 5 so does a population standing on both feet (the init pose under
+    zero actions: 8 foot corners x 4 pyramid rows = 32 rows, 33 .. 37 with joint limits — within the packed path's 40 rows: rounds 3-4 handed it
+    to the one-env kernel).  The hand-over itself is then driven through its thresholds: a redo rate above REDO_RATE_MAX moves the batch to the
+    one-env kernel, a largest row count within HEAVY_ROWS moves it back."""
     n = 8192
     env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="rsi", seed=1)
     assert env.packed and env.batch._auto
@@ -452,13 +453,25 @@ def test_auto_packed_follows_the_workload():
     env.reset("qpos0")                                               # everybody upright on both feet
     zero = torch.zeros((n, 28), device=DEV, dtype=torch.float64)
     env.batch.set_option(A.OPT_AUTORESET, 2)                         # fallen envs restart upright
+    redo0 = env.batch.redo_total()
     for t in range(96):
         env.step(zero)
-    assert not env.packed and env.batch.auto_switches == 1, "a standing population must be handed to the one-env kernel (redo %s)" % (env.batch.redo_reasons(),)
-    env.batch.set_option(A.OPT_AUTORESET, 1)
-    env.reset("rsi")
-    for t in range(128):
-        env.step(torch.randn((n, 28), generator=g, device=DEV, dtype=torch.float64) * 0.9)
+    ne = env.batch.get(A.F_NEFC)
+    assert int((ne >= 32).sum()) > n // 2, "the population stands: %d of %d envs at 32+ rows" % (int((ne >= 32).sum()), n)
+    assert env.packed and env.batch.auto_switches == 0, "a standing population stays on the packed kernel (redo %s)" % (env.batch.redo_reasons(),)
+    assert env.batch.redo_total() - redo0 < 3e-4 * 96 * n
+    # the thresholds: any redo rate is too much -> one-env kernel at the next look; everybody within HEAVY_ROWS -> back
+    env.batch.REDO_RATE_MAX = -1.0
+    for t in range(32):
+        env.step(zero)
+    assert not env.packed and env.batch.auto_switches == 1
+    env.batch.REDO_RATE_MAX = 3e-4; env.batch.HEAVY_ROWS = 0          # (standing envs hold 32+ rows: stays)
+    for t in range(32):
+        env.step(zero)
+    assert not env.packed and env.batch.auto_switches == 1
+    env.batch.HEAVY_ROWS = A.MAXEFC
+    for t in range(32):
+        env.step(zero)
     assert env.packed and env.batch.auto_switches == 2
     env.close()
 
@@ -554,13 +567,13 @@ def test_horizon_launch_forms_agree_with_substeps_and_odd_sizes():
 def test_segment_collector_chooses_the_kernel_from_its_own_horizons():
     """`SegmentCollector` (fused) steps a horizon through dm_batch_rollout and decides, horizon by horizon, between four environments per
     wavefront (one launch per horizon) and one (step launches) from the last horizon's own statistics.  Both an untrained policy's falling
-    population and the reference's shipped policy (standing on both feet: 0.4 % of env-steps beyond a slot's capacity, re-stepped inside
-    their waves — still 12.2 M against 9.2 M env-steps/s, tools/rollout_policy_bench.py) stay on the packed horizon launch; with the
-    tolerated overflow rate set below what the shipped policy produces, the batch is handed to the one-env steps after its first horizon.
+    population and the reference's shipped policy (standing on both feet: 32 .. 37 rows, within the packed path's 40 since round 5) stay on the
+    packed horizon launch; with the tolerated overflow rate set below zero — no population produces less — the batch is handed to the one-env
+    steps after its first horizon.
     Either way the segments follow the generator's protocol."""
     from deepmimic_mujoco_amd.rollout import SegmentCollector
     n, T = 512, 64
-    for shipped, tolerate in ((False, None), (True, None), (True, 1e-4)):
+    for shipped, tolerate in ((False, None), (True, None), (True, -1.0)):
         pol = MlpPolicy.from_tf_checkpoint(CKPT, device=DEV) if shipped else MlpPolicy(device=DEV, seed=1)
         pol.seed(2)
         env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="init", seed=0)
@@ -578,7 +591,7 @@ def test_segment_collector_chooses_the_kernel_from_its_own_horizons():
             assert c._packed_now and c.kernel_switches == 1, "stays on the packed horizon launch (switched on once, at the first horizon)"
             assert not env.packed, "the collector's choice is scoped to its rollout calls: per-step callers of the env keep its own kernel"
         else:
-            assert c.kernel_switches >= 2, "handed to the one-env steps after the first horizon (and back only when no env holds more than 30 rows)"
+            assert c.kernel_switches >= 2, "handed to the one-env steps after the first horizon (and back only when no env holds more than HEAVY_ROWS rows)"
         env.close()
 
 

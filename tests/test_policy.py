@@ -344,7 +344,7 @@ def test_collector_kernel_choice_is_a_function_of_the_last_horizons_statistics()
     from deepmimic_mujoco_amd.rollout import SegmentCollector
 
     class FakeBatch:
-        REDO_RATE_MAX, HEAVY_ROWS = 3e-4, 30
+        REDO_RATE_MAX, HEAVY_ROWS = 3e-4, 38
 
         def __init__(self):
             self.options, self.redo, self.nefc, self._auto = {}, 0, np.zeros(8, dtype=np.int32), True
@@ -377,10 +377,10 @@ def test_collector_kernel_choice_is_a_function_of_the_last_horizons_statistics()
     b.redo += 80                                                         # 10 %: to the one-env steps
     c._choose_kernel()
     assert b.options[A.OPT_PACKED] == 0 and c.kernel_switches == 2
-    b.nefc[3] = 36                                                       # an environment beyond a slot's rows: stays
+    b.nefc[3] = 41                                                       # an environment beyond a slot's rows: stays
     c._choose_kernel()
     assert b.options[A.OPT_PACKED] == 0 and c.kernel_switches == 2
-    b.nefc[3] = 22                                                       # nobody above 30 rows: back
+    b.nefc[3] = 36                                                       # nobody above 38 rows: back
     c._choose_kernel()
     assert b.options[A.OPT_PACKED] == 1 and c.kernel_switches == 3
     c2 = SegmentCollector.__new__(SegmentCollector)

@@ -303,41 +303,57 @@ def _heavy_states(lo, hi, want, seeds=(13, 5, 7)):
 def test_packed_third_row_set_33_to_40_rows_stays_on_the_packed_path():
     """slot_kernel.h slot_constraint<3>: environments with 33 .. 40 constraint rows (a standing humanoid: 32 contact rows + joint limits) are solved by
     the packed path itself — two full row sets plus the partial third one whose residuals are formed from the forces once per sweep — instead of
-    being handed to the one-env code.  On the fibre testbench: states with 34 .. 40 rows share waves with lighter ones; every env agrees with the
-    oracle step by step, nothing is re-stepped (redo total 0), and an environment with <= 32 rows gets bit-identical results whether or not a heavier
-    one shares its wave (its surplus terms are exact zeros)."""
+    being handed to the one-env code.  The three-set code lives in its own instantiation of the step (MAXR = SLOT_MAXROWS), which a horizon launch's
+    wave calls while one of its environments is within three rows of the two-set capacity (slot_step.h slot_rollout); per-step launches keep the lean
+    instantiation and their redo list.  On the fibre testbench, through the horizon form: states with 34 .. 40 rows share waves with lighter ones; every
+    env agrees with the oracle step by step, nothing is re-stepped (redo total 0), and an environment with <= 32 rows gets bit-identical results
+    whether or not a heavier one shares its wave (its surplus terms are exact zeros; its wave runs the other instantiation of the same arithmetic)."""
     from tests.emu.emu import EmuBatch
+    from oracle import oracle as O
     mc = H.mocap()
     heavy = [h for h in _heavy_states(32, 40, want=4)]
     assert len(heavy) >= 3
-    n = 8
+    n, T = 8, 3
     idx, q, v, _ws, _c = H.varied_states(n, seed=21)
     light = (idx.copy(), q.copy(), v.copy())
     slots = [1, 4, 6, 7][:len(heavy)]                    # wave 0: one heavy + three light; wave 1: up to three heavy + one light
     for sl_, h in zip(slots, heavy):
         idx[sl_], q[sl_], v[sl_] = h
-    b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0)
-    b.set_option(A.OPT_PACKED, 1)
-    b.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); b.set(A.F_TIME, np.zeros(n))
-    b.set_state(q, v, frame_idx=idx)
-    ne0 = b.get(A.F_NEFC)
+    acts = np.random.RandomState(6).randn(T, n, 28) * 0.9
+
+    def run(states, horizon=True):
+        b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0)
+        b.set_option(A.OPT_PACKED, 1)
+        b.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); b.set(A.F_TIME, np.zeros(n))
+        b.set_state(states[1], states[2], frame_idx=states[0])
+        ne0 = b.get(A.F_NEFC).copy()
+        if horizon:
+            obs, rew, done = b.rollout(acts)
+        else:
+            obs = np.zeros((T, n, 56)); rew = np.zeros((T, n)); done = np.zeros((T, n), dtype=np.uint8)
+            for t in range(T):
+                b.step(acts[t], 1, out=(obs[t], rew[t], done[t]))
+        return obs, done, ne0, b.get(A.F_QPOS), b.get(A.F_QACC_WARMSTART), b.get(A.F_NEFC), b.get(A.F_SOLVER_ITER), b.redo_total()
+
+    obs, done, ne0, qf, wsf, nef, itf, redo = run((idx, q, v))
     assert all(32 < ne0[s_] <= 40 for s_ in slots), ne0
-    worst, _nd = H.compare_rollout(b, H.oracle_model(), idx, q, v, steps=3, seed=4)
-    assert worst < 1e-10
-    assert b.redo_total() == 0, "an environment within 40 rows left the packed path"
-    # the light environments next to a heavy one: the same bits as among themselves
-    acts = np.random.RandomState(6).randn(2, n, 28) * 0.9
-    res = []
-    for states in ((idx, q, v), light):
-        bb = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0)
-        bb.set_option(A.OPT_PACKED, 1)
-        bb.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); bb.set(A.F_TIME, np.zeros(n))
-        bb.set_state(states[1], states[2], frame_idx=states[0])
-        o = [bb.step(acts[t])[0].copy() for t in range(2)]
-        res.append((o, bb.get(A.F_QPOS), bb.get(A.F_QACC_WARMSTART), bb.get(A.F_NEFC), bb.get(A.F_SOLVER_ITER)))
+    assert redo == 0, "an environment within 40 rows left the packed path"
+    om = H.oracle_model()
+    worst = 0.0
+    for e in range(n):
+        od = O.Data(om); od.reset(); od.set_state(q[e], v[e])
+        for t in range(T):
+            o, r, d, _ = od.env_step(acts[t, e])
+            worst = max(worst, H.rel_err(obs[t, e], o))
+            assert bool(done[t, e]) == d
+        assert int(od.get("nefc")[0]) == nef[e] and int(od.get("solver_iter")[0]) == itf[e]
+    assert worst < 1e-10, worst
+    # the same batch through per-step launches: the lean instantiation, heavy environments through the redo list — the same results to rounding
+    obs1, done1, _n, qf1, _w, nef1, _i, redo1 = run((idx, q, v), horizon=False)
+    assert redo1 >= len(slots) and np.array_equal(nef1, nef) and np.array_equal(done1, done) and H.rel_err(obs1, obs) < 1e-10
+    # the light environments next to a heavy one (three-set instantiation) and among themselves (lean instantiation): the same bits
+    obs2, _d, ne2, qf2, wsf2, nef2, itf2, _r = run(light)
     same = [e for e in range(n) if e not in slots]
-    assert res[1][3].max() <= 32
     for e in same:
-        for t in range(2):
-            assert np.array_equal(res[0][0][t][e], res[1][0][t][e]), (e, t)
-        assert np.array_equal(res[0][1][e], res[1][1][e]) and np.array_equal(res[0][2][e], res[1][2][e]) and res[0][4][e] == res[1][4][e]
+        assert np.array_equal(obs[:, e], obs2[:, e]), e
+        assert np.array_equal(qf[e], qf2[e]) and np.array_equal(wsf[e], wsf2[e]) and itf[e] == itf2[e]

@@ -46,6 +46,9 @@ ev = np.maximum(p[:, 15], 1e-9)
 if n2:
     print("      two-row-set evaluations: %.0f cycles each (PGS %.0f); one-row-set: %.0f each (PGS %.0f)" % (
         p[:, 24].sum() / n2, p[:, 22].sum() / n2, (p[:, 8:14].sum() - p[:, 24].sum()) / max(1e-9, p[:, 15].sum() - n2), (p[:, 12].sum() - p[:, 22].sum()) / max(1e-9, p[:, 15].sum() - n2)))
+n3 = p[:, 25].sum()
+if n3:
+    print("      three-row-set evaluations (33 .. 40 rows somewhere in the wave): %.3f per wave-step, %.0f cycles each (PGS %.0f)" % (p[:, 25].mean(), p[:, 26].sum() / n3, p[:, 27].sum() / n3))
 print("   constrained evaluations per wave-step %.2f of 4; mean wave nmax %.1f; two-row-set evaluations per wave-step %.3f; PGS loop trips per constrained evaluation %.1f" % (
     p[:, 15].mean(), (p[:, 14] / ev).mean(), p[:, 7].mean(), (p[:, 6] / ev).mean()))
 print("   env-steps re-stepped in the wave so far [total, candidates, box slots, contacts, rows, PGS test]:", b.redo_reasons())
