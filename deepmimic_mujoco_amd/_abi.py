@@ -18,7 +18,8 @@ OPT_STEP_QUEUE = 8
 MAX_PIPELINE = 8
 MAX_STEP_QUEUE = 256
 # per-environment capacities of the OPT_PACKED path (include/dmenv.h DM_PACKED_*)
-PACKED_MAXROWS, PACKED_MAXLIMROWS, PACKED_MAXCON, PACKED_MAXFRAME, PACKED_MAXCAND = 40, 16, 13, 8, 32
+PACKED_MAXROWS, PACKED_MAXLIMROWS, PACKED_MAXCON, PACKED_MAXFRAME, PACKED_MAXCAND = 40, 16, 13, 8, 32      # (rows: inside a horizon launch)
+PACKED_MAXROWS_PER_STEP = 32
 (F_QPOS, F_QVEL, F_QACC_WARMSTART, F_TIME, F_FRAME_IDX, F_FRAME_INIT, F_XIPOS, F_COM_Z, F_NCON, F_NEFC,
  F_CONTACT_GEOMS, F_STATUS, F_SOLVER_ITER, F_CTRL, F_EPISODE, F_CYCLE) = range(1, 17)
 

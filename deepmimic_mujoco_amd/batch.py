@@ -106,7 +106,7 @@ class Batch(object):
     # ---- kernel choice by workload (DPVecEnv(packed=None)) ---------------------------------------------------------------
     ADAPT_EVERY = 256            # steps between looks at the batch's row statistics (one small D2H + stream sync each)
     REDO_RATE_MAX = 3e-4         # packed -> one-env: env-steps per env-step that overflowed the packed path's capacities
-    HEAVY_ROWS = A.PACKED_MAXROWS - 2   # (38) one-env -> packed: no environment of the batch holds more constraint rows than this
+    HEAVY_ROWS = 30              # one-env -> packed: no environment of the batch holds more constraint rows than this (per-step packed launches hold 32)
 
     def enable_auto_packed(self, on=True):
         """Let the batch choose between one and four environments per wavefront (DM_OPT_PACKED) from what it is simulating: the packed

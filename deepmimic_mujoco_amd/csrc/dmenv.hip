@@ -19,7 +19,7 @@
 #include "model_host.h"
 
 using namespace dm;
-static_assert((DM_PACKED_MAXROWS == SLOT_MAXROWS || DM_SLOT_MAXROWS != 40 /* an experiment build */) && DM_PACKED_MAXLIMROWS == SLOT_MAXLIMROWS && DM_PACKED_MAXCON == SLOT_MAXCON && DM_PACKED_MAXFRAME == SLOT_MAXFRAME &&
+static_assert((DM_PACKED_MAXROWS == SLOT_MAXROWS || DM_SLOT_MAXROWS != 40 /* an experiment build */) && DM_PACKED_MAXROWS_PER_STEP == 2 * SW && DM_PACKED_MAXLIMROWS == SLOT_MAXLIMROWS && DM_PACKED_MAXCON == SLOT_MAXCON && DM_PACKED_MAXFRAME == SLOT_MAXFRAME &&
               DM_PACKED_MAXCAND == SLOT_MAXCAND, "include/dmenv.h documents the packed path's capacities: keep it in step with slot_kernel.h");
 // ============================================ kernels ======================================================
 // one 64-lane workgroup (= one wavefront) per environment.

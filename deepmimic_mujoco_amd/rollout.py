@@ -252,6 +252,7 @@ class SegmentCollector(object):
     # 67 ms for the same population through one-env launches — the packed horizon stays ahead to about 7 %.  (Round 3's 2 % came from a cost
     # estimate; a run that crossed it at 2.02 % lost a quarter of its rollout throughput for the rest of the training.)
     HORIZON_REDO_RATE_MAX = 7e-2
+    HORIZON_HEAVY_ROWS = 38                # the way back to the packed horizon launch: nobody above this (it holds _abi.PACKED_MAXROWS = 40 rows per env)
 
     def _choose_kernel(self):
         """Four environments per wavefront or one, for the next horizon (envs that leave the choice open: DPVecEnv.horizon_packed_ok).
@@ -277,7 +278,7 @@ class SegmentCollector(object):
             self._last_redo_rate = (redo - self._redo_seen) / float(self.T * self.n)
             want = self._last_redo_rate <= self.HORIZON_REDO_RATE_MAX
         else:
-            want = int(b.get(A.F_NEFC).max()) <= b.HEAVY_ROWS
+            want = int(b.get(A.F_NEFC).max()) <= self.HORIZON_HEAVY_ROWS
         if want != on:
             self.kernel_switches += 1
         self._packed_now = want

@@ -129,7 +129,9 @@ enum {
   DM_OPT_PACKED = 7,      /* 0 (default): one environment per wavefront (k_step_narrow).  1: FOUR environments per wavefront, one 16-lane
                              DPP row each (k_step_packed, csrc/slot_kernel.h) wherever that kernel covers the call: reward modes 0..3 (reward
                              mode 4, v1-quat, always runs on the one-env kernel), with or without the fused policy step.  Per-environment
-                             capacities of that path (csrc/slot_kernel.h SLOT_*): DM_PACKED_MAXROWS constraint rows (of them at most
+                             capacities of that path (csrc/slot_kernel.h SLOT_*): DM_PACKED_MAXROWS constraint rows inside a horizon launch
+                             (dm_batch_rollout, DM_OPT_STEP_QUEUE: two full 16-row sets and a partial third — a humanoid standing on both
+                             feet holds 32 contact rows plus joint limits), DM_PACKED_MAXROWS_PER_STEP in a per-step launch (of them at most
                              DM_PACKED_MAXLIMROWS joint limits), DM_PACKED_MAXCON contacts from at most DM_PACKED_MAXFRAME geom pairs,
                              DM_PACKED_MAXCAND pairs past the bounding spheres; an environment that exceeds one in some step is re-stepped
                              by the one-env code in the same call (dm_batch_redo_total counts them).  The throughput kernel for batches
@@ -154,6 +156,7 @@ enum {
 };
 /* per-environment capacities of the DM_OPT_PACKED path (= csrc/slot_kernel.h SLOT_MAXROWS, SLOT_MAXLIMROWS, SLOT_MAXCON, SLOT_MAXFRAME, SLOT_MAXCAND) */
 #define DM_PACKED_MAXROWS 40
+#define DM_PACKED_MAXROWS_PER_STEP 32
 #define DM_PACKED_MAXLIMROWS 16
 #define DM_PACKED_MAXCON 13
 #define DM_PACKED_MAXFRAME 8

@@ -338,13 +338,13 @@ def test_fused_rollout_step_is_refused_without_the_native_path():
 def test_collector_kernel_choice_is_a_function_of_the_last_horizons_statistics():
     """`SegmentCollector._choose_kernel` (host logic, no device): starts packed, hands a batch to the one-env steps when more than
     HORIZON_REDO_RATE_MAX of the last horizon's env-steps overflowed the packed path, hands it back when no environment holds more than
-    HEAVY_ROWS constraint rows, and leaves batches alone whose configuration pins the kernel."""
+    HORIZON_HEAVY_ROWS constraint rows, and leaves batches alone whose configuration pins the kernel."""
     import numpy as np
     from deepmimic_mujoco_amd import _abi as A
     from deepmimic_mujoco_amd.rollout import SegmentCollector
 
     class FakeBatch:
-        REDO_RATE_MAX, HEAVY_ROWS = 3e-4, 38
+        REDO_RATE_MAX, HEAVY_ROWS = 3e-4, 30
 
         def __init__(self):
             self.options, self.redo, self.nefc, self._auto = {}, 0, np.zeros(8, dtype=np.int32), True

@@ -67,7 +67,12 @@ j=json.loads(sys.stdin.read()); print('standing packed %.3f M  one-env %.3f M' %
   pytest:*)
     ( timeout 1500 python -m pytest ${WHAT#pytest:} -x -q 2>&1 | tail -25 ) | tee -a $OUT/pytest_sel.log ;;
   bench)
-    DM_PROFILE_KEEP=$OUT/raw timeout 900 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-600 $OUT/bench_cfg3.json
+    rm -rf $OUT/rawq $OUT/raw1; mkdir -p $OUT/raw
+    DM_PROFILE_KEEP=$OUT/rawq timeout 900 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-600 $OUT/bench_cfg3.json
+    for f in $OUT/rawq/*; do mv $f $OUT/raw/${TAGP:-r05}_cfg3_queue_$(basename $f); done
+    # the one-launch-set-per-call form with its own counter passes (what vecenv_step times): raw exports for the k_step_narrow summary
+    DM_PROFILE_KEEP=$OUT/raw1 timeout 600 python bench.py --step-queue 0 --no-cpu-baseline --no-gym-loop --no-vecenv-leg --no-horizon-leg > $OUT/bench_cfg3_unqueued_pmc.json 2>/dev/null; cut -c1-200 $OUT/bench_cfg3_unqueued_pmc.json
+    for f in $OUT/raw1/*; do mv $f $OUT/raw/${TAGP:-r05}_cfg3_kstep_$(basename $f); done
     timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 $Q > $OUT/bench_cfg3_driver_window.json 2>/dev/null; cut -c1-300 $OUT/bench_cfg3_driver_window.json ;;
   benchall)
     for rw in alive v3-config; do timeout 300 python bench.py --reward $rw $Q > $OUT/bench_cfg3_$rw.json 2>/dev/null; cut -c1-200 $OUT/bench_cfg3_$rw.json; done
@@ -81,6 +86,10 @@ j=json.loads(sys.stdin.read()); print('standing packed %.3f M  one-env %.3f M' %
       $(find /tmp/p_trace -name "*.db" | head -1) > /dev/null; head -14 $OUT/krollout_summary.md
     ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace1 -- python $OLDPWD/bench.py --_child --step-queue 0 --steps 96 --warmup 16 --prewarm-horizons 1 $Q > /dev/null 2>&1 )
     ROWS=6 python tools/rocprof_summary.py $OUT/kstep_summary.md "one launch set per call — $TAG, MI355X (bench.py --step-queue 0: k_step_narrow, 4096 envs as 2 pipelined sub-batches; what vecenv_step times)" \
-      $(find /tmp/p_trace1 -name "*.db" | head -1) > /dev/null; head -10 $OUT/kstep_summary.md ;;
+      $(find /tmp/p_trace1 -name "*.db" | head -1) > /dev/null; head -10 $OUT/kstep_summary.md
+    # the PMC tables of both summaries from the raw per-launch counter exports the `bench` bundle kept (run `bench` first)
+    ls $OUT/raw/*_cfg3_queue_*_counters.csv > /dev/null 2>&1 && python tools/pmc_table.py $OUT/krollout_summary.md $OUT/raw/${TAGP:-r05}_cfg3_queue > /dev/null
+    ls $OUT/raw/*_cfg3_kstep_*_counters.csv > /dev/null 2>&1 && python tools/pmc_table.py $OUT/kstep_summary.md $OUT/raw/${TAGP:-r05}_cfg3_kstep > /dev/null
+    tail -12 $OUT/krollout_summary.md ;;
   *) echo "unknown bundle $WHAT" ;;
 esac; done
