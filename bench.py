@@ -155,7 +155,11 @@ def cpu_baseline(clip, reward="imitation", budget_s=14.0):
     (OMP_PROC_BIND=close, OMP_PLACES=cores): un-pinned, the runtime piles threads of a 256-logical-CPU host onto a few cores
     (round 1: 129 k env-steps/s at 32 threads, 14 k at 256).  Reported: the physical-core run, next to one core."""
     ncores, nlogical = physical_cores()
-    counts = sorted({1, min(32, ncores), ncores, nlogical})
+    quota = cpu_quota_cores()
+    counts = {1, min(32, ncores), ncores, nlogical}
+    if quota:                       # the container's CPU-time quota in cores: a run with exactly that many threads (more threads only share the same CPU time)
+        counts.add(max(1, min(ncores, int(quota + 0.5))))
+    counts = sorted(counts)
     per = budget_s / len(counts)
     res = {}
     for c in counts:
@@ -170,7 +174,10 @@ def cpu_baseline(clip, reward="imitation", budget_s=14.0):
     b = res[best]
     return {"value": round(b["rate"], 1), "unit": "env-steps/s", "cores": best, "kind": "port", "single_core_value": round(res[1]["rate"], 1),
             "by_threads": {str(c): round(res[c]["rate"], 1) for c in counts}, "physical_cores": ncores, "logical_cpus": nlogical,
-            "cgroup_cpu_quota_cores": cpu_quota_cores(),
+            "cgroup_cpu_quota_cores": quota,
+            "cores_note": ("`cores` is the THREAD count of the fastest run; the container's CPU-time quota is %s cores, so at most that many cores' worth of CPU time "
+                           "was available to it (run with exactly that many threads: %s env-steps/s)" % (quota, res.get(max(1, min(ncores, int(quota + 0.5))), {}).get("rate") and
+                                                                                                      round(res[max(1, min(ncores, int(quota + 0.5)))]["rate"], 1))) if quota else None,
             "sample": "%d envs x %d steps of the same workload (%s, contacts+limits, %s reward, N(0,0.9^2) actions, RSI reset on done) run entirely "
                       "in C (oracle/dm_oracle.c dmo_bench_rollout, fp64), one trajectory per OpenMP task, %d threads (OMP_PROC_BIND=close, "
                       "OMP_PLACES=cores unless threads > cores; tried %s), %.1f s"

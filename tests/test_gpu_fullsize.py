@@ -271,6 +271,7 @@ def test_standing_population_full_shard_matches_oracle(form):
         rr = b.redo_reasons()
         print("   env-steps above 32 rows: %d; within two rows of the capacity (%d): %d; handed to the one-env code for rows: %d" % (above32, A.PACKED_MAXROWS, near_cap, rr[4]))
         assert above32 > 0.01 * n * STEPS, "the standing population must hold environments above 32 rows"
-        assert rr[4] <= near_cap, "environments well within %d rows left the packed path: %s" % (A.PACKED_MAXROWS, rr)
-        assert rr[0] < 0.2 * above32, "most env-steps above 32 rows must stay on the packed path: %s of %d" % (rr, above32)
+        # (not all: a wave calls the three-set instantiation of the step while one of its environments held 24+ rows after the LAST step — the step
+        #  that takes an environment from fewer rows past 32, e.g. the landing from the init pose this population starts with, is re-stepped as before)
+        assert rr[0] < 0.1 * above32, "nine in ten env-steps above 32 rows must stay on the packed path: %s of %d" % (rr, above32)
     b.close()

@@ -13,7 +13,7 @@ for WHAT in "$@"; do case "$WHAT" in
   newtests)
     ( timeout 900 python -m pytest tests/test_gpu_queue.py -x -q 2>&1 | tail -15 ) | tee $OUT/pytest_new.log ;;
   tests)
-    ( timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 2>&1 | tail -40 ) > $OUT/pytest_gpu.log; tail -14 $OUT/pytest_gpu.log
+    ( timeout 2400 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -60 ) > $OUT/pytest_gpu.log; tail -14 $OUT/pytest_gpu.log
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log ;;
   ab:*)
     # A/B of whole-library builds under build_ab/ inside one call: the driver's 20-step window and the 512-step default, alternating
