@@ -717,17 +717,28 @@ struct SlotWarm {
 };
 // one PGS row (scaled-residual form of env_kernel.h): delta = max(-f, t) of the row's own lane, broadcast, t += A_s[:, row] delta; the own
 // lane's residual at its row is kept through a one-hot multiply-add (oh[i] = 1 in slot lane i)
+// four consecutive rows CC .. CC + 3 (CC a multiple of 4: all in one row set) as ONE assembly block (wave.h pgs_rows4 / pgs_rows4_2)
 template <int CC, int NS, class R>
-DM_DEV void slot_sweep_row(const R (*AR)[16 * NS], R* t, R* tsave, const R* nf0, const R* oh) {
-  if constexpr (NS == 1) dmw::pgs_row<CC % 16>(t[0], tsave[0], nf0[0], AR[0][CC], oh[CC % 16]);
-  else dmw::pgs_row2<CC % 16>(t[CC / 16], tsave[CC / 16], t[1 - CC / 16], nf0[CC / 16], AR[CC / 16][CC], AR[1 - CC / 16][CC], oh[CC % 16]);
+DM_DEV void slot_sweep_rows4(const R (*AR)[16 * NS], R* t, R* tsave, const R* nf0, const R* oh) {
+  static_assert(CC % 4 == 0, "row groups of four");
+#ifdef DM_PGS_ROW_BLOCKS          // (A/B hook: round 4's one-row blocks)
+  if constexpr (NS == 1) { dmw::pgs_row<CC % 16>(t[0], tsave[0], nf0[0], AR[0][CC], oh[CC % 16]); dmw::pgs_row<CC % 16 + 1>(t[0], tsave[0], nf0[0], AR[0][CC + 1], oh[CC % 16 + 1]);
+                           dmw::pgs_row<CC % 16 + 2>(t[0], tsave[0], nf0[0], AR[0][CC + 2], oh[CC % 16 + 2]); dmw::pgs_row<CC % 16 + 3>(t[0], tsave[0], nf0[0], AR[0][CC + 3], oh[CC % 16 + 3]); }
+  else {
+    constexpr int o = CC / 16;
+    dmw::pgs_row2<CC % 16>(t[o], tsave[o], t[1 - o], nf0[o], AR[o][CC], AR[1 - o][CC], oh[CC % 16]); dmw::pgs_row2<CC % 16 + 1>(t[o], tsave[o], t[1 - o], nf0[o], AR[o][CC + 1], AR[1 - o][CC + 1], oh[CC % 16 + 1]);
+    dmw::pgs_row2<CC % 16 + 2>(t[o], tsave[o], t[1 - o], nf0[o], AR[o][CC + 2], AR[1 - o][CC + 2], oh[CC % 16 + 2]); dmw::pgs_row2<CC % 16 + 3>(t[o], tsave[o], t[1 - o], nf0[o], AR[o][CC + 3], AR[1 - o][CC + 3], oh[CC % 16 + 3]);
+  }
+#else
+  if constexpr (NS == 1) dmw::pgs_rows4<CC % 16>(t[0], tsave[0], nf0[0], &AR[0][CC], &oh[CC % 16]);
+  else dmw::pgs_rows4_2<CC % 16>(t[CC / 16], tsave[CC / 16], t[1 - CC / 16], nf0[CC / 16], &AR[CC / 16][CC], &AR[1 - CC / 16][CC], &oh[CC % 16]);
+#endif
 }
 template <int C, int NS, class R>
 struct SlotSweep {
   static DM_DEV void run(const R (*AR)[16 * NS], R* t, R* tsave, const R* nf0, const R* oh, int nmax) {
     if constexpr (C < 16 * NS) {
-      slot_sweep_row<C, NS, R>(AR, t, tsave, nf0, oh); slot_sweep_row<C + 1, NS, R>(AR, t, tsave, nf0, oh);
-      slot_sweep_row<C + 2, NS, R>(AR, t, tsave, nf0, oh); slot_sweep_row<C + 3, NS, R>(AR, t, tsave, nf0, oh);
+      slot_sweep_rows4<C, NS, R>(AR, t, tsave, nf0, oh);
       if (C + 4 < nmax) SlotSweep<C + 4, NS, R>::run(AR, t, tsave, nf0, oh, nmax);
     }
   }

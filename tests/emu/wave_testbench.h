@@ -130,6 +130,13 @@ template <int I, class T> inline void pgs_row2(T& t_own, T& tsave_own, T& t_othe
   const T d = std::fmax(nf0, t_own); tsave_own = tsave_own + onehot * t_own; const T b = row_bcast<I>(d);
   t_own = t_own + b * a_own; t_other = t_other + b * a_other;
 }
+template <int I0, class T> inline void pgs_rows4(T& t, T& tsave, T nf0, const T* a, const T* oh) {
+  pgs_row<I0>(t, tsave, nf0, a[0], oh[0]); pgs_row<I0 + 1>(t, tsave, nf0, a[1], oh[1]); pgs_row<I0 + 2>(t, tsave, nf0, a[2], oh[2]); pgs_row<I0 + 3>(t, tsave, nf0, a[3], oh[3]);
+}
+template <int I0, class T> inline void pgs_rows4_2(T& t_own, T& tsave_own, T& t_other, T nf0, const T* a_own, const T* a_other, const T* oh) {
+  pgs_row2<I0>(t_own, tsave_own, t_other, nf0, a_own[0], a_other[0], oh[0]); pgs_row2<I0 + 1>(t_own, tsave_own, t_other, nf0, a_own[1], a_other[1], oh[1]);
+  pgs_row2<I0 + 2>(t_own, tsave_own, t_other, nf0, a_own[2], a_other[2], oh[2]); pgs_row2<I0 + 3>(t_own, tsave_own, t_other, nf0, a_own[3], a_other[3], oh[3]);
+}
 template <int I, class T> inline void pgs_row3(T& t3, T& tsave3, T& t0, T& t1, T nf0, T b, T u0, T u1, T onehot) {
   const T d = std::fmax(nf0, t3); tsave3 = tsave3 + onehot * t3; const T bc = row_bcast<I>(d);
   t3 = t3 + bc * b; t0 = t0 + bc * u0; t1 = t1 + bc * u1;
