@@ -1140,67 +1140,80 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
   R oh[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) { oh[i] = sl == i ? R(1) : R(0); dmw::pin_value(oh[i]); }
-  // one sweep: forces f, scaled residuals t; returns this lane's share of the cost improvement and whether [MJ costChange] would object
-  auto sweep = [&](R& imp, bool& bad) {
-    const int nm = dmw::launder_uniform(nmax);
-    R nf0[NF], tsave[NF];
+  // The loop's state is the NEGATED force nf = -f (what a row's clamp compares against: no negation per sweep) and a lane's share of the cost CHANGE of a
+  // sweep (negative = improvement; the termination test compares its sum against -tolerance: no negation either).  Sign flips and the order of the
+  // summands are exact in floating point, so every force, every residual and every decision is bit-identical to the form with f and an "improvement".
+  R nf[NF], nf3 = -f3;
 #pragma unroll
-    for (int k = 0; k < NF; k++) { nf0[k] = -f[k]; tsave[k] = 0; }
-    SlotSweep<0, NF, R>::run(AR, t, tsave, nf0, oh, nm);
-    imp = 0; bad = false;
+  for (int k = 0; k < NF; k++) nf[k] = -f[k];
+  R pgs_ntol = -pgs_tol;
+  dmw::pin_value(pgs_ntol);
+  // one sweep: negated forces nf, scaled residuals t; returns this lane's share of the cost change and whether [MJ costChange] would object
+  auto sweep = [&](R& chg, bool& bad) {
+    const int nm = dmw::launder_uniform(nmax);
+    R tsave[NF];
+#pragma unroll
+    for (int k = 0; k < NF; k++) tsave[k] = 0;
+    SlotSweep<0, NF, R>::run(AR, t, tsave, nf, oh, nm);
+    chg = 0; bad = false;
 #pragma unroll
     for (int k = 0; k < NF; k++) {
-      const R delta = dmw::max_raw(nf0[k], tsave[k]);
+      const R delta = dmw::max_raw(nf[k], tsave[k]);
       const R change = (delta * diag[k]) * (R(0.5) * delta - tsave[k]);
-      f[k] += delta; imp -= change; bad = bad || (change > pgs_detect);
+      nf[k] -= delta; chg += change; bad = bad || (change > pgs_detect);
     }
     if constexpr (EXT) {
       // the surplus rows: residual formed from the forces as they stand after the 32 rows before them (a frozen environment: no step)
-      R t3 = slot_ext_residual(U, B3, f, diag, f3, tb3, ndinv3, sl);
+      R fnow[NF];
+#pragma unroll
+      for (int k = 0; k < NF; k++) fnow[k] = -nf[k];
+      const R f3now = -nf3;
+      R t3 = slot_ext_residual(U, B3, fnow, diag, f3now, tb3, ndinv3, sl);
       t3 = frozen ? R(0) : t3;
-      const R nf03 = -f3;
       R tsave3 = 0;
-      SlotExtSweep<0, R>::run(U, B3, t3, tsave3, t, nf03, oh, nm - 2 * SW);
-      const R delta = dmw::max_raw(nf03, tsave3);
+      SlotExtSweep<0, R>::run(U, B3, t3, tsave3, t, nf3, oh, nm - 2 * SW);
+      const R delta = dmw::max_raw(nf3, tsave3);
       const R change = (delta * diag3) * (R(0.5) * delta - tsave3);
-      f3 += delta; imp -= change; bad = bad || (change > pgs_detect);
+      nf3 -= delta; chg += change; bad = bad || (change > pgs_detect);
     }
   };
   // The termination test of sweep k (a DPP reduction) is independent of the rows of sweep k + 1: sweep k + 1 is issued speculatively
   // beside it and dropped — forces restored, rows frozen — for the environments that turn out to have converged at sweep k.
-  // Freezing: every row's step becomes exactly zero (t = 0 where a force is held, t < 0 where it is zero), so a finished environment's
-  // forces no longer move while its partners go on.
+  // Freezing: the residuals are set to zero; a row's step is max(-f, t) = max(-f, 0) = 0 whatever force it holds (f >= 0), so a finished
+  // environment's forces no longer move while its partners go on.
   if (dmw::ballot(!frozen) != 0ull) {
-    R imp; bool bad;
-    sweep(imp, bad);
+    R chg; bool bad;
+    sweep(chg, bad);
     if (!frozen) { iter = 1; anybad = bad; }
     bool more = true;
     while (more) {
-      R fprev[NF], fprev3 = f3;
+      R nfprev[NF], nfprev3 = nf3;
 #pragma unroll
-      for (int k = 0; k < NF; k++) fprev[k] = f[k];
-      const R improvement = dmw::sum16(imp) * pgs_scale;          // of the last accepted sweep
-      R imp2; bool bad2;
-      sweep(imp2, bad2);                                          // speculative
+      for (int k = 0; k < NF; k++) nfprev[k] = nf[k];
+      const R schg = dmw::sum16(chg) * pgs_scale;                  // of the last accepted sweep: -improvement
+      R chg2; bool bad2;
+      sweep(chg2, bad2);                                          // speculative
       // (selects, not branches: `frozen` differs from slot to slot, and a divergent region costs more than the handful of moves it guards)
       const bool act = !frozen;
-      const bool conv = (int)act & ((int)(improvement < pgs_tol) | (int)(iter >= maxiter));     // (bit operations: no short-circuit region)
+      const bool conv = (int)act & ((int)(schg > pgs_ntol) | (int)(iter >= maxiter));     // (bit operations: no short-circuit region)
 #pragma unroll
       for (int k = 0; k < NF; k++) {
-        const R tf = fprev[k] > 0 ? R(0) : R(-1);
-        f[k] = conv ? fprev[k] : f[k];
-        t[k] = conv ? tf : t[k];
+        nf[k] = conv ? nfprev[k] : nf[k];
+        t[k] = conv ? R(0) : t[k];
       }
-      if constexpr (EXT) f3 = conv ? fprev3 : f3;
+      if constexpr (EXT) nf3 = conv ? nfprev3 : nf3;
       const bool go = (int)act & (int)!conv;
       iter += go ? 1 : 0;
       anybad = (int)anybad | ((int)go & (int)bad2);
       frozen = (int)frozen | (int)conv;
-      imp = imp2;
+      chg = chg2;
       more = dmw::ballot(!frozen) != 0ull;
       if (PROF) prof[6] += 1;
     }
   }
+#pragma unroll
+  for (int k = 0; k < NF; k++) f[k] = -nf[k];
+  f3 = -nf3;
   if (PROF && NS >= 2) { prof[22] += dmw::clk() - pt0; }
   if (PROF && NS == 3) { prof[27] += dmw::clk() - pt0; }
   SLOT_STAMP(12)
