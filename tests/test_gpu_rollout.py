@@ -146,6 +146,9 @@ def test_bench_prints_one_contract_line():
     assert sp["windows"] == 3 and sp["min"] <= sp["median"] == j["value"] <= sp["max"]
     ve = j["vecenv_step"]
     assert ve["steps"] == 16 and ve["value"] > 1e5 and ve["kernel"] == "k_step_narrow"
+    # the headline states its own precondition: the step queue is a non-default option, and what `value` therefore is
+    assert j["config"]["non_default_options"] == ["DM_OPT_STEP_QUEUE=256"] and "vecenv_step" in j["config"]["value_is"]
+    assert j["config"]["distinct_gpus"] == 1 and j["config"]["rank_devices"] is None        # (single process: no process group to gather the PCI addresses over)
 
 
 @pytest.mark.gpu
@@ -167,6 +170,9 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert j["n_gpus"] == 2 and j["config"]["n_ranks_seen"] == 2 and j["config"]["dist_backend"] == "gloo"
     assert j["config"]["global_envs"] == 1024 and j["config"]["gathers_completed"] >= 1 and j["scaling"] == "weak"
     assert j["value"] > 1e5 and "cpu_baseline" not in j
+    # the start-up line of a multi-rank run says which GPU every rank sits on (gathered over the process group): two ranks sharing the one GPU here
+    assert "rank -> GPU" in out.stderr and "1 distinct GPU(s) for 2 rank(s)" in out.stderr
+    assert len(j["config"]["rank_devices"]) == 2 and j["config"]["distinct_gpus"] == 1 and j["config"]["rank_devices"][0].rsplit(".", 1)[0] == j["config"]["rank_devices"][1].rsplit(".", 1)[0]
 
 
 @pytest.mark.gpu
@@ -186,6 +192,7 @@ def test_bench_rccl_code_path_runs_at_world_size_one():
                           "--no-vecenv-leg", "--no-horizon-leg"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "nccl process group up, 1 ranks (backend reports nccl)" in out.stderr
+    assert "1 distinct GPU(s) for 1 rank(s)" in out.stderr                                  # the PCI address travelled over RCCL (an all_gather of a device tensor)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]       # (RCCL may print to stdout when the group is torn down)
     assert len(lines) == 1, out.stdout[-2000:]
     j = json.loads(lines[0])
