@@ -168,7 +168,7 @@ enum {
  *   101 per-stage shader-clock profile (k_step_prof + dm_batch_read_profile)
  *   102 1: register tier of 32 columns of A + memory strip (default); 0: all 64 columns in registers (k_step)
  *   103 1: force the guarded PGS re-solve path (results must not change)
- *   104 1: longest-first dispatch order, recomputed every step from the previous step's row counts (default); 0: identity */
+ *   104 1: longest-first dispatch order from the previous step's row counts (default: per-step launches order themselves through tickets their envs take at the end of a step, horizon launches are grouped by a counting sort once per launch); 0: identity */
 int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t value);
 
 /* Replaces: MujocoEnv.set_state(qpos, qvel) = sim.set_state(...) + sim.forward() (src/dp_env_v3.py:153,160):
