@@ -107,31 +107,44 @@ class Batch(object):
     ADAPT_EVERY = 256            # steps between looks at the batch's row statistics (one small D2H + stream sync each)
     REDO_RATE_MAX = 3e-4         # packed -> one-env: env-steps per env-step that overflowed the packed path's capacities
     HEAVY_ROWS = 30              # one-env -> packed: no environment of the batch holds more constraint rows than this (per-step packed launches hold 32)
+    HEAVY_ROWS_EXT = 38          # ... -> packed with the three-set code (OPT_PACKED 2: 40 rows per env)
 
     def enable_auto_packed(self, on=True):
         """Let the batch choose between one and four environments per wavefront (DM_OPT_PACKED) from what it is simulating: the packed
-        kernel is 1.4-1.5x faster while environments stay within its per-env capacities (_abi.PACKED_*: 32 rows, 13 contacts), but every environment
-        beyond them is re-stepped one per wave AFTER the packed launch — with a policy that stands on both feet (32+ rows most of the
-        time) that tail costs more than the packing saves.  Every ADAPT_EVERY steps the redo rate (packed) or the largest row count
-        (one-env) of the batch decides; the choice is a deterministic function of the trajectory."""
+        kernel is 1.4-1.5x faster while environments stay within its per-env capacities (_abi.PACKED_*: 32 rows per step, 13 contacts), but every
+        environment beyond them is re-stepped one per wave AFTER the packed launch.  A population that stands on both feet (33 .. 37 rows for a few per
+        cent of its env-steps) is moved to the per-step launches with the three-set code (OPT_PACKED 2: 40 rows per env, ~8 % slower otherwise) and back
+        when nobody holds more than 32 rows; overflows of another kind send the batch to the one-env kernel.  Every ADAPT_EVERY steps the redo rate and
+        its reasons (packed) or the largest row count (one-env) of the batch decide; the choice is a deterministic function of the trajectory."""
         self._auto = bool(on)
         self._auto_ctr = 0
         self._redo_last = self.redo_total() if on else 0
+        self._redo_rows_last = self.redo_reasons()[4] if on else 0
         self.auto_switches = 0
 
     def _adapt(self):
         self._auto_ctr += 1
         if self._auto_ctr % self.ADAPT_EVERY:
             return
-        if self.__dict__.get("options", {}).get(A.OPT_PACKED, 0):
-            redo = self.redo_total()
+        mode = int(self.__dict__.get("options", {}).get(A.OPT_PACKED, 0))
+        if mode:
+            reasons = self.redo_reasons()
+            redo = reasons[0]
             rate = (redo - self._redo_last) / float(self.ADAPT_EVERY * self.n)
-            self._redo_last = redo
+            rows_share = (reasons[4] - self.__dict__.get("_redo_rows_last", 0)) / float(max(1, redo - self._redo_last))
+            self._redo_last = redo; self._redo_rows_last = reasons[4]
             if rate > self.REDO_RATE_MAX:
-                self.set_option(A.OPT_PACKED, 0); self.auto_switches += 1
-        elif int(self.get(A.F_NEFC).max()) <= self.HEAVY_ROWS:
-            self.set_option(A.OPT_PACKED, 1); self.auto_switches += 1
-            self._redo_last = self.redo_total()
+                # too many environments beyond the per-step capacities.  Nearly all of them for ROWS (a population standing on both feet: 33 .. 37): the
+                # per-step launches with the three-set code (OPT_PACKED 2, 40 rows per env); otherwise — or if that was already on — the one-env kernel
+                self.set_option(A.OPT_PACKED, 2 if (mode == 1 and rows_share >= 0.9) else 0); self.auto_switches += 1
+            elif mode == 2 and int((self.get(A.F_NEFC) > A.PACKED_MAXROWS_PER_STEP).sum()) == 0:
+                self.set_option(A.OPT_PACKED, 1); self.auto_switches += 1            # nobody above 32 rows any more: the lean per-step kernel (8 % faster)
+        else:
+            top = int(self.get(A.F_NEFC).max())
+            if top <= self.HEAVY_ROWS_EXT:
+                self.set_option(A.OPT_PACKED, 1 if top <= self.HEAVY_ROWS else 2); self.auto_switches += 1
+                r = self.redo_reasons()
+                self._redo_last = r[0]; self._redo_rows_last = r[4]
 
     # ---- the hot path -------------------------------------------------------------------------------
     def _step_device(self, action, n_substeps, out):

@@ -241,6 +241,7 @@ struct dm_batch {
   int queue_cap = 0; std::vector<StepRow> q; int q_nsub = 1; StepRow* d_rows = nullptr; int rows_cap = 0; long long queue_flushes = 0, queue_steps = 0;
   int horizon_mode = -1; // option 106: dm_batch_rollout on the packed path as ONE launch per horizon (1), as step launches (0), by batch size (-1, default)
   bool packed = false;   // option 105: four environments per wavefront (k_step_packed) where that kernel covers the configuration
+  bool packed_ext = false;   // DM_OPT_PACKED = 2: per-step packed launches with the three-set code (k_step_packed_ext: 40 rows per env, ~8 % slower otherwise)
   bool two_tier = true, reorder = true, has_rows = true; int resident_waves = 2048;   // CUs x 8 single-wave workgroups (LDS-limited)
   bool timing = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f; bool ev_pending = false;
   // pipelined sub-batches (DM_OPT_PIPELINE): the env range is cut into `pipe` contiguous parts, each stepped on its own stream
@@ -424,7 +425,9 @@ extern "C" int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t v) {
       break;
     }
     case 106: b->horizon_mode = v < 0 ? -1 : (v != 0 ? 1 : 0); break;   /* dm_batch_rollout on the packed path: 1 one launch per horizon, 0 step launches, -1 (default) by batch size */
-    case DM_OPT_PACKED: case 105: b->packed = v != 0; break;        /* 1: four environments per wavefront (k_step_packed) where it covers the configuration */
+    case DM_OPT_PACKED: case 105:                                   /* 1: four environments per wavefront (k_step_packed) where it covers the configuration; 2: the same, per-step launches with the three-set code */
+      if (v < 0 || v > 2) return fail(DM_EINVAL, "DM_OPT_PACKED must be 0, 1 or 2");
+      b->packed = v != 0; b->packed_ext = v == 2; break;
     case 104: b->reorder = v != 0; if (!b->reorder) b->B.order = nullptr; break;   /* 1 (default): longest-first dispatch order (k_order) */
     case 100: b->B.env_offset = (int)v; break;  /* global id of env 0 (multi-GPU sharding) */
     case 102: b->two_tier = v != 0; break;       /* 1 (default): register tier of NARROW_ROWS columns + overflow strip; 0: all 64 columns in registers */
@@ -639,8 +642,8 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
       if (b->timing && h == 0) HIPCHK(hipEventRecord(b->ev0, b->ps[0]));     // timing: sub-batch 0's kernel on ITS stream
       if (use_packed) {
         int* rc = b->B.redo_count + 2 * h + b->redo_phase; int* rn = b->B.redo_count + 2 * h + (1 - b->redo_phase);
-        if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, rc, *pol);
-        else hipLaunchKernelGGL(k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, rc);
+        if (pol) hipLaunchKernelGGL(b->packed_ext ? k_step_packed_act_ext : k_step_packed_act, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, rc, *pol);
+        else hipLaunchKernelGGL(b->packed_ext ? k_step_packed_ext : k_step_packed, dim3((hi - lo + SLOTS - 1) / SLOTS), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, rc);
         if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, (const int*)rc, rn, pol ? *pol : nopol);
       }
       else if (pol) hipLaunchKernelGGL(k_step_act, dim3(hi - lo), dim3(64), 0, b->ps[h], b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, lo, hi - lo, *pol);
@@ -658,8 +661,8 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
       // (a step that is not pipelined has joined every sub-batch stream: all of them are idle, so ONE pair of counters is clean — pair 0's
       //  two are cleared here once if a pipelined step used them before)
       int* rc = b->B.redo_count + b->redo_phase; int* rn = b->B.redo_count + (1 - b->redo_phase);
-      if (pol) hipLaunchKernelGGL(k_step_packed_act, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc, *pol);
-      else hipLaunchKernelGGL(k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc);
+      if (pol) hipLaunchKernelGGL(b->packed_ext ? k_step_packed_act_ext : k_step_packed_act, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc, *pol);
+      else hipLaunchKernelGGL(b->packed_ext ? k_step_packed_ext : k_step_packed, dim3((b->n + SLOTS - 1) / SLOTS), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, rc);
       if (b->has_rows) hipLaunchKernelGGL(k_step_redo, dim3(REDO_BLOCKS), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, (const int*)rc, rn, pol ? *pol : nopol);
     }
     else if (pol) hipLaunchKernelGGL(k_step_act, dim3(b->n), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n, *pol);

@@ -47,6 +47,10 @@ __global__ void k_step_packed(const dm::DevModel<Real>* __restrict__ Mp, dm::Bat
                               unsigned char* __restrict__ done, int n_substeps, int first, int count, int* __restrict__ redo_count);
 __global__ void k_step_packed_act(const dm::DevModel<Real>* __restrict__ Mp, dm::Batch<Real> B, const Ext* __restrict__ action, Ext* __restrict__ obs, Ext* __restrict__ reward,
                                   unsigned char* __restrict__ done, int n_substeps, int first, int count, int* __restrict__ redo_count, dmp::PolicyArgs pa);
+__global__ void k_step_packed_ext(const dm::DevModel<Real>* __restrict__ Mp, dm::Batch<Real> B, const Ext* __restrict__ action, Ext* __restrict__ obs, Ext* __restrict__ reward,
+                                  unsigned char* __restrict__ done, int n_substeps, int first, int count, int* __restrict__ redo_count);
+__global__ void k_step_packed_act_ext(const dm::DevModel<Real>* __restrict__ Mp, dm::Batch<Real> B, const Ext* __restrict__ action, Ext* __restrict__ obs, Ext* __restrict__ reward,
+                                      unsigned char* __restrict__ done, int n_substeps, int first, int count, int* __restrict__ redo_count, dmp::PolicyArgs pa);
 __global__ void k_rollout_packed(const dm::DevModel<Real>* __restrict__ Mp, const dm::Batch<Real>* __restrict__ Bp, const dm::StepRow* __restrict__ rows, int n_substeps, int first,
                                  int count, int T, dmp::PolicyArgs pa, long long* __restrict__ wave_clk);
 __global__ void k_step_packed_prof(const dm::DevModel<Real>* __restrict__ Mp, dm::Batch<Real> B, const Ext* __restrict__ action, Ext* __restrict__ obs, Ext* __restrict__ reward,

@@ -266,7 +266,8 @@ class SegmentCollector(object):
             return None
         # the choice holds for this collector's rollout calls only: what the batch was set to (and its per-step chooser, if on) comes back
         # after each call, so `DPVecEnv.step` callers of the same env are not moved to a kernel that is the slower one per step
-        was_on = bool(b.__dict__.get("options", {}).get(A.OPT_PACKED, 0))
+        was_mode = int(b.__dict__.get("options", {}).get(A.OPT_PACKED, 0))      # (0 one env per wave, 1 packed, 2 packed with the three-set code per step)
+        was_on = bool(was_mode)
         was_auto = bool(b.__dict__.get("_auto"))
         on = getattr(self, "_packed_now", None)
         if on is None:
@@ -290,7 +291,7 @@ class SegmentCollector(object):
 
         def restore():
             if want != was_on:
-                b.set_option(A.OPT_PACKED, 1 if was_on else 0)
+                b.set_option(A.OPT_PACKED, was_mode)
             if was_auto:
                 b._auto = True
         return restore

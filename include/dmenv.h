@@ -126,13 +126,15 @@ enum {
                              take the wave slots freed while the previous one drains.  The outputs of such calls are complete
                              once the caller's stream has joined: dm_batch_join() (no host wait), dm_batch_sync(), or any other
                              entry point of the batch.  Results are identical for every P. */
-  DM_OPT_PACKED = 7,      /* 0 (default): one environment per wavefront (k_step_narrow).  1: FOUR environments per wavefront, one 16-lane
+  DM_OPT_PACKED = 7,      /* 0 (default): one environment per wavefront (k_step_narrow).  1 / 2: FOUR environments per wavefront, one 16-lane
                              DPP row each (k_step_packed, csrc/slot_kernel.h) wherever that kernel covers the call: reward modes 0..3 (reward
                              mode 4, v1-quat, always runs on the one-env kernel), with or without the fused policy step.  Per-environment
                              capacities of that path (csrc/slot_kernel.h SLOT_*): DM_PACKED_MAXROWS constraint rows inside a horizon launch
                              (dm_batch_rollout, DM_OPT_STEP_QUEUE: two full 16-row sets and a partial third — a humanoid standing on both
-                             feet holds 32 contact rows plus joint limits), DM_PACKED_MAXROWS_PER_STEP in a per-step launch (of them at most
-                             DM_PACKED_MAXLIMROWS joint limits), DM_PACKED_MAXCON contacts from at most DM_PACKED_MAXFRAME geom pairs,
+                             feet holds 32 contact rows plus joint limits), DM_PACKED_MAXROWS_PER_STEP in a per-step launch — unless the option
+                             is 2: per-step launches then run k_step_packed_ext, the same step with the three-set code compiled in
+                             (DM_PACKED_MAXROWS rows; ~8 % slower for environments that never get there: meant for populations that stand
+                             on both feet) — (of them at most DM_PACKED_MAXLIMROWS joint limits), DM_PACKED_MAXCON contacts from at most DM_PACKED_MAXFRAME geom pairs,
                              DM_PACKED_MAXCAND pairs past the bounding spheres; an environment that exceeds one in some step is re-stepped
                              by the one-env code in the same call (dm_batch_redo_total counts them).  The throughput kernel for batches
                              of two or more waves per SIMD (>= 8192 envs on one MI355X): 1.4-1.5x; at 4096 envs a per-step launch is one

@@ -58,7 +58,7 @@ struct EmuBatch {
   Batch<double> B;
   std::vector<double> qpos, qvel, qws, time, ctrl, xipos, comz, cfg, vel, aovf, imit, kin;
   std::vector<unsigned char> kin_ok;
-  bool two_tier = true, packed = false;
+  bool two_tier = true, packed = false, packed_ext = false;   // packed_ext: DM_OPT_PACKED = 2 (per-step launches with the three-set code: k_step_packed_ext)
   SlotShared<double> slots[SLOTS];
   SlotOrOne<double> roll;          // emu_rollout: the one-env code's LDS ALIASES the four slots', as in k_rollout_packed
   SlotTables slot_tabs;
@@ -111,7 +111,7 @@ void emu_set_option(void* h, int opt, long long v) {
   else if (opt == DM_OPT_DIAGNOSTICS) e->B.diag = v != 0;
   else if (opt == 100) e->B.env_offset = (int)v;
   else if (opt == 102) e->two_tier = v != 0;
-  else if (opt == 105 || opt == DM_OPT_PACKED) e->packed = v != 0;
+  else if (opt == 105 || opt == DM_OPT_PACKED) { e->packed = v != 0; e->packed_ext = v == 2; }
   else if (opt == 103) e->M.pgs_detect = v ? -1e300 : 1e-10;
 }
 void* emu_field(void* h, int field) {
@@ -138,7 +138,8 @@ void emu_step(void* h, const double* action, double* obs, double* reward, unsign
         int pos = first + slot;
         const bool live = pos < n;
         if (!live) pos = n - 1;
-        slot_env_step<double>(e->M, e->B, e->slots[slot], e->slot_tabs, pos, sl, lane, live, action, obs, reward, done, nsub, e->B.redo_count, e->B.redo_list);
+        if (e->packed_ext) slot_env_step<double, false, false, SLOT_MAXROWS>(e->M, e->B, e->slots[slot], e->slot_tabs, pos, sl, lane, live, action, obs, reward, done, nsub, e->B.redo_count, e->B.redo_list);
+        else slot_env_step<double>(e->M, e->B, e->slots[slot], e->slot_tabs, pos, sl, lane, live, action, obs, reward, done, nsub, e->B.redo_count, e->B.redo_list);
       });
     e->redo_total += e->B.redo_count[0];
     for (int i = 0; i < e->B.redo_count[0]; i++) {

@@ -282,3 +282,52 @@ def test_vec_env_step_wait_host_overhead_is_small_at_4096_envs():
         write(cur)
         nxt = env.step(act)[3]
         assert nxt is not cur and len(nxt) == n and all(not d for d in nxt)
+
+
+def test_per_step_kernel_chooser_is_a_function_of_the_redo_statistics():
+    """`Batch._adapt` (host logic, no device): lean packed -> three-set per-step kernel when the redo rate is high and nearly all of it row overflows;
+    -> one-env kernel for overflows of another kind, or when the three-set kernel still overflows; three-set -> lean when nobody holds more than 32 rows;
+    one-env -> lean / three-set by the largest row count."""
+    import numpy as np
+    from deepmimic_mujoco_amd import _abi as A
+    from deepmimic_mujoco_amd.batch import Batch
+
+    class Fake(Batch):
+        def __init__(self):
+            self.n = 100; self.options = {A.OPT_PACKED: 1}; self.reasons = [0, 0, 0, 0, 0, 0]; self.nefc = np.zeros(100, dtype=np.int32)
+            self._auto = True; self._auto_ctr = 0; self._redo_last = 0; self._redo_rows_last = 0; self.auto_switches = 0
+            self.ADAPT_EVERY = 1
+
+        def set_option(self, o, v):
+            self.options[int(o)] = int(v)
+
+        def redo_reasons(self):
+            return list(self.reasons)
+
+        def redo_total(self):
+            return self.reasons[0]
+
+        def get(self, f):
+            assert f == A.F_NEFC
+            return self.nefc
+
+        def __del__(self):
+            pass
+    b = Fake()
+    b._adapt(); assert b.options[A.OPT_PACKED] == 1 and b.auto_switches == 0                # nothing re-stepped: stays
+    b.reasons = [10, 0, 0, 0, 10, 0]                                                          # 10 % of env-steps, all for rows: the three-set kernel
+    b._adapt(); assert b.options[A.OPT_PACKED] == 2 and b.auto_switches == 1
+    b.nefc[:] = 20; b.nefc[3] = 35
+    b._adapt(); assert b.options[A.OPT_PACKED] == 2 and b.auto_switches == 1                # no new overflows, somebody above 32 rows: stays
+    b.nefc[3] = 30
+    b._adapt(); assert b.options[A.OPT_PACKED] == 1 and b.auto_switches == 2                # nobody above 32: the lean kernel again
+    b.reasons = [20, 0, 0, 9, 11, 0]                                                          # overflows of another kind (contacts): the one-env kernel
+    b._adapt(); assert b.options[A.OPT_PACKED] == 0 and b.auto_switches == 3
+    b.nefc[3] = 45
+    b._adapt(); assert b.options[A.OPT_PACKED] == 0                                          # an environment beyond every packed capacity: stays
+    b.nefc[3] = 36
+    b._adapt(); assert b.options[A.OPT_PACKED] == 2 and b.auto_switches == 4                # within 38 rows: the three-set kernel
+    b.reasons = [40, 0, 0, 0, 31, 0]                                                          # it overflows all the same: the one-env kernel
+    b._adapt(); assert b.options[A.OPT_PACKED] == 0 and b.auto_switches == 5
+    b.nefc[:] = 12
+    b._adapt(); assert b.options[A.OPT_PACKED] == 1 and b.auto_switches == 6

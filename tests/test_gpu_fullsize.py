@@ -197,13 +197,14 @@ def test_config2_full_size_p_controller_matches_oracle_every_env(form):
     b.close()
 
 
-@pytest.mark.parametrize("form", ["packed", "horizon", "one-env"])
+@pytest.mark.parametrize("form", ["packed", "packed-ext", "horizon", "one-env"])
 def test_standing_population_full_shard_matches_oracle(form):
     """The regime of a competent policy (src/checkpoint_tmp/DeepMimic/trpo-walk-0: under it 23 % of evaluations hold more than 16 rows):
     4 096 environments started from the noisy init pose (src/dp_env_v3.py:158-164), standing on both feet — 8 foot corners x 4 pyramid edges =
     32 constraint rows, plus whatever joint limits are active — and kept there for 16 steps by small actions.  Most packed waves take the
-    two-row-set path, environments beyond 32 rows go through the redo list (per step) or the in-wave re-step (horizon launch).  Every env,
-    every step against the oracle: obs / reward 1e-9, done flags, row and contact counts, contact lists."""
+    two-row-set path, environments beyond 32 rows go through the redo list (per step), stay in their wave (per step with the three-set code,
+    OPT_PACKED 2: "packed-ext"; inside a horizon launch where the wave predicted them) or take the in-wave re-step (horizon launch, mispredicted).
+    Every env, every step against the oracle: obs / reward 1e-9, done flags, row and contact counts, contact lists."""
     import torch
     from deepmimic_mujoco_amd import Batch
     from deepmimic_mujoco_amd.imitation import ImitationSpec
@@ -213,7 +214,7 @@ def test_standing_population_full_shard_matches_oracle(form):
     T, P = ImitationSpec(H.compiled_model()).table_for(mc)
     b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
     b.set_option(A.OPT_REWARD_MODE, 3); b.set_option(A.OPT_AUTORESET, 0); b.set_option(A.OPT_SEED, SEED); b.set_option(A.OPT_DIAGNOSTICS, 1)
-    b.set_option(A.OPT_PIPELINE, 2); b.set_option(A.OPT_PACKED, 0 if form == "one-env" else 1)
+    b.set_option(A.OPT_PIPELINE, 2); b.set_option(A.OPT_PACKED, 0 if form == "one-env" else 2 if form == "packed-ext" else 1)
     b.reset(1, 1)                                                 # reset_model_init after sim.reset(): init pose + U(-0.01, 0.01) noise, frame redrawn
     q0 = b.get(A.F_QPOS); v0 = b.get(A.F_QVEL)
     fidx = b.get(A.F_FRAME_IDX).copy(); cyc = b.get(A.F_CYCLE).copy()
@@ -265,6 +266,9 @@ def test_standing_population_full_shard_matches_oracle(form):
     assert np.abs(q - oq).max() / max(1.0, np.abs(oq).max()) < 1e-9
     print("standing shard (%s): worst rel err %.2e; %.1f %% of envs reached >= 32 rows, %.1f %% > 32 (max %d); beyond the packed capacities: %s"
           % (form, worst, 100 * heavy, 100 * float((peak > 32).mean()), int(peak.max()), b.redo_reasons() if form != "one-env" else "-"))
+    if form == "packed-ext":
+        rr = b.redo_reasons()
+        assert rr[4] <= near_cap and rr[0] < 0.01 * above32, "the three-set per-step kernel keeps every env-step within 40 rows in its wave: %s of %d" % (rr, above32)
     if form == "horizon":
         # round 5: inside a horizon launch 33 .. 40 rows (both feet flat + joint limits) are solved by the packed path itself (slot_kernel.h
         # slot_constraint<3>, the step's second instantiation): the population's environments above 32 rows were NOT handed to the one-env code

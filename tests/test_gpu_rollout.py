@@ -444,31 +444,43 @@ def test_fused_policy_step_on_tiny_and_odd_batches(n, pipeline):
 @pytest.mark.gpu
 def test_auto_packed_follows_the_workload():
     """DPVecEnv(packed=None) at 8192 envs starts four-per-wave and re-decides from the batch's own row statistics: RSI + random actions
-    (the benchmark regime: envs fall, few rows) stays packed; a population standing on both feet (the init pose under zero actions:
-    8 foot corners x 4 pyramid rows = 32 rows, more with any limit or self-contact) overflows the 32-row capacity of the PER-STEP packed launches (the three-set code for 33 .. 40 rows lives in the
-    horizon launches' second step instantiation: slot_step.h slot_rollout) and is handed to the one-env kernel; once the rows are gone (RSI + random actions again) the batch returns to the packed kernel."""
+    (the benchmark regime: envs fall, few rows) stays on the lean packed kernel; a population standing on both feet (the init pose under zero
+    actions: 8 foot corners x 4 pyramid rows = 32 rows, 33 .. 37 with joint limits) overflows the 32-row capacity of the lean per-step launch, and
+    — its overflows being all ROW overflows — is moved to the per-step launches with the three-set code (OPT_PACKED 2: 40 rows per env; rounds 3-4
+    handed it to the one-env kernel), where next to nothing is re-stepped any more; once nobody holds more than 32 rows (RSI + random actions
+    again) the batch returns to the lean kernel.  The hand-over to the one-env kernel remains for overflows of another kind: driven here
+    through its threshold."""
     n = 8192
     env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="rsi", seed=1)
-    assert env.packed and env.batch._auto
-    env.batch.ADAPT_EVERY = 32
+    b = env.batch
+    assert env.packed and b._auto and b.options[A.OPT_PACKED] == 1
+    b.ADAPT_EVERY = 32
     env.reset("rsi")
     g = torch.Generator(device=DEV); g.manual_seed(0)
     for t in range(96):
         env.step(torch.randn((n, 28), generator=g, device=DEV, dtype=torch.float64) * 0.9)
-    assert env.packed and env.batch.auto_switches == 0, "the benchmark regime must stay on the packed kernel"
+    assert b.options[A.OPT_PACKED] == 1 and b.auto_switches == 0, "the benchmark regime must stay on the lean packed kernel"
     env.reset("qpos0")                                               # everybody upright on both feet
     zero = torch.zeros((n, 28), device=DEV, dtype=torch.float64)
-    env.batch.set_option(A.OPT_AUTORESET, 2)                         # fallen envs restart upright
-    for t in range(96):
+    b.set_option(A.OPT_AUTORESET, 2)                                 # fallen envs restart upright
+    for t in range(64):
         env.step(zero)
-    assert not env.packed and env.batch.auto_switches == 1, "a standing population must be handed to the one-env kernel (redo %s)" % (env.batch.redo_reasons(),)
-    env.batch.set_option(A.OPT_AUTORESET, 1)
+    assert b.options[A.OPT_PACKED] == 2 and b.auto_switches == 1, "a standing population moves to the three-set per-step kernel (redo %s)" % (b.redo_reasons(),)
+    r0 = b.redo_total()
+    for t in range(64):
+        env.step(zero)
+    assert b.options[A.OPT_PACKED] == 2 and b.auto_switches == 1 and b.redo_total() - r0 < 3e-4 * 64 * n, b.redo_reasons()
+    assert int((b.get(A.F_NEFC) > 32).sum()) > 0
+    b.set_option(A.OPT_AUTORESET, 1)
     env.reset("rsi")
     for t in range(128):
         env.step(torch.randn((n, 28), generator=g, device=DEV, dtype=torch.float64) * 0.9)
-    assert env.packed and env.batch.auto_switches == 2
+    assert b.options[A.OPT_PACKED] == 1 and b.auto_switches == 2
+    b.REDO_RATE_MAX = -1.0                                           # any redo rate is too much, and (no redo at all: share 0) not for rows: the one-env kernel
+    for t in range(32):
+        env.step(zero)
+    assert not env.packed and b.auto_switches == 3
     env.close()
-
 
 
 @pytest.mark.gpu

@@ -321,9 +321,9 @@ def test_packed_third_row_set_33_to_40_rows_stays_on_the_packed_path():
         idx[sl_], q[sl_], v[sl_] = h
     acts = np.random.RandomState(6).randn(T, n, 28) * 0.9
 
-    def run(states, horizon=True):
+    def run(states, horizon=True, mode=1):
         b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0)
-        b.set_option(A.OPT_PACKED, 1)
+        b.set_option(A.OPT_PACKED, mode)
         b.set(A.F_QACC_WARMSTART, np.zeros((n, 34))); b.set(A.F_TIME, np.zeros(n))
         b.set_state(states[1], states[2], frame_idx=states[0])
         ne0 = b.get(A.F_NEFC).copy()
@@ -351,6 +351,9 @@ def test_packed_third_row_set_33_to_40_rows_stays_on_the_packed_path():
     # the same batch through per-step launches: the lean instantiation, heavy environments through the redo list — the same results to rounding
     obs1, done1, _n, qf1, _w, nef1, _i, redo1 = run((idx, q, v), horizon=False)
     assert redo1 >= len(slots) and np.array_equal(nef1, nef) and np.array_equal(done1, done) and H.rel_err(obs1, obs) < 1e-10
+    # ... and through the per-step launches with the three-set code (OPT_PACKED 2, k_step_packed_ext): nothing re-stepped, the horizon form's bits
+    obs3, done3, _n, qf3, wsf3, nef3, itf3, redo3 = run((idx, q, v), horizon=False, mode=2)
+    assert redo3 == 0 and np.array_equal(obs3, obs) and np.array_equal(qf3, qf) and np.array_equal(wsf3, wsf) and np.array_equal(itf3, itf)
     # the light environments next to a heavy one (three-set instantiation) and among themselves (lean instantiation): the same bits
     obs2, _d, ne2, qf2, wsf2, nef2, itf2, _r = run(light)
     same = [e for e in range(n) if e not in slots]
