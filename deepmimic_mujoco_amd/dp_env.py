@@ -307,7 +307,9 @@ class DPVecEnv(object):
         diagnostics: keep `sim.data.xipos` / the contact geom list up to date after every step (DM_OPT_DIAGNOSTICS; the batched
         training path does not read them, `DPEnv` and raw `Batch` objects default to on).
         dtype: 64 (default) or 32 — arithmetic of the kernels; observations / actions stay float64 arrays.
-        packed: DM_OPT_PACKED — four environments per wavefront (k_step_packed) instead of one.  True / False pin the kernel.  None
+        packed: DM_OPT_PACKED — four environments per wavefront (k_step_packed) instead of one.  True / False pin the kernel; 2 pins the per-step launches
+        with the three-set code (k_step_packed_ext: 40 constraint rows per env instead of 32, ~8 % slower otherwise — for populations that stand on both
+        feet: 8.96 against 6.18 M env-steps/s one env per wave at 8 192 envs, closed loop).  None
         (default): batches of PACKED_FROM_ENVS environments or more (two or more waves per SIMD on one MI355X; float64; rewards other than
         v1-quat) start on the packed kernel and re-decide every 256 steps from their own row statistics (Batch.enable_auto_packed): it is
         1.4-1.5x faster while environments stay within its per-env capacities (the RSI / early-termination regimes), and hands over to
@@ -361,7 +363,7 @@ class DPVecEnv(object):
         # for the slowest wave of every step
         self.horizon_packed_ok = packed is None and batch_factory is None and self.num_envs >= 256 and dtype == 64 and reward != "v1-quat"
         if packed or auto:
-            b.set_option(A.OPT_PACKED, 1)
+            b.set_option(A.OPT_PACKED, 2 if (packed is not True and packed == 2) else 1)     # (packed=2: per-step launches with the three-set code, see the docstring)
         if auto:
             b.enable_auto_packed(True)
         if step_queue:
