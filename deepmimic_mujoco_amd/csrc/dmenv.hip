@@ -620,7 +620,7 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
       b->redo_mode = mode; b->redo_phase = 0;
     }
   }
-  constexpr int REDO_BLOCKS = 64;
+  constexpr int REDO_BLOCKS = 1024;     // (round 5: 64 persistent one-wave workgroups took 5 ms to walk the 1 100 overflows a standing population of 8 192 envs produces per step on the lean kernel; an empty launch of 1 024 costs the same few microseconds)
   if (b->prof && packed_step) {
     HIPCHK(hipMemsetAsync(b->d_prof, 0, (size_t)b->n * dm::PROF_SLOTS * sizeof(long long), b->stream));
     int* rc = b->B.redo_count + b->redo_phase; int* rn = b->B.redo_count + (1 - b->redo_phase);
