@@ -1459,7 +1459,10 @@ DM_DEV void sweep_row(const R* AR, R& t, R& tsave, R nf0, int ln) {
   if constexpr (I < ROWS && I < MAXROWS) {
     const R delta = dmw::max_raw(nf0, t);                    // every lane evaluates its own; only lane i's is used
     if (ln == I) tsave = t;
-    if constexpr (ROWS <= 16) dmw::row_fmac<I & 15>(t, delta, AR[I]);          // (A/B in one gpurun call: 12.11 -> 12.24 M env-steps/s)
+    // (round 3: one v_fmac_f64_dpp in inline assembly instead of two v_readlane and a multiply-add, 12.11 -> 12.24 M env-steps/s; round 5: the broadcast as a
+    //  compiler-visible v_mov_b64_dpp + a plain multiply-add — one instruction more on the chain, but the scheduler sees the hazards and fills the slots that
+    //  the opaque assembly block had to pad with three s_nop per row: 8 -> 6-7 instructions per row, 12.27 -> 12.38 M, gpurun call f7)
+    if constexpr (ROWS <= 16) t += AR[I] * dmw::row_bcast<I & 15>(delta);
     else { const R di = dmw::bcast(delta, I); t += AR[I] * di; }
   }
 }
