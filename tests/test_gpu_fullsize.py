@@ -9,6 +9,8 @@ Round 4 adds: the step-queue form (DM_OPT_STEP_QUEUE: the per-step calls queued 
 packed kernel, a 64-step horizon (second-episode RSI draws and clip wraps for most environments), BASELINE.json configs[1] (contacts and
 limits off, the P-controller of src/env_torque_test.py:14-20) at its full 4 096 envs on the kernels bench.py times it on, and a STANDING
 population (the shipped policy's regime: 32 rows per env most of the time).
+Round 5 adds: the judged launch of bench.py itself (256 queued steps, one k_rollout_packed launch: every env of all 256 steps), the three-set per-step
+kernels ('packed-ext'), every env's contact list in the standing forms.
 Reference semantics: src/dp_env_v3.py:106-156 (step, is_done, reset_model)."""
 import os
 
@@ -25,13 +27,15 @@ STEPS = 16
 
 
 @pytest.mark.parametrize("clip,n,packed", [("walk", 4096, 0), ("spinkick", 4096, 0), ("dance_b", 8192, 0), ("dance_b", 8192, 1), ("walk", 4096, 1), ("walk", 4096, 2), ("spinkick", 4096, 2), ("dance_b", 8192, 2),
-                                           ("spinkick", 4096, 1), ("walk", 4096, 3), ("dance_b", 8192, 3), ("walk", 4096, 64)])
+                                           ("spinkick", 4096, 1), ("walk", 4096, 3), ("dance_b", 8192, 3), ("walk", 4096, 64), ("walk", 4096, 256)])
 def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     import torch
     STEPS = 16
     queue = packed == 3                              # 3: four per wave, the 16 dm_batch_step calls QUEUED (DM_OPT_STEP_QUEUE) and run as one horizon launch at the join
     if packed == 64:                                 # 64: one 64-step horizon launch — most environments see a second episode's RSI draw, 'walk' (39 frames) wraps
         STEPS, packed = 64, 2
+    if packed == 256:                                # 256: THE JUDGED LAUNCH of bench.py — 256 dm_batch_step calls queued (DM_OPT_STEP_QUEUE = 256) and run as one
+        STEPS, packed, queue = 256, 1, True          #      k_rollout_packed launch at the join: every env of every one of its 256 steps against the oracle
     from deepmimic_mujoco_amd import Batch
     from deepmimic_mujoco_amd.imitation import ImitationSpec
     from oracle import oracle as O
@@ -46,7 +50,7 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     b.set_option(A.OPT_PACKED, 1 if packed else 0)   # 0: one environment per wavefront; 1: four (what DPVecEnv picks from 6 144 envs up);
     horizon = packed == 2                            # 2: four, and all 16 steps in ONE launch (dm_batch_rollout: every wave at its own pace)
     if queue:
-        b.set_option(A.OPT_STEP_QUEUE, 64)
+        b.set_option(A.OPT_STEP_QUEUE, max(64, STEPS))
     b.reset(0, 1)                                                 # env.reset(): sim.reset() + RSI
     fidx = b.get(A.F_FRAME_IDX).copy()
     expect0 = np.array([H.device_rsi_frame(SEED, off + e, 0, F) for e in range(n)], dtype=np.int32)
@@ -122,8 +126,10 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     assert np.abs(w - ow).max() / max(1.0, np.abs(ow).max()) < 1e-7      # accelerations: conditioned like the contact solve
     assert np.abs(tm - ot).max() < 1e-12
     assert ndone > 0 and max_nefc > 16, "the run must contain early terminations and heavy contact (%d done, max nefc %d)" % (ndone, max_nefc)
-    if STEPS == 64:
+    if STEPS >= 64:
         assert int((episode >= 2).sum()) > n // 2, "a 64-step run must reach second-episode RSI draws for most environments"
+    if STEPS == 256:
+        assert int((episode >= 4).sum()) > n // 2, "a 256-step run holds several episodes per environment"
     assert (b.get(A.F_STATUS) & 1).sum() == 0
     if packed:
         print("   packed: env-steps handed to the one-env code [total, candidates, box slots, contacts, rows, PGS test]:", b.redo_reasons())
@@ -250,7 +256,7 @@ def test_standing_population_full_shard_matches_oracle(form):
             o_ncon = np.array([int(d.get("ncon")[0]) for d in ods], dtype=np.int32)
             assert np.array_equal(nefc, o_nefc), "nefc differs at step %d: envs %s" % (t, np.nonzero(nefc != o_nefc)[0][:8])
             assert np.array_equal(ncon, o_ncon)
-            for e in range(0, n, 7):
+            for e in range(n):
                 k = min(int(o_ncon[e]), A.MAXEFC)
                 if k:
                     assert np.array_equal(cg[e][:k], ods[e].get("contact_geom").reshape(-1, 2).astype(np.int32)[:k]), "contact list differs: step %d env %d" % (t, e)
