@@ -37,6 +37,16 @@ constexpr int DOF_PASSES = (NV + SW - 1) / SW, HINGE_PASSES = (NU + SW - 1) / SW
 // (alignas(16): the slots' stride must stay a multiple of 16 bytes — a lane's LDS address is slot base + constant, and only then can the compiler prove
 //  the 16-byte alignment its ds_read_b128 / ds_write_b128 need.  A stride of 9 720 B — the first round-5 layout, 24 B more than round 4's 9 696 — turned
 //  all 1 350 of them into pairs of 8-byte accesses and cost every workload 8 %: gpurun calls h2 / h3.)
+// The slot lane number reaches every stage through dmw::launder (the optimiser must not fold it: address arithmetic hoisted out of the RK loop ends up in
+// scratch memory).  Its RANGE may be known, though (dmw::launder_slot_lane): `d = sl + 16 c < NV` is then true at compile time for the first two of the
+// three passes over the 34 dofs, and those passes need no lane predicate — no exec-masked block each, the loads of all passes in one scheduling region.
+// DM_SLOT_ASSUME: bit k = stage k (kinematics, bias, mass matrix, rows, constraint) knows the range.  Measured per mask with the hoisted pair codes of the
+// elimination (profiles/r05_ab_kernel_variants.md section 6): all five +1.3 % on the horizon launch, none -2.8 %.
+#ifndef DM_SLOT_ASSUME
+#define DM_SLOT_ASSUME 31
+#endif
+#define DM_SLOT_LANE_AT(bit, x) (((DM_SLOT_ASSUME) >> (bit)) & 1 ? dmw::launder_slot_lane(x) : dmw::launder(x))
+
 template <class R>
 struct alignas(16) SlotShared {
   R qpos[36], qvel[NV];
@@ -131,7 +141,7 @@ DM_DEV void slot_subtree_sums(const R (*in)[NC], R (*out)[NC], int sl) {
 // COM of `sim.data.xipos`), kept in registers instead of LDS. ----------------------------------------------------------------------
 template <class R>
 DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, const LaneTopo& lt, R* xip, R* qloc_out = nullptr, R (*aloc_out)[3] = nullptr) {
-  const int sl = dmw::launder(sl_in);
+  const int sl = DM_SLOT_LANE_AT(0, sl_in);
   const int b = sl + 1;
   const bool isbody = sl < NB - 1;
   const int depth = dmw::launder(lt.depth), da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum), panc = dmw::launder(lt.parent), p = panc & 15;
@@ -247,7 +257,7 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
 // ---- velocity stage (env_kernel.h stage_bias): bias forces incl. gravity, smooth generalized force --------------------------------
 template <class R>
 DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, int sl_in, const LaneTopo& lt) {
-  const int sl = dmw::launder(sl_in);
+  const int sl = DM_SLOT_LANE_AT(1, sl_in);
   const int b = sl + 1;
   const bool isbody = sl < NB - 1;
   const int depth = dmw::launder(lt.depth), p = dmw::launder(lt.parent) & 15, da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum);
@@ -315,7 +325,14 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, int sl_in, const L
 // columns of a step are taken one after the other by the slot's 16 lanes, in the order (pass, column, pair) in which the one-env
 // kernel's lane groups apply them, so that entries which several limbs update receive their contributions in the same order. ---------
 // The chunks (16 consecutive pair numbers of one column) of a step, in the one-env kernel's order of application (pass, column, sub-chunk)
+// DM_ELIM_HOIST 1: a lane's pair codes are decoded once per evaluation and used unmasked by all 15 elimination steps (slot_eliminate_step); 0: round 4's form
+// (decoded and masked per chunk, the lane number laundered per step): 1 304 -> 775 integer instructions in the stage, elimination 54.7 k -> 35.8 k cycles per wave-step.
+#ifndef DM_ELIM_HOIST
+#define DM_ELIM_HOIST 1
+#endif
 struct SlotElimChunks { int n; int K[24]; int t0[24]; };
+constexpr bool elim_unmasked_reads_fit() { for (int K = 0; K < NV; K++) if (TOPO.madr[K] + 14 >= 312) return false; return true; }
+static_assert(elim_unmasked_reads_fit(), "an unmasked pair code (e, a <= 14) must address inside qLD[312] from every column's base");
 constexpr SlotElimChunks make_slot_elim_chunks(int S) {
   SlotElimChunks c{};
   const ElimStep st = ELIM_STEPS[S];
@@ -350,7 +367,14 @@ DM_DEV void slot_eliminate_step(SlotShared<R>& s, const SlotTables& tb, int sl, 
     const int K = CH.K[c], np = elim_npairs(K), base = TOPO.madr[K];
     const int t = CH.t0[c] + sl;
     on[c] = t < np;
+#if DM_ELIM_HOIST
+    // the pair code of a lane depends on (lane, t0 / 16) only: unmasked (a lane past the column's pairs reads inside qLD — madr[K] + 14 <= 311 — and
+    // keeps its update to itself), the codes and the addresses formed from them are the same in all 15 steps and the compiler keeps them
+    const int j = CH.t0[c] >> 4;                     // (a constant after unrolling)
+    const int code = (int)(lt.tri >> (8 * j)) & 0xff, e = code >> 4, a = code & 15;
+#else
     const int code = on[c] ? (int)(lt.tri >> (8 * (t >> 4))) & 0xff : 0, e = code >> 4, a = code & 15;
+#endif
     dst[c] = tb.tab_dst[K][a] + (e - a);
     xe[c] = s.r2.qLD[base + e]; xa[c] = s.r2.qLD[base + a];
   }
@@ -372,7 +396,11 @@ template <int S, class R>
 struct SlotEliminateFrom {
   static DM_DEV void run(SlotShared<R>& s, const SlotTables& tb, int sl, const LaneTopo& lt) {
     if constexpr (S < N_ELIM_STEPS) {
+#if DM_ELIM_HOIST
+      slot_eliminate_step<S, R>(s, tb, sl, lt);
+#else
       slot_eliminate_step<S, R>(s, tb, dmw::launder(sl), lt);
+#endif
       SlotEliminateFrom<S + 1, R>::run(s, tb, sl, lt);
     }
   }
@@ -382,7 +410,7 @@ static_assert(elim_group_size(4, 0) % SW == 0 && elim_group_size(3, 2) % SW == 0
 
 template <class R, bool PROF = false>
 DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl_in, const LaneTopo& lt, const DebugOut* dbg, long long* prof = 0) {
-  const int sl = dmw::launder(sl_in);
+  const int sl = DM_SLOT_LANE_AT(2, sl_in);
   long long pt0 = 0, pt1 = 0;
   if (PROF) pt0 = dmw::clk();
 #define SLOT_MSTAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
@@ -418,7 +446,13 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
   }
   dmw::sync();
   SLOT_MSTAMP(16)
+#if DM_ELIM_HOIST
+  LaneTopo le = lt;
+  le.tri = dmw::launder(lt.tri);            // what the steps derive from the pair codes stays inside this evaluation (not hoisted out of the RK loop and spilled)
+  SlotEliminateFrom<0, R>::run(s, tb, sl, le);
+#else
   SlotEliminateFrom<0, R>::run(s, tb, sl, lt);
+#endif
   SLOT_MSTAMP(17)
 #pragma unroll
   for (int c = 0; c < DOF_PASSES; c++) {
@@ -476,7 +510,7 @@ DM_DEV int row_exclusive_scan(int v, int sl, int lane, int* total) {
 template <class R, bool PROF = false, int MAXR = 2 * SW>
 DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int& ovf, long long* prof = 0) {
   static_assert(MAXR == 2 * SW || MAXR == SLOT_MAXROWS, "row capacity: two sets, or two and the partial third");
-  const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
+  const int sl = DM_SLOT_LANE_AT(3, sl_in), lane = dmw::launder(lane_in);
   long long pt0 = 0, pt1 = 0;
   if (PROF) pt0 = dmw::clk();
 #define SLOT_RSTAMP(k) if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }
@@ -921,7 +955,7 @@ DM_DEV void slot_row_setup(const DevModel<R>& M, const SlotShared<R>& s, int r, 
 // NS = 3: the two full sets plus the partial third one (rows 32 .. 39 on the even lanes; see "the partial third row set" above).
 template <class R, int NS, bool PROF = false>
 DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane_in, int nefc, int nmax, int& ovf, const DebugOut* dbg, long long* prof = 0) {
-  const int sl = dmw::launder(sl_in), lane = dmw::launder(lane_in);
+  const int sl = DM_SLOT_LANE_AT(4, sl_in), lane = dmw::launder(lane_in);
   long long pt0 = 0, pt1 = 0, pt_enter = 0;
   if (PROF) { pt0 = dmw::clk(); pt_enter = pt0; }
 #define SLOT_STAMP(k) if constexpr (NS == 1) { DM_MARK("slot_constraint_ns1_" #k); } else if constexpr (NS == 2) { DM_MARK("slot_constraint_ns2_" #k); } else { DM_MARK("slot_constraint_ns3_" #k); } if (PROF) { pt1 = dmw::clk(); prof[k] += pt1 - pt0; pt0 = pt1; }

@@ -116,6 +116,11 @@ DM_DEV void pin_value(float& v) { asm volatile("" : "+v"(v)); }
 // shared across stages (LICM/GVN otherwise precompute every stage's lane->index maps at kernel entry and keep them
 // live across the whole step: hundreds of VGPRs)
 DM_DEV int launder(int v) { asm volatile("" : "+v"(v)); return v; }
+// launder() for the slot lane number of the packed kernels (0 .. 15): the optimiser must not fold the value, but may know its range — `d = sl + 16 c < NV`
+// is then true at compile time for the first two of three passes over the 34 dofs, and those passes need no lane predicate (no exec-masked block each,
+// one scheduling region instead of three: a lone wave's loads of all passes go out together)
+DM_DEV int launder_slot_lane(int v) { asm volatile("" : "+v"(v)); __builtin_assume(v >= 0 && v < 16); return v; }
+DM_DEV unsigned long long launder(unsigned long long v) { asm volatile("" : "+v"(v)); return v; }
 DM_DEV int launder_uniform(int v) { asm volatile("" : "+s"(v)); return v; }   // same for a wave-uniform (SGPR) value
 // a pointer that is the same in every lane, told to the compiler (arguments of a called function arrive in vector registers and count as
 // divergent: loads through them would be vector loads and their addresses would occupy vector registers)

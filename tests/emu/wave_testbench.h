@@ -153,6 +153,8 @@ inline int global_counter_next(int* p) { return (*p)++; }
 inline unsigned row_ballot(bool p, int lane_id) { return (unsigned)((ballot(p) >> (lane_id & 48)) & 0xffffull); }
 inline int pin_zero() { return 0; }
 inline int launder(int v) { return v; }
+inline int launder_slot_lane(int v) { return v; }
+inline unsigned long long launder(unsigned long long v) { return v; }
 inline int launder_uniform(int v) { return v; }
 template <class T> inline T* launder_uniform_ptr(T* p) { return p; }
 template <class T> inline T* uniform_ptr(T* p) { return p; }

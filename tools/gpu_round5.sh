@@ -29,7 +29,7 @@ print('value %.3f M  spread %.2f..%.2f  vecenv %s  horizon %s  launch_us %s' % (
     done; done ;;
   hl:*)
     # horizon-launch leg only, five windows of 1024 steps, imitation and alive rewards: tight A/B of builds whose difference is a per-cent
-    for rep in 1 2; do for v in ${WHAT#hl:}; do for rw in imitation alive; do
+    for rep in 1 2; do for v in ${WHAT#hl:}; do for rw in ${HL_REWARDS:-imitation alive}; do
       o=$(DMENV_LIB=$PWD/build_ab/$v.so timeout 300 python bench.py $Q --no-vecenv-leg --no-horizon-leg --reward $rw --steps 1024 --warmup 0 --repeats 5 2>$OUT/hl_err.txt | python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); print('value %.3f M  spread %.3f..%.3f  launch_us %s' % (j['value']/1e6, j['value_spread']['min']/1e6, j['value_spread']['max']/1e6, j['roofline']['launch'].get('avg_us')))")

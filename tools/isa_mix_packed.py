@@ -82,8 +82,8 @@ NAMES = [("slot_kinematics", "kinematics"), ("slot_bias", "bias forces"), ("slot
 
 def main():
     out_md = sys.argv[1] if len(sys.argv) > 1 else None
-    s_path = os.path.join(tempfile.gettempdir(), "dmenv_packed_isa.s")
-    cmd = [B.hipcc()] + [f for f in B.COMMON if f != "-fPIC"] + B.PACKED_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CS, "-S", "--cuda-device-only",
+    s_path = os.environ.get("DM_ISA_OUT", os.path.join(tempfile.gettempdir(), "dmenv_packed_isa.s"))
+    cmd = [B.hipcc()] + [f for f in B.COMMON if f != "-fPIC"] + B.PACKED_FLAGS + os.environ.get("DM_BUILD_DEFINES", "").split() + ["-I" + os.path.join(ROOT, "include"), "-I" + CS, "-S", "--cuda-device-only",
                                                                                   os.path.join(CS, "kernels_packed.hip"), "-o", s_path]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     lines = ["# Static instruction mix per stage of the packed step (`tools/isa_mix_packed.py`; gfx950 listing of `csrc/kernels_packed.hip`, product flags)", "",
