@@ -101,17 +101,38 @@ static_assert(offsetof(SlotShared<double>, cdof) == offsetof(SlotShared<double>,
               offsetof(SlotShared<float>, cdof) == offsetof(SlotShared<float>, qd) + sizeof(((SlotShared<float>*)0)->qd) &&
               sizeof(((SlotShared<double>*)0)->qd) + sizeof(((SlotShared<double>*)0)->cdof) >= sizeof(double) * NV * (SLOT_MAXROWS - 2 * SW),
               "slot_constraint<3> parks the surplus rows' half-solved vectors in the adjacent qd + cdof regions");
-static_assert(sizeof(SlotShared<double>) * SLOTS + 1576 <= 40 * 1024, "four waves of four environments must fit a CU's 160 KB of LDS");
+static_assert(sizeof(SlotShared<double>) * SLOTS + 1680 <= 40 * 1024, "four waves of four environments must fit a CU's 160 KB of LDS");
 // index tables shared by the four slots of a workgroup (compile-time topology; see LaneTables)
+// DM_LDS_TOPO 1: TOPO.dof_body / TOPO.madr of a lane's dofs come from the wave's LDS tables (104 B) instead of constant memory — in the bias, mass-matrix and
+// D stages they were the first link of a dependent chain, an L2 round trip each on a lone wave (the L1 is flushed by the callee-saved registers' scratch traffic):
+// +0.8 % on the horizon launch (gpurun call g6).  The same two tables as bit fields of a lane register: -3 % (profiles/r05_ab_kernel_variants.md section 6).
+#ifndef DM_LDS_TOPO
+#define DM_LDS_TOPO 1
+#endif
 struct SlotTables {
   unsigned short tab_dst[NV][14];
   unsigned short tab_ent[312];
+#if DM_LDS_TOPO
+  unsigned short madr[NV];
+  unsigned char dof_body[NV + 2];
+#endif
 };
+static_assert(sizeof(SlotShared<double>) * SLOTS + sizeof(SlotTables) <= 40 * 1024, "four waves (four environments and the tables each) must fit a CU's 160 KB of LDS");
+#if DM_LDS_TOPO
+#define DM_DOF_BODY(tb, d) ((int)(tb).dof_body[d])
+#define DM_DOF_MADR(tb, d) ((int)(tb).madr[d])
+#else
+#define DM_DOF_BODY(tb, d) (TOPO.dof_body[d])
+#define DM_DOF_MADR(tb, d) (TOPO.madr[d])
+#endif
 DM_DEV void stage_slot_tables(SlotTables& t, int lane) {
 #pragma unroll
   for (int c = 0; c < (312 + 63) / 64; c++) { const int e = lane + 64 * c; if (e < 312) t.tab_ent[e] = LTAB.tab_ent[e]; }
 #pragma unroll
   for (int c = 0; c < (NV * 14 + 63) / 64; c++) { const int i = lane + 64 * c; if (i < NV * 14) (&t.tab_dst[0][0])[i] = LTAB.tab_dst[i]; }
+#if DM_LDS_TOPO
+  if (lane < NV) { t.madr[lane] = (unsigned short)TOPO.madr[lane]; t.dof_body[lane] = (unsigned char)TOPO.dof_body[lane]; }
+#endif
 }
 
 // ---- subtree sums: out[b][k] = sum over the bodies c of b's subtree of in[c][k], component k = slot lane, one body per pass,
@@ -256,7 +277,7 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
 
 // ---- velocity stage (env_kernel.h stage_bias): bias forces incl. gravity, smooth generalized force --------------------------------
 template <class R>
-DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, int sl_in, const LaneTopo& lt) {
+DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& tb, int sl_in, const LaneTopo& lt) {
   const int sl = DM_SLOT_LANE_AT(1, sl_in);
   const int b = sl + 1;
   const bool isbody = sl < NB - 1;
@@ -314,7 +335,7 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, int sl_in, const L
   for (int c = 0; c < DOF_PASSES; c++) {
     const int d = sl + SW * c;
     if (d < NV) {
-      const R bias = dot6(s.cdof[d], s.r1.v.cvel[TOPO.dof_body[d]]);
+      const R bias = dot6(s.cdof[d], s.r1.v.cvel[DM_DOF_BODY(tb, d)]);
       s.tau[d] = -M.dof_damping[d] * s.qvel[d] - bias + s.act[d];
     }
   }
@@ -419,7 +440,7 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
 #pragma unroll
   for (int c = 0; c < DOF_PASSES; c++) {
     const int d = sl + SW * c;
-    if (d < NV) sinert_mul(f[c], s.r2.i.crb[TOPO.dof_body[d]], s.cdof[d]);
+    if (d < NV) sinert_mul(f[c], s.r2.i.crb[DM_DOF_BODY(tb, d)], s.cdof[d]);
   }
 #pragma unroll
   for (int c = 0; c < DOF_PASSES; c++) {
@@ -457,7 +478,7 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
 #pragma unroll
   for (int c = 0; c < DOF_PASSES; c++) {
     const int d = sl + SW * c;
-    if (d < NV) { const R inv = R(1) / s.r2.qLD[TOPO.madr[d]]; s.qd.o.dinv[d] = inv; s.dsq[d] = sqrt(inv); }
+    if (d < NV) { const R inv = R(1) / s.r2.qLD[DM_DOF_MADR(tb, d)]; s.qd.o.dinv[d] = inv; s.dsq[d] = sqrt(inv); }
   }
   dmw::sync();
 #pragma unroll
@@ -1345,7 +1366,7 @@ DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTable
   SLOT_FSTAMP(0)
   if (dbg) { for (int e = sl; e < NV * NV; e += SW) dbg->out[e] = 0; dmw::sync(); }
   DM_MARK("slot_bias");
-  slot_bias(M, s, sl, lt);
+  slot_bias(M, s, tb, sl, lt);
   SLOT_FSTAMP(1)
   if (dbg) {
     for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) dbg->out[34 * 34 + d] = (double)(-M.dof_damping[d] * s.qvel[d] + s.act[d] - s.tau[d]); }
