@@ -101,7 +101,6 @@ static_assert(offsetof(SlotShared<double>, cdof) == offsetof(SlotShared<double>,
               offsetof(SlotShared<float>, cdof) == offsetof(SlotShared<float>, qd) + sizeof(((SlotShared<float>*)0)->qd) &&
               sizeof(((SlotShared<double>*)0)->qd) + sizeof(((SlotShared<double>*)0)->cdof) >= sizeof(double) * NV * (SLOT_MAXROWS - 2 * SW),
               "slot_constraint<3> parks the surplus rows' half-solved vectors in the adjacent qd + cdof regions");
-static_assert(sizeof(SlotShared<double>) * SLOTS + 1680 <= 40 * 1024, "four waves of four environments must fit a CU's 160 KB of LDS");
 // index tables shared by the four slots of a workgroup (compile-time topology; see LaneTables)
 // DM_LDS_TOPO 1: TOPO.dof_body / TOPO.madr of a lane's dofs come from the wave's LDS tables (104 B) instead of constant memory — in the bias, mass-matrix and
 // D stages they were the first link of a dependent chain, an L2 round trip each on a lone wave (the L1 is flushed by the callee-saved registers' scratch traffic):
