@@ -108,6 +108,12 @@ static_assert(offsetof(SlotShared<double>, cdof) == offsetof(SlotShared<double>,
 #ifndef DM_LDS_TOPO
 #define DM_LDS_TOPO 1
 #endif
+#ifndef DM_ENTRY_SELECT
+#define DM_ENTRY_SELECT 1
+#endif
+#ifndef DM_ENTRY_GROUP
+#define DM_ENTRY_GROUP 5
+#endif
 struct SlotTables {
   unsigned short tab_dst[NV][14];
   unsigned short tab_ent[312];
@@ -453,6 +459,41 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
 #pragma unroll
   for (int c = 0; c < ENT_PASSES; c++) { const int e = sl + SW * c; ijc[c] = tb.tab_ent[e < 312 ? e : 0]; }
   dmw::sync();
+#if DM_ENTRY_SELECT
+  // All twenty passes' entries are formed in registers first and stored afterwards, and the armature of a diagonal entry is added by SELECT (its operand
+  // fetched by every lane).  With a store and a branch per pass the passes were twenty scheduling regions, each waiting out its own four LDS round trips:
+  // 10 k of the stage's 12 k cycles per evaluation on a lone wave.  Same values, same order of operations per entry.
+  R ent[ENT_PASSES];
+  constexpr int EG = DM_ENTRY_GROUP;         // passes whose operands are in flight together (52 LDS reads per group of four)
+  static_assert(ENT_PASSES % EG == 0, "whole groups of passes");
+#pragma unroll
+  for (int g = 0; g < ENT_PASSES / EG; g++) {
+    R ca[EG][6], fb[EG][6], dg[EG];
+#pragma unroll
+    for (int u = 0; u < EG; u++) {
+      const int ij = ijc[EG * g + u], i = ij >> 8, j = ij & 0xff;
+#pragma unroll
+      for (int r = 0; r < 6; r++) { ca[u][r] = s.cdof[j][r]; fb[u][r] = s.r1.fdof[i][r]; }
+      dg[u] = s.qd.o.dinv[i];
+    }
+    dmw::sched_fence();                      // the group's loads above, its arithmetic below: one LDS round trip per group instead of four per pass
+#pragma unroll
+    for (int u = 0; u < EG; u++) {
+      const int ij = ijc[EG * g + u], i = ij >> 8, j = ij & 0xff;
+      const R v = dot6(ca[u], fb[u]);
+      const R vd = v + dg[u];
+      ent[EG * g + u] = i == j ? vd : v;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < ENT_PASSES; c++) {
+    const int e = sl + SW * c;
+    if ((c + 1) * SW <= TOPO.nM || e < TOPO.nM) {
+      s.r2.qLD[e] = ent[c];
+      if (dbg) { const int ij = ijc[c], i = ij >> 8, j = ij & 0xff; dbg->out[i * NV + j] = (double)ent[c]; dbg->out[j * NV + i] = (double)ent[c]; }
+    }
+  }
+#else
 #pragma unroll
   for (int c = 0; c < ENT_PASSES; c++) {
     const int e = sl + SW * c;
@@ -464,6 +505,7 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
       if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
     }
   }
+#endif
   dmw::sync();
   SLOT_MSTAMP(16)
 #if DM_ELIM_HOIST
@@ -480,6 +522,23 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
     if (d < NV) { const R inv = R(1) / s.r2.qLD[DM_DOF_MADR(tb, d)]; s.qd.o.dinv[d] = inv; s.dsq[d] = sqrt(inv); }
   }
   dmw::sync();
+#if DM_ENTRY_SELECT
+  {
+    R sc[ENT_PASSES];                        // (likewise: all operands first, then the stores)
+#pragma unroll
+    for (int c = 0; c < ENT_PASSES; c++) {
+      const int e = sl + SW * c, ee = ((c + 1) * SW <= TOPO.nM || e < TOPO.nM) ? e : 0;
+      const int ij = ijc[c], i = ij >> 8, j = ij & 0xff;
+      const R di = s.qd.o.dinv[i];
+      sc[c] = s.r2.qLD[ee] * (i != j ? di : R(1));
+    }
+#pragma unroll
+    for (int c = 0; c < ENT_PASSES; c++) {
+      const int e = sl + SW * c;
+      if ((c + 1) * SW <= TOPO.nM || e < TOPO.nM) s.r2.qLD[e] = sc[c];
+    }
+  }
+#else
 #pragma unroll
   for (int c = 0; c < ENT_PASSES; c++) {
     const int e = sl + SW * c;
@@ -489,6 +548,7 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
       s.r2.qLD[e] *= sc;
     }
   }
+#endif
   dmw::sync();
   SLOT_MSTAMP(18)
 #undef SLOT_MSTAMP
