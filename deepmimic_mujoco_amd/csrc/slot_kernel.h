@@ -114,6 +114,14 @@ static_assert(offsetof(SlotShared<double>, cdof) == offsetof(SlotShared<double>,
 #ifndef DM_ENTRY_GROUP
 #define DM_ENTRY_GROUP 5
 #endif
+#ifndef DM_BIAS_BATCH
+#define DM_BIAS_BATCH 1
+#endif
+#ifndef DM_KIN_PREFETCH
+#define DM_KIN_PREFETCH 1
+#endif
+constexpr bool root_alone_at_depth_one() { for (int b = 2; b < NB; b++) if (TOPO.body_depth[b] <= 1) return false; return TOPO.body_depth[1] == 1; }
+static_assert(root_alone_at_depth_one(), "slot_bias does the root body (the only one at depth 1) ahead of the level loop");
 struct SlotTables {
   unsigned short tab_dst[NV][14];
   unsigned short tab_ent[312];
@@ -172,6 +180,25 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
   const bool isbody = sl < NB - 1;
   const int depth = dmw::launder(lt.depth), da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum), panc = dmw::launder(lt.parent), p = panc & 15;
   R qloc[4] = {1, 0, 0, 0}, aloc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#if DM_KIN_PREFETCH
+  // The model's constants of this lane's hinges and body — asked for in one go at the top of the stage (clamped indices: every lane asks), so that their
+  // L2 round trip runs under the half-angle sines; fetched where they are used, behind a lane predicate each, they were six exposed round trips per evaluation.
+  R q0h[HINGE_PASSES], axl3[3][3], bpos[3], ipos3[3], Ib6[6], bmass;
+  {
+    const int bb = isbody ? b : 1;
+#pragma unroll
+    for (int c = 0; c < HINGE_PASSES; c++) { const int h = sl + SW * c; q0h[c] = M.qpos0[(h < NU ? h : 0) + 7]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int j = (isbody && b > 1 && k < nd) ? da + k - 5 : 1;
+      axl3[k][0] = M.jnt_axis[j][0]; axl3[k][1] = M.jnt_axis[j][1]; axl3[k][2] = M.jnt_axis[j][2];
+    }
+    for (int k = 0; k < 3; k++) { bpos[k] = M.body_pos[bb][k]; ipos3[k] = M.body_ipos[bb][k]; }
+    for (int k = 0; k < 6; k++) Ib6[k] = M.body_inertia[bb][k];
+    bmass = M.body_mass[bb];
+    dmw::sched_fence();
+  }
+#endif
   if (sl == 0) {
     s.xpos[0][0] = s.xpos[0][1] = s.xpos[0][2] = 0; s.r1.k.off[0][0] = s.r1.k.off[0][1] = s.r1.k.off[0][2] = 0;
     s.r1.k.xquat[0][0] = 1; s.r1.k.xquat[0][1] = s.r1.k.xquat[0][2] = s.r1.k.xquat[0][3] = 0;
@@ -182,7 +209,11 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
   for (int c = 0; c < HINGE_PASSES; c++) {
     const int h = sl + SW * c;
     if (h < NU) {
+#if DM_KIN_PREFETCH
+      const R half = (s.qpos[h + 7] - q0h[c]) * R(0.5);
+#else
       const R half = (s.qpos[h + 7] - M.qpos0[h + 7]) * R(0.5);
+#endif
       const SinCos<R> sc = sincos_once(half);
       s.r1.k.sc[h][0] = sc.c; s.r1.k.sc[h][1] = sc.s;
     }
@@ -193,7 +224,11 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
 #pragma unroll
     for (int k = 0; k < 3; k++) if (k < nd) {
       const int d = da + k, j = d - 5;
+#if DM_KIN_PREFETCH
+      const R axl[3] = {axl3[k][0], axl3[k][1], axl3[k][2]};
+#else
       const R axl[3] = {M.jnt_axis[j][0], M.jnt_axis[j][1], M.jnt_axis[j][2]};
+#endif
       R qm[9];
       quat2mat(qm, qloc);
       mat_vec(aloc[k], qm, axl);
@@ -227,7 +262,11 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
   if (isbody) {
     R v[3];
     if (b == 1) { v[0] = s.qpos[0]; v[1] = s.qpos[1]; v[2] = s.qpos[2]; }
+#if DM_KIN_PREFETCH
+    else mat_vec(v, s.xmat[p], bpos);
+#else
     else mat_vec(v, s.xmat[p], M.body_pos[b]);
+#endif
     for (int k = 0; k < 3; k++) s.r1.k.off[b][k] = v[k];
   }
   dmw::sync();
@@ -257,17 +296,29 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
         cross3(&s.cdof[da + k][3], xp, axw);
       }
     }
+#if DM_KIN_PREFETCH
+    const R ip[3] = {ipos3[0], ipos3[1], ipos3[2]};
+#else
     const R ip[3] = {M.body_ipos[b][0], M.body_ipos[b][1], M.body_ipos[b][2]};
+#endif
     R c[3];
     mat_vec(c, mat, ip);
     c[0] += xp[0]; c[1] += xp[1]; c[2] += xp[2];
     xip[0] = c[0]; xip[1] = c[1]; xip[2] = c[2];
+#if DM_KIN_PREFETCH
+    const R* Ib = Ib6;
+#else
     const R* Ib = M.body_inertia[b];
+#endif
     const R A[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]};
     R T[9], Iw[9];
     for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) T[3 * i + jx] = mat[3 * i] * A[jx] + mat[3 * i + 1] * A[3 + jx] + mat[3 * i + 2] * A[6 + jx];
     for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) Iw[3 * i + jx] = T[3 * i] * mat[3 * jx] + T[3 * i + 1] * mat[3 * jx + 1] + T[3 * i + 2] * mat[3 * jx + 2];
+#if DM_KIN_PREFETCH
+    const R m = bmass;
+#else
     const R m = M.body_mass[b];
+#endif
     const R cc = dot3(c, c);
     R* S = s.r2.i.sin[b];
     S[0] = Iw[0] + m * (cc - c[0] * c[0]); S[1] = Iw[4] + m * (cc - c[1] * c[1]); S[2] = Iw[8] + m * (cc - c[2] * c[2]);
@@ -292,6 +343,63 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& 
     s.r1.v.cacc[0][3] = -M.gravity[0]; s.r1.v.cacc[0][4] = -M.gravity[1]; s.r1.v.cacc[0][5] = -M.gravity[2];
   }
   R S[6] = {0, 0, 0, 0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
+#if DM_BIAS_BATCH
+  // A lone wave waits out every LDS round trip it takes: operands are requested together, a scheduling fence keeps the arithmetic behind them.  The root body
+  // (the only one at depth 1, a static property of the tree) needs nothing but the world's constants: it is done here, beside the other bodies' joint
+  // velocities, and the level loop starts at depth 2 — one level and one hand-off less, same arithmetic.
+  if (isbody && b > 1) {
+    R qd3[3], cd3[3][6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int dk = k < nd ? da + k : da;
+      qd3[k] = s.qvel[dk];
+#pragma unroll
+      for (int r = 0; r < 6; r++) cd3[k][r] = s.cdof[dk][r];
+    }
+    dmw::sched_fence();
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (k < nd) {
+      const R qd = qd3[k];
+      R T[6], cd[6];
+      for (int r = 0; r < 6; r++) T[r] = cd3[k][r] * qd;
+      if (k > 0) { cross_motion(cd, S, T); for (int r = 0; r < 6; r++) C[r] += cd[r]; }
+      for (int r = 0; r < 6; r++) S[r] += T[r];
+    }
+  } else if (b == 1) {
+    R v[6], a[6], qd6[6], cd6[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) { v[r] = s.r1.v.cvel[0][r]; a[r] = s.r1.v.cacc[0][r]; }      // (written by this very lane above: the LDS keeps a wave's accesses in order)
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      qd6[k] = s.qvel[k];
+#pragma unroll
+      for (int r = 0; r < 6; r++) cd6[k][r] = s.cdof[k][r];
+    }
+    dmw::sched_fence();
+    for (int k = 0; k < 3; k++) { const R qd = qd6[k]; for (int r = 0; r < 6; r++) v[r] += cd6[k][r] * qd; }
+    R vb[6];
+    for (int r = 0; r < 6; r++) vb[r] = v[r];
+    for (int k = 3; k < 6; k++) {
+      R cd[6]; cross_motion(cd, vb, cd6[k]);
+      const R qd = qd6[k];
+      for (int r = 0; r < 6; r++) { a[r] += cd[r] * qd; v[r] += cd6[k][r] * qd; }
+    }
+    for (int r = 0; r < 6; r++) { s.r1.v.cvel[1][r] = v[r]; s.r1.v.cacc[1][r] = a[r]; }
+  }
+  dmw::sync();
+#pragma unroll
+  for (int L = 2; L <= MAXDEPTH_BODY; L++) {
+    if (isbody && depth == L) {
+      R v[6], a[6];
+      for (int r = 0; r < 6; r++) { v[r] = s.r1.v.cvel[p][r]; a[r] = s.r1.v.cacc[p][r]; }
+      R cd[6];
+      cross_motion(cd, v, S);
+      for (int r = 0; r < 6; r++) { a[r] += cd[r] + C[r]; v[r] += S[r]; }
+      for (int r = 0; r < 6; r++) { s.r1.v.cvel[b][r] = v[r]; s.r1.v.cacc[b][r] = a[r]; }
+    }
+    dmw::sync();
+  }
+#else
   if (isbody && b > 1) {
 #pragma unroll
     for (int k = 0; k < 3; k++) if (k < nd) {
@@ -326,6 +434,7 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& 
     }
     dmw::sync();
   }
+#endif
   if (isbody) {
     R v[6], a[6];
     for (int r = 0; r < 6; r++) { v[r] = s.r1.v.cvel[b][r]; a[r] = s.r1.v.cacc[b][r]; }
@@ -336,6 +445,26 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& 
   dmw::sync();
   slot_subtree_sums<6, 1, R>(s.r1.v.cfrc, s.r1.v.cvel, sl);       // csub -> the velocity region (dead by now)
   dmw::sync();
+#if DM_BIAS_BATCH
+  {
+    R cdd[DOF_PASSES][6], cvb[DOF_PASSES][6], qv[DOF_PASSES], ac[DOF_PASSES], dmp[DOF_PASSES];
+#pragma unroll
+    for (int c = 0; c < DOF_PASSES; c++) {
+      const int d = sl + SW * c, dd = d < NV ? d : 0, bd = DM_DOF_BODY(tb, dd);
+#pragma unroll
+      for (int r = 0; r < 6; r++) { cdd[c][r] = s.cdof[dd][r]; cvb[c][r] = s.r1.v.cvel[bd][r]; }
+      qv[c] = s.qvel[dd]; ac[c] = s.act[dd]; dmp[c] = M.dof_damping[dd];
+    }
+    dmw::sched_fence();
+#pragma unroll
+    for (int c = 0; c < DOF_PASSES; c++) {
+      const int d = sl + SW * c;
+      const R bias = dot6(cdd[c], cvb[c]);
+      const R t = -dmp[c] * qv[c] - bias + ac[c];
+      if (d < NV) s.tau[d] = t;
+    }
+  }
+#else
 #pragma unroll
   for (int c = 0; c < DOF_PASSES; c++) {
     const int d = sl + SW * c;
@@ -344,6 +473,7 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& 
       s.tau[d] = -M.dof_damping[d] * s.qvel[d] - bias + s.act[d];
     }
   }
+#endif
   dmw::sync();
 }
 
@@ -516,21 +646,42 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
   SlotEliminateFrom<0, R>::run(s, tb, sl, lt);
 #endif
   SLOT_MSTAMP(17)
+#if DM_ENTRY_SELECT
+  {
+    R dgl[DOF_PASSES];                       // (likewise: the three diagonals first, then the three division + square-root chains side by side)
+#pragma unroll
+    for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c, dd = d < NV ? d : 0; dgl[c] = s.r2.qLD[DM_DOF_MADR(tb, dd)]; }
+    dmw::sched_fence();
+#pragma unroll
+    for (int c = 0; c < DOF_PASSES; c++) {
+      const int d = sl + SW * c;
+      const R inv = R(1) / dgl[c], sq = sqrt(inv);
+      if (d < NV) { s.qd.o.dinv[d] = inv; s.dsq[d] = sq; }
+    }
+  }
+#else
 #pragma unroll
   for (int c = 0; c < DOF_PASSES; c++) {
     const int d = sl + SW * c;
     if (d < NV) { const R inv = R(1) / s.r2.qLD[DM_DOF_MADR(tb, d)]; s.qd.o.dinv[d] = inv; s.dsq[d] = sqrt(inv); }
   }
+#endif
   dmw::sync();
 #if DM_ENTRY_SELECT
   {
-    R sc[ENT_PASSES];                        // (likewise: all operands first, then the stores)
+    R sc[ENT_PASSES], di[ENT_PASSES];        // (likewise: all forty operands, a fence, the products, the stores)
 #pragma unroll
     for (int c = 0; c < ENT_PASSES; c++) {
       const int e = sl + SW * c, ee = ((c + 1) * SW <= TOPO.nM || e < TOPO.nM) ? e : 0;
+      const int ij = ijc[c], i = ij >> 8;
+      di[c] = s.qd.o.dinv[i];
+      sc[c] = s.r2.qLD[ee];
+    }
+    dmw::sched_fence();
+#pragma unroll
+    for (int c = 0; c < ENT_PASSES; c++) {
       const int ij = ijc[c], i = ij >> 8, j = ij & 0xff;
-      const R di = s.qd.o.dinv[i];
-      sc[c] = s.r2.qLD[ee] * (i != j ? di : R(1));
+      sc[c] = sc[c] * (i != j ? di[c] : R(1));
     }
 #pragma unroll
     for (int c = 0; c < ENT_PASSES; c++) {
