@@ -117,9 +117,6 @@ static_assert(offsetof(SlotShared<double>, cdof) == offsetof(SlotShared<double>,
 #ifndef DM_BIAS_BATCH
 #define DM_BIAS_BATCH 1
 #endif
-#ifndef DM_KIN_PREFETCH
-#define DM_KIN_PREFETCH 1
-#endif
 constexpr bool root_alone_at_depth_one() { for (int b = 2; b < NB; b++) if (TOPO.body_depth[b] <= 1) return false; return TOPO.body_depth[1] == 1; }
 static_assert(root_alone_at_depth_one(), "slot_bias does the root body (the only one at depth 1) ahead of the level loop");
 struct SlotTables {
@@ -180,25 +177,6 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
   const bool isbody = sl < NB - 1;
   const int depth = dmw::launder(lt.depth), da = dmw::launder(lt.dofadr), nd = dmw::launder(lt.dofnum), panc = dmw::launder(lt.parent), p = panc & 15;
   R qloc[4] = {1, 0, 0, 0}, aloc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#if DM_KIN_PREFETCH
-  // The model's constants of this lane's hinges and body — asked for in one go at the top of the stage (clamped indices: every lane asks), so that their
-  // L2 round trip runs under the half-angle sines; fetched where they are used, behind a lane predicate each, they were six exposed round trips per evaluation.
-  R q0h[HINGE_PASSES], axl3[3][3], bpos[3], ipos3[3], Ib6[6], bmass;
-  {
-    const int bb = isbody ? b : 1;
-#pragma unroll
-    for (int c = 0; c < HINGE_PASSES; c++) { const int h = sl + SW * c; q0h[c] = M.qpos0[(h < NU ? h : 0) + 7]; }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int j = (isbody && b > 1 && k < nd) ? da + k - 5 : 1;
-      axl3[k][0] = M.jnt_axis[j][0]; axl3[k][1] = M.jnt_axis[j][1]; axl3[k][2] = M.jnt_axis[j][2];
-    }
-    for (int k = 0; k < 3; k++) { bpos[k] = M.body_pos[bb][k]; ipos3[k] = M.body_ipos[bb][k]; }
-    for (int k = 0; k < 6; k++) Ib6[k] = M.body_inertia[bb][k];
-    bmass = M.body_mass[bb];
-    dmw::sched_fence();
-  }
-#endif
   if (sl == 0) {
     s.xpos[0][0] = s.xpos[0][1] = s.xpos[0][2] = 0; s.r1.k.off[0][0] = s.r1.k.off[0][1] = s.r1.k.off[0][2] = 0;
     s.r1.k.xquat[0][0] = 1; s.r1.k.xquat[0][1] = s.r1.k.xquat[0][2] = s.r1.k.xquat[0][3] = 0;
@@ -209,11 +187,7 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
   for (int c = 0; c < HINGE_PASSES; c++) {
     const int h = sl + SW * c;
     if (h < NU) {
-#if DM_KIN_PREFETCH
-      const R half = (s.qpos[h + 7] - q0h[c]) * R(0.5);
-#else
       const R half = (s.qpos[h + 7] - M.qpos0[h + 7]) * R(0.5);
-#endif
       const SinCos<R> sc = sincos_once(half);
       s.r1.k.sc[h][0] = sc.c; s.r1.k.sc[h][1] = sc.s;
     }
@@ -224,11 +198,7 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
 #pragma unroll
     for (int k = 0; k < 3; k++) if (k < nd) {
       const int d = da + k, j = d - 5;
-#if DM_KIN_PREFETCH
-      const R axl[3] = {axl3[k][0], axl3[k][1], axl3[k][2]};
-#else
       const R axl[3] = {M.jnt_axis[j][0], M.jnt_axis[j][1], M.jnt_axis[j][2]};
-#endif
       R qm[9];
       quat2mat(qm, qloc);
       mat_vec(aloc[k], qm, axl);
@@ -262,11 +232,7 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
   if (isbody) {
     R v[3];
     if (b == 1) { v[0] = s.qpos[0]; v[1] = s.qpos[1]; v[2] = s.qpos[2]; }
-#if DM_KIN_PREFETCH
-    else mat_vec(v, s.xmat[p], bpos);
-#else
     else mat_vec(v, s.xmat[p], M.body_pos[b]);
-#endif
     for (int k = 0; k < 3; k++) s.r1.k.off[b][k] = v[k];
   }
   dmw::sync();
@@ -296,29 +262,17 @@ DM_DEV void slot_kinematics(const DevModel<R>& M, SlotShared<R>& s, int sl_in, c
         cross3(&s.cdof[da + k][3], xp, axw);
       }
     }
-#if DM_KIN_PREFETCH
-    const R ip[3] = {ipos3[0], ipos3[1], ipos3[2]};
-#else
     const R ip[3] = {M.body_ipos[b][0], M.body_ipos[b][1], M.body_ipos[b][2]};
-#endif
     R c[3];
     mat_vec(c, mat, ip);
     c[0] += xp[0]; c[1] += xp[1]; c[2] += xp[2];
     xip[0] = c[0]; xip[1] = c[1]; xip[2] = c[2];
-#if DM_KIN_PREFETCH
-    const R* Ib = Ib6;
-#else
     const R* Ib = M.body_inertia[b];
-#endif
     const R A[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]};
     R T[9], Iw[9];
     for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) T[3 * i + jx] = mat[3 * i] * A[jx] + mat[3 * i + 1] * A[3 + jx] + mat[3 * i + 2] * A[6 + jx];
     for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) Iw[3 * i + jx] = T[3 * i] * mat[3 * jx] + T[3 * i + 1] * mat[3 * jx + 1] + T[3 * i + 2] * mat[3 * jx + 2];
-#if DM_KIN_PREFETCH
-    const R m = bmass;
-#else
     const R m = M.body_mass[b];
-#endif
     const R cc = dot3(c, c);
     R* S = s.r2.i.sin[b];
     S[0] = Iw[0] + m * (cc - c[0] * c[0]); S[1] = Iw[4] + m * (cc - c[1] * c[1]); S[2] = Iw[8] + m * (cc - c[2] * c[2]);
