@@ -409,6 +409,19 @@ def standing_bench(args, dev, rank, world, local_dev):
         print(json.dumps(out))
 
 
+DISTINCT_GPUS = [1]    # how many physical GPUs the ranks sit on (None: this torch build exposes neither PCI ids nor a device uuid)
+
+
+def distinct_gpus(rows):
+    """rows: per rank [pci domain, bus, device, local hip ordinal, uuid-derived integer].  Distinct PCI addresses when the build reports them; else distinct
+    uuids; else distinct local ordinals (one node: the ordinal IS the GPU); None when nothing tells the ranks' devices apart."""
+    if all(min(r[:3]) >= 0 for r in rows):
+        return len(set(tuple(r[:3]) for r in rows))
+    if all(r[4] != 0 for r in rows):
+        return len(set(r[4] for r in rows))
+    return None
+
+
 RANK_DEVICES = []      # per rank: PCI address of its GPU, gathered over the process group at start-up (multi-rank runs)
 
 
@@ -489,14 +502,22 @@ def main():
         # which physical GPU every rank sits on (PCI domain:bus:device of its HIP device), gathered over the process group itself: a SCALE record then
         # shows that the collective backend saw N distinct GPUs (src/train_mpi.sh:1 starts one worker per slot; src/trpo.py:175-186 sums over them)
         pr = torch.cuda.get_device_properties(dev)
-        mine = torch.tensor([int(getattr(pr, "pci_domain_id", -1)), int(getattr(pr, "pci_bus_id", -1)), int(getattr(pr, "pci_device_id", -1)), local_dev],
-                            dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu")
+        pci = [int(getattr(pr, k, -1)) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        # a torch build without the PCI properties: the device's uuid (its first 8 bytes as an integer) keys distinctness instead, and failing that the
+        # count is reported as unknown (None) — never as "1 GPU" for N real ones
+        uid = 0
+        try:
+            uid = int.from_bytes(bytes.fromhex(str(pr.uuid).replace("-", "").replace("GPU", ""))[:7], "big")
+        except Exception:       # noqa: BLE001
+            uid = 0
+        mine = torch.tensor(pci + [local_dev, uid], dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu")
         every = [torch.zeros_like(mine) for _ in range(n_ranks_seen)]
         dist.all_gather(every, mine)
-        RANK_DEVICES[:] = ["%04x:%02x:%02x.hip%d" % tuple(int(v) & 0xffff for v in t.tolist()) for t in every]
+        RANK_DEVICES[:] = ["%04x:%02x:%02x.hip%d" % tuple(int(v) & 0xffff for v in t.tolist()[:4]) for t in every]
+        DISTINCT_GPUS[0] = distinct_gpus([t.tolist() for t in every])
         if rank == 0:       # start-up line for the scaling log (stderr: stdout carries exactly one JSON line)
-            sys.stderr.write("bench.py: rank -> GPU (pci domain:bus:device.hip-ordinal): %s; %d distinct GPU(s) for %d rank(s)\n"
-                             % (" ".join("%d=%s" % (i, d) for i, d in enumerate(RANK_DEVICES)), len(set(d.rsplit(".", 1)[0] for d in RANK_DEVICES)), n_ranks_seen))
+            sys.stderr.write("bench.py: rank -> GPU (pci domain:bus:device.hip-ordinal): %s; %s distinct GPU(s) for %d rank(s)\n"
+                             % (" ".join("%d=%s" % (i, d) for i, d in enumerate(RANK_DEVICES)), "unknown number of" if DISTINCT_GPUS[0] is None else DISTINCT_GPUS[0], n_ranks_seen))
             n_log = args.envs or WORKLOADS.get(args.workload, WORKLOADS["cfg3"])["envs"]
             sys.stderr.write("bench.py: %s process group up, %d ranks (backend reports %s), device %s; rollout gather every %d steps: "
                              "[%d, %d, 87] f32 = %.1f MB per rank, %.1f MB gathered per rank\n"
@@ -736,7 +757,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f%d" % args.dtype, "data": "synthetic",
             "config": {"workload": label, "envs_per_gpu": n, "global_envs": world * n if world > 1 else n * wl["shards"], "clip": clip,
                        "parallelism": "env-shard x%d" % max(world, wl["shards"]), "n_ranks_seen": n_ranks_seen,
-                       "rank_devices": list(RANK_DEVICES) or None, "distinct_gpus": (len(set(d.rsplit(".", 1)[0] for d in RANK_DEVICES)) if RANK_DEVICES else 1),
+                       "rank_devices": list(RANK_DEVICES) or None, "distinct_gpus": DISTINCT_GPUS[0],
                        "non_default_options": (["DM_OPT_STEP_QUEUE=%d" % queue] if queue else []) + (["DM_OPT_PIPELINE=%d" % P_sub] if (P_sub > 1 and not queue) else []),
                        "value_is": ("queued dm_batch_step calls (open loop, outputs valid after dm_batch_join): the library's horizon launch reached through the per-step entry point; "
                                     "the closed-loop figure — one launch set per call, default options apart from the pipeline depth DPVecEnv sets — is `vecenv_step`") if queue

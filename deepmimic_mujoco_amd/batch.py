@@ -120,7 +120,18 @@ class Batch(object):
         self._auto_ctr = 0
         self._redo_last = self.redo_total() if on else 0
         self._redo_rows_last = self.redo_reasons()[4] if on else 0
+        self._calm_checks = 0
         self.auto_switches = 0
+
+    CALM_CHECKS = 3              # OPT_PACKED 2 -> 1 only after this many consecutive looks with nobody above 32 rows (a population near the redo threshold
+                                 #  holds ~2.5 such environments per step: a single snapshot reads zero one time in twelve and the batch would flip 2 -> 1 -> 2)
+
+    def rebaseline_auto(self):
+        """The redo counters moved while the chooser was suspended (SegmentCollector's horizon launches re-step inside the wave and count there): start
+        the next window from where they stand now."""
+        r = self.redo_reasons()
+        self._redo_last = r[0]; self._redo_rows_last = r[4]
+        self._calm_checks = 0
 
     def _adapt(self):
         self._auto_ctr += 1
@@ -134,17 +145,21 @@ class Batch(object):
             rows_share = (reasons[4] - self.__dict__.get("_redo_rows_last", 0)) / float(max(1, redo - self._redo_last))
             self._redo_last = redo; self._redo_rows_last = reasons[4]
             if rate > self.REDO_RATE_MAX:
+                self._calm_checks = 0
                 # too many environments beyond the per-step capacities.  Nearly all of them for ROWS (a population standing on both feet: 33 .. 37): the
                 # per-step launches with the three-set code (OPT_PACKED 2, 40 rows per env); otherwise — or if that was already on — the one-env kernel
                 self.set_option(A.OPT_PACKED, 2 if (mode == 1 and rows_share >= 0.9) else 0); self.auto_switches += 1
-            elif mode == 2 and int((self.get(A.F_NEFC) > A.PACKED_MAXROWS_PER_STEP).sum()) == 0:
-                self.set_option(A.OPT_PACKED, 1); self.auto_switches += 1            # nobody above 32 rows any more: the lean per-step kernel (8 % faster)
+            elif mode == 2:
+                # nobody above 32 rows at CALM_CHECKS looks in a row: the lean per-step kernel (8 % faster)
+                self._calm_checks = self._calm_checks + 1 if int((self.get(A.F_NEFC) > A.PACKED_MAXROWS_PER_STEP).sum()) == 0 else 0
+                if self._calm_checks >= self.CALM_CHECKS:
+                    self._calm_checks = 0
+                    self.set_option(A.OPT_PACKED, 1); self.auto_switches += 1
         else:
             top = int(self.get(A.F_NEFC).max())
             if top <= self.HEAVY_ROWS_EXT:
                 self.set_option(A.OPT_PACKED, 1 if top <= self.HEAVY_ROWS else 2); self.auto_switches += 1
-                r = self.redo_reasons()
-                self._redo_last = r[0]; self._redo_rows_last = r[4]
+                self.rebaseline_auto()
 
     # ---- the hot path -------------------------------------------------------------------------------
     def _step_device(self, action, n_substeps, out):

@@ -353,6 +353,7 @@ extern "C" int dm_batch_create(const dm_model* m, const dm_mocap* mc, int32_t n,
   A(b->B.kin, (size_t)n * KIN_DOUBLES); A(b->B.kin_ok, n);
   A(b->B.redo_list, n); A(b->B.redo_count, 2 * DM_MAX_PIPELINE); A(b->B.redo_why, 8);
   A(b->d_ord_cnt, DM_MAX_PIPELINE * 3 * ORD_BUCKETS);
+  A(b->d_ord_list, (size_t)3 * ORD_BUCKETS * n);                      // (768 B per env of address space, 8 B of it touched per step; allocated here so that no step call can run out of memory half-way through its parts)
   A(b->d_qpos_in, (size_t)n * NQ); A(b->d_qvel_in, (size_t)n * NV); A(b->d_fidx_in, n); A(b->d_debug, DM_DEBUG_DOUBLES);
   if (sizeof(Real) != sizeof(Ext)) A(b->d_cvt, (size_t)n * NB * 3);   // largest Real field per env: xipos (42)
 #undef A
@@ -484,7 +485,7 @@ extern "C" int dm_batch_reset(dm_batch* b, int32_t mode, int32_t hard, const uin
 }
 
 // the packed path covers this batch's configuration (reward modes alive / v3-config / v2-pose / imitation, the two-tier kernel family)
-static bool packed_covers(const dm_batch* b) { return b->packed && b->B.reward_mode <= 3 && b->two_tier; }
+static bool packed_covers(const dm_batch* b) { return b->packed && b->B.reward_mode <= 4 && b->two_tier; }
 // a dm_batch_step call may be queued: device pointers, no fused policy step, no per-stage profiling, and a configuration for which ONE launch
 // per horizon is the faster form (rollout_as_one_launch)
 static bool rollout_as_one_launch(const dm_batch* b) {
@@ -551,8 +552,9 @@ static int flush_queue(dm_batch* b) {
 // tickets the part's previous launch left (phase p), its envs take theirs from phase p + 1, its first workgroup clears phase p + 2 for the launch
 // after it.  `st` = the stream the launch goes to.  A part's tickets stay a permutation of the part whatever runs in between (horizon launches,
 // resets: only their keys grow stale); a new partition (DM_OPT_PIPELINE) starts afresh.
+// The part's phase and `valid` flag move on only once its launch is known to have gone out (ord_commit after hipGetLastError): a failed launch leaves the
+// descriptor where the last successful one put it, so the next launch reads tickets somebody really counted.
 static int ord_bind(dm_batch* b, Batch<Real>& Bh, int h, int lo, hipStream_t st) {
-  if (!b->d_ord_list) { if (hipMalloc((void**)&b->d_ord_list, (size_t)3 * ORD_BUCKETS * b->n * sizeof(int)) != hipSuccess) return fail(DM_ENOMEM, "dispatch-order lists"); }
   int* cnt = b->d_ord_cnt + (size_t)h * 3 * ORD_BUCKETS;
   if (!b->ord_valid[h]) { HIPCHK(hipMemsetAsync(cnt, 0, 3 * ORD_BUCKETS * sizeof(int), st)); b->ord_phase[h] = 0; }
   const int p = b->ord_phase[h], pn = (p + 1) % 3, pz = (p + 2) % 3;
@@ -563,9 +565,9 @@ static int ord_bind(dm_batch* b, Batch<Real>& Bh, int h, int lo, hipStream_t st)
   Bh.ordl_out = b->d_ord_list + (size_t)pn * ORD_BUCKETS * n + lo;
   Bh.ord_zero = cnt + pz * ORD_BUCKETS;
   Bh.ord_stride = b->n;
-  b->ord_phase[h] = pn; b->ord_valid[h] = true;
   return DM_OK;
 }
+static void ord_commit(dm_batch* b, int h) { b->ord_phase[h] = (b->ord_phase[h] + 1) % 3; b->ord_valid[h] = true; }
 
 static int step_impl(dm_batch* b, const double* action, double* obs, double* reward, uint8_t* done, int32_t nsub, int32_t kind, const dmp::PolicyArgs* pol) {
   if (!b || !action || !obs || !reward || !done || nsub < 1) return fail(DM_EINVAL, "dm_batch_step: bad argument");
@@ -609,7 +611,7 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
   if (b->timing) { if (b->ev_pending) { hipEventSynchronize(b->ev1); hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1); } if (!piped) HIPCHK(hipEventRecord(b->ev0, b->stream)); }
   const bool reorder = b->reorder && b->has_rows && b->n > b->resident_waves;   // more envs than resident waves: later rounds exist, their tail matters
   // the packed kernel covers: models without constraint rows, reward modes alive / v3-config / v2-pose, no fused policy step
-  const bool packed_step = b->packed && b->B.reward_mode <= 3 && b->two_tier;      // this call runs on the packed kernels (profiled or not)
+  const bool packed_step = b->packed && b->B.reward_mode <= 4 && b->two_tier;      // this call runs on the packed kernels (profiled or not)
   const bool use_packed = packed_step && !b->prof;
   const dmp::PolicyArgs nopol{nullptr, nullptr, nullptr, 0, 0ull, 0ull};
   if (packed_step) {
@@ -620,6 +622,7 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
       b->redo_mode = mode; b->redo_phase = 0;
     }
   }
+  unsigned ord_bound = 0;               // parts whose launch of this call took a ticket descriptor (committed below, after the launches went out)
   constexpr int REDO_BLOCKS = 1024;     // (round 5: 64 persistent one-wave workgroups took 5 ms to walk the 1 100 overflows a standing population of 8 192 envs produces per step on the lean kernel; an empty launch of 1 024 costs the same few microseconds)
   if (b->prof && packed_step) {
     HIPCHK(hipMemsetAsync(b->d_prof, 0, (size_t)b->n * dm::PROF_SLOTS * sizeof(long long), b->stream));
@@ -638,7 +641,7 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
       if (hi <= lo) continue;
       HIPCHK(hipStreamWaitEvent(b->ps[h], b->ev_in, 0));
       Batch<Real> Bh = b->B;                                                   // this part's launch orders itself from the tickets its previous launch left
-      if (reorder) { const int rc2 = ord_bind(b, Bh, h, lo, b->ps[h]); if (rc2 != DM_OK) return rc2; }
+      if (reorder) { const int rc2 = ord_bind(b, Bh, h, lo, b->ps[h]); if (rc2 != DM_OK) return rc2; ord_bound |= 1u << h; }
       if (b->timing && h == 0) HIPCHK(hipEventRecord(b->ev0, b->ps[0]));     // timing: sub-batch 0's kernel on ITS stream
       if (use_packed) {
         int* rc = b->B.redo_count + 2 * h + b->redo_phase; int* rn = b->B.redo_count + 2 * h + (1 - b->redo_phase);
@@ -654,9 +657,11 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     b->pipe_pending = true;
   } else if (b->two_tier) {
     // (one launch over the whole batch.  With a pipeline depth configured the tickets are kept per part — a pipelined launch must find exactly its
-    //  part's envs in them, otherwise two streams could step one env at once — so this launch takes none and falls back to the stored order.)
+    //  part's envs in them, otherwise two streams could step one env at once — so this launch takes none and falls back to the stored order: DM_OPT 104
+    //  has no effect on host-pointer steps and other unpipelined launches of a batch whose DM_OPT_PIPELINE is above 1 — a performance matter only,
+    //  results do not depend on the dispatch order; include/dmenv.h says so.)
     Batch<Real> Bh = b->B;
-    if (reorder && b->pipe <= 1) { const int rc2 = ord_bind(b, Bh, 0, 0, b->stream); if (rc2 != DM_OK) return rc2; }
+    if (reorder && b->pipe <= 1) { const int rc2 = ord_bind(b, Bh, 0, 0, b->stream); if (rc2 != DM_OK) return rc2; ord_bound |= 1u; }
     if (use_packed) {
       // (a step that is not pipelined has joined every sub-batch stream: all of them are idle, so ONE pair of counters is clean — pair 0's
       //  two are cleared here once if a pipelined step used them before)
@@ -669,6 +674,7 @@ static int step_impl(dm_batch* b, const double* action, double* obs, double* rew
     else hipLaunchKernelGGL(k_step_narrow, dim3(b->n), dim3(64), 0, b->stream, b->d_model, Bh, (const Ext*)a, o, r, dn, (int)nsub, 0, b->n);
   } else hipLaunchKernelGGL(k_step, dim3(b->n), dim3(64), 0, b->stream, b->d_model, b->B, (const Ext*)a, o, r, dn, (int)nsub);
   HIPCHK(hipGetLastError());
+  for (int h = 0; h < DM_MAX_PIPELINE; h++) if ((ord_bound >> h) & 1u) ord_commit(b, h);
   if (packed_step) b->redo_phase ^= 1;
   if (b->timing && !piped) { HIPCHK(hipEventRecord(b->ev1, b->stream)); b->ev_pending = true; }
   if (kind == DM_PTR_HOST) {

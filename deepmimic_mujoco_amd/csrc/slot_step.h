@@ -165,10 +165,16 @@ DM_DEV void slot_reset_env(const DevModel<R>& M, const Batch<R>& B, SlotShared<R
 // ---- 5-term imitation reward (env_step.h imitation_reward; code.md:1017-1143) for the slot's environment: one extra kinematics pass on
 // the integrated state, whose by-products are the joint features.  Slot lane = body - 1 (lane 0 root, lanes 1..12 joint groups); the four
 // end effectors on lanes 0..3 beside them; linear momentum one dof per lane in three passes; row sums (sum16) instead of wave sums.
+// `refv` (wave-uniform) non-null: dp_env_v1's reward instead (env_step.h v1_reward; src/dp_env_v1.py:82-141, src/mujoco/mujoco_interface.py:169-210) from the
+// SAME features — |angle| instead of angle^2 per joint with the un-normalised JOINT_WEIGHTs, L1 rate distance from row `refv` (the clip's rates frame k -> k + 1),
+// L1 root distance, r = 0.5 e^(-2 pose) + 0.05 e^(-0.1 vel) + 0.2 e^(-5 root) — as selects inside the one pass, so that the step function holds ONE
+// instance of the kinematics stage's code for its reward (round 6: reward mode 4 on the packed kernels).
 template <class R>
-DM_DEV R slot_imitation_reward(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, int sl, const LaneTopo& lt, const R* ref, R shx, R shy) {
+DM_DEV R slot_imitation_reward(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>& s, int sl, const LaneTopo& lt, const R* ref, R shx, R shy, const R* refv = nullptr) {
   R qloc[4], aloc[3][3], xip[3];
   slot_kinematics(M, s, sl, lt, xip, qloc, aloc);          // ends with a sync; s.r2.i.crb holds the composite inertias
+  const bool v1 = refv != nullptr;
+  const R* rv = v1 ? refv : ref;                           // the row the rates are compared with
   const R* P = B.imit_pdev;
   R rq[4] = {s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
   normalize4(rq);
@@ -182,26 +188,26 @@ DM_DEV R slot_imitation_reward(const DevModel<R>& M, const Batch<R>& B, SlotShar
     R q0[4], q1[4];
     for (int k = 0; k < 4; k++) { q0[k] = isroot ? rq[k] : (ball ? qloc[k] : ident[k]); q1[k] = (isroot || ball) ? rquat[k] : ident[k]; }
     const R th = quat_diff_theta(q0, q1);
-    R pe = th * th, ve = 0;
+    R pe = v1 ? fabs(th) : th * th, ve = 0;
     if (isroot) {
       R wv[3];
       const R wloc[3] = {s.qvel[3], s.qvel[4], s.qvel[5]};
       quat_rot(wv, rq, wloc);
       R dv2 = 0, dp2 = 0;
-      for (int k = 0; k < 3; k++) { const R a = ref[10 + k] - wv[k]; ve += a * a; const R c = ref[7 + k] - s.qvel[k]; dv2 += c * c; }
+      for (int k = 0; k < 3; k++) { const R a = rv[10 + k] - wv[k]; ve += v1 ? fabs(a) : a * a; const R c = ref[7 + k] - s.qvel[k]; dv2 += c * c; }
       const R p1[3] = {ref[0] + shx, ref[1] + shy, ref[2]};
-      for (int k = 0; k < 3; k++) { const R a = s.qpos[k] - p1[k]; dp2 += a * a; }
-      root = dp2 + R(0.1) * pe + R(0.01) * dv2 + R(0.001) * ve;
+      for (int k = 0; k < 3; k++) { const R a = s.qpos[k] - p1[k]; dp2 += v1 ? fabs(a) : a * a; }
+      root = v1 ? dp2 : dp2 + R(0.1) * pe + R(0.01) * dv2 + R(0.001) * ve;
     } else if (ball) {
       R wl[3] = {0, 0, 0};
       for (int k = 0; k < 3; k++) { const R rate = s.qvel[da + k]; wl[0] += aloc[k][0] * rate; wl[1] += aloc[k][1] * rate; wl[2] += aloc[k][2] * rate; }
-      for (int k = 0; k < 3; k++) { const R w = ref[61 + 3 * g + k] - wl[k]; ve += w * w; }
+      for (int k = 0; k < 3; k++) { const R w = rv[61 + 3 * g + k] - wl[k]; ve += v1 ? fabs(w) : w * w; }
     } else {
-      const R a = ref[13 + 4 * g] - s.qpos[da + 1], w = ref[61 + 3 * g] - s.qvel[da];
-      pe = a * a; ve = w * w;
+      const R a = ref[13 + 4 * g] - s.qpos[da + 1], w = rv[61 + 3 * g] - s.qvel[da];
+      pe = v1 ? fabs(a) : a * a; ve = v1 ? fabs(w) + fabs(rv[61 + 3 * g + 1]) + fabs(rv[61 + 3 * g + 2]) : w * w;      // (v1: the two unused slots of the row are 0)
     }
-    const R wj = P[isroot ? 12 : g];
-    pose = wj * pe; vel = wj * ve;
+    const R wj = v1 ? (isroot ? R(1) : P[g] / P[12]) : P[isroot ? 12 : g];
+    pose = wj * pe; vel = v1 ? ve : wj * ve;
   }
   if (sl < 4) {
     const int e = sl, b = (int)P[16 + e];
@@ -233,14 +239,15 @@ DM_DEV R slot_imitation_reward(const DevModel<R>& M, const Batch<R>& B, SlotShar
   mx = dmw::sum16(mx) / M.total_mass; my = dmw::sum16(my) / M.total_mass; mz = dmw::sum16(mz) / M.total_mass;
   const R dc[3] = {ref[109] - mx, ref[110] - my, ref[111] - mz};
   const R com = R(0.1) * dot3(dc, dc);
-  const R arg = sl == 0 ? R(-2) * pose : sl == 1 ? R(-0.1) * vel : sl == 2 ? R(-40) * eff : sl == 3 ? R(-5) * root : R(-10) * com;
-  const R wgt = sl == 0 ? R(0.5) : sl == 1 ? R(0.05) : sl == 2 ? R(0.15) : sl == 3 ? R(0.2) : R(0.1);
+  // the terms, one lane each: 0.5 e^(-2 pose) + 0.05 e^(-0.1 vel) + 0.15 e^(-40 eff) + 0.2 e^(-5 root) + 0.1 e^(-10 com); v1: the first two and 0.2 e^(-5 root) on lane 2
+  const R arg = sl == 0 ? R(-2) * pose : sl == 1 ? R(-0.1) * vel : sl == 2 ? (v1 ? R(-5) * root : R(-40) * eff) : sl == 3 ? R(-5) * root : R(-10) * com;
+  const R wgt = sl == 0 ? R(0.5) : sl == 1 ? R(0.05) : sl == 2 ? (v1 ? R(0.2) : R(0.15)) : sl == 3 ? R(0.2) : R(0.1);
   R term = 0;
-  if (sl < 5) term = wgt * exp_once(arg);
+  if (sl < (v1 ? 3 : 5)) term = wgt * exp_once(arg);
   return dmw::sum16(term);
 }
 
-// DPEnv.step for the slot's environment (reward modes alive / v3-config / v2-pose / the 5-term imitation reward; dp_env_v1's reward stays with the one-env kernel).  A slot that is not `live` computes and stores nothing outside LDS.  An environment that exceeded a
+// DPEnv.step for the slot's environment (reward modes alive / v3-config / v2-pose / the 5-term imitation reward / dp_env_v1's reward).  A slot that is not `live` computes and stores nothing outside LDS.  An environment that exceeded a
 // capacity of the packed path during the step (`ovf`) stores nothing either: it is appended to the launch's redo list
 // (redo[0] = counter, list = redo + 1 ...) and re-stepped from its unchanged state by the one-env kernel.
 // CARRY (horizon launches only) + kin_carry (wave-uniform): the slots' LDS is what this wave's previous step left, so a slot's `kin_ok` flag
@@ -313,6 +320,19 @@ DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
     dn = dn || ended;
     dmw::sync_mem();
     if (live && sl == 0) { B.frame_idx[env] = k; B.cycle[env] = cyc; }
+  } else if (B.reward_mode == REW_V1_QUAT) {     // src/dp_env_v1.py:82-158 (env_step.h): the cursor counts steps, the pose reward every `upd` steps, minus the control cost
+    const int idx = B.frame_idx[env] + 1;
+    int upd = (int)floor(B.mocap_dt / (M.timestep * n_substeps));
+    if (upd < 1) upd = 1;
+    // (the four environments of a wave sit at different cursors: the pass is collective, so it runs every step on every slot — its kinematics are the
+    //  next step's first evaluation's anyway (kin_carry) — and a slot takes its value on the steps its own cursor says so)
+    const int k = (idx / upd + B.frame_init[env]) % B.n_frames, kv = k + 1 < B.n_frames ? k + 1 : B.n_frames - 1;
+    const R robs = slot_imitation_reward(M, B, s, sl, lt, B.imit_table + (size_t)k * IMIT_FEAT, R(0), R(0), B.imit_table + (size_t)kv * IMIT_FEAT);
+    R acs = 0;
+    for (int u = 0; u < NU; u++) { const R c = B.ctrl[(size_t)env * NU + u]; acs += c * c; }
+    rew = (idx % upd == 0 ? robs : R(0)) - R(0.1) * acs;
+    dmw::sync_mem();
+    if (live && sl == 0) B.frame_idx[env] = idx;
   }
   if (live && sl == 0) { B.time[env] += M.timestep * n_substeps; reward[env] = rew; done[env] = dn ? 1 : 0; if (B.kin) B.kin_ok[env] = 0; }
   if (B.autoreset) {                              // DummyVecEnv convention: obs of the fresh episode is returned
@@ -321,7 +341,7 @@ DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
   }
   // the slot's kinematics are those of the state the env is left in: the 5-term reward's pass ran on it and no reset replaced it (a slot that
   // is not live repeats a live one's environment and computes the same)
-  if constexpr (CARRY) { if (sl == 0) s.kin_ok() = (B.reward_mode == REW_IMITATION && !ovf && !(dn && B.autoreset != 0)) ? R(1) : R(0); }
+  if constexpr (CARRY) { if (sl == 0) s.kin_ok() = (B.reward_mode >= REW_IMITATION && !ovf && !(dn && B.autoreset != 0)) ? R(1) : R(0); }
   if (live) {
 #pragma unroll
     for (int c = 0; c < (NOBS + SW - 1) / SW; c++) {

@@ -279,18 +279,21 @@ class _InfoList(list):
         for d in self:
             d._owner = self
 
-    def _w(name):                                      # every list mutator marks the list before it acts
-        f = getattr(list, name)
 
-        def g(self, *a, **kw):
-            self.dirty = True
-            return f(self, *a, **kw)
-        g.__name__ = name
-        return g
+def _marking(name):                                    # every list mutator marks the list before it acts
+    f = getattr(list, name)
 
-    for _m in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove", "clear", "sort", "reverse"):
-        locals()[_m] = _w(_m)
-    del _w, _m
+    def g(self, *a, **kw):
+        self.dirty = True
+        return f(self, *a, **kw)
+    g.__name__ = name
+    return g
+
+
+_INFO_LIST_MUTATORS = ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove", "clear", "sort", "reverse")
+for _m in _INFO_LIST_MUTATORS:
+    setattr(_InfoList, _m, _marking(_m))
+del _m
 
 
 class DPVecEnv(object):
@@ -310,18 +313,14 @@ class DPVecEnv(object):
         packed: DM_OPT_PACKED — four environments per wavefront (k_step_packed) instead of one.  True / False pin the kernel; 2 pins the per-step launches
         with the three-set code (k_step_packed_ext: 40 constraint rows per env instead of 32, ~8 % slower otherwise — for populations that stand on both
         feet: 8.96 against 6.18 M env-steps/s one env per wave at 8 192 envs, closed loop).  None
-        (default): batches of PACKED_FROM_ENVS environments or more (two or more waves per SIMD on one MI355X; float64; rewards other than
-        v1-quat) start on the packed kernel and re-decide every 256 steps from their own row statistics (Batch.enable_auto_packed): it is
+        (default): batches of PACKED_FROM_ENVS environments or more (two or more waves per SIMD on one MI355X; float64; every reward mode, v1-quat
+        included since round 6) start on the packed kernel and re-decide every 256 steps from their own row statistics (Batch.enable_auto_packed): it is
         1.4-1.5x faster while environments stay within its per-env capacities (the RSI / early-termination regimes), and hands over to
         the one-env kernel when a competent policy keeps most environments on both feet (32+ rows).  Smaller batches: one env per wave —
         except for models without contacts and limits (BASELINE configs[1]): all waves cost the same there and four per wave is 1.5x
         faster at any size.
         step_queue: DM_OPT_STEP_QUEUE depth (0 = off): queue `batch.step` calls and run them as one horizon launch (see below)."""
         self.num_envs = int(num_envs)
-        if reward == "v1-quat" and (packed or step_queue):
-            # dp_env_v1's reward (mode 4) exists on the one-env kernel only (include/dmenv.h DM_OPT_PACKED): asking for the four-per-wave kernels — or for
-            # the step queue, which rides on them — with it used to fall back silently; now it is refused
-            raise ValueError("reward='v1-quat' runs on the one-environment-per-wavefront kernel only: use packed=None / False and no step_queue")
         self.mocap = MocapDM()
         self.mocap.load_mocap(motion)
         self.mocap_dt = self.mocap.dt
@@ -358,10 +357,10 @@ class DPVecEnv(object):
         b.set_option(A.OPT_ENV_OFFSET, int(env_offset))
         b.set_option(A.OPT_DIAGNOSTICS, 1 if diagnostics else 0)
         rowless = not (contacts or limits)          # no constraint rows: every wave costs the same, the packed kernel wins at any batch size
-        auto = packed is None and batch_factory is None and (self.num_envs >= PACKED_FROM_ENVS or (rowless and self.num_envs >= 256)) and dtype == 64 and reward != "v1-quat"
+        auto = packed is None and batch_factory is None and (self.num_envs >= PACKED_FROM_ENVS or (rowless and self.num_envs >= 256)) and dtype == 64
         # a horizon launch (Batch.rollout, rollout.SegmentCollector) may use the packed kernel at ANY batch size: there a wave does not wait
         # for the slowest wave of every step
-        self.horizon_packed_ok = packed is None and batch_factory is None and self.num_envs >= 256 and dtype == 64 and reward != "v1-quat"
+        self.horizon_packed_ok = packed is None and batch_factory is None and self.num_envs >= 256 and dtype == 64
         if packed or auto:
             b.set_option(A.OPT_PACKED, 2 if (packed is not True and packed == 2) else 1)     # (packed=2: per-step launches with the three-set code, see the docstring)
         if auto:

@@ -294,6 +294,7 @@ class SegmentCollector(object):
                 b.set_option(A.OPT_PACKED, was_mode)
             if was_auto:
                 b._auto = True
+                b.rebaseline_auto()                                         # (the horizon's in-wave re-steps are not the per-step chooser's evidence)
         return restore
 
     def collect(self):

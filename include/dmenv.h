@@ -127,8 +127,8 @@ enum {
                              once the caller's stream has joined: dm_batch_join() (no host wait), dm_batch_sync(), or any other
                              entry point of the batch.  Results are identical for every P. */
   DM_OPT_PACKED = 7,      /* 0 (default): one environment per wavefront (k_step_narrow).  1 / 2: FOUR environments per wavefront, one 16-lane
-                             DPP row each (k_step_packed, csrc/slot_kernel.h) wherever that kernel covers the call: reward modes 0..3 (reward
-                             mode 4, v1-quat, always runs on the one-env kernel), with or without the fused policy step.  Per-environment
+                             DPP row each (k_step_packed, csrc/slot_kernel.h) wherever that kernel covers the call: every reward mode (0..4; mode 4,
+                             v1-quat, included), with or without the fused policy step.  Per-environment
                              capacities of that path (csrc/slot_kernel.h SLOT_*): DM_PACKED_MAXROWS constraint rows inside a horizon launch
                              (dm_batch_rollout, DM_OPT_STEP_QUEUE: two full 16-row sets and a partial third — a humanoid standing on both
                              feet holds 32 contact rows plus joint limits), DM_PACKED_MAXROWS_PER_STEP in a per-step launch — unless the option
@@ -170,7 +170,9 @@ enum {
  *   101 per-stage shader-clock profile (k_step_prof + dm_batch_read_profile)
  *   102 1: register tier of 32 columns of A + memory strip (default); 0: all 64 columns in registers (k_step)
  *   103 1: force the guarded PGS re-solve path (results must not change)
- *   104 1: longest-first dispatch order from the previous step's row counts (default: per-step launches order themselves through tickets their envs take at the end of a step, horizon launches are grouped by a counting sort once per launch); 0: identity */
+ *   104 1: longest-first dispatch order from the previous step's row counts (default: per-step launches order themselves through tickets their envs take at the end of a step, horizon launches are grouped by a counting sort once per launch); 0: identity.
+ *       Tickets are kept per pipelined part (DM_OPT_PIPELINE): a launch over the WHOLE batch of a batch configured with a pipeline depth above 1 (host-pointer
+ *       steps, profiled steps) takes none and runs in the stored order — results never depend on the dispatch order, only the duration of such a launch does */
 int dm_batch_set_option(dm_batch* b, int32_t opt, int64_t value);
 
 /* Replaces: MujocoEnv.set_state(qpos, qvel) = sim.set_state(...) + sim.forward() (src/dp_env_v3.py:153,160):

@@ -128,7 +128,7 @@ void* emu_field(void* h, int field) {
 }
 void emu_step(void* h, const double* action, double* obs, double* reward, unsigned char* done, int nsub) {
   EmuBatch* e = (EmuBatch*)h;
-  if (e->packed && e->B.reward_mode <= 3) {          // the device's routing (dmenv.hip step_impl): four envs per wave, overflowing envs re-stepped one per wave
+  if (e->packed && e->B.reward_mode <= 4) {          // the device's routing (dmenv.hip step_impl): four envs per wave, overflowing envs re-stepped one per wave
     const int n = e->B.n_envs;
     e->B.redo_count[0] = 0;
     for (int first = 0; first < n; first += SLOTS)

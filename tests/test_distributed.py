@@ -147,3 +147,16 @@ def test_double_buffered_gather_single_process():
         assert g.commit(t) is None
     g.drain()
     assert len(g.blocks) == 1 and float(g.blocks[0][0, 0, 0]) == 8.0
+
+
+def test_bench_counts_distinct_gpus_without_pci_ids():
+    """bench.py's start-up line and `config.distinct_gpus` (a SCALE record is read for them; src/train_mpi.sh:1 starts one worker per slot): PCI addresses when
+    the torch build reports them, device uuids when it does not, and None — never a wrong count — when neither tells the ranks' devices apart."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert m.distinct_gpus([[0, 5, 0, 0, 7], [0, 6, 0, 1, 8]]) == 2
+    assert m.distinct_gpus([[0, 5, 0, 0, 7]] * 8) == 1                              # eight ranks sharing one device (the gloo test on the one-GPU box)
+    assert m.distinct_gpus([[-1, -1, -1, 0, 7], [-1, -1, -1, 1, 8]]) == 2           # no PCI properties: uuids
+    assert m.distinct_gpus([[-1, -1, -1, 0, 0], [-1, -1, -1, 1, 0]]) is None        # nothing to tell them apart: unknown, not "1"

@@ -282,6 +282,27 @@ def test_vec_env_step_wait_host_overhead_is_small_at_4096_envs():
         write(cur)
         nxt = env.step(act)[3]
         assert nxt is not cur and len(nxt) == n and all(not d for d in nxt)
+    # every listed mutator flips .dirty; copies and slices are plain lists (the caller's own objects, nothing to track)
+    from deepmimic_mujoco_amd.dp_env import _InfoList, _INFO_LIST_MUTATORS
+    args = {"__setitem__": (0, {}), "__delitem__": (0,), "__iadd__": ([{}],), "__imul__": (1,), "append": ({},), "extend": ([{}],), "insert": (0, {}), "pop": (), "remove": None,
+            "clear": (), "sort": None, "reverse": ()}
+    assert set(args) == set(_INFO_LIST_MUTATORS)
+    for name in _INFO_LIST_MUTATORS:
+        l = _InfoList(3)
+        assert not l.dirty and getattr(_InfoList, name) is not getattr(list, name)
+        a = args[name]
+        if name == "remove":
+            a = (l[0],)
+        if name == "sort":
+            getattr(l, name)(key=id)
+        else:
+            getattr(l, name)(*a)
+        assert l.dirty, name
+    l = _InfoList(3)
+    l[0:2] = [{}, {}]
+    assert l.dirty
+    l = _InfoList(3)
+    assert type(l.copy()) is list and type(l[0:2]) is list and not l.dirty
 
 
 def test_per_step_kernel_chooser_is_a_function_of_the_redo_statistics():
@@ -295,7 +316,7 @@ def test_per_step_kernel_chooser_is_a_function_of_the_redo_statistics():
     class Fake(Batch):
         def __init__(self):
             self.n = 100; self.options = {A.OPT_PACKED: 1}; self.reasons = [0, 0, 0, 0, 0, 0]; self.nefc = np.zeros(100, dtype=np.int32)
-            self._auto = True; self._auto_ctr = 0; self._redo_last = 0; self._redo_rows_last = 0; self.auto_switches = 0
+            self._auto = True; self._auto_ctr = 0; self._redo_last = 0; self._redo_rows_last = 0; self.auto_switches = 0; self._calm_checks = 0
             self.ADAPT_EVERY = 1
 
         def set_option(self, o, v):
@@ -320,7 +341,15 @@ def test_per_step_kernel_chooser_is_a_function_of_the_redo_statistics():
     b.nefc[:] = 20; b.nefc[3] = 35
     b._adapt(); assert b.options[A.OPT_PACKED] == 2 and b.auto_switches == 1                # no new overflows, somebody above 32 rows: stays
     b.nefc[3] = 30
-    b._adapt(); assert b.options[A.OPT_PACKED] == 1 and b.auto_switches == 2                # nobody above 32: the lean kernel again
+    # nobody above 32 — but one snapshot is not evidence (round 6: a population near the redo threshold reads zero one look in twelve): three looks in a row
+    b._adapt(); assert b.options[A.OPT_PACKED] == 2 and b.auto_switches == 1
+    b._adapt(); assert b.options[A.OPT_PACKED] == 2 and b.auto_switches == 1
+    b.nefc[3] = 33
+    b._adapt(); assert b.options[A.OPT_PACKED] == 2 and b._calm_checks == 0                  # somebody is back above 32: the count starts again
+    b.nefc[3] = 30
+    for _ in range(Batch.CALM_CHECKS - 1):
+        b._adapt(); assert b.options[A.OPT_PACKED] == 2 and b.auto_switches == 1
+    b._adapt(); assert b.options[A.OPT_PACKED] == 1 and b.auto_switches == 2                # the lean kernel again
     b.reasons = [20, 0, 0, 9, 11, 0]                                                          # overflows of another kind (contacts): the one-env kernel
     b._adapt(); assert b.options[A.OPT_PACKED] == 0 and b.auto_switches == 3
     b.nefc[3] = 45
@@ -331,3 +360,7 @@ def test_per_step_kernel_chooser_is_a_function_of_the_redo_statistics():
     b._adapt(); assert b.options[A.OPT_PACKED] == 0 and b.auto_switches == 5
     b.nefc[:] = 12
     b._adapt(); assert b.options[A.OPT_PACKED] == 1 and b.auto_switches == 6
+    # the collector's horizon launches count their in-wave re-steps into the same counters while the chooser is suspended: its restore() re-baselines
+    b.reasons = [5000, 0, 0, 0, 5000, 0]
+    b.rebaseline_auto()
+    b._adapt(); assert b.options[A.OPT_PACKED] == 1 and b.auto_switches == 6                # nothing of that is this window's evidence

@@ -225,6 +225,13 @@ def test_bench_eight_ranks_share_the_gpu_over_gloo():
     assert j["config"]["global_envs"] == 8 * 256 and j["config"]["gathers_completed"] >= 1 and j["scaling"] == "weak"
     assert j["config"]["clip"] == "dance_b" and j["value"] > 1e4 and "cpu_baseline" not in j
     assert "rollout gather" in out.stderr, "the multi-rank start-up line (rank count, gather size) is missing"
+    # what a SCALE record is read for (round 6): every rank reported its device over the process group, all eight sit on the one GPU of this box, and
+    # both blocks of the double buffer travelled (300 steps = one whole 256-step horizon + a started one)
+    c = j["config"]
+    assert len(c["rank_devices"]) == 8 and len(set(d.rsplit(".", 1)[0] for d in c["rank_devices"])) == 1
+    assert c["distinct_gpus"] == 1, "eight ranks on one visible device: %r" % (c["distinct_gpus"],)
+    assert "1 distinct GPU(s) for 8 rank(s)" in out.stderr
+    assert c["gathers_completed"] >= 1 and c["envs_per_gpu"] == 256
 
 
 @pytest.mark.gpu

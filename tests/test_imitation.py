@@ -372,7 +372,8 @@ def test_v1_reward_definition_numpy_vs_oracle_and_known_answers():
         assert np.allclose(t_c, sp.v1_reward_terms(f0, T[kk], T[kv]), rtol=1e-10, atol=1e-12) and abs(r_c - sp.v1_reward(f0, T[kk], T[kv])) < 1e-12
 
 
-def _rollout_v1_vs_oracle(batch, n, steps, nsub, seed, clip="walk"):
+def _rollout_v1_vs_oracle(batch, n, steps, nsub, seed, clip="walk", horizon=None):
+    """horizon: None — one `batch.step` per step; otherwise a callable (actions [T, n, 28]) -> (obs, rew, done) [T, n, ...] that runs all steps as ONE launch."""
     from oracle import oracle as O
     sp, mc, T, P = _imit_inputs(clip)
     F = len(T)
@@ -390,15 +391,19 @@ def _rollout_v1_vs_oracle(batch, n, steps, nsub, seed, clip="walk"):
         ods[e].reset(); ods[e].set_state(q[e], v[e])
     cur = np.zeros(n, int)
     worst = 0.0; zero_steps = 0
+    acts = rng.randn(steps, n, 28) * 0.3
+    if horizon is not None:
+        obs_T, rew_T, done_T = horizon(acts)
     for t in range(steps):
-        a = rng.randn(n, 28) * 0.3
-        obs, rew, done = batch.step(a, nsub)[:3]
+        a = acts[t]
+        obs, rew, done = (obs_T[t], rew_T[t], done_T[t]) if horizon is not None else batch.step(a, nsub)[:3]
         for e in range(n):
             o, r, d, cur[e] = O.env_step_v1(om, ods[e], a[e], nsub, T, P, float(mc.dt), cur[e], int(idx[e]))
             worst = max(worst, abs(rew[e] - r), H.rel_err(obs[e], o))
             assert bool(done[e]) == d, (t, e)
             zero_steps += int(abs(r + 0.1 * np.square(a[e]).sum()) < 1e-15)
-        assert np.array_equal(batch.get(A.F_FRAME_IDX), cur.astype(np.int32))
+        if horizon is None or t == steps - 1:
+            assert np.array_equal(batch.get(A.F_FRAME_IDX), cur.astype(np.int32))
     return worst, zero_steps
 
 
@@ -414,19 +419,64 @@ def test_v1_reward_mode_on_the_wave_testbench_matches_oracle():
     assert worst < 1e-10 and zeros == 0
 
 
+def test_v1_reward_mode_on_the_packed_kernels_of_the_wave_testbench_matches_oracle():
+    """Round 6: reward mode 4 in the packed epilogue (slot_step.h slot_imitation_reward with `refv`) — four environments per wavefront at DIFFERENT step
+    cursors (the pose reward falls on every second step of each, src/dp_env_v1.py:131-141), per step and as one horizon launch (the kinematics of the
+    reward pass carried into the next step); six environments: the second wave holds two live slots."""
+    from tests.emu.emu import EmuBatch
+    sp, mc, T, P = _imit_inputs()
+    n = 6
+    for form in ("per-step", "horizon"):
+        b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0, imitation=(T, P), mocap_dt=float(mc.dt))
+        b.set_option(A.OPT_PACKED, 1)
+        worst, zeros = _rollout_v1_vs_oracle(b, n, steps=4, nsub=1, seed=2, horizon=(lambda acts: b.rollout(acts, 1)) if form == "horizon" else None)
+        assert worst < 1e-10 and zeros == n * 2, (form, worst, zeros)
+        assert b.redo_total() == 0
+    b = EmuBatch(H.compiled_model(), mc.data_config, mc.data_vel, n, 0, imitation=(T, P), mocap_dt=float(mc.dt))
+    b.set_option(A.OPT_PACKED, 1)
+    worst, zeros = _rollout_v1_vs_oracle(b, n, steps=3, nsub=2, seed=3)
+    assert worst < 1e-10 and zeros == 0
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["one-env", "packed", "horizon", "queue"])
 @pytest.mark.parametrize("clip", ["walk", "dance_b"])
-def test_v1_reward_mode_on_gpu_matches_oracle(clip):
+def test_v1_reward_mode_on_gpu_matches_oracle(clip, form):
+    """dp_env_v1's reward (src/dp_env_v1.py:82-141, src/mujoco/mujoco_interface.py:169-210) on every launch form (round 6: the packed epilogue): one env per
+    wave, four per wave per step, one horizon launch (dm_batch_rollout), the step queue."""
+    import torch
     from deepmimic_mujoco_amd import Batch
     sp, mc, T, P = _imit_inputs(clip)
     n = 16
     b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
-    worst, zeros = _rollout_v1_vs_oracle(b, n, steps=8, nsub=1, seed=7, clip=clip)
-    print("v1-quat reward rollout (%s): worst |diff| %.2e, steps without a reward evaluation %d" % (clip, worst, zeros))
+    b.set_option(A.OPT_PACKED, 0 if form == "one-env" else 1)
+    horizon = None
+    if form in ("horizon", "queue"):
+        def horizon(acts):
+            dev = torch.device("cuda:0")
+            S = acts.shape[0]
+            a = torch.zeros((S + 1, n, 28), dtype=torch.float64, device=dev); a[:S] = torch.from_numpy(acts).to(dev)
+            o = torch.empty((S, n, 56), dtype=torch.float64, device=dev); r = torch.empty((S, n), dtype=torch.float64, device=dev)
+            d = torch.empty((S, n), dtype=torch.uint8, device=dev)
+            if form == "horizon":
+                b.rollout(a, (o, r, d), 1)
+            else:
+                b.set_option(A.OPT_STEP_QUEUE, 64)
+                for t in range(S):
+                    b.step(a[t], 1, (o[t], r[t], d[t]))
+                assert b.queue_stats() == (0, 0, S)
+            b.join(); torch.cuda.current_stream().synchronize()
+            if form == "queue":
+                assert b.queue_stats() == (1, S, 0), "the queued v1-quat steps ran as one horizon launch"
+            return o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()
+    worst, zeros = _rollout_v1_vs_oracle(b, n, steps=8, nsub=1, seed=7, clip=clip, horizon=horizon)
+    print("v1-quat reward rollout (%s, %s): worst |diff| %.2e, steps without a reward evaluation %d" % (clip, form, worst, zeros))
     assert worst < 1e-9 and zeros == (n * 4 if clip == "walk" else 0)
+    if form != "one-env":
+        assert b.redo_total() == 0
     b.close()
     from deepmimic_mujoco_amd import DPVecEnv
-    env = DPVecEnv(8, motion=clip, device=0, reward="v1-quat", autoreset="rsi", seed=1)
+    env = DPVecEnv(8, motion=clip, device=0, reward="v1-quat", autoreset="rsi", seed=1, packed=(form != "one-env"), step_queue=(4 if form == "queue" else 0))
     env.reset("rsi")
     assert np.all(env.batch.get(A.F_FRAME_IDX) == 0)
     obs, rew, done, _ = env.step(np.zeros((8, 28)))

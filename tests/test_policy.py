@@ -355,6 +355,9 @@ def test_collector_kernel_choice_is_a_function_of_the_last_horizons_statistics()
         def enable_auto_packed(self, on):
             self._auto = bool(on)
 
+        def rebaseline_auto(self):
+            pass
+
         def redo_total(self):
             return self.redo
 
