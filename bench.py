@@ -545,7 +545,8 @@ def main():
                        autoreset="rsi", seed=0, contacts=full, limits=full,
                        action_mode="raw" if full else "p-control", env_offset=shard * n, frame_skip=1, dtype=args.dtype,
                        packed=(True if (args.horizon_launch or queue) else None) if args.packed is None else bool(args.packed))
-    default_packed = (n >= 6144 or not full) and args.dtype == 64          # what DPVecEnv(packed=None) starts on (dp_env.PACKED_FROM_ENVS)
+    from deepmimic_mujoco_amd.dp_env import PACKED_FROM_ENVS
+    default_packed = (n >= PACKED_FROM_ENVS or not full) and args.dtype == 64          # what DPVecEnv(packed=None) starts on
     step_kernel = ("k_rollout_packed" if ((args.horizon_launch or queue) and full and n <= 8192) else "k_step_packed") if env.packed else "k_step_narrow"
     stream = torch.cuda.Stream(device=dev)
     env.batch.set_stream(stream.cuda_stream)

@@ -246,7 +246,11 @@ class DPEnv(object):
         return self._get_obs()
 
 
-PACKED_FROM_ENVS = 6144       # DPVecEnv(packed=None): batches of at least this many environments step four per wavefront
+# DPVecEnv(packed=None): batches of at least this many environments step four per wavefront.  Measured closed loop (one launch set per call, two pipelined
+# sub-batches, BASELINE configs[2]; profiles/r06_ab_kernel_variants.md section 3, gpurun call a5), M env-steps/s one-env / packed kernel: 2 048 envs 7.49 / 7.33,
+# 3 072: 10.59 / 10.27, 4 096: 12.41 / 13.32, 6 144: 12.39 / 18.65 — the crossover sits between 3 072 and 4 096 since round 5's cuts of the packed step
+# (rounds 3-4: 12.3 / 11.4 at 4 096, hence the old threshold of 6 144).
+PACKED_FROM_ENVS = 4096
 
 
 class _Info(dict):

@@ -50,7 +50,7 @@ def test_full_shard_matches_oracle_every_env_every_step(clip, n, packed):
     b = Batch(H.compiled_model(), mc.data_config, mc.data_vel, n, device=0, mocap_dt=float(mc.dt), imitation=(T, P))
     b.set_option(A.OPT_REWARD_MODE, 3); b.set_option(A.OPT_AUTORESET, 1); b.set_option(A.OPT_SEED, SEED)
     b.set_option(A.OPT_ENV_OFFSET, off); b.set_option(A.OPT_DIAGNOSTICS, 1); b.set_option(A.OPT_PIPELINE, 2)
-    b.set_option(A.OPT_PACKED, 1 if packed else 0)   # 0: one environment per wavefront; 1: four (what DPVecEnv picks from 6 144 envs up);
+    b.set_option(A.OPT_PACKED, 1 if packed else 0)   # 0: one environment per wavefront; 1: four (what DPVecEnv picks from 4 096 envs up);
     horizon = packed == 2                            # 2: four, and all 16 steps in ONE launch (dm_batch_rollout: every wave at its own pace)
     if queue:
         b.set_option(A.OPT_STEP_QUEUE, max(64, STEPS))
