@@ -15,7 +15,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 #                        (+1.0 .. +1.6 % env-steps/s), register-class priority in the greedy allocator +0.4 %.
 #   dmenv.hip          — the one-env step kernels (two waves per SIMD at 256 registers: 2 % SLOWER under max-ilp), everything else, the C ABI: defaults.
 # Neither option touches floating-point semantics: results are bit-identical.
-PACKED_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-greedy-regclass-priority-trumps-globalness=1"]
+#                        -enable-ipra (round 6): inter-procedural register allocation — the horizon launch's called step bodies (internal functions, slot_step.h
+#                        DM_CALL_SLOT) are compiled without callee-saved registers: no 337-register save / restore per call, +3.7 % (profiles/r06_ab_kernel_variants.md §4).
+PACKED_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-enable-ipra"]
 UNITS = [("dmenv.hip", []), ("kernels_packed.hip", PACKED_FLAGS)]
 
 

@@ -369,6 +369,27 @@ DM_DEV bool slot_env_step(const DevModel<R>& M, const Batch<R>& B, SlotShared<R>
 // An environment that exceeds a capacity of the packed path in some step is re-stepped right here by the one-env code (env_step, all 64
 // lanes, from its unchanged state in memory) before the wave goes on: `one_s` / `one_x` may alias the slots' LDS (nothing in it outlives
 // a step; the observations the policy reads are fetched again from the rows just written).  NR = the one-env code's register tier.
+// The called step bodies without callee-saved registers (round 6).  Rounds 3-5 paid a save / restore of 337 registers per lane around every call (1.5 KB of
+// the 2.1 KB frame; 40 KB of HBM traffic per env-step, 17x the algorithmic bytes): the AMDGPU calling convention makes half the register file callee-saved and the step
+// uses all of it, while its caller keeps a handful of values across the call.  LLVM's inter-procedural register allocation (-mllvm -enable-ipra) compiles an INTERNAL,
+// non-recursive function without callee-saved registers and hands its callers the exact clobber set — unless one of its call sites is marked `tail`, which the
+// optimiser does to every call that passes no pointer into the caller's frame (round 4 concluded "does not fire on this backend" from exactly that).  So the callees
+// are `static` (wave.h DM_DEV_CALL64) and receive the address of a caller-local word, which they write: the call cannot be a tail call, the frame shrinks from
+// 1 536 to 192 bytes, and the horizon launch gains 3.7 % (20.43 against 19.69 M env-steps/s, driver window 17.25 against 16.25: profiles/r06_ab_kernel_variants.md
+// section 4, gpurun call a6; bit-identical results).
+#ifdef DM_STATIC_CALLS
+#define DM_CALL_SLOT_PARAM , int* call_slot
+#define DM_CALL_SLOT_TOUCH(v) (*call_slot = (v))
+#define DM_CALL_SLOT_ARG , &call_slot_mem
+#define DM_CALL_SLOT_DECL int call_slot_mem = 0; asm volatile("" :: "v"(&call_slot_mem) : "memory")
+#define DM_CALL_SLOT_USE asm volatile("" :: "v"(call_slot_mem))
+#else
+#define DM_CALL_SLOT_PARAM
+#define DM_CALL_SLOT_TOUCH(v) ((void)0)
+#define DM_CALL_SLOT_ARG
+#define DM_CALL_SLOT_DECL ((void)0)
+#define DM_CALL_SLOT_USE ((void)0)
+#endif
 template <class R> union SlotOrOne {
   SlotShared<R> sh[SLOTS];
   struct { Shared<R> s; StepScratch<R> x; } one;
@@ -376,7 +397,8 @@ template <class R> union SlotOrOne {
 // (a real call: the one-env step keeps its own register allocation and spill slots, the hot loop around it is compiled as if it were not there)
 template <class R, int NR>
 DM_DEV_CALL64 void restep_one_env(const DevModel<R>* M, const Batch<R>* B, Shared<R>* s, StepScratch<R>* x, int env, int lane, const double* action, double* obs,
-                                    double* reward, unsigned char* done, int n_substeps) {
+                                    double* reward, unsigned char* done, int n_substeps DM_CALL_SLOT_PARAM) {
+  DM_CALL_SLOT_TOUCH(0);
   using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global; using dmw::in_constant;
   const Batch<R> Bv = *in_constant(B);                  // (the struct's pointers are generic too: a copy whose members are told to be global)
   env_step<R, NR>(*in_constant(M), global_members(Bv), *in_lds(uniform_ptr(s)), *in_lds(uniform_ptr(x)), dmw::uniform(env), lane, in_global(uniform_ptr(action)),
@@ -389,10 +411,11 @@ DM_DEV_CALL64 void restep_one_env(const DevModel<R>* M, const Batch<R>* B, Share
 // slot_forward).  slot_rollout picks per wave-step.  Returns (stored ? 1 : 0) | row count of the slot's environment << 8.
 template <class R, int MAXR>
 DM_DEV_CALL64 int slot_env_step_call(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
-                                     const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int kin_carry) {
+                                     const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, int kin_carry DM_CALL_SLOT_PARAM) {
   using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global; using dmw::in_constant;
   const Batch<R> Bv = *in_constant(B);
   SlotShared<R>& sr = *in_lds(s);
+  DM_CALL_SLOT_TOUCH(env);
   const bool stored = slot_env_step<R, false, true, MAXR>(*in_constant(M), global_members(Bv), sr, *in_lds(uniform_ptr(tb)), env, sl, lane, live, in_global(uniform_ptr(action)),
                                                           in_global(uniform_ptr(obs)), in_global(uniform_ptr(reward)), in_global(uniform_ptr(done)), dmw::uniform(n_substeps), (int*)0, (int*)0,
                                                           (long long*)0, dmw::uniform(kin_carry) != 0);
@@ -401,7 +424,8 @@ DM_DEV_CALL64 int slot_env_step_call(const DevModel<R>* M, const Batch<R>* B, Sl
 #ifdef DM_ROLLOUT_PROF     // diagnostic build (tools/profile_horizon.py): the step with per-stage shader-clock stamps, one 32-counter record per call
 template <class R, int MAXR>
 DM_DEV_CALL64 int slot_env_step_call_prof(const DevModel<R>* M, const Batch<R>* B, SlotShared<R>* s, SlotTables* tb, int env, int sl, int lane, bool live,
-                                          const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, long long* prof_out, int kin_carry) {
+                                          const double* action, double* obs, double* reward, unsigned char* done, int n_substeps, long long* prof_out, int kin_carry DM_CALL_SLOT_PARAM) {
+  DM_CALL_SLOT_TOUCH(env);
   using dmw::uniform_ptr; using dmw::in_lds; using dmw::in_global; using dmw::in_constant;
   const Batch<R> Bv = *in_constant(B);
   SlotShared<R>& sr = *in_lds(s);
@@ -429,6 +453,7 @@ DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<
   int carry = 0;                              // the slots' LDS is what this wave's previous step left (no in-wave re-step overwrote it): slot_env_step kin_carry
   // rows the slot's environment held after its last step: decides which instantiation of the step this wave calls next (wave-uniform: the largest of the four)
   int last_rows = B.nefc[env];
+  DM_CALL_SLOT_DECL;
   for (int t = 0; t < T; t++) {
     // (every step reads the model afresh: hoisting those loads out of the loop would keep hundreds of registers alive across it)
     const DevModel<R>& M = *dmw::launder_uniform_ptr(&M_in);
@@ -443,16 +468,16 @@ DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<
     int ret;
 #ifdef DM_ROLLOUT_PROF
     if (prof_acc) {        // [0..31] sums over the horizon's steps, [32..63] the record of the step just taken
-      ret = heavy ? slot_env_step_call_prof<R, SLOT_MAXROWS>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, prof_acc + 32, carry)
-                  : slot_env_step_call_prof<R, 2 * SW>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, prof_acc + 32, carry);
+      ret = heavy ? slot_env_step_call_prof<R, SLOT_MAXROWS>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, prof_acc + 32, carry DM_CALL_SLOT_ARG)
+                  : slot_env_step_call_prof<R, 2 * SW>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, prof_acc + 32, carry DM_CALL_SLOT_ARG);
       if (lane == 0) { for (int k = 0; k < 31; k++) prof_acc[k] += prof_acc[32 + k]; if (heavy) prof_acc[28] += 1; }
     } else
 #endif
     // (measured, round 4: the step body inlined here instead of called — the batch descriptor and tables read afresh every step so that nothing is
     //  hoisted — removes the callee's register save / restore (1.6 KB per lane per call) and is 10 % SLOWER: 15.0 against 16.7 M env-steps/s,
     //  profiles/r04_ab_kernel_variants.md; the loop around the body costs the allocator more than the calls cost the memory system)
-    ret = heavy ? slot_env_step_call<R, SLOT_MAXROWS>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, carry)
-                : slot_env_step_call<R, 2 * SW>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, carry);
+    ret = heavy ? slot_env_step_call<R, SLOT_MAXROWS>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, carry DM_CALL_SLOT_ARG)
+                : slot_env_step_call<R, 2 * SW>(&M, &B, &sh[slot], &tb, env, sl, lane, live, a_t, o_t, r_t, d_t, n_substeps, carry DM_CALL_SLOT_ARG);
     const bool stored = (ret & 1) != 0;
     last_rows = (stored || !live) ? (ret >> 8) : SLOT_MAXROWS;       // (an environment that left the packed path: assume it is heavy)
     const int need = (live && !stored) ? 1 : 0;
@@ -462,7 +487,7 @@ DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<
       any = true;
       const int e = dmw::bcast_i(env, SW * k);
       dmw::sync_mem();
-      restep_one_env<R, NR>(&M, &B, &one_s, &one_x, e, lane, a_t, o_t, r_t, d_t, n_substeps);
+      restep_one_env<R, NR>(&M, &B, &one_s, &one_x, e, lane, a_t, o_t, r_t, d_t, n_substeps DM_CALL_SLOT_ARG);
       if (lane == 0) dmw::global_counter_next(B.redo_why);       // running total (dm_batch_redo_total)
       dmw::sync_mem();
     }
@@ -475,6 +500,7 @@ DM_DEV void slot_rollout(const DevModel<R>& M_in, const Batch<R>& B, SlotShared<
       }
       dmw::sync_mem();
     }
+    DM_CALL_SLOT_USE;
     policy(t);                                                   // (float64 build: its scratch stays inside the slots' r1 region and the kinematics survive it)
     carry = (any || policy_clobbers_kin) ? 0 : 1;
     dmw::sync_mem();                                             // state / action rows written by other lanes of this wave are read next step

@@ -17,7 +17,14 @@
 #define DM_DEV __device__ __forceinline__
 #define DM_DEV_NOINLINE __device__ __noinline__
 // a real call from a one-wave workgroup (the callee inherits its callers' register budget: the backend propagates the kernel's work-group size)
+// Internal linkage (round 6): with -mllvm -enable-ipra (csrc/build.py PACKED_FLAGS) an internal, non-recursive function none of whose call sites is a `tail` call is
+// compiled WITHOUT callee-saved registers — see DM_CALL_SLOT in slot_step.h.  -DDM_NO_STATIC_CALLS: rounds 3-5's external functions (A/B).
+#ifndef DM_NO_STATIC_CALLS
+#define DM_STATIC_CALLS 1
+#define DM_DEV_CALL64 static __device__ __noinline__
+#else
 #define DM_DEV_CALL64 __device__ __noinline__
+#endif
 #define DM_CONSTANT __device__ constexpr
 
 namespace dmw {
