@@ -18,6 +18,8 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 #                        -enable-ipra (round 6): inter-procedural register allocation — the horizon launch's called step bodies (internal functions, slot_step.h
 #                        DM_CALL_SLOT) are compiled without callee-saved registers: no 337-register save / restore per call, +3.7 % (profiles/r06_ab_kernel_variants.md §4).
 PACKED_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-enable-ipra"]
+if os.environ.get("DM_PACKED_FLAGS") is not None:      # experiments: replace the packed unit's backend options altogether (tools/build_variant.sh)
+    PACKED_FLAGS = os.environ["DM_PACKED_FLAGS"].split()
 UNITS = [("dmenv.hip", []), ("kernels_packed.hip", PACKED_FLAGS)]
 
 

@@ -1374,12 +1374,18 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
 #pragma unroll
     for (int k = 0; k < NF; k++) tsave[k] = 0;
     SlotSweep<0, NF, R>::run(AR, t, tsave, nf, oh, nm);
-    chg = 0; bad = false;
+    bad = false;
 #pragma unroll
     for (int k = 0; k < NF; k++) {
       const R delta = dmw::max_raw(nf[k], tsave[k]);
       const R change = (delta * diag[k]) * (R(0.5) * delta - tsave[k]);
-      nf[k] -= delta; chg += change; bad = bad || (change > pgs_detect);
+#ifdef DM_PGS_CHG_ZERO          // (A/B hook: rounds 3-5 started the sum from 0 — one dependent v_add_f64 per sweep at the head of the termination reduction)
+      if (k == 0) chg = 0;
+      chg += change;
+#else
+      chg = k == 0 ? change : chg + change;      // (0 + c == c bit for bit except for the sign of a zero, which no comparison downstream sees)
+#endif
+      nf[k] -= delta; bad = bad || (change > pgs_detect);
     }
     if constexpr (EXT) {
       // the surplus rows: residual formed from the forces as they stand after the 32 rows before them (a frozen environment: no step)

@@ -501,6 +501,38 @@ static int sphere_sphere(rawcon* con, const double* c1, double r1, const double*
   addscl3(con->pos, c1, con->frame, r1 + 0.5 * con->dist);
   return 1;
 }
+/* ---- diagnostics (round 6; no effect on any result): which CASE of the two own narrow-phase routines a call took --------------------------------------
+ * The contact LIST — (geom1, geom2) per contact, the quantity the parity bar wants bit-exact — of these two routines can differ from MuJoCo's
+ * mjc_BoxBox / mjc_CapsuleBox by construction; the tallies bound how often (tests/test_oracle_physics.py):
+ *   box-box      [0] separated (no contact: a separating axis beyond the margin — the same decision in any exact SAT)
+ *                [1] edge-edge: ONE contact here; MuJoCo's routine also reports one point for an edge-edge configuration            -> same count
+ *                [2] face axis, no clipped vertex within the margin: no contact                                                      -> same count
+ *                [3] face axis, 1 .. 4 clipped vertices within the margin, all kept (polygon order)                                  -> same count; the ORDER
+ *                    of the points inside the pair may differ (MuJoCo walks the incident face's vertices, then the reference face's), which does not change
+ *                    the (geom1, geom2) list
+ *                [4] face axis, 5 .. 8 clipped vertices within the margin, PRUNED to the 4 deepest here; MuJoCo's routine returns up to 8   -> COUNT DIFFERS
+ *   capsule-box  [5] rejected (slab test / closest point beyond radius + margin): no contact                                          -> same count
+ *                [6] one contact, NEITHER end of the axis segment within radius + margin of the box (the capsule touches with its side)
+ *                [7] one contact, ONE end within reach (an end pokes the box)
+ *                [8] one contact, BOTH ends within reach (the capsule lies along the box)
+ *                [9] one contact, the axis passes through the box's interior (zero-distance plateau; any of the above end counts)
+ *                    MuJoCo's routine adds a SECOND sphere-box contact at another point of the segment unless the capsule points at or away from the
+ *                    closest corner, whenever that second sphere is within the margin: it cannot in [6] with a short reach interval, it can in [7],
+ *                    it does in [8]                                                                                                   -> COUNT MAY DIFFER (1 here, 2 there)
+ * Enabled by dmo_narrow_cases(out, 1) (reset + on); off by default so that the timed cpu_baseline leg does not pay for the end tests. */
+static long long g_np_case[10];
+static int g_np_diag = 0;
+static void np_tally(int k) {
+  if (!g_np_diag) return;
+#pragma omp atomic
+  g_np_case[k]++;
+}
+/* out[10] <- the tallies; mode 1: reset and switch on, 0: switch off, -1: just read */
+void dmo_narrow_cases(long long* out, int mode) {
+  if (out) for (int k = 0; k < 10; k++) out[k] = g_np_case[k];
+  if (mode == 1) { for (int k = 0; k < 10; k++) g_np_case[k] = 0; g_np_diag = 1; }
+  if (mode == 0) g_np_diag = 0;
+}
 /* OWN ALGORITHM for box-box (MuJoCo's mjc_BoxBox, ~700 lines derived from ODE, is not restated): separating-axis test
  * over the 6 face normals and 9 edge cross products; the axis of least penetration decides between
  *   - face contact: the incident face of the other box is clipped (Sutherland-Hodgman) against the side planes of the
@@ -516,12 +548,12 @@ static int box_box(rawcon* con, const double* p1, const double* m1, const double
   double best = -1e300; int code = -1;
   for (int i = 0; i < 3; i++) {
     double sep = fabs(dot3(d, A[i])) - (s1[i] + s2[0] * aR[i][0] + s2[1] * aR[i][1] + s2[2] * aR[i][2]);
-    if (sep > margin) return 0;
+    if (sep > margin) { np_tally(0); return 0; }
     if (sep > best) { best = sep; code = i; }
   }
   for (int j = 0; j < 3; j++) {
     double sep = fabs(dot3(d, B[j])) - (s2[j] + s1[0] * aR[0][j] + s1[1] * aR[1][j] + s1[2] * aR[2][j]);
-    if (sep > margin) return 0;
+    if (sep > margin) { np_tally(0); return 0; }
     if (sep > best) { best = sep; code = 3 + j; }
   }
   double ebest = -1e300, en[3] = {0, 0, 0}; int ei = -1, ej = -1;
@@ -533,7 +565,7 @@ static int box_box(rawcon* con, const double* p1, const double* m1, const double
     double rA = s1[0] * fabs(dot3(A[0], L)) + s1[1] * fabs(dot3(A[1], L)) + s1[2] * fabs(dot3(A[2], L));
     double rB = s2[0] * fabs(dot3(B[0], L)) + s2[1] * fabs(dot3(B[1], L)) + s2[2] * fabs(dot3(B[2], L));
     double dl = dot3(d, L), sep = fabs(dl) - rA - rB;
-    if (sep > margin) return 0;
+    if (sep > margin) { np_tally(0); return 0; }
     if (sep > ebest) { ebest = sep; ei = i; ej = j; double sg = dl < 0 ? -1 : 1; en[0] = sg * L[0]; en[1] = sg * L[1]; en[2] = sg * L[2]; }
   }
   if (ei >= 0 && ebest > best + 1e-6) {
@@ -551,6 +583,7 @@ static int box_box(rawcon* con, const double* p1, const double* m1, const double
     con->dist = ebest;
     copy3(con->frame, en); zero3(con->frame + 3);
     for (int k = 0; k < 3; k++) con->pos[k] = 0.5 * (qa[k] + qb[k]);
+    np_tally(1);
     return 1;
   }
   /* face contact: reference box owns the axis */
@@ -585,6 +618,7 @@ static int box_box(rawcon* con, const double* p1, const double* m1, const double
   /* candidates within the margin of the reference face; keep the (up to) 4 deepest, in polygon order */
   double dist[8]; int keep[8], nk = 0;
   for (int a = 0; a < np; a++) { dist[a] = poly[cur][a][2] - sr[ax]; keep[a] = dist[a] < margin; nk += keep[a]; }
+  np_tally(nk == 0 ? 2 : nk <= 4 ? 3 : 4);
   while (nk > 4) { int worst = -1; for (int a = 0; a < np; a++) if (keep[a] && (worst < 0 || dist[a] > dist[worst])) worst = a; keep[worst] = 0; nk--; }
   int cnt = 0;
   for (int a = 0; a < np; a++) if (keep[a]) {
@@ -737,7 +771,16 @@ static int narrowphase(const dmo_model* m, const dmo_data* d, int g1, int g2, do
 #undef SEGBOX_G
     for (int k = 0; k < 3; k++) { center[k] = c0[k] + ts * u[k]; clamped[k] = clampd(center[k], -s2[k], s2[k]); t[k] = center[k] - clamped[k]; }
     double dist = norm3(t);
-    if (dist - s1[0] > margin) return 0;
+    if (dist - s1[0] > margin) { np_tally(5); return 0; }
+    if (g_np_diag) {   /* (diagnostics only) how many ends of the axis segment lie within radius + margin of the box */
+      int ends_in = 0;
+      for (int sg = -1; sg <= 1; sg += 2) {
+        double e2 = 0;
+        for (int k = 0; k < 3; k++) { double pk = c0[k] + sg * L * u[k], dk = pk - clampd(pk, -s2[k], s2[k]); e2 += dk * dk; }
+        if (sqrt(e2) - s1[0] <= margin) ends_in++;
+      }
+      np_tally(dist <= MINVAL ? 9 : 6 + ends_in);
+    }
     if (dist <= MINVAL) {
       double closest = 2 * fmax(s2[0], fmax(s2[1], s2[2])); int kk = 0;
       for (int i = 0; i < 6; i++) { double fd = fabs((i % 2 ? 1 : -1) * s2[i / 2] - center[i / 2]); if (closest > fd) { closest = fd; kk = i; } }

@@ -167,6 +167,10 @@ int dmo_model_set(dmo_model* m, const char* field, double v);
 int dmo_data_get(const dmo_model* m, const dmo_data* d, const char* field, double* out, int max);
 int dmo_data_set(const dmo_model* m, dmo_data* d, const char* field, const double* in, int n);
 
+/* diagnostics: tallies of the narrow-phase cases of the two own routines (box-box [0..4], capsule-box [5..9]; see dm_oracle.c);
+ * mode 1: reset + switch on, 0: switch off, -1: read only.  No effect on any result. */
+void dmo_narrow_cases(long long* out, int mode);
+
 int dmo_sizeof_model(void);
 int dmo_sizeof_data(void);
 

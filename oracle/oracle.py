@@ -91,6 +91,7 @@ def lib():
         L.dmo_bench_rollout.restype = C.c_long
         L.dmo_bench_rollout.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, C.c_double, C.c_ulonglong,
                                         C.c_int, C.POINTER(C.c_long), dp]
+        L.dmo_narrow_cases.argtypes = [C.POINTER(C.c_longlong), C.c_int]
         _LIB = L
     return _LIB
 
@@ -251,6 +252,18 @@ def bench_rollout(model, datas, steps, data_config, data_vel, table=None, params
     tot = lib().dmo_bench_rollout(model.h, arr, n, int(steps), _dp(cfg), _dp(vel), cfg.shape[0], None if tb is None else _dp(tb),
                                   None if p is None else _dp(p), float(sigma), int(seed), int(nthreads), C.byref(nd), _dp(rs))
     return int(tot), int(nd.value), float(rs[0])
+
+
+NARROW_CASES = ("box-box: separated", "box-box: edge-edge, 1 contact", "box-box: face axis, 0 within margin", "box-box: face, 1..4 kept",
+                "box-box: face, 5..8 within margin PRUNED to 4", "capsule-box: rejected", "capsule-box: 1 contact, no end within reach",
+                "capsule-box: 1 contact, one end within reach", "capsule-box: 1 contact, both ends within reach", "capsule-box: 1 contact, axis through the interior")
+
+
+def narrow_cases(mode=-1):
+    """Tallies of the narrow-phase cases of the oracle's two own routines (dm_oracle.c): mode 1 = reset + on, 0 = off, -1 = read."""
+    out = (C.c_longlong * 10)()
+    lib().dmo_narrow_cases(out, int(mode))
+    return np.array(list(out), dtype=np.int64)
 
 
 def v1_reward(model, f0, f1, f1v, params):

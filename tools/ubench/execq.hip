@@ -31,6 +31,20 @@ __global__ void __launch_bounds__(64) k(double* out, long long* cyc, unsigned lo
       asm volatile("v_max_f64 %2, %3, %0\n\tv_fma_f64 %1, %4, %0, %1\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %2, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
                    "v_max_f64 %2, %3, %0\n\tv_fma_f64 %1, %4, %0, %1\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %2, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf"
                    : "+v"(a0), "+v"(a1), "=&v"(a2) : "v"(a3), "v"(c), "v"(c));
+    } else if constexpr (KIND == 4) { // row variant: v_max ; v_fma(ts) ; v_mov_b64_dpp ; plain v_fma     (x 2)
+      asm volatile("v_max_f64 %2, %3, %0\n\tv_fma_f64 %1, %4, %0, %1\n\ts_nop 0\n\tv_mov_b64_dpp %6, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %0, %6, %5, %0\n\t"
+                   "v_max_f64 %2, %3, %0\n\tv_fma_f64 %1, %4, %0, %1\n\ts_nop 0\n\tv_mov_b64_dpp %6, %2 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %0, %6, %5, %0"
+                   : "+v"(a0), "+v"(a1), "=&v"(a2) : "v"(a3), "v"(c), "v"(c), "v"(a4));
+    } else if constexpr (KIND == 6) { // current row without the tsave multiply-add (s_nop 1 in its place)
+      asm volatile("v_max_f64 %2, %3, %0\n\ts_nop 1\n\tv_fmac_f64_dpp %0, %2, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_max_f64 %2, %3, %0\n\ts_nop 1\n\tv_fmac_f64_dpp %0, %2, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+                   : "+v"(a0), "+v"(a1), "=&v"(a2) : "v"(a3), "v"(c), "v"(c));
+    } else if constexpr (KIND == 7) { // dependent pair without DPP: v_max ; v_fma (what two dependent f64 operations cost)
+      asm volatile("v_max_f64 %2, %3, %0\n\tv_fma_f64 %0, %2, %5, %0\n\tv_max_f64 %2, %3, %0\n\tv_fma_f64 %0, %2, %5, %0"
+                   : "+v"(a0), "+v"(a1), "=&v"(a2) : "v"(a3), "v"(c), "v"(c));
+    } else if constexpr (KIND == 8) { // dependent chain of v_fmac_f64_dpp alone (acc += bcast(acc) * a: DPP source = the accumulator just written) with its 2 wait states
+      asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+                   : "+v"(a0), "+v"(a1), "=&v"(a2) : "v"(a3), "v"(c), "v"(c));
     } else {                          // 8 independent v_add_f32
       asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\t"
                    "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2" : "+v"(f0), "+v"(f1) : "v"(1.0f));
@@ -51,7 +65,7 @@ template <int KIND> double run(unsigned long long mask, int blocks) {
   hipMemcpy(h.data(), cyc, blocks * sizeof(long long), hipMemcpyDeviceToHost);
   double s = 0; for (auto v : h) s += (double)v;
   hipFree(out); hipFree(cyc);
-  const int per = KIND == 2 ? 2 : 8;        // instructions (KIND 2: rows) per repetition
+  const int per = (KIND == 2 || KIND >= 4) ? 2 : 8;        // instructions (KIND 2: rows) per repetition
   return s / blocks / REPS / per;
 }
 
@@ -66,5 +80,12 @@ int main() {
     for (int q = 0; q < 4; q++) v[q] = kd == 0 ? run<0>(masks[q], 256) : kd == 1 ? run<1>(masks[q], 256) : kd == 2 ? run<2>(masks[q], 256) : run<3>(masks[q], 256);
     printf("| %s | %.4f | %.4f (%.2f) | %.4f (%.2f) | %.4f (%.2f) |\n", names[kd], v[0], v[1], v[1] / v[0], v[2], v[2] / v[0], v[3], v[3] / v[0]);
   }
+  // round 6: what bounds a PGS row — alternatives for the (max -> broadcast -> multiply-add) chain, full EXEC, ticks per ROW
+  printf("\nrow-chain alternatives (full EXEC), ticks per row:\n");
+  printf("  current block (v_max, v_fma ts, s_nop 0, v_fmac_f64_dpp)          %.2f\n", run<2>(masks[0], 256));
+  printf("  v_max, v_fma ts, s_nop 0, v_mov_b64_dpp, v_fma                    %.2f\n", run<4>(masks[0], 256));
+  printf("  v_max, s_nop 1, v_fmac_f64_dpp (no tsave multiply-add)            %.2f\n", run<6>(masks[0], 256));
+  printf("  v_max, v_fma without any DPP (two dependent f64 operations)       %.2f\n", run<7>(masks[0], 256));
+  printf("  s_nop 1, v_fmac_f64_dpp on its own result (one op + hazard)       %.2f\n", run<8>(masks[0], 256));
   return 0;
 }
