@@ -29,6 +29,7 @@ constexpr int SLOT_MAXROWS = DM_SLOT_MAXROWS, SLOT_MAXLIMROWS = 16, SLOT_MAXCON 
 constexpr int SLOT_EXTROWS = SLOT_MAXROWS - 2 * SW;
 static_assert(SLOT_EXTROWS == 8 || SLOT_EXTROWS == 0, "the partial third row set holds eight rows (or is absent)");     // rows 32 .. 39: the partial third row set of slot_constraint<3> (owned by the even lanes)
 constexpr int PAIR_PASSES = MAXPAIR / SW;
+static_assert(MAXPAIR <= 128 && NG <= 16, "a candidate word holds the pair number in 7 bits and both geom numbers in 4 bits each");
 constexpr int DOF_PASSES = (NV + SW - 1) / SW, HINGE_PASSES = (NU + SW - 1) / SW, Q_PASSES = (NQ + SW - 1) / SW, ENT_PASSES = (310 + SW - 1) / SW;
 
 // per-slot LDS working set.  r1 / r2 are reused along one forward evaluation:
@@ -711,6 +712,60 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
     pk[p] = M.pair_rec[pr].g1 | (M.pair_rec[pr].g2 << 8) | ((M.pair_rec[pr].t1t2 & 0xff) << 16);
     pbound[p] = M.pair_rec[pr].bound;
   }
+#ifndef DM_ROWS_PRELOAD
+#define DM_ROWS_PRELOAD 5          // (bit 1 measured -1.1 %: profiles/r06_ab_kernel_variants.md section 7) bit 0: geom + limit constants up front; bit 1: the plane pairs' body + local normal up front; bit 2: geom numbers in the candidate word
+#endif
+#if DM_ROWS_PRELOAD & 1
+  // (round 6) every model constant of this section — the lane's geom (body, local position) and its two hinges' limit flags and bounds — is requested HERE, beside the
+  // pair records, unconditionally: the section used to fetch them one after the other behind lane predicates (flag -> lower bound -> upper bound, per hinge pass:
+  // eight exposed L2 round trips per evaluation on a wave that has nothing else to run).  Same arithmetic on the same operands: bit-identical rows.
+  int gb0 = 0; R gp0[3] = {0, 0, 0};
+  if (M.enable_contact) { gb0 = M.geom_body[sl]; gp0[0] = M.geom_pos[sl][0]; gp0[1] = M.geom_pos[sl][1]; gp0[2] = M.geom_pos[sl][2]; }
+  int jl[HINGE_PASSES]; R jlo[HINGE_PASSES], jhi[HINGE_PASSES];
+#pragma unroll
+  for (int c = 0; c < HINGE_PASSES; c++) {
+    const int h = sl + SW * c, hh = h < NU ? h + 1 : 1;
+    jl[c] = M.enable_limit ? (int)M.jnt_limited[hh] : 0; jlo[c] = M.enable_limit ? M.jnt_lo[hh] : R(0); jhi[c] = M.enable_limit ? M.jnt_hi[hh] : R(0);
+  }
+  dmw::sched_fence();
+  // ... and behind them (they need the pair records' geom numbers: a second round trip, hidden behind this section's arithmetic) what a PLANE pair's broad-phase
+  // test reads: the body and the local normal of geom 1 — for every pass, whatever the pair's type (the loads are cheaper than a branch around them; the broad
+  // phase used to fetch body -> normal inside the divergent plane branch of each pass: two exposed round trips per pass that holds plane pairs)
+  int pbody[PAIR_PASSES]; R pnl[PAIR_PASSES][3];
+#pragma unroll
+  for (int p = 0; p < ((DM_ROWS_PRELOAD & 2) ? PAIR_PASSES : 0); p++) {
+    const int g1 = pk[p] & 0xff;
+    pbody[p] = M.enable_contact ? (int)M.geom_body[g1] : 0;
+    pnl[p][0] = M.enable_contact ? M.geom_mat[g1][2] : R(0); pnl[p][1] = M.enable_contact ? M.geom_mat[g1][5] : R(0); pnl[p][2] = M.enable_contact ? M.geom_mat[g1][8] : R(0);
+  }
+  if (M.enable_contact) {
+    const int g = sl;                                        // NG == SW: one geom per lane
+    R v[3];
+    mat_vec(v, s.xmat[gb0], gp0);
+    W.gpos[g][0] = s.xpos[gb0][0] + v[0]; W.gpos[g][1] = s.xpos[gb0][1] + v[1]; W.gpos[g][2] = s.xpos[gb0][2] + v[2];
+  }
+  // ---- joint limits: hinge h = sl + 16 c, dof h + 6
+  if (M.enable_limit) {
+#pragma unroll
+    for (int c = 0; c < HINGE_PASSES; c++) {
+      const int h = sl + SW * c;
+      const bool lim = h < NU && jl[c] != 0;
+      const R q = s.qpos[(h < NU ? h : 0) + 7];
+      const R dlo = q - jlo[c], dhi = jhi[c] - q;
+      const bool vlo = lim && dlo < 0, vhi = lim && !vlo && dhi < 0;
+      const bool viol = vlo || vhi;
+      const R dist = vlo ? dlo : (vhi ? dhi : R(0));
+      const int pos_sign = vlo ? 1 : 0;
+      const unsigned mask = dmw::row_ballot(viol, lane);
+      if (viol) {
+        const int r = nrow + __builtin_popcount(mask & below);
+        if (r < SLOT_MAXLIMROWS) { W.rowi[r] = ROW_LIMIT | ((h + 6) << 8) | (pos_sign << 16); W.rowv[r] = dist; }
+      }
+      nrow += __builtin_popcount(mask);
+    }
+    if (nrow > SLOT_MAXLIMROWS) ovf |= 8;
+  }
+#else
   if (M.enable_contact) {
     const int g = sl, gb = M.geom_body[g];                   // NG == SW: one geom per lane
     R v[3];
@@ -739,6 +794,7 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
     }
     if (nrow > SLOT_MAXLIMROWS) ovf |= 8;
   }
+#endif
   dmw::sync();
   SLOT_RSTAMP(19)
   int ncon = 0, nfr = 0;
@@ -755,14 +811,21 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
           const R d[3] = {W.gpos[g2][0] - W.gpos[g1][0], W.gpos[g2][1] - W.gpos[g1][1], W.gpos[g2][2] - W.gpos[g1][2]};
           if (t1 == GEOM_PLANE) {
             // plane normal = third column of its world orientation  xmat[body] * geom_mat
+#if (DM_ROWS_PRELOAD & 3) == 3
+            const R* a = s.xmat[pbody[p]];
+            const R b2 = pnl[p][0], b5 = pnl[p][1], b8 = pnl[p][2];
+#else
             const int gb = M.geom_body[g1];
             const R* a = s.xmat[gb]; const R* bm = M.geom_mat[g1];
-            const R nx = a[0] * bm[2] + a[1] * bm[5] + a[2] * bm[8], ny = a[3] * bm[2] + a[4] * bm[5] + a[5] * bm[8], nz = a[6] * bm[2] + a[7] * bm[5] + a[8] * bm[8];
+            const R b2 = bm[2], b5 = bm[5], b8 = bm[8];
+#endif
+            const R nx = a[0] * b2 + a[1] * b5 + a[2] * b8, ny = a[3] * b2 + a[4] * b5 + a[5] * b8, nz = a[6] * b2 + a[7] * b5 + a[8] * b8;
             cand = d[0] * nx + d[1] * ny + d[2] * nz <= pbound[p];
           } else cand = dot3(d, d) <= pbound[p] * pbound[p];
         }
         const unsigned mask = dmw::row_ballot(cand, lane);
-        if (cand) { const int k = ncand + __builtin_popcount(mask & below); if (k < SLOT_MAXCAND) W.cand[k] = (unsigned short)pidx; }
+        // candidate word: pair number | geom 1 << 7 | geom 2 << 11 (round 6: the narrow phase asks for the pair record AND both geoms' local frames in one go)
+        if (cand) { const int k = ncand + __builtin_popcount(mask & below); if (k < SLOT_MAXCAND) W.cand[k] = (unsigned short)((DM_ROWS_PRELOAD & 4) ? (pidx | (g1 << 7) | (g2 << 11)) : pidx); }
         ncand += __builtin_popcount(mask);
       }
     }
@@ -775,9 +838,14 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
       // ---- narrow phase: candidate k of the environment on lane k % 16
       const int kc = trip * SW + sl;
       const bool has = kc < ncand;
-      const int pidx = has ? W.cand[kc] : 0;
+      const int cw = has ? (int)W.cand[kc] : 0;
+      const int pidx = cw & 127;
       const auto& rec = M.pair_rec[pidx];
-      const int g1 = rec.g1, g2 = rec.g2, tt = rec.t1t2, meta = rec.meta;
+      const int g1 = (DM_ROWS_PRELOAD & 4) ? (cw >> 7) & 15 : rec.g1, g2 = (DM_ROWS_PRELOAD & 4) ? (cw >> 11) & 15 : rec.g2;          // (= rec.g1, rec.g2: known before the record arrives)
+      const int tt = rec.t1t2, meta = rec.meta;
+      R bm1[9], bm2[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) { bm1[k] = M.geom_mat[g1][k]; bm2[k] = M.geom_mat[g2][k]; }
       const R margin = rec.margin;
       const R z1[3] = {rec.s1[0], rec.s1[1], rec.s1[2]}, z2[3] = {rec.s2[0], rec.s2[1], rec.s2[2]};
       const int t1 = tt & 0xff, t2 = (tt >> 8) & 0xff, dim = (tt >> 16) & 0xff;
@@ -786,9 +854,9 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
       if (has) {
         R p1[3], p2[3], m1[9], m2[9];
         {
-          const R* a = s.xmat[meta & 0xff]; const R* bm = M.geom_mat[g1];
+          const R* a = s.xmat[meta & 0xff]; const R* bm = bm1;
           for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) m1[3 * i + jx] = a[3 * i] * bm[jx] + a[3 * i + 1] * bm[3 + jx] + a[3 * i + 2] * bm[6 + jx];
-          const R* c = s.xmat[(meta >> 8) & 0xff]; const R* dm2 = M.geom_mat[g2];
+          const R* c = s.xmat[(meta >> 8) & 0xff]; const R* dm2 = bm2;
           for (int i = 0; i < 3; i++) for (int jx = 0; jx < 3; jx++) m2[3 * i + jx] = c[3 * i] * dm2[jx] + c[3 * i + 1] * dm2[3 + jx] + c[3 * i + 2] * dm2[6 + jx];
           for (int k = 0; k < 3; k++) { p1[k] = W.gpos[g1][k]; p2[k] = W.gpos[g2][k]; }
         }
@@ -1493,6 +1561,45 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
 #undef SLOT_STAMP
 }
 
+// ---- stages as internal functions (round 6 experiment, DM_STAGE_CALLS bit mask: 1 the constraint stage, 2 the collision stage) ------------------------------
+// With inter-procedural register allocation a call costs no register save / restore (slot_step.h DM_CALL_SLOT): a stage compiled as a function of its own gets a
+// register assignment that the 30 000 other instructions of the step cannot perturb (round 5: "the kernel's speed is a property of its register ASSIGNMENT").
+// The pointer to the caller's `ovf` is the frame pointer that keeps the call from being a tail call.
+#ifndef DM_STAGE_CALLS
+#define DM_STAGE_CALLS 2
+#endif
+#if !defined(DM_WAVE_TESTBENCH)
+template <class R, int NS>
+static __device__ __noinline__ void slot_constraint_call(const DevModel<R>* M, SlotShared<R>* s, int sl, int lane, int nefc, int nmax, int* ovf) {
+  int o = *ovf;
+  slot_constraint<R, NS, false>(*dmw::in_constant(M), *dmw::in_lds(s), sl, lane, nefc, dmw::uniform(nmax), o, (const DebugOut*)0, (long long*)0);
+  *ovf = o;
+}
+template <class R>
+static __device__ __noinline__ void slot_mass_call(const DevModel<R>* M, SlotShared<R>* s, const SlotTables* tb, int sl, LaneTopo lt, int* frame_word) {
+  *frame_word = sl;
+  slot_mass_matrix<R, false>(*dmw::in_constant(M), *dmw::in_lds(s), *dmw::in_lds(tb), sl, lt, (const DebugOut*)0, (long long*)0);
+}
+template <class R>
+static __device__ __noinline__ void slot_bias_call(const DevModel<R>* M, SlotShared<R>* s, const SlotTables* tb, int sl, LaneTopo lt, int* frame_word) {
+  *frame_word = sl;
+  slot_bias(*dmw::in_constant(M), *dmw::in_lds(s), *dmw::in_lds(tb), sl, lt);
+}
+template <class R>
+static __device__ __noinline__ void slot_kinematics_call(const DevModel<R>* M, SlotShared<R>* s, int sl, LaneTopo lt, R* xip) {
+  R x[3];
+  slot_kinematics(*dmw::in_constant(M), *dmw::in_lds(s), sl, lt, x);
+  xip[0] = x[0]; xip[1] = x[1]; xip[2] = x[2];
+}
+template <class R, int MAXR>
+static __device__ __noinline__ int slot_rows_call(const DevModel<R>* M, SlotShared<R>* s, int sl, int lane, int* ovf) {
+  int o = *ovf;
+  const int n = slot_rows<R, false, MAXR>(*dmw::in_constant(M), *dmw::in_lds(s), sl, lane, o, (long long*)0);
+  *ovf = o;
+  return n;
+}
+#endif
+
 // ---- no rows anywhere in the wave: qacc = L^-1 D^-1/2 (D^-1/2 L^-T tau), the constrained formula with an empty sum (so that an
 // environment's result does not depend on whether a partner has rows).  Every lane of the slot carries the whole vector. -----------
 template <class R>
@@ -1532,20 +1639,37 @@ DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTable
     dmw::sync();
     if (sl == 0) s.kin_ok() = R(0);              // one use: the next evaluation starts from another state
   }
+#if !defined(DM_WAVE_TESTBENCH)
+  if ((DM_STAGE_CALLS & 16) && !PROF) { if (!skip_kin) slot_kinematics_call<R>(&M, &s, sl, lt, xip); }
+  else
+#endif
   if (!skip_kin) slot_kinematics(M, s, sl, lt, xip);
   SLOT_FSTAMP(0)
   if (dbg) { for (int e = sl; e < NV * NV; e += SW) dbg->out[e] = 0; dmw::sync(); }
   DM_MARK("slot_bias");
+#if !defined(DM_WAVE_TESTBENCH)
+  int frame_word = 0;
+  if ((DM_STAGE_CALLS & 8) && !PROF) slot_bias_call<R>(&M, &s, &tb, sl, lt, &frame_word);
+  else
+#endif
   slot_bias(M, s, tb, sl, lt);
   SLOT_FSTAMP(1)
   if (dbg) {
     for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) dbg->out[34 * 34 + d] = (double)(-M.dof_damping[d] * s.qvel[d] + s.act[d] - s.tau[d]); }
   }
   DM_MARK("slot_mass_factor");
+#if !defined(DM_WAVE_TESTBENCH)
+  if ((DM_STAGE_CALLS & 4) && !PROF && !dbg) { slot_mass_call<R>(&M, &s, &tb, sl, lt, &frame_word); asm volatile("" :: "v"(frame_word)); }
+  else
+#endif
   slot_mass_matrix<R, PROF>(M, s, tb, sl, lt, dbg, prof);
   SLOT_FSTAMP(2)
   DM_MARK("slot_rows");
   int nefc = 0;
+#if !defined(DM_WAVE_TESTBENCH)
+  if ((DM_STAGE_CALLS & 2) && !PROF && (M.enable_contact || M.enable_limit)) nefc = slot_rows_call<R, MAXR>(&M, &s, sl, lane, &ovf);
+  else
+#endif
   if (M.enable_contact || M.enable_limit) nefc = slot_rows<R, PROF, MAXR>(M, s, sl, lane, ovf, prof);
   else { if (sl == 0) { s.nefc = 0; s.ncon = 0; } dmw::sync(); }
   SLOT_FSTAMP(3)
@@ -1554,6 +1678,10 @@ DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTable
   if (nmax == 0) slot_smooth_solve(s, sl, dbg);
 #ifdef DM_FORCE_EXT      // test hook (testbench builds only): every constrained evaluation through the three-set code — results must not change
   else if (nmax > 0 && MAXR > 2 * SW) slot_constraint<R, MAXR > 2 * SW ? 3 : 2, PROF>(M, s, sl, lane, nefc, nmax > 2 * SW ? nmax : 2 * SW + 1, ovf, dbg, prof);
+#endif
+#if !defined(DM_WAVE_TESTBENCH)
+  else if ((DM_STAGE_CALLS & 1) && !PROF && !dbg && nmax <= 16) slot_constraint_call<R, 1>(&M, &s, sl, lane, nefc, nmax, &ovf);
+  else if ((DM_STAGE_CALLS & 1) && !PROF && !dbg && nmax <= 2 * SW) slot_constraint_call<R, 2>(&M, &s, sl, lane, nefc, nmax, &ovf);
 #endif
   else if (nmax <= 16) slot_constraint<R, 1, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof);
   else if (nmax <= 2 * SW) { slot_constraint<R, 2, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof); if (PROF) prof[7] += 1; }
