@@ -73,7 +73,7 @@ struct alignas(16) SlotShared {
       unsigned short cand[SLOT_MAXCAND];                        // candidate pair numbers past the broad phase, in pair-list order (16 bits each: the eight more
                                                                 //  row codes of round 5 must not move anything behind them — see the layout note below)
       int coni[SLOT_MAXCON + 1];                                // pair number | frame << 8 of a staged contact
-#if DM_SLOT_MAXROWS == 40 && !defined(DM_NO_LAYOUT_PAD)
+#if DM_SLOT_MAXROWS == 40
       char keep_r4_layout_[32];
 #endif
     } rw;
@@ -86,16 +86,13 @@ struct alignas(16) SlotShared {
   // horizon launches: qpos[35] — the spare element behind the 35 coordinates — is the slot's `kin_ok` flag: nonzero = the kinematics in this block
   // are those of the env's current state (slot_step.h kin_carry).  (A field of its own changes the slots' stride: measured 1.5 % slower.)
   DM_DEV R& kin_ok() { return qpos[NQ]; }
-#ifdef DM_SLOT_PAD          // experiment: the slots' stride modulo the LDS bank period (profiles/r04_ab_kernel_variants.md)
-  char pad_[DM_SLOT_PAD];
-#endif
 };
 static_assert(NQ == 35, "qpos[36] has one spare element");
 static_assert(sizeof(SlotShared<double>) % 16 == 0 && sizeof(SlotShared<float>) % 16 == 0, "slot stride: a multiple of 16 bytes");
 // Layout note (round 5, gpurun calls h2-h5): the float64 slot is kept at round 4's 9 696 bytes with `r2` at its old offset.  Growing `rowi` from 32 to 40
 // codes in place (r2 and the tail 32 B further back, stride 9 720 or 9 728) made EVERY workload 8 % slower — 16.5 against 18.2 M env-steps/s on the judged
 // line, with or without the three-set code compiled in — while the same code on the old offsets is 1.7 % faster than round 4.
-#if DM_SLOT_MAXROWS == 40 && !defined(DM_NO_LAYOUT_PAD) && !defined(DM_SLOT_PAD)
+#if DM_SLOT_MAXROWS == 40
 static_assert(sizeof(SlotShared<double>) == 9696, "the float64 slot layout is a measured quantity: see the layout note");
 #endif
 static_assert(offsetof(SlotShared<double>, cdof) == offsetof(SlotShared<double>, qd) + sizeof(((SlotShared<double>*)0)->qd) &&
@@ -103,47 +100,29 @@ static_assert(offsetof(SlotShared<double>, cdof) == offsetof(SlotShared<double>,
               sizeof(((SlotShared<double>*)0)->qd) + sizeof(((SlotShared<double>*)0)->cdof) >= sizeof(double) * NV * (SLOT_MAXROWS - 2 * SW),
               "slot_constraint<3> parks the surplus rows' half-solved vectors in the adjacent qd + cdof regions");
 // index tables shared by the four slots of a workgroup (compile-time topology; see LaneTables)
-// DM_LDS_TOPO 1: TOPO.dof_body / TOPO.madr of a lane's dofs come from the wave's LDS tables (104 B) instead of constant memory — in the bias, mass-matrix and
+// TOPO.dof_body / TOPO.madr of a lane's dofs come from the wave's LDS tables (104 B) instead of constant memory — in the bias, mass-matrix and
 // D stages they were the first link of a dependent chain, an L2 round trip each on a lone wave (the L1 is flushed by the callee-saved registers' scratch traffic):
 // +0.8 % on the horizon launch (gpurun call g6).  The same two tables as bit fields of a lane register: -3 % (profiles/r05_ab_kernel_variants.md section 6).
-#ifndef DM_LDS_TOPO
-#define DM_LDS_TOPO 1
-#endif
-#ifndef DM_ENTRY_SELECT
-#define DM_ENTRY_SELECT 1
-#endif
 #ifndef DM_ENTRY_GROUP
 #define DM_ENTRY_GROUP 5
-#endif
-#ifndef DM_BIAS_BATCH
-#define DM_BIAS_BATCH 1
 #endif
 constexpr bool root_alone_at_depth_one() { for (int b = 2; b < NB; b++) if (TOPO.body_depth[b] <= 1) return false; return TOPO.body_depth[1] == 1; }
 static_assert(root_alone_at_depth_one(), "slot_bias does the root body (the only one at depth 1) ahead of the level loop");
 struct SlotTables {
   unsigned short tab_dst[NV][14];
   unsigned short tab_ent[312];
-#if DM_LDS_TOPO
   unsigned short madr[NV];
   unsigned char dof_body[NV + 2];
-#endif
 };
 static_assert(sizeof(SlotShared<double>) * SLOTS + sizeof(SlotTables) <= 40 * 1024, "four waves (four environments and the tables each) must fit a CU's 160 KB of LDS");
-#if DM_LDS_TOPO
 #define DM_DOF_BODY(tb, d) ((int)(tb).dof_body[d])
 #define DM_DOF_MADR(tb, d) ((int)(tb).madr[d])
-#else
-#define DM_DOF_BODY(tb, d) (TOPO.dof_body[d])
-#define DM_DOF_MADR(tb, d) (TOPO.madr[d])
-#endif
 DM_DEV void stage_slot_tables(SlotTables& t, int lane) {
 #pragma unroll
   for (int c = 0; c < (312 + 63) / 64; c++) { const int e = lane + 64 * c; if (e < 312) t.tab_ent[e] = LTAB.tab_ent[e]; }
 #pragma unroll
   for (int c = 0; c < (NV * 14 + 63) / 64; c++) { const int i = lane + 64 * c; if (i < NV * 14) (&t.tab_dst[0][0])[i] = LTAB.tab_dst[i]; }
-#if DM_LDS_TOPO
   if (lane < NV) { t.madr[lane] = (unsigned short)TOPO.madr[lane]; t.dof_body[lane] = (unsigned char)TOPO.dof_body[lane]; }
-#endif
 }
 
 // ---- subtree sums: out[b][k] = sum over the bodies c of b's subtree of in[c][k], component k = slot lane, one body per pass,
@@ -298,7 +277,6 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& 
     s.r1.v.cacc[0][3] = -M.gravity[0]; s.r1.v.cacc[0][4] = -M.gravity[1]; s.r1.v.cacc[0][5] = -M.gravity[2];
   }
   R S[6] = {0, 0, 0, 0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
-#if DM_BIAS_BATCH
   // A lone wave waits out every LDS round trip it takes: operands are requested together, a scheduling fence keeps the arithmetic behind them.  The root body
   // (the only one at depth 1, a static property of the tree) needs nothing but the world's constants: it is done here, beside the other bodies' joint
   // velocities, and the level loop starts at depth 2 — one level and one hand-off less, same arithmetic.
@@ -354,42 +332,6 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& 
     }
     dmw::sync();
   }
-#else
-  if (isbody && b > 1) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) if (k < nd) {
-      const R qd = s.qvel[da + k];
-      R T[6], cd[6];
-      for (int r = 0; r < 6; r++) T[r] = s.cdof[da + k][r] * qd;
-      if (k > 0) { cross_motion(cd, S, T); for (int r = 0; r < 6; r++) C[r] += cd[r]; }
-      for (int r = 0; r < 6; r++) S[r] += T[r];
-    }
-  }
-  dmw::sync();
-#pragma unroll
-  for (int L = 1; L <= MAXDEPTH_BODY; L++) {
-    if (isbody && depth == L) {
-      R v[6], a[6];
-      for (int r = 0; r < 6; r++) { v[r] = s.r1.v.cvel[p][r]; a[r] = s.r1.v.cacc[p][r]; }
-      if (b == 1) {
-        for (int k = 0; k < 3; k++) { const R qd = s.qvel[k]; for (int r = 0; r < 6; r++) v[r] += s.cdof[k][r] * qd; }
-        R vb[6];
-        for (int r = 0; r < 6; r++) vb[r] = v[r];
-        for (int k = 3; k < 6; k++) {
-          R cd[6]; cross_motion(cd, vb, s.cdof[k]);
-          const R qd = s.qvel[k];
-          for (int r = 0; r < 6; r++) { a[r] += cd[r] * qd; v[r] += s.cdof[k][r] * qd; }
-        }
-      } else {
-        R cd[6];
-        cross_motion(cd, v, S);
-        for (int r = 0; r < 6; r++) { a[r] += cd[r] + C[r]; v[r] += S[r]; }
-      }
-      for (int r = 0; r < 6; r++) { s.r1.v.cvel[b][r] = v[r]; s.r1.v.cacc[b][r] = a[r]; }
-    }
-    dmw::sync();
-  }
-#endif
   if (isbody) {
     R v[6], a[6];
     for (int r = 0; r < 6; r++) { v[r] = s.r1.v.cvel[b][r]; a[r] = s.r1.v.cacc[b][r]; }
@@ -400,7 +342,6 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& 
   dmw::sync();
   slot_subtree_sums<6, 1, R>(s.r1.v.cfrc, s.r1.v.cvel, sl);       // csub -> the velocity region (dead by now)
   dmw::sync();
-#if DM_BIAS_BATCH
   {
     R cdd[DOF_PASSES][6], cvb[DOF_PASSES][6], qv[DOF_PASSES], ac[DOF_PASSES], dmp[DOF_PASSES];
 #pragma unroll
@@ -419,16 +360,6 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& 
       if (d < NV) s.tau[d] = t;
     }
   }
-#else
-#pragma unroll
-  for (int c = 0; c < DOF_PASSES; c++) {
-    const int d = sl + SW * c;
-    if (d < NV) {
-      const R bias = dot6(s.cdof[d], s.r1.v.cvel[DM_DOF_BODY(tb, d)]);
-      s.tau[d] = -M.dof_damping[d] * s.qvel[d] - bias + s.act[d];
-    }
-  }
-#endif
   dmw::sync();
 }
 
@@ -436,11 +367,8 @@ DM_DEV void slot_bias(const DevModel<R>& M, SlotShared<R>& s, const SlotTables& 
 // columns of a step are taken one after the other by the slot's 16 lanes, in the order (pass, column, pair) in which the one-env
 // kernel's lane groups apply them, so that entries which several limbs update receive their contributions in the same order. ---------
 // The chunks (16 consecutive pair numbers of one column) of a step, in the one-env kernel's order of application (pass, column, sub-chunk)
-// DM_ELIM_HOIST 1: a lane's pair codes are decoded once per evaluation and used unmasked by all 15 elimination steps (slot_eliminate_step); 0: round 4's form
-// (decoded and masked per chunk, the lane number laundered per step): 1 304 -> 775 integer instructions in the stage, elimination 54.7 k -> 35.8 k cycles per wave-step.
-#ifndef DM_ELIM_HOIST
-#define DM_ELIM_HOIST 1
-#endif
+// A lane's pair codes are decoded once per evaluation and used unmasked by all 15 elimination steps (slot_eliminate_step) — round 4 decoded and masked them per chunk,
+// the lane number laundered per step: 1 304 -> 775 integer instructions in the stage, elimination 54.7 k -> 35.8 k cycles per wave-step (round 5).
 struct SlotElimChunks { int n; int K[24]; int t0[24]; };
 constexpr bool elim_unmasked_reads_fit() { for (int K = 0; K < NV; K++) if (TOPO.madr[K] + 14 >= 312) return false; return true; }
 static_assert(elim_unmasked_reads_fit(), "an unmasked pair code (e, a <= 14) must address inside qLD[312] from every column's base");
@@ -478,14 +406,10 @@ DM_DEV void slot_eliminate_step(SlotShared<R>& s, const SlotTables& tb, int sl, 
     const int K = CH.K[c], np = elim_npairs(K), base = TOPO.madr[K];
     const int t = CH.t0[c] + sl;
     on[c] = t < np;
-#if DM_ELIM_HOIST
     // the pair code of a lane depends on (lane, t0 / 16) only: unmasked (a lane past the column's pairs reads inside qLD — madr[K] + 14 <= 311 — and
     // keeps its update to itself), the codes and the addresses formed from them are the same in all 15 steps and the compiler keeps them
     const int j = CH.t0[c] >> 4;                     // (a constant after unrolling)
     const int code = (int)(lt.tri >> (8 * j)) & 0xff, e = code >> 4, a = code & 15;
-#else
-    const int code = on[c] ? (int)(lt.tri >> (8 * (t >> 4))) & 0xff : 0, e = code >> 4, a = code & 15;
-#endif
     dst[c] = tb.tab_dst[K][a] + (e - a);
     xe[c] = s.r2.qLD[base + e]; xa[c] = s.r2.qLD[base + a];
   }
@@ -507,11 +431,7 @@ template <int S, class R>
 struct SlotEliminateFrom {
   static DM_DEV void run(SlotShared<R>& s, const SlotTables& tb, int sl, const LaneTopo& lt) {
     if constexpr (S < N_ELIM_STEPS) {
-#if DM_ELIM_HOIST
       slot_eliminate_step<S, R>(s, tb, sl, lt);
-#else
-      slot_eliminate_step<S, R>(s, tb, dmw::launder(sl), lt);
-#endif
       SlotEliminateFrom<S + 1, R>::run(s, tb, sl, lt);
     }
   }
@@ -544,7 +464,6 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
 #pragma unroll
   for (int c = 0; c < ENT_PASSES; c++) { const int e = sl + SW * c; ijc[c] = tb.tab_ent[e < 312 ? e : 0]; }
   dmw::sync();
-#if DM_ENTRY_SELECT
   // All twenty passes' entries are formed in registers first and stored afterwards, and the armature of a diagonal entry is added by SELECT (its operand
   // fetched by every lane).  With a store and a branch per pass the passes were twenty scheduling regions, each waiting out its own four LDS round trips:
   // 10 k of the stage's 12 k cycles per evaluation on a lone wave.  Same values, same order of operations per entry.
@@ -578,30 +497,12 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
       if (dbg) { const int ij = ijc[c], i = ij >> 8, j = ij & 0xff; dbg->out[i * NV + j] = (double)ent[c]; dbg->out[j * NV + i] = (double)ent[c]; }
     }
   }
-#else
-#pragma unroll
-  for (int c = 0; c < ENT_PASSES; c++) {
-    const int e = sl + SW * c;
-    if ((c + 1) * SW <= TOPO.nM || e < TOPO.nM) {
-      const int ij = ijc[c], i = ij >> 8, j = ij & 0xff;
-      R v = dot6(s.cdof[j], s.r1.fdof[i]);
-      if (i == j) v += s.qd.o.dinv[i];
-      s.r2.qLD[e] = v;
-      if (dbg) { dbg->out[i * NV + j] = (double)v; dbg->out[j * NV + i] = (double)v; }
-    }
-  }
-#endif
   dmw::sync();
   SLOT_MSTAMP(16)
-#if DM_ELIM_HOIST
   LaneTopo le = lt;
   le.tri = dmw::launder(lt.tri);            // what the steps derive from the pair codes stays inside this evaluation (not hoisted out of the RK loop and spilled)
   SlotEliminateFrom<0, R>::run(s, tb, sl, le);
-#else
-  SlotEliminateFrom<0, R>::run(s, tb, sl, lt);
-#endif
   SLOT_MSTAMP(17)
-#if DM_ENTRY_SELECT
   {
     R dgl[DOF_PASSES];                       // (likewise: the three diagonals first, then the three division + square-root chains side by side)
 #pragma unroll
@@ -614,15 +515,7 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
       if (d < NV) { s.qd.o.dinv[d] = inv; s.dsq[d] = sq; }
     }
   }
-#else
-#pragma unroll
-  for (int c = 0; c < DOF_PASSES; c++) {
-    const int d = sl + SW * c;
-    if (d < NV) { const R inv = R(1) / s.r2.qLD[DM_DOF_MADR(tb, d)]; s.qd.o.dinv[d] = inv; s.dsq[d] = sqrt(inv); }
-  }
-#endif
   dmw::sync();
-#if DM_ENTRY_SELECT
   {
     R sc[ENT_PASSES], di[ENT_PASSES];        // (likewise: all forty operands, a fence, the products, the stores)
 #pragma unroll
@@ -644,17 +537,6 @@ DM_DEV void slot_mass_matrix(const DevModel<R>& M, SlotShared<R>& s, const SlotT
       if ((c + 1) * SW <= TOPO.nM || e < TOPO.nM) s.r2.qLD[e] = sc[c];
     }
   }
-#else
-#pragma unroll
-  for (int c = 0; c < ENT_PASSES; c++) {
-    const int e = sl + SW * c;
-    if ((c + 1) * SW <= TOPO.nM || e < TOPO.nM) {
-      const int ij = ijc[c], i = ij >> 8, j = ij & 0xff;
-      const R sc = i != j ? s.qd.o.dinv[i] : R(1);
-      s.r2.qLD[e] *= sc;
-    }
-  }
-#endif
   dmw::sync();
   SLOT_MSTAMP(18)
 #undef SLOT_MSTAMP
@@ -712,10 +594,6 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
     pk[p] = M.pair_rec[pr].g1 | (M.pair_rec[pr].g2 << 8) | ((M.pair_rec[pr].t1t2 & 0xff) << 16);
     pbound[p] = M.pair_rec[pr].bound;
   }
-#ifndef DM_ROWS_PRELOAD
-#define DM_ROWS_PRELOAD 5          // (bit 1 measured -1.1 %: profiles/r06_ab_kernel_variants.md section 7) bit 0: geom + limit constants up front; bit 1: the plane pairs' body + local normal up front; bit 2: geom numbers in the candidate word
-#endif
-#if DM_ROWS_PRELOAD & 1
   // (round 6) every model constant of this section — the lane's geom (body, local position) and its two hinges' limit flags and bounds — is requested HERE, beside the
   // pair records, unconditionally: the section used to fetch them one after the other behind lane predicates (flag -> lower bound -> upper bound, per hinge pass:
   // eight exposed L2 round trips per evaluation on a wave that has nothing else to run).  Same arithmetic on the same operands: bit-identical rows.
@@ -728,16 +606,8 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
     jl[c] = M.enable_limit ? (int)M.jnt_limited[hh] : 0; jlo[c] = M.enable_limit ? M.jnt_lo[hh] : R(0); jhi[c] = M.enable_limit ? M.jnt_hi[hh] : R(0);
   }
   dmw::sched_fence();
-  // ... and behind them (they need the pair records' geom numbers: a second round trip, hidden behind this section's arithmetic) what a PLANE pair's broad-phase
-  // test reads: the body and the local normal of geom 1 — for every pass, whatever the pair's type (the loads are cheaper than a branch around them; the broad
-  // phase used to fetch body -> normal inside the divergent plane branch of each pass: two exposed round trips per pass that holds plane pairs)
-  int pbody[PAIR_PASSES]; R pnl[PAIR_PASSES][3];
-#pragma unroll
-  for (int p = 0; p < ((DM_ROWS_PRELOAD & 2) ? PAIR_PASSES : 0); p++) {
-    const int g1 = pk[p] & 0xff;
-    pbody[p] = M.enable_contact ? (int)M.geom_body[g1] : 0;
-    pnl[p][0] = M.enable_contact ? M.geom_mat[g1][2] : R(0); pnl[p][1] = M.enable_contact ? M.geom_mat[g1][5] : R(0); pnl[p][2] = M.enable_contact ? M.geom_mat[g1][8] : R(0);
-  }
+  // (measured and dropped: the plane pairs' body + local normal for all seven broad-phase passes requested here as well — 28 more loads, 49 registers: -1.1 %,
+  //  profiles/r06_ab_kernel_variants.md section 7)
   if (M.enable_contact) {
     const int g = sl;                                        // NG == SW: one geom per lane
     R v[3];
@@ -765,36 +635,6 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
     }
     if (nrow > SLOT_MAXLIMROWS) ovf |= 8;
   }
-#else
-  if (M.enable_contact) {
-    const int g = sl, gb = M.geom_body[g];                   // NG == SW: one geom per lane
-    R v[3];
-    mat_vec(v, s.xmat[gb], M.geom_pos[g]);
-    W.gpos[g][0] = s.xpos[gb][0] + v[0]; W.gpos[g][1] = s.xpos[gb][1] + v[1]; W.gpos[g][2] = s.xpos[gb][2] + v[2];
-  }
-  // ---- joint limits: hinge h = sl + 16 c, dof h + 6
-  if (M.enable_limit) {
-#pragma unroll
-    for (int c = 0; c < HINGE_PASSES; c++) {
-      const int h = sl + SW * c;
-      bool viol = false;
-      R dist = 0; int pos_sign = 0;
-      if (h < NU && M.jnt_limited[h + 1]) {
-        const R q = s.qpos[h + 7];
-        const R dlo = q - M.jnt_lo[h + 1], dhi = M.jnt_hi[h + 1] - q;
-        if (dlo < 0) { viol = true; dist = dlo; pos_sign = 1; }
-        else if (dhi < 0) { viol = true; dist = dhi; pos_sign = 0; }
-      }
-      const unsigned mask = dmw::row_ballot(viol, lane);
-      if (viol) {
-        const int r = nrow + __builtin_popcount(mask & below);
-        if (r < SLOT_MAXLIMROWS) { W.rowi[r] = ROW_LIMIT | ((h + 6) << 8) | (pos_sign << 16); W.rowv[r] = dist; }
-      }
-      nrow += __builtin_popcount(mask);
-    }
-    if (nrow > SLOT_MAXLIMROWS) ovf |= 8;
-  }
-#endif
   dmw::sync();
   SLOT_RSTAMP(19)
   int ncon = 0, nfr = 0;
@@ -811,21 +651,16 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
           const R d[3] = {W.gpos[g2][0] - W.gpos[g1][0], W.gpos[g2][1] - W.gpos[g1][1], W.gpos[g2][2] - W.gpos[g1][2]};
           if (t1 == GEOM_PLANE) {
             // plane normal = third column of its world orientation  xmat[body] * geom_mat
-#if (DM_ROWS_PRELOAD & 3) == 3
-            const R* a = s.xmat[pbody[p]];
-            const R b2 = pnl[p][0], b5 = pnl[p][1], b8 = pnl[p][2];
-#else
             const int gb = M.geom_body[g1];
             const R* a = s.xmat[gb]; const R* bm = M.geom_mat[g1];
             const R b2 = bm[2], b5 = bm[5], b8 = bm[8];
-#endif
             const R nx = a[0] * b2 + a[1] * b5 + a[2] * b8, ny = a[3] * b2 + a[4] * b5 + a[5] * b8, nz = a[6] * b2 + a[7] * b5 + a[8] * b8;
             cand = d[0] * nx + d[1] * ny + d[2] * nz <= pbound[p];
           } else cand = dot3(d, d) <= pbound[p] * pbound[p];
         }
         const unsigned mask = dmw::row_ballot(cand, lane);
         // candidate word: pair number | geom 1 << 7 | geom 2 << 11 (round 6: the narrow phase asks for the pair record AND both geoms' local frames in one go)
-        if (cand) { const int k = ncand + __builtin_popcount(mask & below); if (k < SLOT_MAXCAND) W.cand[k] = (unsigned short)((DM_ROWS_PRELOAD & 4) ? (pidx | (g1 << 7) | (g2 << 11)) : pidx); }
+        if (cand) { const int k = ncand + __builtin_popcount(mask & below); if (k < SLOT_MAXCAND) W.cand[k] = (unsigned short)(pidx | (g1 << 7) | (g2 << 11)); }
         ncand += __builtin_popcount(mask);
       }
     }
@@ -841,7 +676,7 @@ DM_DEV int slot_rows(const DevModel<R>& M, SlotShared<R>& s, int sl_in, int lane
       const int cw = has ? (int)W.cand[kc] : 0;
       const int pidx = cw & 127;
       const auto& rec = M.pair_rec[pidx];
-      const int g1 = (DM_ROWS_PRELOAD & 4) ? (cw >> 7) & 15 : rec.g1, g2 = (DM_ROWS_PRELOAD & 4) ? (cw >> 11) & 15 : rec.g2;          // (= rec.g1, rec.g2: known before the record arrives)
+      const int g1 = (cw >> 7) & 15, g2 = (cw >> 11) & 15;          // (= rec.g1, rec.g2: known before the record arrives)
       const int tt = rec.t1t2, meta = rec.meta;
       R bm1[9], bm2[9];
 #pragma unroll
@@ -1008,18 +843,8 @@ struct SlotWarm {
 template <int CC, int NS, class R>
 DM_DEV void slot_sweep_rows4(const R (*AR)[16 * NS], R* t, R* tsave, const R* nf0, const R* oh) {
   static_assert(CC % 4 == 0, "row groups of four");
-#ifdef DM_PGS_ROW_BLOCKS          // (A/B hook: round 4's one-row blocks)
-  if constexpr (NS == 1) { dmw::pgs_row<CC % 16>(t[0], tsave[0], nf0[0], AR[0][CC], oh[CC % 16]); dmw::pgs_row<CC % 16 + 1>(t[0], tsave[0], nf0[0], AR[0][CC + 1], oh[CC % 16 + 1]);
-                           dmw::pgs_row<CC % 16 + 2>(t[0], tsave[0], nf0[0], AR[0][CC + 2], oh[CC % 16 + 2]); dmw::pgs_row<CC % 16 + 3>(t[0], tsave[0], nf0[0], AR[0][CC + 3], oh[CC % 16 + 3]); }
-  else {
-    constexpr int o = CC / 16;
-    dmw::pgs_row2<CC % 16>(t[o], tsave[o], t[1 - o], nf0[o], AR[o][CC], AR[1 - o][CC], oh[CC % 16]); dmw::pgs_row2<CC % 16 + 1>(t[o], tsave[o], t[1 - o], nf0[o], AR[o][CC + 1], AR[1 - o][CC + 1], oh[CC % 16 + 1]);
-    dmw::pgs_row2<CC % 16 + 2>(t[o], tsave[o], t[1 - o], nf0[o], AR[o][CC + 2], AR[1 - o][CC + 2], oh[CC % 16 + 2]); dmw::pgs_row2<CC % 16 + 3>(t[o], tsave[o], t[1 - o], nf0[o], AR[o][CC + 3], AR[1 - o][CC + 3], oh[CC % 16 + 3]);
-  }
-#else
   if constexpr (NS == 1) dmw::pgs_rows4<CC % 16>(t[0], tsave[0], nf0[0], &AR[0][CC], &oh[CC % 16]);
   else dmw::pgs_rows4_2<CC % 16>(t[CC / 16], tsave[CC / 16], t[1 - CC / 16], nf0[CC / 16], &AR[CC / 16][CC], &AR[1 - CC / 16][CC], &oh[CC % 16]);
-#endif
 }
 template <int C, int NS, class R>
 struct SlotSweep {
@@ -1447,12 +1272,7 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
     for (int k = 0; k < NF; k++) {
       const R delta = dmw::max_raw(nf[k], tsave[k]);
       const R change = (delta * diag[k]) * (R(0.5) * delta - tsave[k]);
-#ifdef DM_PGS_CHG_ZERO          // (A/B hook: rounds 3-5 started the sum from 0 — one dependent v_add_f64 per sweep at the head of the termination reduction)
-      if (k == 0) chg = 0;
-      chg += change;
-#else
       chg = k == 0 ? change : chg + change;      // (0 + c == c bit for bit except for the sign of a zero, which no comparison downstream sees)
-#endif
       nf[k] -= delta; bad = bad || (change > pgs_detect);
     }
     if constexpr (EXT) {
@@ -1561,36 +1381,12 @@ DM_DEV void slot_constraint(const DevModel<R>& M, SlotShared<R>& s, int sl_in, i
 #undef SLOT_STAMP
 }
 
-// ---- stages as internal functions (round 6 experiment, DM_STAGE_CALLS bit mask: 1 the constraint stage, 2 the collision stage) ------------------------------
-// With inter-procedural register allocation a call costs no register save / restore (slot_step.h DM_CALL_SLOT): a stage compiled as a function of its own gets a
-// register assignment that the 30 000 other instructions of the step cannot perturb (round 5: "the kernel's speed is a property of its register ASSIGNMENT").
-// The pointer to the caller's `ovf` is the frame pointer that keeps the call from being a tail call.
-#ifndef DM_STAGE_CALLS
-#define DM_STAGE_CALLS 2
-#endif
+// ---- the collision stage as an internal function (round 6) --------------------------------------------------------------------------------------------------
+// With inter-procedural register allocation a call costs no register save / restore (slot_step.h DM_CALL_SLOT), so a stage compiled as a function of its own gets a
+// register assignment that the 30 000 other instructions of the step cannot perturb — and ONE copy of its code serves every kernel of the unit.  Measured per stage
+// (profiles/r06_ab_kernel_variants.md section 7): the collision stage +0.6 % alone, +1.7 % with its constants requested up front; the constraint stage -1.3 %;
+// mass matrix, bias, kinematics nothing.  The pointer to the caller's `ovf` is the frame pointer that keeps the call from being a tail call.
 #if !defined(DM_WAVE_TESTBENCH)
-template <class R, int NS>
-static __device__ __noinline__ void slot_constraint_call(const DevModel<R>* M, SlotShared<R>* s, int sl, int lane, int nefc, int nmax, int* ovf) {
-  int o = *ovf;
-  slot_constraint<R, NS, false>(*dmw::in_constant(M), *dmw::in_lds(s), sl, lane, nefc, dmw::uniform(nmax), o, (const DebugOut*)0, (long long*)0);
-  *ovf = o;
-}
-template <class R>
-static __device__ __noinline__ void slot_mass_call(const DevModel<R>* M, SlotShared<R>* s, const SlotTables* tb, int sl, LaneTopo lt, int* frame_word) {
-  *frame_word = sl;
-  slot_mass_matrix<R, false>(*dmw::in_constant(M), *dmw::in_lds(s), *dmw::in_lds(tb), sl, lt, (const DebugOut*)0, (long long*)0);
-}
-template <class R>
-static __device__ __noinline__ void slot_bias_call(const DevModel<R>* M, SlotShared<R>* s, const SlotTables* tb, int sl, LaneTopo lt, int* frame_word) {
-  *frame_word = sl;
-  slot_bias(*dmw::in_constant(M), *dmw::in_lds(s), *dmw::in_lds(tb), sl, lt);
-}
-template <class R>
-static __device__ __noinline__ void slot_kinematics_call(const DevModel<R>* M, SlotShared<R>* s, int sl, LaneTopo lt, R* xip) {
-  R x[3];
-  slot_kinematics(*dmw::in_constant(M), *dmw::in_lds(s), sl, lt, x);
-  xip[0] = x[0]; xip[1] = x[1]; xip[2] = x[2];
-}
 template <class R, int MAXR>
 static __device__ __noinline__ int slot_rows_call(const DevModel<R>* M, SlotShared<R>* s, int sl, int lane, int* ovf) {
   int o = *ovf;
@@ -1639,35 +1435,22 @@ DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTable
     dmw::sync();
     if (sl == 0) s.kin_ok() = R(0);              // one use: the next evaluation starts from another state
   }
-#if !defined(DM_WAVE_TESTBENCH)
-  if ((DM_STAGE_CALLS & 16) && !PROF) { if (!skip_kin) slot_kinematics_call<R>(&M, &s, sl, lt, xip); }
-  else
-#endif
   if (!skip_kin) slot_kinematics(M, s, sl, lt, xip);
   SLOT_FSTAMP(0)
   if (dbg) { for (int e = sl; e < NV * NV; e += SW) dbg->out[e] = 0; dmw::sync(); }
   DM_MARK("slot_bias");
-#if !defined(DM_WAVE_TESTBENCH)
-  int frame_word = 0;
-  if ((DM_STAGE_CALLS & 8) && !PROF) slot_bias_call<R>(&M, &s, &tb, sl, lt, &frame_word);
-  else
-#endif
   slot_bias(M, s, tb, sl, lt);
   SLOT_FSTAMP(1)
   if (dbg) {
     for (int c = 0; c < DOF_PASSES; c++) { const int d = sl + SW * c; if (d < NV) dbg->out[34 * 34 + d] = (double)(-M.dof_damping[d] * s.qvel[d] + s.act[d] - s.tau[d]); }
   }
   DM_MARK("slot_mass_factor");
-#if !defined(DM_WAVE_TESTBENCH)
-  if ((DM_STAGE_CALLS & 4) && !PROF && !dbg) { slot_mass_call<R>(&M, &s, &tb, sl, lt, &frame_word); asm volatile("" :: "v"(frame_word)); }
-  else
-#endif
   slot_mass_matrix<R, PROF>(M, s, tb, sl, lt, dbg, prof);
   SLOT_FSTAMP(2)
   DM_MARK("slot_rows");
   int nefc = 0;
 #if !defined(DM_WAVE_TESTBENCH)
-  if ((DM_STAGE_CALLS & 2) && !PROF && (M.enable_contact || M.enable_limit)) nefc = slot_rows_call<R, MAXR>(&M, &s, sl, lane, &ovf);
+  if (!PROF && (M.enable_contact || M.enable_limit)) nefc = slot_rows_call<R, MAXR>(&M, &s, sl, lane, &ovf);      // (the diagnostic build keeps the stage inline for its stamps)
   else
 #endif
   if (M.enable_contact || M.enable_limit) nefc = slot_rows<R, PROF, MAXR>(M, s, sl, lane, ovf, prof);
@@ -1678,10 +1461,6 @@ DM_DEV void slot_forward(const DevModel<R>& M, SlotShared<R>& s, const SlotTable
   if (nmax == 0) slot_smooth_solve(s, sl, dbg);
 #ifdef DM_FORCE_EXT      // test hook (testbench builds only): every constrained evaluation through the three-set code — results must not change
   else if (nmax > 0 && MAXR > 2 * SW) slot_constraint<R, MAXR > 2 * SW ? 3 : 2, PROF>(M, s, sl, lane, nefc, nmax > 2 * SW ? nmax : 2 * SW + 1, ovf, dbg, prof);
-#endif
-#if !defined(DM_WAVE_TESTBENCH)
-  else if ((DM_STAGE_CALLS & 1) && !PROF && !dbg && nmax <= 16) slot_constraint_call<R, 1>(&M, &s, sl, lane, nefc, nmax, &ovf);
-  else if ((DM_STAGE_CALLS & 1) && !PROF && !dbg && nmax <= 2 * SW) slot_constraint_call<R, 2>(&M, &s, sl, lane, nefc, nmax, &ovf);
 #endif
   else if (nmax <= 16) slot_constraint<R, 1, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof);
   else if (nmax <= 2 * SW) { slot_constraint<R, 2, PROF>(M, s, sl, lane, nefc, nmax, ovf, dbg, prof); if (PROF) prof[7] += 1; }

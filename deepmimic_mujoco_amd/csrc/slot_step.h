@@ -62,15 +62,11 @@ DM_DEV void slot_rk4_step(const DevModel<R>& M, SlotShared<R>& s, const SlotTabl
     // (the RK state is not touched by the evaluation: out of the architectural registers for its duration — wave.h park)
     typedef decltype(dmw::park(R(0))) ParkedR;
     ParkedR pk[5][DOF_PASSES];
-#ifndef DM_NO_RK_PARK
 #pragma unroll
     for (int c = 0; c < DOF_PASSES; c++) { pk[0][c] = dmw::park(x0q.r[c]); pk[1][c] = dmw::park(x0v.r[c]); pk[2][c] = dmw::park(vprev.r[c]); pk[3][c] = dmw::park(sumv.r[c]); pk[4][c] = dmw::park(suma.r[c]); }
-#endif
     slot_forward<R, PROF, CARRY, MAXR>(M, s, tb, sl, lane, lt, xip, ovf, (const DebugOut*)0, prof);
-#ifndef DM_NO_RK_PARK
 #pragma unroll
     for (int c = 0; c < DOF_PASSES; c++) { x0q.r[c] = dmw::unpark(pk[0][c]); x0v.r[c] = dmw::unpark(pk[1][c]); vprev.r[c] = dmw::unpark(pk[2][c]); sumv.r[c] = dmw::unpark(pk[3][c]); suma.r[c] = dmw::unpark(pk[4][c]); }
-#endif
 #pragma unroll
     for (int c = 0; c < DOF_PASSES; c++) {
       const int d = sl + SW * c;
