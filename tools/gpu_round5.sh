@@ -85,7 +85,7 @@ j=json.loads(sys.stdin.read()); print('standing packed %.3f M  one-env %.3f M' %
     ROWS=8 python tools/rocprof_summary.py $OUT/krollout_summary.md "step queue -> horizon launches — $TAG, MI355X (bench.py default: cfg3 + 5-term imitation reward, 4096 envs, dm_batch_step calls queued 256 per launch; 3 launches)" \
       $(find /tmp/p_trace -name "*.db" | head -1) > /dev/null; head -14 $OUT/krollout_summary.md
     ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p_trace1 -- python $OLDPWD/bench.py --_child --step-queue 0 --steps 96 --warmup 16 --prewarm-horizons 1 $Q > /dev/null 2>&1 )
-    ROWS=6 python tools/rocprof_summary.py $OUT/kstep_summary.md "one launch set per call — $TAG, MI355X (bench.py --step-queue 0: k_step_narrow, 4096 envs as 2 pipelined sub-batches; what vecenv_step times)" \
+    ROWS=6 python tools/rocprof_summary.py $OUT/kstep_summary.md "one launch set per call — $TAG, MI355X (bench.py --step-queue 0: the kernel DPVecEnv picks at 4096 envs — k_step_packed + k_step_redo since round 6 — as 2 pipelined sub-batches; what vecenv_step times)" \
       $(find /tmp/p_trace1 -name "*.db" | head -1) > /dev/null; head -10 $OUT/kstep_summary.md
     # the PMC tables of both summaries from the raw per-launch counter exports the `bench` bundle kept (run `bench` first)
     ls $OUT/raw/*_cfg3_queue_*_counters.csv > /dev/null 2>&1 && python tools/pmc_table.py $OUT/krollout_summary.md $OUT/raw/${TAGP:-r05}_cfg3_queue > /dev/null
