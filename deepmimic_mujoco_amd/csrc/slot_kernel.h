@@ -762,6 +762,7 @@ struct SlotSolveLTStep {
 };
 template <int NVEC, class R> struct SlotSolveLTStep<0, NVEC, R> { static DM_DEV void run(R (*)[NV], const R*, const R*) {} };
 template <int NVEC, class R> DM_DEV void slot_solve_LT(R (*x)[NV], const R* qLD) {
+  // (measured, round 6: the factor rows requested TWO rows ahead here and in the forward solve — nothing, 20.85 against 20.85 M: profiles/r06_ab_kernel_variants.md section 10)
   R cur[14];
   dmw::reload_fence();
   load_factor_row<NV - 1>(cur, qLD);
