@@ -14,6 +14,10 @@ for T in "$@"; do O=gpurun_out/$T
   [ -f $O/kstep_summary.md ] && stamp $O/kstep_summary.md $T $P/r06_kstep_summary.md
   [ -f $O/hstage.log ] && stamp $O/hstage.log $T $P/r06_horizon_stage_cycles.md
   [ -f $O/stage.log ] && stamp $O/stage.log $T $P/r06_packed_stage_cycles.md
+  [ -f $O/fuzz_parity.log ] && stamp $O/fuzz_parity.log $T $P/r06_fuzz_parity.log
+  [ -f $O/standing_synth.log ] && stamp $O/standing_synth.log $T $P/r06_standing_synth.log
+  [ -f $O/standing_step_bench.log ] && stamp $O/standing_step_bench.log $T $P/r06_standing_step_bench.log
+  [ -f $O/hstage_standing.log ] && stamp $O/hstage_standing.log $T $P/r06_horizon_stage_cycles_standing.md
   [ -f $O/trpo_train_60s.json ] && cp $O/trpo_train_60s.json $P/r06_trpo_learning_curve.json && echo "r06_trpo_learning_curve.json $C $T" >> $P/r06_commits.txt
   [ -f $O/trpo_update_profile.json ] && cp $O/trpo_update_profile.json $P/r06_trpo_update_profile_native.json && echo "r06_trpo_update_profile_native.json $C $T" >> $P/r06_commits.txt
   [ -f $O/trpo_imitation_60s.json ] && cp $O/trpo_imitation_60s.json $P/r06_trpo_imitation_curve.json && echo "r06_trpo_imitation_curve.json $C $T" >> $P/r06_commits.txt
