@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
-SOURCES = ["dmenv.hip", "kernels_packed.hip", "kernels.h", "env_kernel.h", "env_step.h", "model_host.h", "topology.h", "wave.h", "policy_kernel.h", "vf_kernel.h", "pg_kernel.h", "slot_kernel.h", "slot_step.h"]
+SOURCES = ["dmenv.hip", "kernels_packed.hip", "kernels_rollout.hip", "kernels.h", "env_kernel.h", "env_step.h", "model_host.h", "topology.h", "wave.h", "policy_kernel.h", "vf_kernel.h", "pg_kernel.h", "slot_kernel.h", "slot_step.h"]
 OUT = os.path.join(HERE, "libdmenv.so")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-shift-count-negative", "-Wno-implicit-const-int-float-conversion"]
 # Two translation units, each with the backend options its kernels want (round 4, A/B in profiles/r04_ab_kernel_variants.md):
@@ -20,7 +20,12 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 PACKED_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-enable-ipra"]
 if os.environ.get("DM_PACKED_FLAGS") is not None:      # experiments: replace the packed unit's backend options altogether (tools/build_variant.sh)
     PACKED_FLAGS = os.environ["DM_PACKED_FLAGS"].split()
-UNITS = [("dmenv.hip", []), ("kernels_packed.hip", PACKED_FLAGS)]
+#   kernels_rollout.hip — k_rollout_packed and its called step bodies: the packed options + the IR-level load-store vectoriser off (round 6: +0.8 .. +1.4 % on the
+#                        horizon launch, -1 % on the per-step packed kernel, hence a unit of its own).
+ROLLOUT_FLAGS = PACKED_FLAGS + ["-mllvm", "-amdgpu-load-store-vectorizer=false"]
+if os.environ.get("DM_ROLLOUT_FLAGS") is not None:
+    ROLLOUT_FLAGS = os.environ["DM_ROLLOUT_FLAGS"].split()
+UNITS = [("dmenv.hip", []), ("kernels_packed.hip", PACKED_FLAGS), ("kernels_rollout.hip", ROLLOUT_FLAGS)]
 
 
 def hipcc():

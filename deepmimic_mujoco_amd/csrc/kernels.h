@@ -1,6 +1,7 @@
-// kernels.h — what the two translation units of libdmenv.so share: the build's arithmetic type and the prototypes of the packed step kernels.
+// kernels.h — what the three translation units of libdmenv.so share: the build's arithmetic type and the prototypes of the packed step kernels.
 //   dmenv.hip           one-env step kernels, reset / state / ordering / learner kernels, the C ABI (host side)
-//   kernels_packed.hip  the four-environments-per-wavefront kernels (slot_kernel.h / slot_step.h): compiled with their own backend options
+//   kernels_rollout.hip the horizon launch (k_rollout_packed + the step bodies it calls): the packed options and the load-store vectoriser off
+//   kernels_packed.hip  the four-environments-per-wavefront per-step kernels (slot_kernel.h / slot_step.h): compiled with their own backend options
 //                       (csrc/build.py PACKED_FLAGS — one wave per SIMD with the whole register file wants a scheduler that goes for
 //                       instruction-level parallelism, the two-waves-per-SIMD one-env kernels do not: profiles/r04_ab_kernel_variants.md)
 #pragma once

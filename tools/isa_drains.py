@@ -19,14 +19,14 @@ CS = os.path.join(ROOT, "deepmimic_mujoco_amd", "csrc")
 sys.path.insert(0, ROOT)
 from deepmimic_mujoco_amd.csrc import build as B  # noqa: E402
 
-SYM = "_ZN2dm18slot_env_step_callIdLi32E"
+SYM = "_ZN2dmL18slot_env_step_callIdLi32E"
 
 
 def main():
     out_md = sys.argv[1] if len(sys.argv) > 1 else None
     s_path = os.environ.get("DM_ISA_OUT", os.path.join(tempfile.gettempdir(), "dmenv_packed_isa.s"))
-    cmd = [B.hipcc()] + [f for f in B.COMMON if f != "-fPIC"] + B.PACKED_FLAGS + os.environ.get("DM_BUILD_DEFINES", "").split() + [
-        "-I" + os.path.join(ROOT, "include"), "-I" + CS, "-S", "--cuda-device-only", os.path.join(CS, "kernels_packed.hip"), "-o", s_path]
+    cmd = [B.hipcc()] + [f for f in B.COMMON if f != "-fPIC"] + B.ROLLOUT_FLAGS + os.environ.get("DM_BUILD_DEFINES", "").split() + [
+        "-I" + os.path.join(ROOT, "include"), "-I" + CS, "-S", "--cuda-device-only", os.path.join(CS, "kernels_rollout.hip"), "-o", s_path]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     rows = []
     on = False

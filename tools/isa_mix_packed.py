@@ -1,5 +1,5 @@
 """Static instruction mix per stage of the packed step (the lean instantiation slot_env_step_call<double, 32> that k_rollout_packed calls, and the
-three-set one <double, 40>): the device listing of csrc/kernels_packed.hip — compiled with the product's backend options — split on the DM_MARK
+three-set one <double, 40>): the device listing of csrc/kernels_rollout.hip — compiled with the product's backend options — split on the DM_MARK
 comments, every instruction put into one bucket:
   f64 arith     v_*_f64 except moves / compares / DPP forms        dpp f64      v_fmac_f64_dpp / v_mov_b64_dpp (row broadcasts)
   dpp b32       v_mov_b32_dpp (lane permutations of sum16 etc.)    mov/sel      v_mov*, v_cndmask*, v_accvgpr_* (data movement inside the register file)
@@ -83,13 +83,13 @@ NAMES = [("slot_kinematics", "kinematics"), ("slot_bias", "bias forces"), ("slot
 def main():
     out_md = sys.argv[1] if len(sys.argv) > 1 else None
     s_path = os.environ.get("DM_ISA_OUT", os.path.join(tempfile.gettempdir(), "dmenv_packed_isa.s"))
-    cmd = [B.hipcc()] + [f for f in B.COMMON if f != "-fPIC"] + B.PACKED_FLAGS + os.environ.get("DM_BUILD_DEFINES", "").split() + ["-I" + os.path.join(ROOT, "include"), "-I" + CS, "-S", "--cuda-device-only",
-                                                                                  os.path.join(CS, "kernels_packed.hip"), "-o", s_path]
+    cmd = [B.hipcc()] + [f for f in B.COMMON if f != "-fPIC"] + B.ROLLOUT_FLAGS + os.environ.get("DM_BUILD_DEFINES", "").split() + ["-I" + os.path.join(ROOT, "include"), "-I" + CS, "-S", "--cuda-device-only",
+                                                                                  os.path.join(CS, "kernels_rollout.hip"), "-o", s_path]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
-    lines = ["# Static instruction mix per stage of the packed step (`tools/isa_mix_packed.py`; gfx950 listing of `csrc/kernels_packed.hip`, product flags)", "",
+    lines = ["# Static instruction mix per stage of the packed step (`tools/isa_mix_packed.py`; gfx950 listing of `csrc/kernels_rollout.hip`, product flags)", "",
              __doc__.split("usage:")[0].strip(), ""]
-    for sym, title in (("_ZN2dm18slot_env_step_callIdLi32E", "lean instantiation `slot_env_step_call<double, 32>` (one and two row sets)"),
-                       ("_ZN2dm18slot_env_step_callIdLi40E", "three-set instantiation `slot_env_step_call<double, 40>`")):
+    for sym, title in (("_ZN2dmL18slot_env_step_callIdLi32E", "lean instantiation `slot_env_step_call<double, 32>` (one and two row sets)"),
+                       ("_ZN2dmL18slot_env_step_callIdLi40E", "three-set instantiation `slot_env_step_call<double, 40>`")):
         sec = sections(s_path, sym)
         lines += ["## " + title, "", "| stage | " + " | ".join(BUCKETS) + " | all | f64 arith share |", "|---|" + "---|" * (len(BUCKETS) + 2)]
         tot = collections.Counter()
