@@ -22,7 +22,8 @@ if os.environ.get("DM_PACKED_FLAGS") is not None:      # experiments: replace th
     PACKED_FLAGS = os.environ["DM_PACKED_FLAGS"].split()
 #   kernels_rollout.hip — k_rollout_packed and its called step bodies: the packed options + the IR-level load-store vectoriser off (round 6: +0.8 .. +1.4 % on the
 #                        horizon launch, -1 % on the per-step packed kernel, hence a unit of its own).
-ROLLOUT_FLAGS = PACKED_FLAGS + ["-mllvm", "-amdgpu-load-store-vectorizer=false"]
+#                        -amdgpu-use-amdgpu-trackers: the backend's own register-pressure trackers in the scheduler: +0.5 .. +1.3 % there (section 17 of the same file).
+ROLLOUT_FLAGS = PACKED_FLAGS + ["-mllvm", "-amdgpu-load-store-vectorizer=false", "-mllvm", "-amdgpu-use-amdgpu-trackers=true"]
 if os.environ.get("DM_ROLLOUT_FLAGS") is not None:
     ROLLOUT_FLAGS = os.environ["DM_ROLLOUT_FLAGS"].split()
 UNITS = [("dmenv.hip", []), ("kernels_packed.hip", PACKED_FLAGS), ("kernels_rollout.hip", ROLLOUT_FLAGS)]
