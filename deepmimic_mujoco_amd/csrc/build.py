@@ -68,7 +68,7 @@ def build(force=False, verbose=False):
     """libdmenv.so (float64 arithmetic: the parity build) and libdmenv32.so (-DDM_REAL_FLOAT: the same kernels in float32, the
     `dtype 32` batch), compiled side by side.  Returns the path of libdmenv.so."""
     import threading
-    srcs = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(REPO, "include", "dmenv.h")]
+    srcs = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(REPO, "include", "dmenv.h"), os.path.abspath(__file__)]      # (this file: the units' backend options)
     extra = os.environ.get("DM_BUILD_DEFINES", "").split()
     todo = [(out, defs) for out, defs in ((OUT, []), (OUT32, ["-DDM_REAL_FLOAT"])) if force or _stale(out, srcs)]
     errs = []
