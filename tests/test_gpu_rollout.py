@@ -729,3 +729,19 @@ def test_two_env_sets_on_two_streams_step_like_each_alone():
         assert int(ref[i][2].sum()) > 0, "the run must contain auto-resets"
     for e in envs:
         e.close()
+
+
+@pytest.mark.gpu
+def test_default_kernel_choice_by_batch_size():
+    """DPVecEnv(packed=None) starts four-per-wave from PACKED_FROM_ENVS = 4 096 environments (round 6: 13.3 against 12.4 M env-steps/s closed loop there, 10.3 against
+    10.6 M at 3 072 — profiles/r06_ab_kernel_variants.md section 3) and one env per wave below; contact-free models take the packed kernel from 256 envs."""
+    from deepmimic_mujoco_amd.dp_env import PACKED_FROM_ENVS
+    assert PACKED_FROM_ENVS == 4096
+    for n, contacts, want in ((4096, True, True), (3072, True, False), (512, False, True)):
+        env = DPVecEnv(n, motion="walk", device=0, reward="alive", autoreset="rsi", seed=0, contacts=contacts, limits=contacts)
+        assert bool(env.packed) == want, (n, contacts, env.packed)
+        assert bool(env.batch.__dict__.get("_auto")) == want            # the chooser keeps watching the batch's own row statistics
+        env.reset("rsi")
+        obs, rew, done, _ = env.step(np.zeros((n, 28)))
+        assert np.isfinite(obs).all() and obs.shape == (n, 56)
+        env.close()
