@@ -136,10 +136,11 @@ enum {
                              (DM_PACKED_MAXROWS rows; ~8 % slower for environments that never get there: meant for populations that stand
                              on both feet) — (of them at most DM_PACKED_MAXLIMROWS joint limits), DM_PACKED_MAXCON contacts from at most DM_PACKED_MAXFRAME geom pairs,
                              DM_PACKED_MAXCAND pairs past the bounding spheres; an environment that exceeds one in some step is re-stepped
-                             by the one-env code in the same call (dm_batch_redo_total counts them).  The throughput kernel for batches
-                             of two or more waves per SIMD (>= 8192 envs on one MI355X): 1.4-1.5x; at 4096 envs a per-step launch is one
-                             round of lone waves and the one-env kernel stays ahead, while horizon launches (dm_batch_rollout,
-                             DM_OPT_STEP_QUEUE) use it at any size.  Results agree with the oracle to the same 1e-9 bar and do not depend
+                             by the one-env code in the same call (dm_batch_redo_total counts them).  The throughput kernel from 4096 envs up
+                             on one MI355X (round 6, closed loop with two pipelined sub-batches: 13.3 against 12.4 M env-steps/s at 4096 envs,
+                             18.7 against 12.4 M at 6144; below — 10.3 against 10.6 M at 3072 — a per-step launch is less than one round of
+                             lone waves and the one-env kernel stays ahead), while horizon launches (dm_batch_rollout, DM_OPT_STEP_QUEUE)
+                             use it at any size.  Results agree with the oracle to the same 1e-9 bar and do not depend
                              on which environments share a wave; they differ from the one-env kernel's in the last bits (other
                              summation orders). */
   DM_OPT_STEP_QUEUE = 8   /* 0 (default): every dm_batch_step call launches.  Q = 1..DM_MAX_STEP_QUEUE: dm_batch_step calls with DEVICE
